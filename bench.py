@@ -1,0 +1,273 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec (2-view) of the full PeCLR pretraining step
+(ResNet-50 encoder -> projection head -> equivariance alignment -> NT-Xent -> backward ->
+LARS/Adam step), per-device view batch 128 (256 images/step/device), synthetic 224x224 inputs,
+at 1/2/4/8 MI355X (BASELINE.json: configs[1] at N=1, the same per-GPU work under data parallel
+for N>1 -- weak scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
+  "roofline"     the dominant hand-written kernel (by time): algorithmic bytes/flops per launch
+                 / its average launch duration measured with HIP events on the launch stream
+                 inside the timed region (one C-ABI entry point = one launch);
+  "kernels"      the same figures for every hand-written kernel of the step;
+  "backbone"     the end-to-end MFMA figure of the PyTorch-ROCm/MIOpen encoder (not ours);
+  "cpu_baseline" the same step on the host cores: torch-CPU ResNet + the NumPy oracle head
+                 (oracle/peclr_oracle.py) + the foreach LARS/Adam, on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TF = 157.3    # v_mfma_f32_32x32x2_f32, dense
+MFMA_BF16_PEAK_TF = 2500.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--resnet", default="50")
+    ap.add_argument("--pairs", type=int, default=128, help="view pairs per device (N); 2N images/step/device")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="backbone compute dtype (configs[1] is fp32; head/logits/loss are always fp32)")
+    ap.add_argument("--channels-last", type=int, default=0)
+    ap.add_argument("--accum", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=16, help="pairs in the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def synthetic_batch(n, size, seed, device):
+    """randn images (post-normalisation ~ N(0,1)), integer-degree float64 angles
+    in [-45,45], int64 jitter in [-14,0]; generator seed = the reference's seed 5 (+ rank)."""
+    g = torch.Generator().manual_seed(seed)
+    b = {"transformed_image1": torch.randn(n, 3, size, size, generator=g),
+         "transformed_image2": torch.randn(n, 3, size, size, generator=g),
+         "jitter_x_1": torch.randint(-14, 1, (n,), generator=g),
+         "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+         "jitter_y_1": torch.randint(-14, 1, (n,), generator=g),
+         "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+         "angle_1": torch.randint(-45, 46, (n,), generator=g).double(),
+         "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+    return {k: v.to(device) for k, v in b.items()}
+
+
+def build_model(args, device, pairs):
+    from peclr_amd import Hybrid2Model, hybrid2_config
+
+    din = 512 if args.resnet in ("18", "34") else 2048
+    cfg = hybrid2_config(resnet_size=args.resnet, projection_head_input_dim=din, augmentation=["crop", "rotate"],
+                         batch_size=pairs, num_of_mini_batch=args.accum, pretrained=False)
+    torch.manual_seed(5)
+    return Hybrid2Model(cfg).to(device).train()
+
+
+def kernel_table(event_log, m_rows, m_global, din, hid, n_params):
+    """Average launch duration per hand-written kernel (HIP events) + algorithmic work per launch
+    (element size 4 B everywhere on this fp32 path)."""
+    from peclr_amd import _capi
+
+    d = 128
+    s1 = _capi.pick_split_k(m_rows, hid, din)
+    s2 = _capi.pick_split_k(m_rows, d, hid)
+    work = {  # name -> (bound, flops, bytes)
+        "gemm_k1_fwd": ("mfma", 2 * m_rows * din * hid, 4 * (m_rows * din + din * hid + s1 * m_rows * hid)),
+        "bn_relu_fwd": ("hbm", 0, 4 * m_rows * hid * (s1 + 2)),
+        "gemm_k2_fwd": ("mfma", 2 * m_rows * hid * d, 4 * (m_rows * hid + hid * d + s2 * m_rows * d)),
+        "align_fwd": ("hbm", 0, m_rows * (512 * s2 + 512 + 512 + 48)),
+        "ntxent_fwd": ("mfma", 2 * m_rows * m_global * d, 512 * (m_rows + m_global)),
+        "ntxent_finalize": ("hbm", 0, 4 * m_rows * (_capi.ntxent_jsplit(m_rows, m_global, False) + 10)),
+        "ntxent_bwd": ("mfma", 4 * m_rows * m_global * d,
+                       512 * (m_rows + m_global) + 512 * m_rows * _capi.ntxent_jsplit(m_rows, m_global, True)),
+        "slab_reduce": ("hbm", 0, 512 * m_rows * (_capi.ntxent_jsplit(m_rows, m_global, True) + 1)),
+        "align_bwd": ("hbm", 0, m_rows * (4 * 512 + 16)),
+        "gemm_dw2": ("mfma", 2 * m_rows * hid * d, 4 * (m_rows * d + m_rows * hid + hid * d)),
+        "gemm_da": ("mfma", 2 * m_rows * hid * d, 4 * (m_rows * d + hid * d + m_rows * hid)),
+        "bn_relu_bwd": ("hbm", 0, 4 * m_rows * hid * 3),
+        "gemm_dw1": ("mfma", 2 * m_rows * din * hid, 4 * (m_rows * hid + m_rows * din + din * hid)),
+        "gemm_dh": ("mfma", 2 * m_rows * din * hid, 4 * (m_rows * hid + din * hid + m_rows * din)),
+        "lars_sumsq": ("hbm", 0, 8 * n_params),
+        "lars_adam_update": ("hbm", 0, 28 * n_params),
+    }
+    out = {}
+    for name, pairs in event_log.items():
+        ms = [s.elapsed_time(e) for s, e in pairs]
+        if not ms or name not in work:
+            continue
+        # lars_* run once per parameter group: a "launch" here is the per-step total over groups
+        per_step = name.startswith("lars_")
+        avg_us = 1e3 * sum(ms) / len(ms)
+        bound, flops, nbytes = work[name]
+        entry = {"bound": bound, "launches": len(ms), "avg_us": round(avg_us, 3), "bytes": nbytes, "flops": flops}
+        if per_step:
+            groups = 2
+            entry["avg_us"] = round(avg_us * groups, 3)
+            entry["launches"] = len(ms) // groups
+            entry["note"] = "per optimiser step (sum over the 2 parameter groups)"
+            avg_us *= groups
+        if bound == "hbm":
+            ach = nbytes / (avg_us * 1e-6) / 1e9
+            entry.update(achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5))
+        else:
+            ach = flops / (avg_us * 1e-6) / 1e12
+            entry.update(achieved=round(ach, 3), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                         frac=round(ach / MFMA_F32_PEAK_TF, 5))
+        out[name] = entry
+    return out
+
+
+def cpu_baseline(args):
+    """The same step on the host: torch-CPU ResNet (same module) + oracle head (NumPy) + foreach
+    LARS/Adam.  Bounded sample: ONE timed step (after one untimed step) of 2 x cpu_pairs views."""
+    import numpy as np
+
+    from oracle import peclr_oracle as O
+    from peclr_amd.optim import LARSAdam
+
+    n = args.cpu_pairs
+    model = build_model(args, torch.device("cpu"), n)
+    params = [p for name, p in model.named_parameters() if "final_layer" not in name]
+    opt = LARSAdam([{"params": params, "weight_decay": 1e-6}], lr=1e-3, lars=True, fused=False)
+    batch = synthetic_batch(n, args.size, 5, torch.device("cpu"))
+    ph = model.projection_head
+    head = [ph[0].weight, ph[0].bias, ph[1].weight, ph[1].bias, ph[3].weight]
+
+    def step():
+        x = torch.cat([batch["transformed_image1"], batch["transformed_image2"]])
+        h = model.encoder(x)
+        r = O.head_loss_fwd_bwd(h.detach().numpy(), *[t.detach().numpy() for t in head], n, crop=True,
+                                rotate=True,
+                                jitter_x=torch.cat([batch["jitter_x_1"], batch["jitter_x_2"]]).numpy(),
+                                jitter_y=torch.cat([batch["jitter_y_1"], batch["jitter_y_2"]]).numpy(),
+                                angle=torch.cat([batch["angle_1"], batch["angle_2"]]).numpy(),
+                                image_hw=(args.size, args.size))
+        h.backward(torch.from_numpy(np.ascontiguousarray(r["dh"])))
+        for t, k in zip(head, ("dw1", "db1", "dgamma", "dbeta", "dw2")):
+            t.grad = torch.from_numpy(np.ascontiguousarray(r[k].astype(np.float32)))
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return float(r["loss"])
+
+    step()
+    t0 = time.perf_counter()
+    step()
+    dt = time.perf_counter() - t0
+    return {"value": round(2 * n / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"1 timed step (after 1 untimed) of ResNet-{args.resnet} on 2x{n} synthetic "
+                      f"{args.size}x{args.size} views, fp32, torch-CPU encoder + NumPy oracle head + foreach "
+                      f"LARS/Adam; {dt:.2f} s"}
+
+
+def main():
+    args = parse()
+    warnings.simplefilter("ignore")
+    from peclr_amd import Trainer, _capi
+    from peclr_amd import dist as pdist
+    from peclr_amd.resnet import conv_flops_per_image
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: peclr_amd has no CPU path for its kernels")
+    local = pdist.init_from_env()
+    world, rank = pdist.world_size(), pdist.rank()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    device = torch.device("cuda", local)
+    torch.backends.cudnn.benchmark = True  # MIOpen find: settle conv algorithms during warm-up
+
+    model = build_model(args, device, args.pairs)
+    if args.channels_last:
+        model.encoder = model.encoder.to(memory_format=torch.channels_last)
+    trainer = Trainer(max_epochs=100, accumulate_grad_batches=args.accum, precision=args.dtype).attach(model)
+    trainer.zero_grad()
+    batch = synthetic_batch(args.pairs, args.size, 5 + rank, device)
+    if args.channels_last:
+        for k in ("transformed_image1", "transformed_image2"):
+            batch[k] = batch[k].contiguous(memory_format=torch.channels_last)
+
+    def one_step(i):
+        for micro in range(args.accum):  # one optimiser step = `accum` micro-batches
+            out = trainer.training_micro_step(batch, i * args.accum + micro)
+        return out
+
+    for i in range(args.warmup):
+        out = one_step(i)
+    _capi.EVENT_LOG = {}
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    event_log, _capi.EVENT_LOG = _capi.EVENT_LOG, None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(out["loss"])
+
+    if rank == 0:
+        images = world * 2 * args.pairs * args.accum * args.steps
+        n_params = sum(p.numel() for n, p in model.named_parameters() if "final_layer" not in n)
+        din = model.config.projection_head_input_dim
+        kernels = kernel_table(event_log, 2 * args.pairs, world * 2 * args.pairs, din, 512, n_params)
+        dominant = max(kernels, key=lambda k: kernels[k]["avg_us"] * (1 if k.startswith("lars_") else 1))
+        roof = {k: kernels[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+        roof.update(kernel=dominant, avg_us=kernels[dominant]["avg_us"], traffic=None,
+                    algorithmic_bytes=kernels[dominant]["bytes"], algorithmic_flops=kernels[dominant]["flops"])
+        flops_img = conv_flops_per_image(model.encoder.features, (args.size, args.size))
+        step_flops = 3 * flops_img * 2 * args.pairs * args.accum
+        peak_tf = MFMA_F32_PEAK_TF if args.dtype == "fp32" else MFMA_BF16_PEAK_TF
+        ach_tf = step_flops * args.steps / dt / 1e12
+        result = {
+            "metric": "images/sec (2-view) ResNet-50 bs128 @1/2/4/8 MI355X; NT-Xent loss Δ vs ref",
+            "value": round(images / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"ResNet-{args.resnet} encoder, 2x{args.pairs} synthetic {args.size}x{args.size} "
+                                   f"views per GPU, crop+rotate equivariance alignment, NT-Xent tau=0.5, "
+                                   f"LARS(Adam) step, {args.dtype}",
+                       "global_batch": world * 2 * args.pairs * args.accum, "parallelism": f"dp{world}",
+                       "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last),
+                       "bn": "per-rank batch statistics"},
+            "loss": round(loss, 6),
+            "roofline": roof,
+            "kernels": kernels,
+            "backbone": {"note": "PyTorch-ROCm/MIOpen encoder (not hand-written); 3x forward conv FLOPs",
+                         "flops_per_step_per_gpu": step_flops, "achieved": round(ach_tf, 2), "peak": peak_tf,
+                         "unit": "TFLOP/s", "frac": round(ach_tf / peak_tf, 4)},
+            "hand_written_us_per_step": round(sum(k["avg_us"] * (1 if n.startswith("lars_") else
+                                                                  k["launches"] / (args.steps * args.accum))
+                                                  for n, k in kernels.items()), 1),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

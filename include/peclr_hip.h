@@ -1,0 +1,181 @@
+/*
+ * peclr_hip.h -- C ABI of libpeclr_hip.so: the MI355X (gfx950) kernels of the PeCLR
+ * pretraining hot path.
+ *
+ * The reference (dahiyaaneesh/peclr) is pure Python and has NO FFI of its own: every op on
+ * its hot path is a chain of stock PyTorch ops.  This header is therefore the boundary a
+ * native replacement exports, one entry point per op chain of SURVEY.md section 2.2
+ * (K1..K8); each declaration cites the reference lines it replaces (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates
+ *     or frees memory; scratch buffers are caller-provided (sized with the *_jsplit /
+ *     *_pick_split_k policy queries).  Buffers are row-major, contiguous, 16-byte aligned.
+ *   - one entry point = one kernel launch (so a HIP-event pair around a call times exactly
+ *     the kernel that rocprofv3 reports).
+ *   - every call is asynchronous on the given hipStream_t (`stream`), re-entrant, keeps no
+ *     global mutable state, and may be called concurrently on different streams.
+ *   - return value: 0 = ok; negative = argument error (PECLR_ERR_*); positive = hipError_t
+ *     of the failed launch.  No exceptions cross the ABI.
+ *   - "slabs": a split-K producer writes S partial results [S][rows][cols]; the consuming
+ *     kernel sums them on load (fused reduction).  S == 1 means a plain dense tensor.
+ *   - row layout of two-view tensors: rows [0,N) are view-1 samples, rows [N,2N) view-2
+ *     samples (hybrid2_model.py:30-32).  Multi-GPU gathered tensors repeat that block per
+ *     rank; `n_half` (= N per rank) defines the positive-pair map: partner(i) = i + n_half
+ *     if (i / n_half) is even else i - n_half.
+ */
+#ifndef PECLR_HIP_H
+#define PECLR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* peclr_stream_t; /* hipStream_t */
+
+#define PECLR_OK 0
+#define PECLR_ERR_NULL (-1)        /* required pointer is null */
+#define PECLR_ERR_SHAPE (-2)       /* unsupported / inconsistent shape */
+#define PECLR_ERR_ALIGN (-3)       /* pointer or leading dimension not 16-byte aligned */
+#define PECLR_ERR_WORKSPACE (-4)   /* workspace too small */
+#define PECLR_ERR_UNSUPPORTED (-5) /* unsupported flag / dtype */
+
+/* GEMM operand layouts: C[M,N] = A . B  with                                              */
+#define PECLR_GEMM_NT 0 /* A[M,K] row-major, B[N,K] row-major  (y = x W^T : nn.Linear fwd) */
+#define PECLR_GEMM_NN 1 /* A[M,K] row-major, B[K,N] row-major  (dx = dy W)                 */
+#define PECLR_GEMM_TN 2 /* A[K,M] row-major, B[K,N] row-major  (dW = dy^T x)               */
+
+/* align flags */
+#define PECLR_ALIGN_CROP 1        /* "crop" in config.augmentation   (hybrid2_model.py:58)  */
+#define PECLR_ALIGN_ROTATE 2      /* "rotate" in config.augmentation (hybrid2_model.py:76)  */
+#define PECLR_ALIGN_SINGLE_NORM 4 /* SimCLR.contrastive_step: one F.normalize, no alignment
+                                     (simclr_model.py:44-47)                                */
+
+int peclr_version(void);
+const char* peclr_error_string(int code);
+
+/* ---- K1 / K2-GEMM and their backward GEMMs -------------------------------------------
+ * Replaces nn.Linear forward/backward of the projection head (simclr_model.py:22-26,29-33).
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (bit-exact fmaf chain).
+ * split_k == 1: C = A.B (+ bias[N] if non-null).  split_k > 1: slabs[s] (each [M,N], ld = N)
+ * receive the K-partials, C and bias are ignored (the consumer adds the bias).
+ * Feature dimensions (the contiguous dimension of each operand, and N) must be multiples
+ * of 4; M (batch rows) is arbitrary.                                                      */
+int peclr_gemm_f32(int layout, int M, int N, int K, const float* A, int lda, const float* B,
+                   int ldb, float* C, int ldc, const float* bias, int split_k, float* slabs,
+                   peclr_stream_t stream);
+/* The library's own split-K policy for a given problem (>= 1). */
+int peclr_gemm_pick_split_k(int M, int N, int K);
+
+/* out[i] = sum_s slabs[s][i] (+ bias[i % cols] if non-null), i < rows*cols. */
+int peclr_slab_reduce_f32(const float* slabs, int n_slabs, int rows, int cols, const float* bias,
+                          float* out, peclr_stream_t stream);
+
+/* ---- K2: BatchNorm1d (train or eval) + ReLU --------------------------------------------
+ * Replaces nn.BatchNorm1d(H) + nn.ReLU (simclr_model.py:27-28).  Input = split-K slabs of
+ * the first Linear plus its bias.  training != 0: batch statistics over all M rows (biased
+ * variance), running stats updated with momentum and the unbiased variance,
+ * num_batches_tracked incremented (all three nullable).  training == 0: running stats.
+ * Outputs: a_pre [M,H] (pre-BN activations, kept for the backward), a_out [M,H],
+ * save_mean[H], save_invstd[H].                                                           */
+int peclr_bn_relu_fwd_f32(const float* a_slabs, int n_slabs, const float* bias, int M, int H,
+                          const float* gamma, const float* beta, float eps, float momentum,
+                          int training, float* running_mean, float* running_var,
+                          int64_t* num_batches_tracked, float* a_pre, float* a_out,
+                          float* save_mean, float* save_invstd, peclr_stream_t stream);
+/* Backward of the above: d_a_out -> d_a_pre [M,H], dgamma, dbeta, dbias[H].  training != 0:
+ * batch statistics took part in the forward (full BN backward); training == 0: the statistics
+ * were constants (frozen BN).                                                               */
+int peclr_bn_relu_bwd_f32(const float* d_a_out, const float* a_pre, const float* save_mean,
+                          const float* save_invstd, const float* gamma, const float* beta, int M,
+                          int H, int training, float* d_a_pre, float* dgamma, float* dbeta,
+                          float* dbias, peclr_stream_t stream);
+
+/* ---- K3..K7: projection stats + normalise + un-translate + un-rotate + normalise -------
+ * Replaces Hybrid2Model.get_projection_stats / F.normalize / translate_encodings /
+ * rotate_encoding / F.normalize (hybrid2_model.py:40-85, utils.py:271-346).
+ * p_slabs: [n_slabs][M][D] split-K partials of the second Linear.  D must be 128.
+ * jitter_*: int64 [n_pairs] per view exactly as the batch dict holds them
+ * (data_set.py:357-384); extent_x / extent_y are float(image_shape[0]) / float(shape[1]).
+ * angle1/2: float64 [n_pairs] per view, NOT negated (the kernel applies the minus signs of
+ * hybrid2_model.py:74,80).  Pointers of disabled flags may be null.
+ * Outputs: p_out [M,D] (reduced raw projections), z_out [M,D], norms [2][M] (clamped
+ * ||p|| and clamped post-alignment norm), row_stats [M][8] per-sample
+ * {x_mean,x_median,x_min,x_max,y_mean,y_median,y_min,y_max} (nullable).                   */
+int peclr_align_fwd_f32(const float* p_slabs, int n_slabs, int M, int D, int n_pairs, int flags,
+                        const int64_t* jitter_x1, const int64_t* jitter_x2,
+                        const int64_t* jitter_y1, const int64_t* jitter_y2, float extent_x,
+                        float extent_y, const double* angle1, const double* angle2, float* p_out,
+                        float* z_out, float* norms, float* row_stats, peclr_stream_t stream);
+/* Backward: dz [M,D] -> dp [M,D].  Range and centroid are constants (utils.py:312,338-339). */
+int peclr_align_bwd_f32(const float* dz, const float* p, const float* z, const float* norms, int M,
+                        int D, int n_pairs, int flags, const double* angle1, const double* angle2,
+                        float* dp, peclr_stream_t stream);
+
+/* ---- K8: NT-Xent ------------------------------------------------------------------------
+ * Replaces vanila_contrastive_loss (utils.py:154-186) without materialising S, exp(S), the
+ * mask or the M x (M-1) gather.  One entry point per kernel launch.
+ * z_rows: the Mr rows this call owns (global row index = row_offset + r); z_all: all Mg rows
+ * (negatives).  Single GPU: z_rows == z_all, Mr == Mg, row_offset == 0.
+ *
+ * peclr_ntxent_jsplit: the library's column-split policy (how many key-column slices the
+ * grid is split into) for the forward (backward == 0) or backward (backward != 0) launch;
+ * callers size `partial` / `dz_slabs` with it.
+ * peclr_ntxent_fwd_f32: partial[jsplit][Mr] = per-slice sums of exp(S_ij/tau) over j != i,
+ * pos[Mr] = S_{i,partner(i)}/tau; sim_out (nullable): [Mr][Mg] per-pair similarities.
+ * peclr_ntxent_finalize_f32 (one workgroup, fixed summation order): row_lse[Mr] =
+ * log sum_s partial[s][r]; out17[16] = loss_scale * sum_r (row_lse[r] - pos[r]); when row_stats
+ * is non-null, out17[0..15] = the batch-mean projection statistics (hybrid2_model.py:92-106)
+ * of the [2*n_pairs_stats][8] row_stats matrix.
+ * peclr_ntxent_bwd_f32: dz_slabs[s][Mr][D] = per-slice partials of
+ *   (*dloss) * grad_scale * inv_tau * sum_{j != i} [e_ij (1/neg_i + 1/neg_j) - 2 [j == partner(i)]] z_j
+ * (sum the slabs with peclr_slab_reduce_f32; jsplit == 1 writes the dense dz directly).
+ * lse_all[Mg] = row_lse of every global row (all-gathered on multi-GPU); grad_scale = 1/Mg for
+ * the reference's mean reduction; dloss: device scalar (the incoming gradient of the loss).  */
+int peclr_ntxent_jsplit(int Mr, int Mg, int backward);
+int peclr_ntxent_fwd_f32(const float* z_rows, int Mr, int row_offset, const float* z_all, int Mg,
+                         int D, int n_half, float inv_tau, float* sim_out, float* partial,
+                         float* pos, int jsplit, peclr_stream_t stream);
+int peclr_ntxent_finalize_f32(const float* partial, int jsplit, const float* pos, int Mr,
+                              float loss_scale, float* row_lse, const float* row_stats,
+                              int n_pairs_stats, float* out17, peclr_stream_t stream);
+int peclr_ntxent_bwd_f32(const float* z_rows, int Mr, int row_offset, const float* z_all, int Mg,
+                         int D, int n_half, float inv_tau, const float* lse_all,
+                         const float* dloss, float grad_scale, float* dz_slabs, int jsplit,
+                         peclr_stream_t stream);
+
+/* ---- optimiser: LARSWrapper(Adam) fused over a list of tensors --------------------------
+ * Replaces pl_bolts LARSWrapper.step + torch.optim.Adam.step as wired by
+ * BaseModel.configure_optimizers (base_model.py:57-104).  Two launches per parameter group
+ * instead of ~15 launches + 2 host syncs per tensor.
+ * ptrs: device array [4][n_tensors] of float* {param, grad, exp_avg, exp_avg_sq};
+ * sizes: device array [n_tensors] of int64 element counts.  The work list is n_chunks chunks
+ * of at most PECLR_OPT_CHUNK elements: chunk_tensor[c] / chunk_offset[c] give the tensor and
+ * the element offset of chunk c (chunks of one tensor are consecutive), and
+ * tensor_chunk_begin[t] .. tensor_chunk_begin[t+1] is tensor t's chunk range.
+ * peclr_lars_sumsq_f32: norms_ws[2][n_chunks] = per-chunk sums of squares of param and grad.
+ * peclr_lars_adam_update_f32: combines a tensor's chunk sums in a fixed order
+ * (bit-reproducible), applies the LARS trust ratio + weight decay and the Adam update.
+ * use_lars == 0: plain Adam with L2 weight decay (torch.optim.Adam semantics; norms_ws unused).
+ * bias_corr1/2 = 1 - beta^step, computed by the host.  The LARS-scaled gradient is consumed in
+ * registers and NOT written back to grad.                                                   */
+#define PECLR_OPT_CHUNK 4096
+int peclr_lars_sumsq_f32(float* const* ptrs, const int64_t* sizes, int n_tensors,
+                         const int32_t* chunk_tensor, const int64_t* chunk_offset, int n_chunks,
+                         float* norms_ws, peclr_stream_t stream);
+int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* sizes, int n_tensors,
+                               const int32_t* chunk_tensor, const int64_t* chunk_offset,
+                               const int32_t* tensor_chunk_begin, int n_chunks,
+                               const float* norms_ws, float lr, float beta1, float beta2,
+                               float adam_eps, float weight_decay, float bias_corr1,
+                               float bias_corr2, int use_lars, float lars_eta, float lars_eps,
+                               int lars_clip, peclr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PECLR_HIP_H */

@@ -1,0 +1,286 @@
+"""ctypes binding of libpeclr_hip.so (include/peclr_hip.h) for torch device tensors.
+
+This is the ONLY place the product touches the native library, and there is no fallback:
+if the library is missing, or a tensor is not a contiguous fp32 HIP tensor, the call raises.
+PyTorch is plumbing here (device memory + the current hipStream_t); every function below is a
+thin argument marshaller around one C entry point.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+import torch  # must be imported BEFORE the CDLL: the .so binds to torch's libamdhip64.so.7
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpeclr_hip.so")
+_LIB = None
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+ALIGN_CROP, ALIGN_ROTATE, ALIGN_SINGLE_NORM = 1, 2, 4
+OPT_CHUNK = 4096
+
+# name -> (restype, argtypes); mirrors include/peclr_hip.h one to one
+_P = c_void_p
+SIGNATURES = {
+    "peclr_version": (c_int, []),
+    "peclr_error_string": (c_char_p, [c_int]),
+    "peclr_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P]),
+    "peclr_gemm_pick_split_k": (c_int, [c_int, c_int, c_int]),
+    "peclr_slab_reduce_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "peclr_bn_relu_fwd_f32": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, c_float, c_float, c_int, _P, _P,
+                                      _P, _P, _P, _P, _P, _P]),
+    "peclr_bn_relu_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "peclr_align_fwd_f32": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float,
+                                    _P, _P, _P, _P, _P, _P, _P]),
+    "peclr_align_bwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "peclr_ntxent_jsplit": (c_int, [c_int, c_int, c_int]),
+    "peclr_ntxent_fwd_f32": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, c_float, _P, _P, _P, c_int, _P]),
+    "peclr_ntxent_finalize_f32": (c_int, [_P, c_int, _P, c_int, c_float, _P, _P, c_int, _P, _P]),
+    "peclr_ntxent_bwd_f32": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, c_float, _P, _P, c_float, _P,
+                                     c_int, _P]),
+    "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
+    "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, c_int, _P, c_float, c_float, c_float,
+                                           c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
+                                           _P]),
+}
+
+
+class PeclrHipError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load libpeclr_hip.so (once).  Raises if it has not been built -- there is no fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_LIB_PATH):
+            raise PeclrHipError(
+                f"{_LIB_PATH} is missing: build it with `make -C peclr_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "peclr_amd has no CPU or PyTorch fallback for its HIP kernels.")
+        handle = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().peclr_error_string(rc).decode()
+        raise PeclrHipError(f"{what} failed: {msg} (code {rc})")
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=torch.float32, what: str = "tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PeclrHipError(f"{what}: expected a HIP device tensor, got device={t.device} "
+                            "(peclr_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise PeclrHipError(f"{what}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise PeclrHipError(f"{what}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---- optional per-kernel HIP-event timing (bench.py): one entry point = one launch, so an event
+# pair recorded on the launch stream around a call times exactly that kernel.
+EVENT_LOG = None  # None = off; dict name -> list[(start, end)] when bench.py turns it on
+
+
+class _timed:
+    __slots__ = ("name", "s", "e")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if EVENT_LOG is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()  # current stream == the stream the kernel is launched on
+
+    def __exit__(self, *exc):
+        if EVENT_LOG is not None:
+            self.e.record()
+            EVENT_LOG.setdefault(self.name, []).append((self.s, self.e))
+        return False
+
+
+# ------------------------------------------------------------------ GEMM
+def pick_split_k(m: int, n: int, k: int) -> int:
+    return lib().peclr_gemm_pick_split_k(m, n, k)
+
+
+def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None,
+         split_k: int = 1, tag: Optional[str] = None) -> torch.Tensor:
+    """Returns C [M,N] (split_k == 1) or slabs [split_k, M, N]."""
+    if layout == GEMM_NT:
+        (m, k), (n, k2) = a.shape, b.shape
+    elif layout == GEMM_NN:
+        (m, k), (k2, n) = a.shape, b.shape
+    else:
+        (k, m), (k2, n) = a.shape, b.shape
+    if k != k2:
+        raise PeclrHipError(f"gemm: contraction mismatch {tuple(a.shape)} x {tuple(b.shape)} layout {layout}")
+    if split_k == 1:
+        out = torch.empty((m, n), device=a.device, dtype=torch.float32)
+        c_ptr, slab_ptr = out.data_ptr(), None
+    else:
+        out = torch.empty((split_k, m, n), device=a.device, dtype=torch.float32)
+        c_ptr, slab_ptr = None, out.data_ptr()
+    with _timed(tag or f"gemm_{('nt', 'nn', 'tn')[layout]}_{m}x{n}x{k}"):
+        rc = lib().peclr_gemm_f32(layout, m, n, k, _ptr(a, what="gemm A"), a.stride(0), _ptr(b, what="gemm B"),
+                                  b.stride(0), c_ptr, n, _ptr(bias, what="gemm bias"), split_k, slab_ptr,
+                                  _stream())
+    _check(rc, "peclr_gemm_f32")
+    return out
+
+
+def slab_reduce(slabs: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    s, rows, cols = slabs.shape
+    out = torch.empty((rows, cols), device=slabs.device, dtype=torch.float32)
+    with _timed("slab_reduce"):
+        rc = lib().peclr_slab_reduce_f32(_ptr(slabs), s, rows, cols, _ptr(bias), out.data_ptr(), _stream())
+    _check(rc, "peclr_slab_reduce_f32")
+    return out
+
+
+# ------------------------------------------------------------------ BN + ReLU
+def bn_relu_fwd(a_slabs, bias, gamma, beta, eps, momentum, training, running_mean, running_var,
+                num_batches_tracked):
+    s, m, h = a_slabs.shape
+    dev = a_slabs.device
+    a_pre = torch.empty((m, h), device=dev, dtype=torch.float32)
+    a_out = torch.empty((m, h), device=dev, dtype=torch.float32)
+    save = torch.empty((2, h), device=dev, dtype=torch.float32)
+    with _timed("bn_relu_fwd"):
+        rc = lib().peclr_bn_relu_fwd_f32(
+            _ptr(a_slabs), s, _ptr(bias), m, h, _ptr(gamma), _ptr(beta), eps, momentum, int(training),
+            _ptr(running_mean), _ptr(running_var),
+            _ptr(num_batches_tracked, torch.int64, "num_batches_tracked"), a_pre.data_ptr(), a_out.data_ptr(),
+            save[0].data_ptr(), save[1].data_ptr(), _stream())
+    _check(rc, "peclr_bn_relu_fwd_f32")
+    return a_pre, a_out, save
+
+
+def bn_relu_bwd(d_a_out, a_pre, save, gamma, beta, training=True):
+    m, h = a_pre.shape
+    d_a_pre = torch.empty_like(a_pre)
+    dparams = torch.empty((3, h), device=a_pre.device, dtype=torch.float32)  # dgamma, dbeta, dbias
+    with _timed("bn_relu_bwd"):
+        rc = lib().peclr_bn_relu_bwd_f32(_ptr(d_a_out), _ptr(a_pre), save[0].data_ptr(), save[1].data_ptr(),
+                                         _ptr(gamma), _ptr(beta), m, h, int(training), d_a_pre.data_ptr(),
+                                         dparams[0].data_ptr(), dparams[1].data_ptr(), dparams[2].data_ptr(),
+                                         _stream())
+    _check(rc, "peclr_bn_relu_bwd_f32")
+    return d_a_pre, dparams[0], dparams[1], dparams[2]
+
+
+# ------------------------------------------------------------------ align
+def align_fwd(p_slabs, n_pairs, flags, jitter, extents, angles, want_stats=True):
+    """jitter = (jx1, jx2, jy1, jy2) int64 tensors or None; angles = (a1, a2) float64 or None."""
+    s, m, d = p_slabs.shape
+    dev = p_slabs.device
+    p = torch.empty((m, d), device=dev, dtype=torch.float32)
+    z = torch.empty((m, d), device=dev, dtype=torch.float32)
+    norms = torch.empty((2, m), device=dev, dtype=torch.float32)
+    row_stats = torch.empty((m, 8), device=dev, dtype=torch.float32) if want_stats else None
+    j = [_ptr(t, torch.int64, "jitter") for t in jitter] if jitter is not None else [None] * 4
+    a = [_ptr(t, torch.float64, "angle") for t in angles] if angles is not None else [None] * 2
+    with _timed("align_fwd"):
+        rc = lib().peclr_align_fwd_f32(_ptr(p_slabs), s, m, d, n_pairs, flags, j[0], j[1], j[2], j[3],
+                                       float(extents[0]), float(extents[1]), a[0], a[1], p.data_ptr(),
+                                       z.data_ptr(), norms.data_ptr(), _ptr(row_stats), _stream())
+    _check(rc, "peclr_align_fwd_f32")
+    return p, z, norms, row_stats
+
+
+def align_bwd(dz, p, z, norms, n_pairs, flags, angles):
+    m, d = p.shape
+    dp = torch.empty_like(p)
+    a = [_ptr(t, torch.float64, "angle") for t in angles] if angles is not None else [None] * 2
+    with _timed("align_bwd"):
+        rc = lib().peclr_align_bwd_f32(_ptr(dz, what="dz"), _ptr(p), _ptr(z), _ptr(norms), m, d, n_pairs,
+                                       flags, a[0], a[1], dp.data_ptr(), _stream())
+    _check(rc, "peclr_align_bwd_f32")
+    return dp
+
+
+# ------------------------------------------------------------------ NT-Xent
+def ntxent_jsplit(mr: int, mg: int, backward: bool) -> int:
+    js = lib().peclr_ntxent_jsplit(mr, mg, int(backward))
+    if js < 1:
+        raise PeclrHipError(f"peclr_ntxent_jsplit: unsupported shape Mr={mr} Mg={mg}")
+    return js
+
+
+def ntxent_fwd(z_rows, row_offset, z_all, n_half, inv_tau, loss_scale, row_stats=None, n_pairs_stats=0,
+               want_sim=False):
+    """Main kernel + finalize kernel.  Returns (out17, row_lse, sim)."""
+    mr, d = z_rows.shape
+    mg = z_all.shape[0]
+    dev = z_rows.device
+    js = ntxent_jsplit(mr, mg, False)
+    partial = torch.empty((js, mr), device=dev, dtype=torch.float32)
+    pos = torch.empty(mr, device=dev, dtype=torch.float32)
+    row_lse = torch.empty(mr, device=dev, dtype=torch.float32)
+    out17 = torch.zeros(17, device=dev, dtype=torch.float32)
+    sim = torch.empty((mr, mg), device=dev, dtype=torch.float32) if want_sim else None
+    with _timed("ntxent_fwd"):
+        rc = lib().peclr_ntxent_fwd_f32(_ptr(z_rows, what="z_rows"), mr, row_offset, _ptr(z_all, what="z_all"),
+                                        mg, d, n_half, inv_tau, _ptr(sim), partial.data_ptr(), pos.data_ptr(),
+                                        js, _stream())
+    _check(rc, "peclr_ntxent_fwd_f32")
+    with _timed("ntxent_finalize"):
+        rc = lib().peclr_ntxent_finalize_f32(partial.data_ptr(), js, pos.data_ptr(), mr, loss_scale,
+                                             row_lse.data_ptr(), _ptr(row_stats), n_pairs_stats,
+                                             out17.data_ptr(), _stream())
+    _check(rc, "peclr_ntxent_finalize_f32")
+    return out17, row_lse, sim
+
+
+def ntxent_bwd(z_rows, row_offset, z_all, n_half, inv_tau, lse_all, dloss, grad_scale):
+    mr, d = z_rows.shape
+    mg = z_all.shape[0]
+    js = ntxent_jsplit(mr, mg, True)
+    slabs = torch.empty((js, mr, d), device=z_rows.device, dtype=torch.float32)
+    with _timed("ntxent_bwd"):
+        rc = lib().peclr_ntxent_bwd_f32(_ptr(z_rows, what="z_rows"), mr, row_offset, _ptr(z_all, what="z_all"),
+                                        mg, d, n_half, inv_tau, _ptr(lse_all, what="lse_all"),
+                                        _ptr(dloss, what="dloss"), grad_scale, slabs.data_ptr(), js, _stream())
+    _check(rc, "peclr_ntxent_bwd_f32")
+    return slabs[0] if js == 1 else slab_reduce(slabs)
+
+
+# ------------------------------------------------------------------ optimiser
+def lars_adam_step(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_chunk_begin, n_chunks, norms_ws,
+                   lr, beta1, beta2, adam_eps, weight_decay, bias_corr1, bias_corr2, use_lars, lars_eta,
+                   lars_eps, lars_clip):
+    p = _ptr(ptrs, torch.int64, "ptrs")
+    sz = _ptr(sizes, torch.int64, "sizes")
+    ct = _ptr(chunk_tensor, torch.int32, "chunk_tensor")
+    co = _ptr(chunk_offset, torch.int64, "chunk_offset")
+    if use_lars:
+        with _timed("lars_sumsq"):
+            rc = lib().peclr_lars_sumsq_f32(p, sz, n_tensors, ct, co, n_chunks, _ptr(norms_ws), _stream())
+        _check(rc, "peclr_lars_sumsq_f32")
+    with _timed("lars_adam_update"):
+        rc = lib().peclr_lars_adam_update_f32(
+            p, sz, n_tensors, ct, co, _ptr(tensor_chunk_begin, torch.int32, "tensor_chunk_begin"), n_chunks,
+            _ptr(norms_ws), lr, beta1, beta2, adam_eps, weight_decay, bias_corr1, bias_corr2, int(use_lars),
+            lars_eta, lars_eps, int(lars_clip), _stream())
+    _check(rc, "peclr_lars_adam_update_f32")

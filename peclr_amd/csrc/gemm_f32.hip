@@ -1,0 +1,221 @@
+// K1 / K2-GEMM and the backward GEMMs of the projection head (simclr_model.py:22-33) as ONE
+// templated fp32 MFMA kernel.
+//
+// Roofline: fp32-in MFMA (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD, 157 TF chip peak).  At the
+// head's sizes (M = 2N <= a few hundred rows) the problem is a handful of 64x64 tiles, so the
+// first Linear (K = Din = 2048) is split along K into slabs whose reduction is fused into the
+// consumer (BN kernel) -- no atomics, deterministic order.
+//
+// Tiling: 256-thread workgroup = 2x2 waves, each wave one 32x32 accumulator (16 VGPRs);
+// workgroup tile 64x64, BK = 32, register-staged double-buffered LDS (one barrier per K-tile).
+// Operand LDS images, chosen by which dimension is contiguous in HBM so that every global
+// load is a coalesced float4:
+//   K-contiguous operand  -> [64 rows][BK+4]   read as ds_read_b128 (4 k-values per lane)
+//   M/N-contiguous operand-> [BK rows][64+4]   read as ds_read_b32  (lanes along m)
+// The k index inside a K-tile is PERMUTED consistently on both operands
+// (k = 8t + 4*(lane>>5) + e for MFMA e of group t), which is free for a contraction and lets
+// the K-contiguous image be read 16 bytes at a time; both read patterns are bank-conflict
+// free (row stride 36 dwords under the 64-bank b128 rule, 68 dwords under the 32-bank b32
+// rule).
+#include "common.hpp"
+
+namespace peclr {
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LDK = BK + 4;  // floats
+constexpr int LDM = 64 + 4;  // floats
+constexpr int TILE_FLOATS = 64 * LDK;  // 2304 >= 32 * LDM = 2176
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* out;
+    const float* bias;
+    int M, N, K, lda, ldb, ldo, kchunk;
+    size_t slab_stride;  // 0 when writing C directly
+};
+
+// Global -> registers for one 64 x BK operand tile (2 float4 per thread).
+template <bool KC>
+__device__ __forceinline__ void tile_load(const float* __restrict__ P, int ld, int row0, int rows,
+                                          int k0, int kend, int tid, float4 (&r)[2]) {
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KC) {
+            const int row = row0 + (tid >> 3) + 32 * rep;
+            const int k = k0 + (tid & 7) * 4;
+            if (row < rows && k < kend) v = *reinterpret_cast<const float4*>(P + (size_t)row * ld + k);
+        } else {
+            const int k = k0 + (tid >> 4) + 16 * rep;
+            const int row = row0 + (tid & 15) * 4;
+            if (k < kend && row < rows) v = *reinterpret_cast<const float4*>(P + (size_t)k * ld + row);
+        }
+        r[rep] = v;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void tile_store(float* tile, int tid, const float4 (&r)[2]) {
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        if (KC)
+            *reinterpret_cast<float4*>(tile + ((tid >> 3) + 32 * rep) * LDK + (tid & 7) * 4) = r[rep];
+        else
+            *reinterpret_cast<float4*>(tile + ((tid >> 4) + 16 * rep) * LDM + (tid & 15) * 4) = r[rep];
+    }
+}
+
+// Fragment of k-group t (4 k-values) for the lane's row `row` (0..63 inside the tile).
+template <bool KC>
+__device__ __forceinline__ float4 frag(const float* tile, int row, int t, int kh) {
+    if (KC) return *reinterpret_cast<const float4*>(tile + row * LDK + 8 * t + 4 * kh);
+    const float* p = tile + (8 * t + 4 * kh) * LDM + row;
+    return make_float4(p[0], p[LDM], p[2 * LDM], p[3 * LDM]);
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_FLOATS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    float4 ra[2], rb[2];
+    if (nk > 0) {
+        tile_load<A_KC>(g.A, g.lda, m0, g.M, kbeg, kend, tid, ra);
+        tile_load<B_KC>(g.B, g.ldb, n0, g.N, kbeg, kend, tid, rb);
+        tile_store<A_KC>(lds[0][0], tid, ra);
+        tile_store<B_KC>(lds[0][1], tid, rb);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const int k0 = kbeg + (kt + 1) * BK;
+            tile_load<A_KC>(g.A, g.lda, m0, g.M, k0, kend, tid, ra);
+            tile_load<B_KC>(g.B, g.ldb, n0, g.N, k0, kend, tid, rb);
+        }
+        const float* ta = lds[cur][0];
+        const float* tb = lds[cur][1];
+#pragma unroll
+        for (int t = 0; t < BK / 8; ++t) {
+            const float4 a = frag<A_KC>(ta, wm * 32 + i, t, kh);
+            const float4 b = frag<B_KC>(tb, wn * 32 + i, t, kh);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+        if (more) {
+            tile_store<A_KC>(lds[cur ^ 1][0], tid, ra);
+            tile_store<B_KC>(lds[cur ^ 1][1], tid, rb);
+        }
+        __syncthreads();
+    }
+
+    float* out = g.out + (size_t)blockIdx.z * g.slab_stride;
+    const int n = n0 + wn * 32 + i;
+    if (n < g.N) {
+        const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + mfma32_row(r, kh);
+            if (m < g.M) out[(size_t)m * g.ldo + n] = acc[r] + bv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
+                                                          size_t count4, int cols, const float* __restrict__ bias,
+                                                          float* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < count4; v += stride) {
+        float4 s = reinterpret_cast<const float4*>(slabs)[v];
+        for (int k = 1; k < n_slabs; ++k) {
+            const float4 t = reinterpret_cast<const float4*>(slabs + (size_t)k * count4 * 4)[v];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        if (bias) {
+            const int c = (int)((v * 4) % (size_t)cols);
+            const float4 b = *reinterpret_cast<const float4*>(bias + c);
+            s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        }
+        reinterpret_cast<float4*>(out)[v] = s;
+    }
+}
+
+inline int kchunk_for(int K, int split_k) {
+    const int per = (K + split_k - 1) / split_k;
+    return ((per + BK - 1) / BK) * BK;
+}
+
+}  // namespace
+}  // namespace peclr
+
+using namespace peclr;
+
+extern "C" int peclr_gemm_pick_split_k(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 1;
+    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    long s = 256 / tiles;               // aim for >= one workgroup per CU
+    const long by_k = K / (2 * BK);     // keep >= 2 K-tiles per slab
+    if (s > by_k) s = by_k;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    const int kc = kchunk_for(K, (int)s);
+    return (K + kc - 1) / kc;           // effective number of non-empty slabs
+}
+
+extern "C" int peclr_gemm_f32(int layout, int M, int N, int K, const float* A, int lda, const float* B,
+                              int ldb, float* C, int ldc, const float* bias, int split_k, float* slabs,
+                              peclr_stream_t stream) {
+    if (!A || !B) return PECLR_ERR_NULL;
+    if (split_k < 1) return PECLR_ERR_SHAPE;
+    if (split_k == 1 && !C) return PECLR_ERR_NULL;
+    if (split_k > 1 && !slabs) return PECLR_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0) return PECLR_ERR_SHAPE;
+    if (layout < PECLR_GEMM_NT || layout > PECLR_GEMM_TN) return PECLR_ERR_UNSUPPORTED;
+    const bool a_kc = layout != PECLR_GEMM_TN;
+    const bool b_kc = layout == PECLR_GEMM_NT;
+    // float4 loads run along each operand's contiguous dimension
+    if ((a_kc ? K : M) % 4 || (b_kc ? K : N) % 4 || lda % 4 || ldb % 4) return PECLR_ERR_ALIGN;
+    if (!aligned16(A) || !aligned16(B) || (bias && !aligned16(bias))) return PECLR_ERR_ALIGN;
+    if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N) || (split_k == 1 && ldc < N)) return PECLR_ERR_SHAPE;
+
+    GemmArgs g;
+    g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
+    g.kchunk = kchunk_for(K, split_k);
+    if (split_k == 1) { g.out = C; g.ldo = ldc; g.bias = bias; g.slab_stride = 0; }
+    else { g.out = slabs; g.ldo = N; g.bias = nullptr; g.slab_stride = (size_t)M * N; }
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, split_k), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g);
+    else if (a_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, g);
+    return launch_status();
+}
+
+extern "C" int peclr_slab_reduce_f32(const float* slabs, int n_slabs, int rows, int cols, const float* bias,
+                                     float* out, peclr_stream_t stream) {
+    if (!slabs || !out) return PECLR_ERR_NULL;
+    if (n_slabs < 1 || rows <= 0 || cols <= 0) return PECLR_ERR_SHAPE;
+    if (cols % 4 || !aligned16(slabs) || !aligned16(out) || (bias && !aligned16(bias))) return PECLR_ERR_ALIGN;
+    const size_t count4 = (size_t)rows * cols / 4;
+    int blocks = (int)((count4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs,
+                       n_slabs, count4, cols, bias, out);
+    return launch_status();
+}

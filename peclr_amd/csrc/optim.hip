@@ -1,0 +1,133 @@
+// Fused multi-tensor LARSWrapper(Adam) step (BaseModel.configure_optimizers, base_model.py:57-104;
+// pl_bolts 0.2.2 LARSWrapper.step/update_p + torch.optim.Adam).
+//
+// The reference walks ~160 tensors in Python, 2 torch.norm + 2 host syncs (`if p_norm != 0`)
+// + ~12 elementwise launches per tensor.  Here one parameter group is two launches:
+//   1. per-chunk sums of squares of p and g  -> norms_ws[2][n_chunks]
+//   2. per-chunk update: combine the tensor's chunk sums in a fixed order (bit-reproducible),
+//      LARS trust ratio, weight decay, Adam moments and the parameter update in registers.
+// Roofline: HBM.  Algorithmic bytes per parameter: 8 (norm pass) + 16 read + 12 written = 36 B.
+#include "common.hpp"
+
+namespace peclr {
+namespace {
+
+constexpr int CHUNK = PECLR_OPT_CHUNK;  // 256 threads x 16 elements
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    const float t = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(float* const* __restrict__ ptrs,
+                                                    const int64_t* __restrict__ sizes, int n_tensors,
+                                                    const int32_t* __restrict__ chunk_tensor,
+                                                    const int64_t* __restrict__ chunk_offset, int n_chunks,
+                                                    float* __restrict__ norms_ws) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const int t = chunk_tensor[c];
+    const int64_t off = chunk_offset[c];
+    const int64_t n = min((int64_t)CHUNK, sizes[t] - off);
+    const float* p = ptrs[t] + off;
+    const float* g = ptrs[n_tensors + t] + off;
+    float sp = 0.f, sg = 0.f;
+    for (int64_t k = threadIdx.x; k < n; k += 256) {
+        const float a = p[k], b = g[k];
+        sp += a * a;
+        sg += b * b;
+    }
+    sp = block_sum(sp, red);
+    sg = block_sum(sg, red);
+    if (threadIdx.x == 0) {
+        norms_ws[c] = sp;
+        norms_ws[n_chunks + c] = sg;
+    }
+}
+
+struct OptArgs {
+    float lr, beta1, beta2, adam_eps, weight_decay, bias_corr1, bias_corr2, lars_eta, lars_eps;
+    int use_lars, lars_clip;
+};
+
+__global__ __launch_bounds__(256) void lars_adam_kernel(float* const* __restrict__ ptrs,
+                                                        const int64_t* __restrict__ sizes, int n_tensors,
+                                                        const int32_t* __restrict__ chunk_tensor,
+                                                        const int64_t* __restrict__ chunk_offset,
+                                                        const int32_t* __restrict__ tensor_chunk_begin,
+                                                        int n_chunks, const float* __restrict__ norms_ws,
+                                                        OptArgs a) {
+    const int c = blockIdx.x;
+    const int t = chunk_tensor[c];
+    const int64_t off = chunk_offset[c];
+    const int64_t n = min((int64_t)CHUNK, sizes[t] - off);
+    float* p = ptrs[t] + off;
+    const float* g = ptrs[n_tensors + t] + off;
+    float* m = ptrs[2 * n_tensors + t] + off;
+    float* v = ptrs[3 * n_tensors + t] + off;
+
+    float trust = 1.f, wd = a.weight_decay;
+    if (a.use_lars) {
+        // every thread combines the tensor's chunk sums in the same order (uniform, cached)
+        float sp = 0.f, sg = 0.f;
+        for (int k = tensor_chunk_begin[t]; k < tensor_chunk_begin[t + 1]; ++k) {
+            sp += norms_ws[k];
+            sg += norms_ws[n_chunks + k];
+        }
+        const float pn = sqrtf(sp), gn = sqrtf(sg);
+        if (pn != 0.f && gn != 0.f) {
+            trust = a.lars_eta * pn / (gn + pn * wd + a.lars_eps);
+            if (a.lars_clip) trust = fminf(trust / a.lr, 1.f);
+        } else {
+            wd = 0.f;  // update_p leaves the gradient untouched
+        }
+    }
+    const float step_size = a.lr / a.bias_corr1;
+    const float inv_bc2_sqrt = 1.f / sqrtf(a.bias_corr2);
+    for (int64_t k = threadIdx.x; k < n; k += 256) {
+        const float pk = p[k];
+        const float gk = (g[k] + wd * pk) * trust;
+        const float mk = a.beta1 * m[k] + (1.f - a.beta1) * gk;
+        const float vk = a.beta2 * v[k] + (1.f - a.beta2) * gk * gk;
+        m[k] = mk;
+        v[k] = vk;
+        p[k] = pk - step_size * (mk / (sqrtf(vk) * inv_bc2_sqrt + a.adam_eps));
+    }
+}
+
+}  // namespace
+}  // namespace peclr
+
+using namespace peclr;
+
+extern "C" int peclr_lars_sumsq_f32(float* const* ptrs, const int64_t* sizes, int n_tensors,
+                                    const int32_t* chunk_tensor, const int64_t* chunk_offset, int n_chunks,
+                                    float* norms_ws, peclr_stream_t stream) {
+    if (!ptrs || !sizes || !chunk_tensor || !chunk_offset || !norms_ws) return PECLR_ERR_NULL;
+    if (n_tensors <= 0 || n_chunks <= 0) return PECLR_ERR_SHAPE;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream), ptrs, sizes,
+                       n_tensors, chunk_tensor, chunk_offset, n_chunks, norms_ws);
+    return launch_status();
+}
+
+extern "C" int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* sizes, int n_tensors,
+                                          const int32_t* chunk_tensor, const int64_t* chunk_offset,
+                                          const int32_t* tensor_chunk_begin, int n_chunks, const float* norms_ws,
+                                          float lr, float beta1, float beta2, float adam_eps, float weight_decay,
+                                          float bias_corr1, float bias_corr2, int use_lars, float lars_eta,
+                                          float lars_eps, int lars_clip, peclr_stream_t stream) {
+    if (!ptrs || !sizes || !chunk_tensor || !chunk_offset || !tensor_chunk_begin) return PECLR_ERR_NULL;
+    if (use_lars && !norms_ws) return PECLR_ERR_NULL;
+    if (n_tensors <= 0 || n_chunks <= 0) return PECLR_ERR_SHAPE;
+    if (!(bias_corr1 > 0.f) || !(bias_corr2 > 0.f)) return PECLR_ERR_SHAPE;
+    OptArgs a = {lr, beta1, beta2, adam_eps, weight_decay, bias_corr1, bias_corr2, lars_eta, lars_eps,
+                 use_lars, lars_clip};
+    hipLaunchKernelGGL(lars_adam_kernel, dim3(n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream), ptrs, sizes,
+                       n_tensors, chunk_tensor, chunk_offset, tensor_chunk_begin, n_chunks, norms_ws, a);
+    return launch_status();
+}

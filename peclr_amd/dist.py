@@ -1,0 +1,162 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm)
+across xGMI; gloo on CPU for the tests.
+
+The reference is single-device (`Trainer(gpus="0")`, peclr_training.py:73-81; no collective call
+anywhere), so the multi-GPU semantics are defined here:
+
+  p ranks x N_local pairs  ==  the single-device reference on the concatenated batch of p*N_local
+  pairs (same loss, same summed parameter gradients), up to BatchNorm statistics, which stay
+  per-rank (local BN; the per-rank step is then exactly the reference's step on that rank's rows
+  as far as BN is concerned).
+
+Exchange steps per optimisation step:
+  1. all-gather of the projected embeddings z [2*N_local,128] fp32 (128 KiB/rank at N_local=128)
+     and of one packed vector [row_lse | partial loss] (1 KiB/rank): latency-bound, two small
+     RCCL all-gathers (`ops.ntxent`).
+  2. SUM all-reduce of the parameter gradients (RN-50: ~94 MB fp32), in a few LARGE flat buckets:
+     xGMI is point-to-point (7 links x ~153 GB/s per GPU), ring collectives are bound by one link
+     and RCCL needs big messages to stripe across links, so the bucket size defaults to 64 MiB and
+     buckets are launched from autograd hooks as soon as their last gradient lands (overlap with the
+     rest of the backward).  `encoder.final_layer.*` never receives a gradient and is skipped.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def is_initialized() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if is_initialized() else 1
+
+
+def rank(group=None) -> int:
+    return dist.get_rank(group) if is_initialized() else 0
+
+
+def init_from_env(backend: Optional[str] = None) -> int:
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).
+    Returns the local rank.  No-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if world > 1 and not is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kwargs = {}
+        if backend == "nccl":
+            kwargs["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world, **kwargs)
+    return local
+
+
+def all_gather_cat(t: Tensor, group=None) -> Tensor:
+    """[rows, ...] on every rank -> [world*rows, ...], rank-major.  Not differentiable (the callers
+    carry their own closed-form backward)."""
+    world = world_size(group)
+    if world == 1:
+        return t
+    t = t.contiguous()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out
+
+
+class _Bucket:
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.params = params
+        numel = sum(p.numel() for p in params)
+        self.flat = torch.zeros(numel, device=params[0].device, dtype=params[0].dtype)
+        self.views, o = [], 0
+        for p in params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        self.pending = len(params)
+        self.handle = None
+
+
+class GradReducer:
+    """Bucketed SUM all-reduce of gradients, overlapped with backward.
+
+    Every parameter's `.grad` is a view into its bucket's flat buffer, so autograd accumulates
+    straight into the communication buffer (no pack/unpack copies).  `p.register_post_accumulate_
+    grad_hook` counts arrivals; the bucket's all-reduce is issued asynchronously when the last one
+    lands.  Call `prepare()` before each backward that ends an accumulation window, `finish()` before
+    the optimiser step, and `zero_grad()` instead of `optimizer.zero_grad()`.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):
+        self.group = group
+        self.world = world_size(group)
+        params = [p for p in params if p.requires_grad]
+        # buckets in REVERSE registration order: the last layers' grads are ready first
+        self.buckets: List[_Bucket] = []
+        cur, cur_bytes = [], 0
+        for p in reversed(params):
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > bucket_bytes or p.dtype != cur[0].dtype):
+                self.buckets.append(_Bucket(cur))
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self.buckets.append(_Bucket(cur))
+        self._armed = False
+        self._owner = {}
+        for b in self.buckets:
+            for p, v in zip(b.params, b.views):
+                p.grad = v
+                self._owner[p] = b
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    def _hook(self, p):
+        if not self._armed or self.world == 1:
+            return
+        b = self._owner[p]
+        b.pending -= 1
+        if b.pending == 0:
+            b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def prepare(self, unused: Iterable[torch.nn.Parameter] = ()):
+        """Arm the hooks for the coming backward.  `unused`: parameters that will NOT receive a
+        gradient in it (e.g. encoder.final_layer.*), so their buckets do not wait for them."""
+        self._armed = True
+        skip = set(unused)
+        for b in self.buckets:
+            b.pending = sum(1 for p in b.params if p not in skip)
+            b.handle = None
+
+    def finish(self):
+        """Wait for every in-flight bucket; reduce any bucket whose hooks never completed."""
+        if self.world > 1:
+            for b in self.buckets:
+                if b.handle is None:
+                    b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            for b in self.buckets:
+                b.handle.wait()
+                b.handle = None
+        self._armed = False
+
+    def zero_grad(self):
+        for b in self.buckets:
+            b.flat.zero_()
+            for p, v in zip(b.params, b.views):
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    p.grad = v  # re-attach if something replaced the view
+
+
+def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None):
+    """Make every rank start from rank `src`'s parameters and buffers."""
+    if world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)

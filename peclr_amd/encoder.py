@@ -1,0 +1,67 @@
+"""Encoder wrapper: the reference's `ResNetModel` (resnet_model.py:6-55) and its factory
+`get_wrapper_model` (utils.py:412-428), on the in-tree ResNet.
+
+state_dict contract kept (needed by peclr_to_torchvision and the published checkpoints):
+`features.{0,1,4,5,6,7}.*` = conv1, bn1, layer1..4 in torchvision's order, plus the unused
+`final_layer.0.{weight,bias}` = Linear(in_features, 21*3+1) that lives in the optimiser but
+never receives a gradient in "pretraining" mode (resnet_model.py:27-29,51-52).
+"""
+from __future__ import annotations
+
+import os
+import warnings
+
+from torch import nn
+
+from . import resnet as _resnet
+from .config import Config
+
+
+class ResNetModel(nn.Module):
+    def __init__(self, config, mode: str = ""):
+        super().__init__()
+        self.mode = mode
+        resnet_name = config.model.backend_model.lower()
+        model_function = self.get_resnet(resnet_name)
+        model = model_function(pretrained=config.model.pretrained, norm_layer=nn.BatchNorm2d)
+        self.features = nn.Sequential(model.conv1, model.bn1, model.relu, model.maxpool, model.layer1,
+                                      model.layer2, model.layer3, model.layer4,
+                                      nn.AdaptiveAvgPool2d(output_size=(1, 1)))
+        self.final_layer = nn.Sequential(nn.Linear(model.fc.in_features, 21 * 3 + 1))
+
+    def get_resnet(self, resnet_name):
+        table = {"resnet18": _resnet.resnet18, "resnet34": _resnet.resnet34, "resnet50": _resnet.resnet50,
+                 "resnet101": _resnet.resnet101, "resnet152": _resnet.resnet152}
+        if resnet_name not in table:
+            raise NotImplementedError  # resnet_model.py:42-43
+        return table[resnet_name]
+
+    def forward(self, x):
+        z = self.features(x).flatten(start_dim=1)
+        if self.mode == "pretraining":
+            return z
+        z = self.final_layer(z)
+        return z[:, : 21 * 3], None, z[:, -1]
+
+
+def get_wrapper_model(config, pretrained, wrapper: bool = False):
+    """utils.py:412-428.  `pretrained=True` means ImageNet weights in the reference (a download);
+    there is no network on the target, so it resolves to `config.pretrained_path` or
+    $PECLR_IMAGENET_WEIGHTS/resnet<size>.pth when present and to random init (with a warning)
+    otherwise."""
+    if wrapper:
+        raise NameError("WrapperModel is undefined in the reference as well (utils.py:425-426)")
+    weights = False
+    if pretrained:
+        cand = config.get("pretrained_path") if hasattr(config, "get") else None
+        if not cand and os.environ.get("PECLR_IMAGENET_WEIGHTS"):
+            cand = os.path.join(os.environ["PECLR_IMAGENET_WEIGHTS"], f"resnet{config.resnet_size}.pth")
+        if cand and os.path.exists(cand):
+            weights = cand
+        else:
+            warnings.warn("pretrained ImageNet weights requested but no local weight file is available "
+                          "(no network): the encoder is randomly initialised", stacklevel=2)
+    cfg = Config({"model": {"backend_model": "resnet" + str(config.resnet_size), "norm_layer": "bn",
+                            "use_var": False, "pretrained": weights},
+                  "dataset": {"np": 21}, "loss": {"hmap": {"enabled": False}}})
+    return ResNetModel(config=cfg, mode="pretraining")

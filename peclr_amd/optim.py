@@ -1,0 +1,178 @@
+"""Optimiser plumbing of `BaseModel.configure_optimizers` (base_model.py:57-104).
+
+The reference wires torch.optim.Adam -> pl_bolts LARSWrapper -> pl_bolts
+LinearWarmupCosineAnnealingLR (pl_bolts==0.2.2; not vendored, not installed here: PARITY UNPINNED,
+restated from its published behaviour, see oracle/peclr_oracle.py:lars_adam_step).
+
+  LARSAdam                       torch.optim.Optimizer with LARSWrapper(Adam) semantics.
+      fused=True  (HIP tensors): ONE fused multi-tensor HIP launch pair per parameter group
+                                 (peclr_lars_adam_step_f32) -- no per-tensor norms, no host syncs.
+      fused=False                the same update written with torch foreach ops (any device); used for
+                                 CPU runs and as the comparison arm in tests.
+  LARSWrapper(optimizer)         the reference's spelling: wraps an Adam built by the caller.
+  LinearWarmupCosineAnnealingLR  closed-form warm-up + cosine schedule, stepped per optimiser step.
+"""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import torch
+from torch.optim import Optimizer
+from torch.optim.lr_scheduler import LRScheduler
+
+from . import _capi
+
+
+class _FusedGroup:
+    """Device-side work list for one parameter group (rebuilt if the set of tensors changes)."""
+
+    def __init__(self, params, grads, exp_avg, exp_avg_sq):
+        dev = params[0].device
+        n = len(params)
+        self.key = tuple(t.data_ptr() for t in (*params, *grads))
+        ptrs = [t.data_ptr() for seq in (params, grads, exp_avg, exp_avg_sq) for t in seq]
+        sizes = [p.numel() for p in params]
+        chunk_tensor, chunk_offset, begin = [], [], [0]
+        for t, sz in enumerate(sizes):
+            for off in range(0, sz, _capi.OPT_CHUNK):
+                chunk_tensor.append(t)
+                chunk_offset.append(off)
+            begin.append(len(chunk_tensor))
+        self.n_tensors, self.n_chunks = n, len(chunk_tensor)
+        self.ptrs = torch.tensor(ptrs, dtype=torch.int64, device=dev)
+        self.sizes = torch.tensor(sizes, dtype=torch.int64, device=dev)
+        self.chunk_tensor = torch.tensor(chunk_tensor, dtype=torch.int32, device=dev)
+        self.chunk_offset = torch.tensor(chunk_offset, dtype=torch.int64, device=dev)
+        self.begin = torch.tensor(begin, dtype=torch.int32, device=dev)
+        self.norms_ws = torch.empty(2 * self.n_chunks, dtype=torch.float32, device=dev)
+
+
+class LARSAdam(Optimizer):
+    """Adam (torch defaults: betas (0.9, 0.999), eps 1e-8) with the LARSWrapper pre-step:
+
+        for every param with a grad, if |p| != 0 and |g| != 0:
+            trust = eta*|p| / (|g| + wd*|p| + lars_eps);  if clip: trust = min(trust / lr, 1)
+            g <- (g + wd*p) * trust
+        Adam step on g with weight_decay = 0.
+
+    `lars=False` gives plain torch.optim.Adam (L2 weight decay) -- the non-"LARS" branch of
+    configure_optimizers (base_model.py:99-100).
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lars=True, eta=0.02,
+                 lars_eps=1e-8, clip=True, fused=None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.lars, self.eta, self.lars_eps, self.clip = lars, eta, lars_eps, clip
+        first = self.param_groups[0]["params"][0]
+        self.fused = first.is_cuda if fused is None else fused
+        if self.fused and not first.is_cuda:
+            raise _capi.PeclrHipError("LARSAdam(fused=True) needs HIP device parameters")
+        self._fused_cache = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            for p in params:
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+            step = self.state[params[0]]["step"]
+            b1, b2 = group["betas"]
+            bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+            lr = float(group["lr"])
+            grads = [p.grad for p in params]
+            m = [self.state[p]["exp_avg"] for p in params]
+            v = [self.state[p]["exp_avg_sq"] for p in params]
+            if self.fused:
+                self._step_fused(gi, params, grads, m, v, lr, b1, b2, group["eps"], group["weight_decay"], bc1,
+                                 bc2)
+            else:
+                self._step_foreach(params, grads, m, v, lr, b1, b2, group["eps"], group["weight_decay"], bc1,
+                                   bc2)
+        return loss
+
+    # ---- HIP: one launch pair per group
+    def _step_fused(self, gi, params, grads, m, v, lr, b1, b2, eps, wd, bc1, bc2):
+        for t in (*params, *grads):
+            if not (t.is_contiguous() and t.dtype == torch.float32):
+                raise _capi.PeclrHipError("LARSAdam(fused): parameters and grads must be contiguous fp32")
+        key = tuple(t.data_ptr() for t in (*params, *grads))
+        fg = self._fused_cache.get(gi)
+        if fg is None or fg.key != key:
+            fg = self._fused_cache[gi] = _FusedGroup(params, grads, m, v)
+        _capi.lars_adam_step(fg.ptrs, fg.sizes, fg.n_tensors, fg.chunk_tensor, fg.chunk_offset, fg.begin,
+                             fg.n_chunks, fg.norms_ws, lr, b1, b2, eps, wd, bc1, bc2, self.lars, self.eta,
+                             self.lars_eps, self.clip)
+
+    # ---- torch foreach restatement (any device)
+    def _step_foreach(self, params, grads, m, v, lr, b1, b2, eps, wd, bc1, bc2):
+        if self.lars:
+            p_norm = torch.stack(torch._foreach_norm(params))
+            g_norm = torch.stack(torch._foreach_norm(grads))
+            trust = self.eta * p_norm / (g_norm + p_norm * wd + self.lars_eps)
+            if self.clip:
+                trust = torch.clamp(trust / lr, max=1.0) if lr > 0 else torch.ones_like(trust)
+            active = (p_norm != 0) & (g_norm != 0)
+            trust = torch.where(active, trust, torch.ones_like(trust))
+            wds = torch.where(active, torch.full_like(trust, wd), torch.zeros_like(trust))
+            g_eff = torch._foreach_mul(params, list(wds.unbind()))
+            torch._foreach_add_(g_eff, grads)
+            torch._foreach_mul_(g_eff, list(trust.unbind()))
+        elif wd != 0:
+            g_eff = torch._foreach_add(grads, params, alpha=wd)
+        else:
+            g_eff = list(grads)
+        torch._foreach_mul_(m, b1)
+        torch._foreach_add_(m, g_eff, alpha=1 - b1)
+        torch._foreach_mul_(v, b2)
+        torch._foreach_addcmul_(v, g_eff, g_eff, value=1 - b2)
+        denom = torch._foreach_sqrt(v)
+        torch._foreach_div_(denom, math.sqrt(bc2))
+        torch._foreach_add_(denom, eps)
+        torch._foreach_addcdiv_(params, m, denom, value=-lr / bc1)
+
+
+def LARSWrapper(optimizer: Optimizer, eta: float = 0.02, clip: bool = True, eps: float = 1e-8) -> LARSAdam:
+    """The reference's call shape `LARSWrapper(torch.optim.Adam(groups, lr=...))` (base_model.py:91):
+    returns a LARSAdam over the SAME parameter groups and hyper-parameters."""
+    if not isinstance(optimizer, torch.optim.Adam):
+        raise TypeError("LARSWrapper here wraps torch.optim.Adam only (what the reference passes)")
+    groups = [{k: v for k, v in g.items() if k in ("params", "lr", "betas", "eps", "weight_decay")}
+              for g in optimizer.param_groups]
+    return LARSAdam(groups, lars=True, eta=eta, lars_eps=eps, clip=clip)
+
+
+class LinearWarmupCosineAnnealingLR(LRScheduler):
+    """Linear warm-up from `warmup_start_lr` to the base lr over `warmup_epochs` steps, then cosine
+    annealing to `eta_min` at `max_epochs` (closed form of the pl_bolts scheduler; "epochs" are
+    optimiser steps because the reference registers it with interval="step", base_model.py:102)."""
+
+    def __init__(self, optimizer, warmup_epochs: int, max_epochs: int, warmup_start_lr: float = 0.0,
+                 eta_min: float = 0.0, last_epoch: int = -1):
+        self.warmup_epochs, self.max_epochs = warmup_epochs, max_epochs
+        self.warmup_start_lr, self.eta_min = warmup_start_lr, eta_min
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self) -> List[float]:
+        t = self.last_epoch
+        out = []
+        for base in self.base_lrs:
+            if t < self.warmup_epochs:
+                lr = self.warmup_start_lr + t * (base - self.warmup_start_lr) / max(self.warmup_epochs - 1, 1)
+            else:
+                lr = self.eta_min + 0.5 * (base - self.eta_min) * (
+                    1 + math.cos(math.pi * (t - self.warmup_epochs) / max(self.max_epochs - self.warmup_epochs, 1)))
+            out.append(lr)
+        return out

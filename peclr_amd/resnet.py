@@ -1,0 +1,160 @@
+"""ResNet-18/34/50/101/152 in plain torch.nn with torchvision-identical topology, parameter
+names and state_dict order (torchvision is not installed on the target image).
+
+The reference builds its encoder from `torchvision.models.resnet*` (resnet_model.py:15,31-43).
+Per BASELINE.json:north_star the convolutional backbone stays on PyTorch-ROCm (MIOpen); this file
+only restates the architecture: 7x7/2 conv + BN + ReLU + 3x3/2 max-pool, BasicBlock [2,2,2,2] /
+[3,4,6,3], Bottleneck v1.5 (stride on the 3x3) [3,4,6,3] / [3,4,23,3] / [3,8,36,3], kaiming-normal
+(fan_out) conv init, BN weight 1 / bias 0.  PARITY UNPINNED against torchvision 0.8.0 itself (not
+importable here); pinned by state_dict key/shape lists (tests/test_resnet.py).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Type, Union
+
+import torch
+from torch import Tensor, nn
+
+
+def conv3x3(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False)
+
+
+def conv1x1(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, 1, stride=stride, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = norm_layer(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = norm_layer(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x: Tensor) -> Tensor:
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.conv1 = conv1x1(inplanes, planes)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = conv3x3(planes, planes, stride)  # v1.5: stride on the 3x3
+        self.bn2 = norm_layer(planes)
+        self.conv3 = conv1x1(planes, planes * self.expansion)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x: Tensor) -> Tensor:
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+class ResNet(nn.Module):
+    def __init__(self, block: Type[Union[BasicBlock, Bottleneck]], layers: List[int], num_classes: int = 1000,
+                 norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self._norm_layer = norm_layer
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride),
+                                       self._norm_layer(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample, self._norm_layer)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes, norm_layer=self._norm_layer) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+_SPECS = {"resnet18": (BasicBlock, [2, 2, 2, 2]), "resnet34": (BasicBlock, [3, 4, 6, 3]),
+          "resnet50": (Bottleneck, [3, 4, 6, 3]), "resnet101": (Bottleneck, [3, 4, 23, 3]),
+          "resnet152": (Bottleneck, [3, 8, 36, 3])}
+
+
+def _make(name: str, pretrained: Union[bool, str] = False, norm_layer=None, **kw) -> ResNet:
+    block, layers = _SPECS[name]
+    model = ResNet(block, layers, norm_layer=norm_layer, **kw)
+    if isinstance(pretrained, str):  # explicit weight file (no network on the target)
+        model.load_state_dict(torch.load(pretrained, map_location="cpu"))
+    return model
+
+
+def resnet18(pretrained=False, **kw): return _make("resnet18", pretrained, **kw)
+def resnet34(pretrained=False, **kw): return _make("resnet34", pretrained, **kw)
+def resnet50(pretrained=False, **kw): return _make("resnet50", pretrained, **kw)
+def resnet101(pretrained=False, **kw): return _make("resnet101", pretrained, **kw)
+def resnet152(pretrained=False, **kw): return _make("resnet152", pretrained, **kw)
+
+
+def conv_flops_per_image(model: nn.Module, hw=(224, 224)) -> int:
+    """2*MACs of every Conv2d/Linear for one forward pass of one image (hook-based counter);
+    bench.py uses it for the end-to-end MFMA roofline of the backbone."""
+    total = [0]
+
+    def conv_hook(m, inp, out):
+        kh, kw = m.kernel_size
+        total[0] += 2 * out.numel() // out.shape[0] * (m.in_channels // m.groups) * kh * kw
+
+    def lin_hook(m, inp, out):
+        total[0] += 2 * m.in_features * m.out_features
+
+    hooks = []
+    for m in model.modules():
+        if isinstance(m, nn.Conv2d):
+            hooks.append(m.register_forward_hook(conv_hook))
+        elif isinstance(m, nn.Linear):
+            hooks.append(m.register_forward_hook(lin_hook))
+    was = model.training
+    model.eval()
+    with torch.no_grad():
+        dev = next(model.parameters()).device
+        model(torch.zeros(1, 3, *hw, device=dev))
+    model.train(was)
+    for h in hooks:
+        h.remove()
+    return total[0]

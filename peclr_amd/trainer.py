@@ -1,0 +1,116 @@
+"""Minimal training loop with the Lightning 1.0.8 semantics the reference's step relies on
+(peclr_training.py:73-81,96): loss / accumulate_grad_batches, backward per
+micro-batch, optimizer.step + zero_grad + scheduler.step every K-th batch (interval="step"),
+epoch-end hooks, top-k checkpoints on `checkpoint_saving_loss`.  One process per GPU; gradients
+are SUM-all-reduced over RCCL/xGMI by `dist.GradReducer`, overlapped with backward.
+
+Not a Lightning re-implementation: no loggers, no callbacks API, no dataloader management.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+from typing import Callable, Dict, Iterable, List, Optional
+
+import torch
+
+from . import dist as pdist
+from .port import save_checkpoint
+
+
+class Trainer:
+    def __init__(self, max_epochs: int = 1, accumulate_grad_batches: int = 1, precision: str = "fp32",
+                 checkpoint_dir: Optional[str] = None, save_top_k: int = 1, process_group=None,
+                 bucket_bytes: int = 64 << 20, channels_last: bool = False):
+        self.max_epochs = max_epochs
+        self.accumulate_grad_batches = accumulate_grad_batches
+        self.precision = precision
+        self.checkpoint_dir = checkpoint_dir
+        self.save_top_k = save_top_k
+        self.process_group = process_group
+        self.bucket_bytes = bucket_bytes
+        self.channels_last = channels_last
+        self.world_size = pdist.world_size(process_group)
+        self.global_step = 0
+        self.current_epoch = 0
+        self._saved: List[tuple] = []
+        self.model = self.optimizer = self.scheduler = self.reducer = None
+
+    # ---- setup
+    def attach(self, model):
+        model.trainer = self
+        model.process_group = self.process_group
+        model.setup("fit")
+        pdist.broadcast_module_state(model, 0, self.process_group)
+        self.model = model
+        if self.world_size > 1:
+            self.reducer = pdist.GradReducer(model.parameters(), self.process_group, self.bucket_bytes)
+        (self.optimizer,), (sched,) = model.configure_optimizers()
+        self.scheduler = sched["scheduler"]
+        self._unused = [p for n, p in model.named_parameters() if "final_layer" in n]
+        return self
+
+    def _autocast(self):
+        if self.precision in ("bf16", "16", 16, "fp16"):
+            dtype = torch.bfloat16 if self.precision == "bf16" else torch.float16
+            dev = "cuda" if next(self.model.parameters()).is_cuda else "cpu"
+            return torch.autocast(dev, dtype=dtype)
+        return contextlib.nullcontext()
+
+    def zero_grad(self):
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+
+    # ---- one micro-batch; returns the step's output dict
+    def training_micro_step(self, batch: Dict[str, torch.Tensor], batch_idx: int) -> Dict[str, torch.Tensor]:
+        k = self.accumulate_grad_batches
+        last = (batch_idx + 1) % k == 0
+        if self.reducer is not None and last:
+            self.reducer.prepare(self._unused)
+        with self._autocast():
+            out = self.model.training_step(batch, batch_idx)
+        (out["loss"] / k).backward()
+        if last:
+            if self.reducer is not None:
+                self.reducer.finish()
+            self.optimizer.step()
+            self.zero_grad()
+            self.scheduler.step()
+            self.global_step += 1
+        return {key: v.detach() for key, v in out.items()}
+
+    def fit(self, model, train_batches: Callable[[int], Iterable[Dict[str, torch.Tensor]]],
+            val_batches: Optional[Callable[[int], Iterable[Dict[str, torch.Tensor]]]] = None):
+        """`train_batches(epoch)` yields batch dicts already on the model's device."""
+        if self.model is not model:
+            self.attach(model)
+        self.zero_grad()
+        for epoch in range(self.max_epochs):
+            self.current_epoch = epoch
+            model.train()
+            outputs = [self.training_micro_step(b, i) for i, b in enumerate(train_batches(epoch))]
+            if val_batches is not None:
+                model.eval()
+                with torch.no_grad():
+                    vouts = [model.validation_step(b, i) for i, b in enumerate(val_batches(epoch))]
+                if vouts:
+                    model.validation_epoch_end(vouts)
+            if outputs:
+                model.training_epoch_end(outputs)
+                self._checkpoint(model, epoch)
+        return model
+
+    def _checkpoint(self, model, epoch):
+        if self.checkpoint_dir is None or pdist.rank(self.process_group) != 0:
+            return
+        monitor = float(model.logged["checkpoint_saving_loss"]) if hasattr(model, "logged") else float("nan")
+        path = os.path.join(self.checkpoint_dir, f"epoch={epoch}.ckpt")
+        save_checkpoint(path, model, self.optimizer, self.scheduler, epoch, self.global_step, monitor)
+        self._saved.append((monitor, path))
+        self._saved.sort(key=lambda t: t[0])
+        while self.save_top_k > 0 and len(self._saved) > self.save_top_k:
+            _, worst = self._saved.pop()
+            if os.path.exists(worst):
+                os.remove(worst)

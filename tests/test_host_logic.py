@@ -1,0 +1,256 @@
+"""Host logic above the C ABI, on CPU: module surface, autograd wiring, optimiser plumbing,
+trainer, checkpoint export.  The kernels are replaced by the oracle-backed test double
+(tests/_capi_double.py); goldens come from the reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import peclr_oracle as O
+from tests import _capi_double
+from tests.conftest import GOLDEN, load_golden
+
+
+@pytest.fixture(autouse=True)
+def cpu_kernels(monkeypatch):
+    _capi_double.install(monkeypatch)
+
+
+class FixedEncoder(torch.nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.h = torch.nn.Parameter(torch.from_numpy(h))
+
+    def forward(self, x):
+        return self.h
+
+
+def build_model(cls, g, aug):
+    from peclr_amd import Config
+
+    cfg = Config(projection_head_input_dim=g["in_w1"].shape[1], projection_head_hidden_dim=g["in_w1"].shape[0],
+                 output_dim=128, augmentation=aug, batch_size=8, num_samples=64, num_of_mini_batch=1, lr=1e-4,
+                 opt_weight_decay=1e-6, warmup_epochs=10, optimizer="LARS")
+    model = cls(cfg)
+    model.encoder = FixedEncoder(g["h"])
+    ph = model.projection_head
+    with torch.no_grad():
+        for t, k in ((ph[0].weight, "in_w1"), (ph[0].bias, "in_b1"), (ph[1].weight, "in_gamma"),
+                     (ph[1].bias, "in_beta"), (ph[3].weight, "in_w2")):
+            t.copy_(torch.from_numpy(g[k]))
+    return model.train()
+
+
+def golden_batch(g):
+    n = int(g["n_pairs"])
+    hh, ww = (int(v) for v in g["image_hw"]) if "image_hw" in g else (4, 4)
+    b = {"transformed_image1": torch.zeros(n, 1, hh, ww), "transformed_image2": torch.zeros(n, 1, hh, ww)}
+    for k in g:
+        if k.startswith("batch_"):
+            b[k[6:]] = torch.from_numpy(g[k])
+    return b
+
+
+@pytest.mark.parametrize("tag,aug", [("none", []), ("crop_rotate", ["crop", "rotate"])])
+def test_training_step_surface_and_autograd_wiring(tag, aug):
+    from peclr_amd import Hybrid2Model
+
+    g = load_golden(f"g4_hybrid2_{tag}.npz")
+    model = build_model(Hybrid2Model, g, aug)
+    out = model.training_step(golden_batch(g), 0)
+    assert list(out.keys()) == [str(k) for k in g["out_keys"]]
+    assert abs(float(out["loss"]) - float(g["loss"])) < 5e-6
+    for k in out:
+        assert out[k].dim() == 0
+        assert abs(float(out[k]) - float(g[f"out_{k}"])) < 5e-6
+    assert out["loss"].requires_grad and not out["proj1x_mean"].requires_grad
+    out["loss"].backward()
+    ph = model.projection_head
+    for k, v in dict(dh=model.encoder.h.grad, dw1=ph[0].weight.grad, dgamma=ph[1].weight.grad,
+                     dbeta=ph[1].bias.grad, dw2=ph[3].weight.grad).items():
+        np.testing.assert_allclose(v.numpy(), g[k], rtol=0, atol=3e-5 * max(1.0, float(np.abs(g[k]).max())))
+    np.testing.assert_allclose(ph[1].running_var.numpy(), g["running_var1"], atol=1e-6)
+    assert set(model.plot_params) == {"image1", "image2", "params"}
+
+
+def test_get_transformed_projections_and_forward():
+    from peclr_amd import Hybrid2Model
+
+    g = load_golden("g4_hybrid2_crop_rotate.npz")
+    model = build_model(Hybrid2Model, g, ["crop", "rotate"])
+    z1, z2 = model.get_transformed_projections(golden_batch(g))
+    n = int(g["n_pairs"])
+    assert z1.shape == (n, 128) and z2.shape == (n, 128)
+    np.testing.assert_allclose(z1.detach().norm(dim=1).numpy(), 1.0, atol=1e-6)
+    assert list(model.train_metrics.keys()) == list(O.stat_keys())
+    model.eval()
+    out = model(torch.zeros(2 * n, 1, 4, 4))
+    assert set(out) == {"embedding", "projection"} and out["projection"].shape == (2 * n, 128)
+
+
+def test_state_dict_contract():
+    import warnings
+
+    from peclr_amd import Hybrid2Model, hybrid2_config
+
+    with open(os.path.join(GOLDEN, "g8_state_dict.json")) as f:
+        g = json.load(f)
+    warnings.simplefilter("ignore")
+    model = Hybrid2Model(hybrid2_config(resnet_size="18", projection_head_input_dim=2048))
+    sd = model.state_dict()
+    head = {k: list(v.shape) for k, v in sd.items() if k.startswith("projection_head")}
+    assert list(head.items()) == list(g["head_state_dict"].items())  # names, order and shapes
+    keys = list(sd)
+    assert keys[0] == "encoder.features.0.weight" and keys[1] == "encoder.features.1.weight"
+    assert keys.index("encoder.final_layer.0.bias") + 1 == keys.index("projection_head.0.weight")
+    for attr in g["init_attrs"]:
+        assert hasattr(model, attr)
+    outs = [{"loss": torch.tensor(1.0), "a": torch.tensor(2.0)}, {"loss": torch.tensor(3.0), "a": torch.tensor(6.0)}]
+    model.training_epoch_end(outs)
+    assert {k: float(v) for k, v in model.train_metrics_epoch.items()} == g["epoch_end"]["train_metrics_epoch"]
+    assert {k: float(v) for k, v in model.logged.items()} == g["epoch_end"]["logged"]
+    model.validation_epoch_end(outs)
+    assert {k: float(v) for k, v in model.validation_metrics_epoch.items()} == \
+        g["epoch_end"]["validation_metrics_epoch"]
+
+
+def test_configure_optimizers_matches_reference_numbers():
+    import warnings
+
+    from peclr_amd import Hybrid2Model, hybrid2_config
+    from peclr_amd.optim import LARSAdam, LinearWarmupCosineAnnealingLR
+
+    with open(os.path.join(GOLDEN, "g7_optim.json")) as f:
+        g = json.load(f)
+    warnings.simplefilter("ignore")
+    for c in g["cases"]:
+        cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, batch_size=c["batch_size"],
+                             num_samples=c["num_samples"], num_of_mini_batch=c["accum"])
+        if c["lr_max_epochs"] is not None:
+            cfg["lr_max_epochs"] = c["lr_max_epochs"]
+        model = Hybrid2Model(cfg)
+        model.trainer = type("T", (), {"world_size": c["world_size"], "max_epochs": c["trainer_max_epochs"]})()
+        model.setup("fit")
+        assert model.train_iters_per_epoch == c["train_iters_per_epoch"]
+        (opt,), (sched,) = model.configure_optimizers()
+        assert isinstance(opt, LARSAdam) and opt.lars
+        assert [grp["lr"] for grp in opt.param_groups] == pytest.approx(c["lr"], rel=1e-12) or \
+            [grp["initial_lr"] for grp in opt.param_groups] == pytest.approx(c["lr"], rel=1e-12)
+        assert [grp["weight_decay"] for grp in opt.param_groups] == c["weight_decay"]
+        assert list(opt.param_groups[0]["betas"]) == c["betas"] and opt.param_groups[0]["eps"] == c["eps"]
+        s = sched["scheduler"]
+        assert isinstance(s, LinearWarmupCosineAnnealingLR)
+        assert (s.warmup_epochs, s.max_epochs, s.warmup_start_lr, s.eta_min) == \
+            (c["warmup_epochs"], c["max_epochs"], c["warmup_start_lr"], c["eta_min"])
+        assert {k: v for k, v in sched.items() if k != "scheduler"} == c["sched_keys"]
+    # weight-decay membership incl. the substring quirks
+    names = g["membership"]["decay"] + g["membership"]["no_decay"]
+    named = [(n, torch.nn.Parameter(torch.zeros(1))) for n in names]
+    groups = model.exclude_from_wt_decay(iter(named), weight_decay=1e-6)
+    ids = {id(p): n for n, p in named}
+    assert [ids[id(p)] for p in groups[0]["params"]] == g["membership"]["decay"]
+    assert [ids[id(p)] for p in groups[1]["params"]] == g["membership"]["no_decay"]
+    # non-LARS branch
+    model.config.optimizer = "adam"
+    (opt,), (sched,) = model.configure_optimizers()
+    assert not opt.lars and type(sched["scheduler"]).__name__ == g["cosine"]["sched_type"]
+
+
+def test_lars_adam_foreach_matches_oracle_and_schedule():
+    from peclr_amd.optim import LARSAdam, LinearWarmupCosineAnnealingLR
+
+    rng = np.random.default_rng(3)
+    p0 = rng.standard_normal((40, 30)).astype(np.float32)
+    p = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    zero = torch.nn.Parameter(torch.zeros(7))
+    opt = LARSAdam([{"params": [p, zero], "weight_decay": 1e-6}], lr=2e-3, lars=True, fused=False)
+    sched = LinearWarmupCosineAnnealingLR(opt, warmup_epochs=4, max_epochs=10)
+    pr, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    for step in range(8):
+        lr = O.warmup_cosine_lr(step, 2e-3, 4, 10)
+        assert opt.param_groups[0]["lr"] == pytest.approx(lr, abs=1e-12)
+        g = rng.standard_normal(p0.shape).astype(np.float32)
+        p.grad = torch.from_numpy(g.copy())
+        zero.grad = torch.from_numpy(rng.standard_normal(7).astype(np.float32))
+        z_before = zero.detach().clone()
+        opt.step()
+        sched.step()
+        pr, m, v, _ = O.lars_adam_step(pr, g, m, v, step + 1, lr, 1e-6)
+        np.testing.assert_allclose(p.detach().numpy(), pr, atol=1e-6)
+        if lr == 0:
+            assert torch.equal(zero.detach(), z_before)
+    with pytest.raises(Exception):
+        LARSAdam([p], fused=True)  # fused needs HIP tensors: no silent fallback
+
+
+def test_trainer_accumulation_and_checkpoint_roundtrip(tmp_path):
+    import warnings
+
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config, peclr_to_torchvision, get_encoder_state_dict
+    from peclr_amd import resnet
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(0)
+    n = 2
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, augmentation=["crop", "rotate"],
+                         batch_size=n, num_samples=8, num_of_mini_batch=2, pretrained=False)
+    model = Hybrid2Model(cfg)
+
+    def batches(epoch):
+        g = torch.Generator().manual_seed(epoch)
+        for _ in range(4):
+            yield {"transformed_image1": torch.randn(n, 3, 32, 32, generator=g),
+                   "transformed_image2": torch.randn(n, 3, 32, 32, generator=g),
+                   "jitter_x_1": torch.randint(-14, 1, (n,), generator=g),
+                   "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+                   "jitter_y_1": torch.randint(-14, 1, (n,), generator=g),
+                   "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+                   "angle_1": torch.randint(-45, 46, (n,), generator=g).double(),
+                   "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+
+    tr = Trainer(max_epochs=2, accumulate_grad_batches=2, checkpoint_dir=str(tmp_path), save_top_k=1)
+    tr.fit(model, batches, val_batches=lambda e: list(batches(e))[:1])
+    assert tr.global_step == 4  # 2 epochs x 4 micro-batches / accumulate 2
+    assert set(model.train_metrics_epoch) == set(O.stat_keys()) | {"loss"}
+    assert "checkpoint_saving_loss" in model.logged and list(model.validation_metrics_epoch) == ["loss"]
+    ckpts = os.listdir(tmp_path)
+    assert len(ckpts) == 1 and ckpts[0].startswith("epoch=")
+    path = os.path.join(tmp_path, ckpts[0])
+    # export: every `features` entry lands in a torchvision-layout ResNet, fc untouched
+    target = resnet.resnet18()
+    fc_before = target.fc.weight.detach().clone()
+    peclr_to_torchvision(target, path)
+    saved = torch.load(path, map_location="cpu")["state_dict"]  # top-k keeps the best epoch, not the last
+    tsd = target.state_dict()
+    assert torch.equal(tsd["conv1.weight"], saved["encoder.features.0.weight"])
+    assert torch.equal(tsd["layer4.1.bn2.running_var"], saved["encoder.features.7.1.bn2.running_var"])
+    assert list(saved) == list(model.state_dict())
+    assert torch.equal(target.fc.weight, fc_before)
+    enc = get_encoder_state_dict(path)
+    assert list(enc)[0] == "features.0.weight" and "final_layer.0.bias" in enc
+    with pytest.raises(Exception, match="not of type ResNet"):
+        peclr_to_torchvision(torch.nn.Linear(2, 2), path)
+
+
+def test_resnet_state_dict_layout():
+    from peclr_amd import resnet
+
+    for name, n_entries, n_params in (("resnet18", 122, 11689512), ("resnet50", 320, 25557032),
+                                      ("resnet152", 932, 60192808)):
+        m = getattr(resnet, name)()
+        sd = m.state_dict()
+        assert len(sd) == n_entries, name                      # torchvision's state_dict length
+        assert sum(p.numel() for p in m.parameters()) == n_params, name   # torchvision's parameter count
+        keys = list(sd)
+        assert keys[:6] == ["conv1.weight", "bn1.weight", "bn1.bias", "bn1.running_mean", "bn1.running_var",
+                            "bn1.num_batches_tracked"]
+        assert keys[-2:] == ["fc.weight", "fc.bias"]
+    b = resnet.resnet50().layer1[0]
+    assert [n for n, _ in b.named_children()] == ["conv1", "bn1", "conv2", "bn2", "conv3", "bn3", "relu",
+                                                  "downsample"]
+    assert b.conv2.stride == (1, 1) and resnet.resnet50().layer2[0].conv2.stride == (2, 2)  # v1.5
+    x = torch.randn(2, 3, 64, 64)
+    assert resnet.resnet18()(x).shape == (2, 1000)
+    assert abs(resnet.conv_flops_per_image(resnet.resnet50()) / 1e9 - 8.18) < 0.05
