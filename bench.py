@@ -31,6 +31,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# MIOpen JIT-compiles every convolution kernel on first use (~70 s for ResNet-50 on a fresh box: the
+# PyTorch wheel ships no gfx950 kernel database).  Keep its user find-db / kernel cache in-tree so a
+# populated cache travels with the repo snapshot; an empty or stale one only costs the JIT again.
+_MIOPEN_DIR = os.path.join(ROOT, ".miopen")
+os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(_MIOPEN_DIR, "db"))
+os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(_MIOPEN_DIR, "cache"))
+for _d in (os.environ["MIOPEN_USER_DB_PATH"], os.environ["MIOPEN_CUSTOM_CACHE_DIR"]):
+    os.makedirs(_d, exist_ok=True)
+
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
@@ -50,6 +59,9 @@ def parse():
                     help="backbone compute dtype (configs[1] is fp32; head/logits/loss are always fp32)")
     ap.add_argument("--channels-last", type=int, default=0)
     ap.add_argument("--accum", type=int, default=1)
+    ap.add_argument("--miopen-find", type=int, default=0,
+                    help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find; tens of minutes of kernel "
+                         "JIT on a box without a populated user find-db)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16, help="pairs in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -191,7 +203,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     device = torch.device("cuda", local)
-    torch.backends.cudnn.benchmark = True  # MIOpen find: settle conv algorithms during warm-up
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
     model = build_model(args, device, args.pairs)
     if args.channels_last:
