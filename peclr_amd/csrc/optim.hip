@@ -14,6 +14,8 @@ namespace {
 
 constexpr int CHUNK = PECLR_OPT_CHUNK;  // 256 threads x 16 elements
 
+__device__ __forceinline__ bool aligned16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -37,10 +39,25 @@ __global__ __launch_bounds__(256) void sumsq_kernel(float* const* __restrict__ p
     const float* p = ptrs[t] + off;
     const float* g = ptrs[n_tensors + t] + off;
     float sp = 0.f, sg = 0.f;
-    for (int64_t k = threadIdx.x; k < n; k += 256) {
-        const float a = p[k], b = g[k];
-        sp += a * a;
-        sg += b * b;
+    if (n == CHUNK && aligned16_dev(p) && aligned16_dev(g)) {
+        // full chunk: 4 float4 per thread per tensor, all 8 loads in flight before the first FMA
+        float4 a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = reinterpret_cast<const float4*>(p)[threadIdx.x + 256 * j];
+            b[j] = reinterpret_cast<const float4*>(g)[threadIdx.x + 256 * j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sp += a[j].x * a[j].x + a[j].y * a[j].y + a[j].z * a[j].z + a[j].w * a[j].w;
+            sg += b[j].x * b[j].x + b[j].y * b[j].y + b[j].z * b[j].z + b[j].w * b[j].w;
+        }
+    } else {
+        for (int64_t k = threadIdx.x; k < n; k += 256) {
+            const float a = p[k], b = g[k];
+            sp += a * a;
+            sg += b * b;
+        }
     }
     sp = block_sum(sp, red);
     sg = block_sum(sg, red);
@@ -89,14 +106,44 @@ __global__ __launch_bounds__(256) void lars_adam_kernel(float* const* __restrict
     }
     const float step_size = a.lr / a.bias_corr1;
     const float inv_bc2_sqrt = 1.f / sqrtf(a.bias_corr2);
-    for (int64_t k = threadIdx.x; k < n; k += 256) {
-        const float pk = p[k];
-        const float gk = (g[k] + wd * pk) * trust;
-        const float mk = a.beta1 * m[k] + (1.f - a.beta1) * gk;
-        const float vk = a.beta2 * v[k] + (1.f - a.beta2) * gk * gk;
-        m[k] = mk;
-        v[k] = vk;
-        p[k] = pk - step_size * (mk / (sqrtf(vk) * inv_bc2_sqrt + a.adam_eps));
+    const float b1 = a.beta1, b2 = a.beta2, eps = a.adam_eps;
+    auto upd = [&](float& pk, float gk, float& mk, float& vk) {
+        gk = (gk + wd * pk) * trust;
+        mk = b1 * mk + (1.f - b1) * gk;
+        vk = b2 * vk + (1.f - b2) * gk * gk;
+        pk = pk - step_size * (mk / (sqrtf(vk) * inv_bc2_sqrt + eps));
+    };
+    if (n == CHUNK && aligned16_dev(p) && aligned16_dev(g) && aligned16_dev(m) && aligned16_dev(v)) {
+        // full chunk: 16 x 16-byte loads in flight per thread (1 KiB per wave-instruction), then the
+        // update in registers and 12 x 16-byte stores
+        float4 pp[4], gg[4], mm[4], vv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = threadIdx.x + 256 * j;
+            pp[j] = reinterpret_cast<const float4*>(p)[k];
+            gg[j] = reinterpret_cast<const float4*>(g)[k];
+            mm[j] = reinterpret_cast<const float4*>(m)[k];
+            vv[j] = reinterpret_cast<const float4*>(v)[k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = threadIdx.x + 256 * j;
+            upd(pp[j].x, gg[j].x, mm[j].x, vv[j].x);
+            upd(pp[j].y, gg[j].y, mm[j].y, vv[j].y);
+            upd(pp[j].z, gg[j].z, mm[j].z, vv[j].z);
+            upd(pp[j].w, gg[j].w, mm[j].w, vv[j].w);
+            reinterpret_cast<float4*>(m)[k] = mm[j];
+            reinterpret_cast<float4*>(v)[k] = vv[j];
+            reinterpret_cast<float4*>(p)[k] = pp[j];
+        }
+    } else {
+        for (int64_t k = threadIdx.x; k < n; k += 256) {
+            float pk = p[k], mk = m[k], vk = v[k];
+            upd(pk, g[k], mk, vk);
+            m[k] = mk;
+            v[k] = vk;
+            p[k] = pk;
+        }
     }
 }
 

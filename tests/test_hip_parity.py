@@ -83,7 +83,7 @@ def test_gemm_argument_errors(capi):
 
 
 # ------------------------------------------------------------------ BN + ReLU
-@pytest.mark.parametrize("m,h,slabs", [(256, 512, 8), (12, 96, 1), (7, 40, 3), (64, 33, 2)])
+@pytest.mark.parametrize("m,h,slabs", [(256, 512, 8), (12, 96, 1), (7, 40, 3), (64, 36, 2), (1100, 24, 2)])
 def test_bn_relu_fwd_bwd(capi, m, h, slabs):
     parts = rnd((slabs, m, h), 10)
     bias, gamma, beta = rnd((h,), 11), 0.5 + np.abs(rnd((h,), 12)), rnd((h,), 13, 0.2)
