@@ -158,8 +158,11 @@ int peclr_ntxent_bwd_f32(const float* z_rows, int Mr, int row_offset, const floa
  * the element offset of chunk c (chunks of one tensor are consecutive), and
  * tensor_chunk_begin[t] .. tensor_chunk_begin[t+1] is tensor t's chunk range.
  * peclr_lars_sumsq_f32: norms_ws[2][n_chunks] = per-chunk sums of squares of param and grad.
- * peclr_lars_adam_update_f32: combines a tensor's chunk sums in a fixed order
- * (bit-reproducible), applies the LARS trust ratio + weight decay and the Adam update.
+ * peclr_lars_adam_update_f32: ONE launch for all parameter groups (the reference has two: decayed /
+ * not decayed, base_model.py:30-51): tensor_group[t] (device, nullable when n_groups == 1) selects
+ * the tensor's entry of the HOST arrays group_lr / group_weight_decay (n_groups <= 8, copied into
+ * the kernel arguments).  It combines a tensor's chunk sums in a fixed order (bit-reproducible),
+ * applies the LARS trust ratio + weight decay and the Adam update.
  * use_lars == 0: plain Adam with L2 weight decay (torch.optim.Adam semantics; norms_ws unused).
  * bias_corr1/2 = 1 - beta^step, computed by the host.  The LARS-scaled gradient is consumed in
  * registers and NOT written back to grad.                                                   */
@@ -169,11 +172,12 @@ int peclr_lars_sumsq_f32(float* const* ptrs, const int64_t* sizes, int n_tensors
                          float* norms_ws, peclr_stream_t stream);
 int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* sizes, int n_tensors,
                                const int32_t* chunk_tensor, const int64_t* chunk_offset,
-                               const int32_t* tensor_chunk_begin, int n_chunks,
-                               const float* norms_ws, float lr, float beta1, float beta2,
-                               float adam_eps, float weight_decay, float bias_corr1,
-                               float bias_corr2, int use_lars, float lars_eta, float lars_eps,
-                               int lars_clip, peclr_stream_t stream);
+                               const int32_t* tensor_chunk_begin, const int32_t* tensor_group,
+                               int n_chunks, const float* norms_ws, const float* group_lr,
+                               const float* group_weight_decay, int n_groups, float beta1,
+                               float beta2, float adam_eps, float bias_corr1, float bias_corr2,
+                               int use_lars, float lars_eta, float lars_eps, int lars_clip,
+                               peclr_stream_t stream);
 
 #ifdef __cplusplus
 }

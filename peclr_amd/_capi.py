@@ -41,7 +41,7 @@ SIGNATURES = {
     "peclr_ntxent_bwd_f32": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, c_float, _P, _P, c_float, _P,
                                      c_int, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
-    "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, c_int, _P, c_float, c_float, c_float,
+    "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
                                            _P]),
 }
@@ -267,20 +267,25 @@ def ntxent_bwd(z_rows, row_offset, z_all, n_half, inv_tau, lse_all, dloss, grad_
 
 
 # ------------------------------------------------------------------ optimiser
-def lars_adam_step(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_chunk_begin, n_chunks, norms_ws,
-                   lr, beta1, beta2, adam_eps, weight_decay, bias_corr1, bias_corr2, use_lars, lars_eta,
-                   lars_eps, lars_clip):
+def lars_adam_step(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_chunk_begin, tensor_group, n_chunks,
+                   norms_ws, group_lr, group_wd, beta1, beta2, adam_eps, bias_corr1, bias_corr2, use_lars,
+                   lars_eta, lars_eps, lars_clip):
+    """group_lr / group_wd: Python float lists, one entry per parameter group (host arrays)."""
     p = _ptr(ptrs, torch.int64, "ptrs")
     sz = _ptr(sizes, torch.int64, "sizes")
     ct = _ptr(chunk_tensor, torch.int32, "chunk_tensor")
     co = _ptr(chunk_offset, torch.int64, "chunk_offset")
+    ng = len(group_lr)
+    lr_arr = (c_float * ng)(*group_lr)
+    wd_arr = (c_float * ng)(*group_wd)
     if use_lars:
         with _timed("lars_sumsq"):
             rc = lib().peclr_lars_sumsq_f32(p, sz, n_tensors, ct, co, n_chunks, _ptr(norms_ws), _stream())
         _check(rc, "peclr_lars_sumsq_f32")
     with _timed("lars_adam_update"):
         rc = lib().peclr_lars_adam_update_f32(
-            p, sz, n_tensors, ct, co, _ptr(tensor_chunk_begin, torch.int32, "tensor_chunk_begin"), n_chunks,
-            _ptr(norms_ws), lr, beta1, beta2, adam_eps, weight_decay, bias_corr1, bias_corr2, int(use_lars),
-            lars_eta, lars_eps, int(lars_clip), _stream())
+            p, sz, n_tensors, ct, co, _ptr(tensor_chunk_begin, torch.int32, "tensor_chunk_begin"),
+            _ptr(tensor_group, torch.int32, "tensor_group"), n_chunks, _ptr(norms_ws),
+            ctypes.cast(lr_arr, c_void_p), ctypes.cast(wd_arr, c_void_p), ng, beta1, beta2, adam_eps, bias_corr1,
+            bias_corr2, int(use_lars), lars_eta, lars_eps, int(lars_clip), _stream())
     _check(rc, "peclr_lars_adam_update_f32")

@@ -24,19 +24,15 @@ constexpr double PI = 3.14159265358979323846;
 // Lower median (torch.median: sorted[(64-1)//2]) of one value per lane.
 __device__ __forceinline__ float wave_lower_median(float v, int lane) {
     int rank = 0;
-#pragma unroll
+#pragma unroll 8  // SGPR broadcasts; a full 64-way unroll spills scalar registers
     for (int k = 0; k < 64; ++k) {
-        const float u = __shfl(v, k, kWave);
+        const float u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
         rank += (u < v) || (u == v && k < lane);
     }
     const unsigned long long m = __ballot(rank == 31);
     const int src = __ffsll((long long)m) - 1;
     return __shfl(v, src, kWave);
 }
-
-struct Rot {
-    float r00, r10, r01, r11;  // [x y] -> x*r00 + y*r10, x*r01 + y*r11
-};
 
 // get_rotation_2D_matrix (utils.py:287-296) for rotate_encoding(projections, -angles):
 // theta = (-angle) * pi / 180 in float64, entries rounded to float32.

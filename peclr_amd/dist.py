@@ -74,12 +74,13 @@ def all_gather_cat(t: Tensor, group=None) -> Tensor:
 class _Bucket:
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = params
-        numel = sum(p.numel() for p in params)
+        pad = lambda n: (n + 63) // 64 * 64  # 256-byte slots: every view stays 16-byte aligned, so the
+        numel = sum(pad(p.numel()) for p in params)  # fused optimiser keeps its 16-byte vector path
         self.flat = torch.zeros(numel, device=params[0].device, dtype=params[0].dtype)
         self.views, o = [], 0
         for p in params:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
+            o += pad(p.numel())
         self.pending = len(params)
         self.handle = None
 

@@ -24,10 +24,25 @@ from torch.optim.lr_scheduler import LRScheduler
 from . import _capi
 
 
-class _FusedGroup:
-    """Device-side work list for one parameter group (rebuilt if the set of tensors changes)."""
+def _is_dense(t: torch.Tensor) -> bool:
+    """Dense in SOME dimension order (contiguous, channels_last, ...): storage has no gaps/overlaps."""
+    if t.is_contiguous() or t.numel() <= 1:
+        return True
+    dims = sorted(range(t.dim()), key=lambda d: t.stride(d))
+    expect = 1
+    for d in dims:
+        if t.size(d) == 1:
+            continue
+        if t.stride(d) != expect:
+            return False
+        expect *= t.size(d)
+    return True
 
-    def __init__(self, params, grads, exp_avg, exp_avg_sq):
+
+class _FusedWorkList:
+    """Device-side work list over ALL parameter groups (rebuilt if the set of tensors changes)."""
+
+    def __init__(self, params, grads, exp_avg, exp_avg_sq, group_of):
         dev = params[0].device
         n = len(params)
         self.key = tuple(t.data_ptr() for t in (*params, *grads))
@@ -45,6 +60,7 @@ class _FusedGroup:
         self.chunk_tensor = torch.tensor(chunk_tensor, dtype=torch.int32, device=dev)
         self.chunk_offset = torch.tensor(chunk_offset, dtype=torch.int64, device=dev)
         self.begin = torch.tensor(begin, dtype=torch.int32, device=dev)
+        self.group = torch.tensor(group_of, dtype=torch.int32, device=dev)
         self.norms_ws = torch.empty(2 * self.n_chunks, dtype=torch.float32, device=dev)
 
 
@@ -71,50 +87,72 @@ class LARSAdam(Optimizer):
             raise _capi.PeclrHipError("LARSAdam(fused=True) needs HIP device parameters")
         self._fused_cache = {}
 
+    def _prepare(self, group):
+        """Lazy state init + step count for one group; returns (params, grads, m, v, step)."""
+        params = [p for p in group["params"] if p.grad is not None]
+        for p in params:
+            st = self.state[p]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+        grads = [p.grad for p in params]
+        m = [self.state[p]["exp_avg"] for p in params]
+        v = [self.state[p]["exp_avg_sq"] for p in params]
+        return params, grads, m, v, (self.state[params[0]]["step"] if params else 0)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for gi, group in enumerate(self.param_groups):
-            params = [p for p in group["params"] if p.grad is not None]
-            if not params:
-                continue
-            for p in params:
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-            step = self.state[params[0]]["step"]
-            b1, b2 = group["betas"]
+        prepared = [(g, *self._prepare(g)) for g in self.param_groups]
+        prepared = [t for t in prepared if t[1]]
+        if not prepared:
+            return loss
+        uniform = len({(tuple(g["betas"]), g["eps"], st) for g, _, _, _, _, st in prepared}) == 1
+        if self.fused and uniform and len(prepared) <= 8:
+            self._step_fused(prepared)  # ONE launch pair for every parameter group
+            return loss
+        for g, params, grads, m, v, step in prepared:
+            b1, b2 = g["betas"]
             bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
-            lr = float(group["lr"])
-            grads = [p.grad for p in params]
-            m = [self.state[p]["exp_avg"] for p in params]
-            v = [self.state[p]["exp_avg_sq"] for p in params]
             if self.fused:
-                self._step_fused(gi, params, grads, m, v, lr, b1, b2, group["eps"], group["weight_decay"], bc1,
-                                 bc2)
+                self._step_fused([(g, params, grads, m, v, step)])
             else:
-                self._step_foreach(params, grads, m, v, lr, b1, b2, group["eps"], group["weight_decay"], bc1,
+                self._step_foreach(params, grads, m, v, float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], bc1,
                                    bc2)
         return loss
 
-    # ---- HIP: one launch pair per group
-    def _step_fused(self, gi, params, grads, m, v, lr, b1, b2, eps, wd, bc1, bc2):
-        for t in (*params, *grads):
-            if not (t.is_contiguous() and t.dtype == torch.float32):
-                raise _capi.PeclrHipError("LARSAdam(fused): parameters and grads must be contiguous fp32")
+    # ---- HIP: two launches per optimiser step (sum of squares; update), all groups at once
+    def _step_fused(self, prepared):
+        params = [p for t in prepared for p in t[1]]
+        grads = [x for t in prepared for x in t[2]]
+        m = [x for t in prepared for x in t[3]]
+        v = [x for t in prepared for x in t[4]]
+        # The kernel walks raw storage, so every tensor must be dense (any permutation: NCHW or
+        # channels_last) and grad / moments must share the parameter's strides.
+        for p_, g_, m_, v_ in zip(params, grads, m, v):
+            if p_.dtype != torch.float32 or g_.dtype != torch.float32:
+                raise _capi.PeclrHipError("LARSAdam(fused): parameters and grads must be fp32")
+            if not _is_dense(p_):
+                raise _capi.PeclrHipError("LARSAdam(fused): parameters must be dense (non-overlapping, no gaps)")
+            if g_.stride() != p_.stride() or m_.stride() != p_.stride() or v_.stride() != p_.stride():
+                raise _capi.PeclrHipError("LARSAdam(fused): grad / exp_avg / exp_avg_sq must share the parameter's "
+                                          f"strides (param {tuple(p_.stride())}, grad {tuple(g_.stride())})")
         key = tuple(t.data_ptr() for t in (*params, *grads))
-        fg = self._fused_cache.get(gi)
-        if fg is None or fg.key != key:
-            fg = self._fused_cache[gi] = _FusedGroup(params, grads, m, v)
-        _capi.lars_adam_step(fg.ptrs, fg.sizes, fg.n_tensors, fg.chunk_tensor, fg.chunk_offset, fg.begin,
-                             fg.n_chunks, fg.norms_ws, lr, b1, b2, eps, wd, bc1, bc2, self.lars, self.eta,
-                             self.lars_eps, self.clip)
+        wl = self._fused_cache.get("all")
+        if wl is None or wl.key != key:
+            group_of = [gi for gi, t in enumerate(prepared) for _ in t[1]]
+            wl = self._fused_cache["all"] = _FusedWorkList(params, grads, m, v, group_of)
+        g0, step = prepared[0][0], prepared[0][5]
+        b1, b2 = g0["betas"]
+        _capi.lars_adam_step(wl.ptrs, wl.sizes, wl.n_tensors, wl.chunk_tensor, wl.chunk_offset, wl.begin, wl.group,
+                             wl.n_chunks, wl.norms_ws, [float(t[0]["lr"]) for t in prepared],
+                             [float(t[0]["weight_decay"]) for t in prepared], b1, b2, g0["eps"], 1.0 - b1 ** step,
+                             1.0 - b2 ** step, self.lars, self.eta, self.lars_eps, self.clip)
 
     # ---- torch foreach restatement (any device)
     def _step_foreach(self, params, grads, m, v, lr, b1, b2, eps, wd, bc1, bc2):

@@ -380,11 +380,13 @@ def test_lars_adam_fused_matches_foreach_and_oracle(lars):
     arms = {}
     for fused in (True, False):
         ps = [torch.nn.Parameter(dev(p)) for p in p0]
+        ps[0] = torch.nn.Parameter(ps[0].detach().contiguous(memory_format=torch.channels_last))  # dense NHWC
         opt = LARSAdam([{"params": ps[:3], "weight_decay": 1e-6}, {"params": ps[3:], "weight_decay": 0.0}],
                        lr=1.1e-3, lars=lars, fused=fused)
         for step in range(3):
             for i, p in enumerate(ps):
                 p.grad = dev(np.random.default_rng(100 * step + i).standard_normal(p.shape).astype(np.float32))
+            ps[0].grad = ps[0].grad.contiguous(memory_format=torch.channels_last)
             opt.step()
         arms[fused] = [host(p) for p in ps]
     for a, b in zip(arms[True], arms[False]):
