@@ -61,6 +61,9 @@ def parse():
                     help="NHWC activations/weights for the MIOpen backbone (default): its gfx950 igemm kernels "
                          "are NHWC-native, NCHW costs ~11%% of the step in layout transposes "
                          "(profiles/r01a vs r01b)")
+    ap.add_argument("--fused-bn", type=int, default=1,
+                    help="backbone BatchNorm2d/add/ReLU glue on the hand-written NHWC kernels (needs fp32 + "
+                         "--channels-last 1); 0 = stock PyTorch/MIOpen ops")
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--miopen-find", type=int, default=0,
                     help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find; tens of minutes of kernel "
@@ -123,13 +126,16 @@ def kernel_table(event_log, m_rows, m_global, din, hid, n_params):
         "lars_adam_update": ("hbm", 0, 28 * n_params),
     }
     out = {}
-    for name, pairs in event_log.items():
-        ms = [s.elapsed_time(e) for s, e in pairs]
-        if not ms or name not in work:
+    for name, recs in event_log.items():
+        ms = [r[0].elapsed_time(r[1]) for r in recs]
+        if not ms:
             continue
         per_step = False
         avg_us = 1e3 * sum(ms) / len(ms)
-        bound, flops, nbytes = work[name]
+        if name in work:
+            bound, flops, nbytes = work[name]
+        else:  # shape-dependent launches (bn2d_*): the wrapper recorded each launch's algorithmic work
+            bound, flops, nbytes = "hbm", 0, sum(r[2] for r in recs) / len(recs)
         entry = {"bound": bound, "launches": len(ms), "avg_us": round(avg_us, 3), "bytes": nbytes, "flops": flops}
         if per_step:
             groups = 2
@@ -146,6 +152,19 @@ def kernel_table(event_log, m_rows, m_global, din, hid, n_params):
                          frac=round(ach / MFMA_F32_PEAK_TF, 5))
         out[name] = entry
     return out
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, gfx950 corrections applied by tools/pmc_traffic.py) --
+    PMC counters cannot be collected from inside the timed run.  None if no profile covers it."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    entry = table.get(kernel)
+    return entry.get("traffic_bytes_per_launch") if entry else None
 
 
 def cpu_baseline(args):
@@ -210,6 +229,11 @@ def main():
     model = build_model(args, device, args.pairs)
     if args.channels_last:
         model.encoder = model.encoder.to(memory_format=torch.channels_last)
+    fused_bn = bool(args.fused_bn and args.channels_last and args.dtype == "fp32")
+    if fused_bn:
+        from peclr_amd.bn2d import enable_hip_batchnorm
+
+        enable_hip_batchnorm(model.encoder)
     trainer = Trainer(max_epochs=100, accumulate_grad_batches=args.accum, precision=args.dtype).attach(model)
     trainer.zero_grad()
     batch = synthetic_batch(args.pairs, args.size, 5 + rank, device)
@@ -247,9 +271,12 @@ def main():
         n_params = sum(p.numel() for n, p in model.named_parameters() if "final_layer" not in n)
         din = model.config.projection_head_input_dim
         kernels = kernel_table(event_log, 2 * args.pairs, world * 2 * args.pairs, din, 512, n_params)
-        dominant = max(kernels, key=lambda k: kernels[k]["avg_us"])
+        # dominant = largest share of the step's hand-written GPU time (avg duration x launches)
+        dominant = max(kernels, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
         roof = {k: kernels[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
-        roof.update(kernel=dominant, avg_us=kernels[dominant]["avg_us"], traffic=None,
+        roof.update(kernel=dominant, avg_us=kernels[dominant]["avg_us"],
+                    launches_per_step=kernels[dominant]["launches"] // (args.steps * args.accum),
+                    traffic=pmc_traffic(dominant),
                     algorithmic_bytes=kernels[dominant]["bytes"], algorithmic_flops=kernels[dominant]["flops"])
         flops_img = conv_flops_per_image(model.encoder.features, (args.size, args.size))
         step_flops = 3 * flops_img * 2 * args.pairs * args.accum
@@ -264,7 +291,7 @@ def main():
                                    f"views per GPU, crop+rotate equivariance alignment, NT-Xent tau=0.5, "
                                    f"LARS(Adam) step, {args.dtype}",
                        "global_batch": world * 2 * args.pairs * args.accum, "parallelism": f"dp{world}",
-                       "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last),
+                       "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn,
                        "bn": "per-rank batch statistics"},
             "loss": round(loss, 6),
             "roofline": roof,

@@ -40,6 +40,14 @@ SIGNATURES = {
     "peclr_ntxent_finalize_f32": (c_int, [_P, c_int, _P, c_int, c_float, _P, _P, c_int, _P, _P]),
     "peclr_ntxent_bwd_f32": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, c_float, _P, _P, c_float, _P,
                                      c_int, _P]),
+    "peclr_bn2d_n_split": (c_int, [c_int, c_int]),
+    "peclr_bn2d_stats_f32": (c_int, [_P, c_int, c_int, _P, c_int, _P]),
+    "peclr_bn2d_finalize_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P,
+                                        _P, _P, _P, _P]),
+    "peclr_bn2d_apply_f32": (c_int, [_P, _P, c_int, c_int, _P, c_int, _P, _P]),
+    "peclr_bn2d_bwd_reduce_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "peclr_bn2d_bwd_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "peclr_bn2d_bwd_apply_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
@@ -102,10 +110,11 @@ EVENT_LOG = None  # None = off; dict name -> list[(start, end)] when bench.py tu
 
 
 class _timed:
-    __slots__ = ("name", "s", "e")
+    """`nbytes` / `flops`: the launch's ALGORITHMIC work when it is shape-dependent (summed per name)."""
+    __slots__ = ("name", "s", "e", "nbytes", "flops")
 
-    def __init__(self, name):
-        self.name = name
+    def __init__(self, name, nbytes=0, flops=0):
+        self.name, self.nbytes, self.flops = name, nbytes, flops
 
     def __enter__(self):
         if EVENT_LOG is not None:
@@ -116,7 +125,7 @@ class _timed:
     def __exit__(self, *exc):
         if EVENT_LOG is not None:
             self.e.record()
-            EVENT_LOG.setdefault(self.name, []).append((self.s, self.e))
+            EVENT_LOG.setdefault(self.name, []).append((self.s, self.e, self.nbytes, self.flops))
         return False
 
 
@@ -289,3 +298,79 @@ def lars_adam_step(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_ch
             ctypes.cast(lr_arr, c_void_p), ctypes.cast(wd_arr, c_void_p), ng, beta1, beta2, adam_eps, bias_corr1,
             bias_corr2, int(use_lars), lars_eta, lars_eps, int(lars_clip), _stream())
     _check(rc, "peclr_lars_adam_update_f32")
+
+
+# ------------------------------------------------------------------ backbone glue: BN2d (+add) (+ReLU), NHWC
+def _nhwc_ptr(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise PeclrHipError(f"{what}: expected a HIP device tensor (peclr_amd has no CPU path)")
+    if t.dtype != torch.float32 or t.dim() != 4:
+        raise PeclrHipError(f"{what}: expected a 4-D fp32 tensor, got {t.dtype} {tuple(t.shape)}")
+    if not t.is_contiguous(memory_format=torch.channels_last):
+        raise PeclrHipError(f"{what}: tensor must be channels_last (NHWC) contiguous")
+    return t.data_ptr()
+
+
+def bn2d_n_split(r: int, c: int) -> int:
+    n = lib().peclr_bn2d_n_split(r, c)
+    if n < 1:
+        raise PeclrHipError(f"fused BatchNorm2d: unsupported shape R={r} C={c} (C must be a ResNet width)")
+    return n
+
+
+def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, relu):
+    n, c, h, w = x.shape
+    r = n * h * w
+    dev = x.device
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    save = torch.empty((2, c), device=dev, dtype=torch.float32)
+    ss = torch.empty((2, c), device=dev, dtype=torch.float32)
+    xp = _nhwc_ptr(x, "bn2d x")
+    part_ptr, ns = None, 0
+    if training:
+        ns = bn2d_n_split(r, c)
+        partial = torch.empty((ns, 2, c), device=dev, dtype=torch.float32)
+        part_ptr = partial.data_ptr()
+        with _timed("bn2d_stats", 4 * r * c):
+            rc = lib().peclr_bn2d_stats_f32(xp, r, c, part_ptr, ns, _stream())
+        _check(rc, "peclr_bn2d_stats_f32")
+    with _timed("bn2d_finalize", 8 * ns * c):
+        rc = lib().peclr_bn2d_finalize_f32(xp, part_ptr, ns, r, c, int(training), eps, momentum, _ptr(gamma),
+                                           _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                           _ptr(nbt, torch.int64, "num_batches_tracked") if training else None,
+                                           save[0].data_ptr(), save[1].data_ptr(), ss.data_ptr(), _stream())
+    _check(rc, "peclr_bn2d_finalize_f32")
+    with _timed("bn2d_apply", (12 if residual is not None else 8) * r * c):
+        rc = lib().peclr_bn2d_apply_f32(xp, _nhwc_ptr(residual, "bn2d residual") if residual is not None else None,
+                                        r, c, ss.data_ptr(), int(relu), y.data_ptr(), _stream())
+    _check(rc, "peclr_bn2d_apply_f32")
+    return y, save, ss
+
+
+def bn2d_bwd(dy, x, y, save, ss, training, relu, want_dres):
+    n, c, h, w = x.shape
+    r = n * h * w
+    dev = x.device
+    ns = bn2d_n_split(r, c)
+    partial = torch.empty((ns, 2, c), device=dev, dtype=torch.float32)
+    dparams = torch.empty((2, c), device=dev, dtype=torch.float32)  # dgamma, dbeta
+    coef = torch.empty((2, c), device=dev, dtype=torch.float32)
+    dx = torch.empty_like(x, memory_format=torch.channels_last)
+    dres = torch.empty_like(x, memory_format=torch.channels_last) if want_dres else None
+    dyp, xp = _nhwc_ptr(dy, "bn2d dy"), _nhwc_ptr(x, "bn2d x")
+    yp = _nhwc_ptr(y, "bn2d y") if y is not None else None
+    with _timed("bn2d_bwd_reduce", (12 if y is not None else 8) * r * c):
+        rc = lib().peclr_bn2d_bwd_reduce_f32(dyp, xp, yp, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
+                                             ss.data_ptr(), partial.data_ptr(), ns, _stream())
+    _check(rc, "peclr_bn2d_bwd_reduce_f32")
+    with _timed("bn2d_bwd_finalize", 8 * ns * c):
+        rc = lib().peclr_bn2d_bwd_finalize_f32(partial.data_ptr(), ns, r, c, int(training), ss.data_ptr(),
+                                               dparams[0].data_ptr(), dparams[1].data_ptr(), coef.data_ptr(),
+                                               _stream())
+    _check(rc, "peclr_bn2d_bwd_finalize_f32")
+    with _timed("bn2d_bwd_apply", (12 + (4 if y is not None else 0) + (4 if want_dres else 0)) * r * c):
+        rc = lib().peclr_bn2d_bwd_apply_f32(dyp, xp, yp, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
+                                            ss.data_ptr(), coef.data_ptr(), dx.data_ptr(),
+                                            dres.data_ptr() if dres is not None else None, _stream())
+    _check(rc, "peclr_bn2d_bwd_apply_f32")
+    return dx, dparams[0], dparams[1], dres

@@ -1,0 +1,78 @@
+"""Fused BatchNorm2d (+ residual add) (+ ReLU) for the NHWC backbone (kernels: csrc/bn2d.hip).
+
+`FusedBatchNormAct2d` IS an `nn.BatchNorm2d` (same parameters, buffers and state_dict keys -- the
+reference builds its ResNet with `norm_layer=nn.BatchNorm2d`, resnet_model.py:15) whose forward also
+takes the block's residual and a ReLU flag, so a ResNet block can hand the whole
+"bn -> (+identity) -> relu" tail to one fused HIP pass.
+
+Two execution modes, chosen EXPLICITLY (no silent dispatch):
+  hip = False (default)  stock PyTorch ops: F.batch_norm, add, relu -- any device / layout / dtype;
+                         this is the PyTorch-ROCm backbone BASELINE.json:north_star describes.
+  hip = True             the hand-written HIP kernels; requires fp32 channels_last HIP tensors and
+                         raises otherwise.  Turn it on with `enable_hip_batchnorm(module)`.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+from torch.nn import functional as F
+
+from . import _capi
+
+
+class _BN2dAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool):
+        training = bn.training or not bn.track_running_stats
+        y, save, ss = _capi.bn2d_fwd(x, residual, weight, bias, bn.running_mean, bn.running_var,
+                                     bn.num_batches_tracked, training, bn.eps,
+                                     bn.momentum if bn.momentum is not None else 0.1, relu)
+        # the ReLU mask can be recomputed from x unless a residual was added before it
+        keep_y = y if (relu and residual is not None) else None
+        ctx.save_for_backward(x, save, ss, *([keep_y] if keep_y is not None else []))
+        ctx.cfg = (training, relu, residual is not None, keep_y is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        training, relu, has_res, has_y = ctx.cfg
+        x, save, ss = ctx.saved_tensors[:3]
+        y = ctx.saved_tensors[3] if has_y else None
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx, dgamma, dbeta, dres = _capi.bn2d_bwd(dy, x, y, save, ss, training, relu,
+                                                 has_res and ctx.needs_input_grad[3])
+        if has_res and dres is None and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dgamma, dbeta, dres, None, None
+
+
+class FusedBatchNormAct2d(nn.BatchNorm2d):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, **kw):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine,
+                         track_running_stats=track_running_stats, **kw)
+        self.hip = False
+        self.default_relu = False  # stem BN inside an nn.Sequential: fuse the ReLU that follows it
+
+    def forward(self, x: Tensor, residual: Optional[Tensor] = None, relu: Optional[bool] = None) -> Tensor:
+        relu = self.default_relu if relu is None else relu
+        if self.hip:
+            if not self.affine or (self.training and self.momentum is None):
+                raise _capi.PeclrHipError("fused BatchNorm2d needs affine=True and a fixed momentum")
+            return _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu)
+        y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+
+def enable_hip_batchnorm(module: nn.Module, enabled: bool = True) -> int:
+    """Switch every FusedBatchNormAct2d under `module` to the HIP kernels (or back).  The caller is
+    responsible for feeding fp32 channels_last HIP tensors; anything else raises."""
+    n = 0
+    for m in module.modules():
+        if isinstance(m, FusedBatchNormAct2d):
+            m.hip = enabled
+            n += 1
+    return n

@@ -14,6 +14,7 @@ import warnings
 from torch import nn
 
 from . import resnet as _resnet
+from .bn2d import FusedBatchNormAct2d
 from .config import Config
 
 
@@ -23,8 +24,13 @@ class ResNetModel(nn.Module):
         self.mode = mode
         resnet_name = config.model.backend_model.lower()
         model_function = self.get_resnet(resnet_name)
-        model = model_function(pretrained=config.model.pretrained, norm_layer=nn.BatchNorm2d)
-        self.features = nn.Sequential(model.conv1, model.bn1, model.relu, model.maxpool, model.layer1,
+        # FusedBatchNormAct2d IS an nn.BatchNorm2d (the reference passes norm_layer=nn.BatchNorm2d):
+        # identical parameters/buffers/state_dict; it can additionally run as one fused HIP pass
+        model = model_function(pretrained=config.model.pretrained, norm_layer=FusedBatchNormAct2d)
+        # features.2 (the stem ReLU) is fused into features.1; an Identity keeps the Sequential indices
+        # (and therefore every state_dict key) where the reference has them
+        model.bn1.default_relu = True
+        self.features = nn.Sequential(model.conv1, model.bn1, nn.Identity(), model.maxpool, model.layer1,
                                       model.layer2, model.layer3, model.layer4,
                                       nn.AdaptiveAvgPool2d(output_size=(1, 1)))
         self.final_layer = nn.Sequential(nn.Linear(model.fc.in_features, 21 * 3 + 1))

@@ -15,6 +15,8 @@ from typing import List, Optional, Type, Union
 import torch
 from torch import Tensor, nn
 
+from .bn2d import FusedBatchNormAct2d
+
 
 def conv3x3(cin, cout, stride=1):
     return nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False)
@@ -22,6 +24,17 @@ def conv3x3(cin, cout, stride=1):
 
 def conv1x1(cin, cout, stride=1):
     return nn.Conv2d(cin, cout, 1, stride=stride, bias=False)
+
+
+def _bn(bn, x, residual=None, relu=False):
+    """bn -> (+residual) -> (relu): one fused HIP pass when `bn` is a FusedBatchNormAct2d, the stock
+    three ops otherwise (any other norm_layer)."""
+    if isinstance(bn, FusedBatchNormAct2d):
+        return bn(x, residual, relu)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return torch.relu(y) if relu else y
 
 
 class BasicBlock(nn.Module):
@@ -38,12 +51,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x: Tensor) -> Tensor:
-        identity = x
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        if self.downsample is not None:
-            identity = self.downsample(x)
-        return self.relu(out + identity)
+        identity = x if self.downsample is None else self.downsample(x)
+        out = _bn(self.bn1, self.conv1(x), relu=True)
+        return _bn(self.bn2, self.conv2(out), identity, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -62,20 +72,17 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x: Tensor) -> Tensor:
-        identity = x
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        if self.downsample is not None:
-            identity = self.downsample(x)
-        return self.relu(out + identity)
+        identity = x if self.downsample is None else self.downsample(x)
+        out = _bn(self.bn1, self.conv1(x), relu=True)
+        out = _bn(self.bn2, self.conv2(out), relu=True)
+        return _bn(self.bn3, self.conv3(out), identity, relu=True)
 
 
 class ResNet(nn.Module):
     def __init__(self, block: Type[Union[BasicBlock, Bottleneck]], layers: List[int], num_classes: int = 1000,
                  norm_layer=None):
         super().__init__()
-        norm_layer = norm_layer or nn.BatchNorm2d
+        norm_layer = norm_layer or FusedBatchNormAct2d  # an nn.BatchNorm2d (same state_dict) that can fuse
         self._norm_layer = norm_layer
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
@@ -106,7 +113,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x: Tensor) -> Tensor:
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(_bn(self.bn1, self.conv1(x), relu=True))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 

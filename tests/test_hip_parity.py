@@ -405,3 +405,96 @@ def test_product_has_no_cpu_path(capi):
     z = torch.nn.functional.normalize(torch.randn(8, 128))
     with pytest.raises(capi.PeclrHipError, match="no CPU path|device tensor"):
         ops.ntxent(z, 4)
+
+
+# ------------------------------------------------------------------ backbone glue: fused BN2d (+add) (+ReLU)
+@pytest.mark.parametrize("shape", [(4, 64, 8, 8), (2, 256, 5, 7), (3, 2048, 2, 2), (8, 512, 4, 4), (2, 128, 3, 3),
+                                   (16, 64, 56, 56), (5, 1024, 1, 1)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True), (False, True)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn2d_fused_matches_torch(shape, relu, res, training):
+    """Reference = torch's own BatchNorm2d / add / relu in float64 on the CPU (what the reference's
+    torchvision blocks execute)."""
+    from peclr_amd.bn2d import FusedBatchNormAct2d
+
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h)
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.7)
+    r = torch.randn(shape, generator=g) if res else None
+    dy = torch.randn(shape, generator=g)
+    bn = FusedBatchNormAct2d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g)
+        bn.bias.uniform_(-0.3, 0.3, generator=g)
+        bn.running_mean.uniform_(-0.2, 0.2, generator=g)
+        bn.running_var.uniform_(0.8, 1.2, generator=g)
+    ref = torch.nn.BatchNorm2d(c).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    bn.train(training)
+    ref.train(training)
+    xr = x.double().requires_grad_()
+    rr = r.double().requires_grad_() if res else None
+    yr = ref(xr)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy.double())
+
+    bn = bn.to(DEV)
+    bn.hip = True
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    rd = r.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_() if res else None
+    yd = bn(xd, rd, relu)
+    assert yd.is_contiguous(memory_format=torch.channels_last)
+    yd.backward(dy.to(DEV).contiguous(memory_format=torch.channels_last))
+    np.testing.assert_allclose(host(yd), yr.detach().numpy(), atol=2e-5)
+    scale = max(1.0, float(xr.grad.abs().max()))
+    np.testing.assert_allclose(host(xd.grad), xr.grad.numpy(), atol=3e-5 * scale)
+    if res:
+        np.testing.assert_allclose(host(rd.grad), rr.grad.numpy(), atol=1e-6)
+    gs = max(1.0, float(ref.weight.grad.abs().max()))
+    np.testing.assert_allclose(host(bn.weight.grad), ref.weight.grad.numpy(), atol=1e-4 * gs, rtol=1e-5)
+    np.testing.assert_allclose(host(bn.bias.grad), ref.bias.grad.numpy(), atol=1e-4 * gs, rtol=1e-5)
+    np.testing.assert_allclose(host(bn.running_mean), ref.running_mean.numpy(), atol=1e-5)
+    np.testing.assert_allclose(host(bn.running_var), ref.running_var.numpy(), atol=1e-5)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+def test_bn2d_fused_large_mean_is_stable_and_rejects_bad_input():
+    from peclr_amd import _capi
+    from peclr_amd.bn2d import FusedBatchNormAct2d
+
+    x = torch.randn(8, 64, 16, 16) * 0.05 + 30.0          # |mean| >> std: E[x^2]-mean^2 would cancel
+    bn = FusedBatchNormAct2d(64).to(DEV).train()
+    bn.hip = True
+    y = bn(x.to(DEV).contiguous(memory_format=torch.channels_last))
+    ref = torch.nn.functional.batch_norm(x.double(), None, None, None, None, True)
+    np.testing.assert_allclose(host(y), ref.numpy(), atol=2e-3)   # fp32 input quantisation at x ~ 30
+    with pytest.raises(_capi.PeclrHipError, match="channels_last"):
+        bn(torch.randn(2, 64, 4, 4, device=DEV))                   # NCHW: no silent fallback
+    with pytest.raises(_capi.PeclrHipError, match="HIP device"):
+        bn(torch.randn(2, 64, 4, 4))
+
+
+def test_resnet_fused_bn_equals_stock_on_gpu():
+    """Whole ResNet-18 encoder, NHWC fp32: HIP BN/add/ReLU glue vs PyTorch's stock ops."""
+    import copy
+
+    from peclr_amd import resnet
+    from peclr_amd.bn2d import enable_hip_batchnorm
+
+    torch.manual_seed(0)
+    stock = resnet.resnet18().to(DEV).to(memory_format=torch.channels_last).train()
+    fused = copy.deepcopy(stock)
+    assert enable_hip_batchnorm(fused) == 20
+    x = torch.randn(8, 3, 64, 64, device=DEV).contiguous(memory_format=torch.channels_last)
+    ys, yf = stock(x), fused(x)
+    np.testing.assert_allclose(host(yf), host(ys), atol=2e-4, rtol=1e-4)
+    ys.square().mean().backward()
+    yf.square().mean().backward()
+    for (n, ps), (_, pf) in zip(stock.named_parameters(), fused.named_parameters()):
+        scale = max(1e-3, float(ps.grad.abs().max()))
+        assert float((ps.grad - pf.grad).abs().max()) <= 2e-3 * scale, n
+    for (n, bs), (_, bf) in zip(stock.named_buffers(), fused.named_buffers()):
+        np.testing.assert_allclose(host(bf.float()), host(bs.float()), atol=1e-4, rtol=1e-4, err_msg=n)
