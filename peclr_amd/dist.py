@@ -79,7 +79,9 @@ class _Bucket:
         self.flat = torch.zeros(numel, device=params[0].device, dtype=params[0].dtype)
         self.views, o = [], 0
         for p in params:
-            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            # same sizes AND strides as the parameter (dense NCHW or channels_last): autograd's
+            # gradient-layout contract, and what the fused optimiser walks raw storage with
+            self.views.append(self.flat[o:o + p.numel()].as_strided(p.size(), p.stride()))
             o += pad(p.numel())
         self.pending = len(params)
         self.handle = None

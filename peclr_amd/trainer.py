@@ -21,7 +21,7 @@ from .port import save_checkpoint
 class Trainer:
     def __init__(self, max_epochs: int = 1, accumulate_grad_batches: int = 1, precision: str = "fp32",
                  checkpoint_dir: Optional[str] = None, save_top_k: int = 1, process_group=None,
-                 bucket_bytes: int = 64 << 20, channels_last: bool = False):
+                 bucket_bytes: int = 64 << 20, channels_last: bool = False, grad_buckets=None):
         self.max_epochs = max_epochs
         self.accumulate_grad_batches = accumulate_grad_batches
         self.precision = precision
@@ -30,6 +30,7 @@ class Trainer:
         self.process_group = process_group
         self.bucket_bytes = bucket_bytes
         self.channels_last = channels_last
+        self.grad_buckets = grad_buckets  # None: only when world_size > 1; True: always (flat grad buffers)
         self.world_size = pdist.world_size(process_group)
         self.global_step = 0
         self.current_epoch = 0
@@ -43,7 +44,7 @@ class Trainer:
         model.setup("fit")
         pdist.broadcast_module_state(model, 0, self.process_group)
         self.model = model
-        if self.world_size > 1:
+        if self.world_size > 1 or self.grad_buckets:
             self.reducer = pdist.GradReducer(model.parameters(), self.process_group, self.bucket_bytes)
         (self.optimizer,), (sched,) = model.configure_optimizers()
         self.scheduler = sched["scheduler"]

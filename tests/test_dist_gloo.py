@@ -33,11 +33,12 @@ class Encoder(torch.nn.Module):
 
     def __init__(self):
         super().__init__()
+        self.conv = torch.nn.Conv2d(3, 3, 3, padding=1).to(memory_format=torch.channels_last)  # NHWC weight
         self.lin = torch.nn.Linear(3 * 4 * 4, DIN)
         self.final_layer = torch.nn.Linear(DIN, 4)  # never used: like encoder.final_layer
 
     def forward(self, x):
-        return torch.tanh(self.lin(x.flatten(1)))
+        return torch.tanh(self.lin(self.conv(x).flatten(1)))
 
 
 def make_model(bn_eval):
@@ -94,6 +95,10 @@ def worker(rank, world, port, out_dir):
     out = model.training_step(batch, 0)
     out["loss"].backward()
     tr.reducer.finish()
+    for p in model.parameters():  # grads live in the flat buckets with the PARAMETER's strides
+        assert p.grad.stride() == p.stride() and p.grad.untyped_storage().data_ptr() in {
+            b.flat.untyped_storage().data_ptr() for b in tr.reducer.buckets}
+    assert model.encoder.conv.weight.is_contiguous(memory_format=torch.channels_last)
     grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
     torch.save({"loss": out["loss"].detach(), "grads": grads,
                 "stats": {k: v for k, v in out.items() if k != "loss"}}, os.path.join(out_dir, f"r{rank}.pt"))
