@@ -130,19 +130,12 @@ def kernel_table(event_log, m_rows, m_global, din, hid, n_params):
         ms = [r[0].elapsed_time(r[1]) for r in recs]
         if not ms:
             continue
-        per_step = False
         avg_us = 1e3 * sum(ms) / len(ms)
         if name in work:
             bound, flops, nbytes = work[name]
         else:  # shape-dependent launches (bn2d_*): the wrapper recorded each launch's algorithmic work
             bound, flops, nbytes = "hbm", 0, sum(r[2] for r in recs) / len(recs)
         entry = {"bound": bound, "launches": len(ms), "avg_us": round(avg_us, 3), "bytes": nbytes, "flops": flops}
-        if per_step:
-            groups = 2
-            entry["avg_us"] = round(avg_us * groups, 3)
-            entry["launches"] = len(ms) // groups
-            entry["note"] = "per optimiser step (sum over the 2 parameter groups)"
-            avg_us *= groups
         if bound == "hbm":
             ach = nbytes / (avg_us * 1e-6) / 1e9
             entry.update(achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5))

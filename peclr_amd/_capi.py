@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_void_p
 from typing import Optional
 
 import torch  # must be imported BEFORE the CDLL: the .so binds to torch's libamdhip64.so.7

@@ -106,9 +106,9 @@ __global__ __launch_bounds__(T) void bn2d_stats_kernel(const float* __restrict__
     }
 }
 
-// Finalize kernels: a workgroup owns 32 channels; its 8 row lanes each combine every 8th row-slice
-// partial in float64 (coalesced 128-byte reads), then lane 0 adds the 8 lane sums in a fixed order.
-constexpr int FC = 32, FL = T / FC;
+// Finalize kernels: a 1024-thread workgroup owns 32 channels; its 32 row lanes each combine every 32nd row-slice
+// partial in float64 (coalesced 128-byte reads), then lane 0 adds the 32 lane sums in a fixed order.
+constexpr int FT = 1024, FC = 32, FL = FT / FC;
 __device__ __forceinline__ void combine_partials(const float* __restrict__ partial, int n_split, int C, int c, int lane,
                                                  double (*red)[2][FC], double& a, double& b) {
     double s = 0.0, q = 0.0;
@@ -138,7 +138,7 @@ __device__ __forceinline__ void combine_partials(const float* __restrict__ parti
         }
 }
 
-__global__ __launch_bounds__(T) void bn2d_stats_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial,
+__global__ __launch_bounds__(FT) void bn2d_stats_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial,
                                                                 int n_split, int R, int C, float eps, float momentum,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* running_mean, float* running_var, int64_t* nbt,
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(T) void bn2d_bwd_reduce_kernel(const float* __restr
 // dbeta, dgamma, and the two per-channel coefficients of the dx pass:
 //   training: dx = k1*dy' + (k2 + k3*xhat)  with k1 = gamma*invstd, k2 = -k1*dbeta/R, k3 = -k1*dgamma/R
 //   eval    : dx = k1*dy'
-__global__ __launch_bounds__(T) void bn2d_bwd_finalize_kernel(const float* __restrict__ partial, int n_split, int R, int C,
+__global__ __launch_bounds__(FT) void bn2d_bwd_finalize_kernel(const float* __restrict__ partial, int n_split, int R, int C,
                                                               int training, const float* __restrict__ scale_shift,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef) {
@@ -384,7 +384,7 @@ extern "C" int peclr_bn2d_finalize_f32(const float* x, const float* partial, int
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (training) {
         if (!x || !partial || n_split < 1) return PECLR_ERR_NULL;
-        hipLaunchKernelGGL(bn2d_stats_finalize_kernel, dim3((C + FC - 1) / FC), dim3(T), 0, s, x, partial, n_split, R, C, eps,
+        hipLaunchKernelGGL(bn2d_stats_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FT), 0, s, x, partial, n_split, R, C, eps,
                            momentum, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd,
                            scale_shift);
     } else {
@@ -432,7 +432,7 @@ extern "C" int peclr_bn2d_bwd_finalize_f32(const float* partial, int n_split, in
                                            peclr_stream_t stream) {
     if (!partial || !scale_shift || !dgamma || !dbeta || !coef) return PECLR_ERR_NULL;
     if (n_split < 1 || R <= 0 || C <= 0) return PECLR_ERR_SHAPE;
-    hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(T), 0, static_cast<hipStream_t>(stream), partial,
+    hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FT), 0, static_cast<hipStream_t>(stream), partial,
                        n_split, R, C, training, scale_shift, dgamma, dbeta, coef);
     return launch_status();
 }

@@ -5,8 +5,9 @@ LinearWarmupCosineAnnealingLR (pl_bolts==0.2.2; not vendored, not installed here
 restated from its published behaviour, see oracle/peclr_oracle.py:lars_adam_step).
 
   LARSAdam                       torch.optim.Optimizer with LARSWrapper(Adam) semantics.
-      fused=True  (HIP tensors): ONE fused multi-tensor HIP launch pair per parameter group
-                                 (peclr_lars_adam_step_f32) -- no per-tensor norms, no host syncs.
+      fused=True  (HIP tensors): ONE fused multi-tensor HIP launch pair per optimiser step for all
+                                 parameter groups (peclr_lars_sumsq_f32 + peclr_lars_adam_update_f32)
+                                 -- no per-tensor norm launches, no host syncs.
       fused=False                the same update written with torch foreach ops (any device); used for
                                  CPU runs and as the comparison arm in tests.
   LARSWrapper(optimizer)         the reference's spelling: wraps an Adam built by the caller.
