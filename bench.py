@@ -62,8 +62,8 @@ def parse():
                          "are NHWC-native, NCHW costs ~11%% of the step in layout transposes "
                          "(profiles/r01a vs r01b)")
     ap.add_argument("--fused-bn", type=int, default=1,
-                    help="backbone BatchNorm2d/add/ReLU glue on the hand-written NHWC kernels (needs fp32 + "
-                         "--channels-last 1); 0 = stock PyTorch/MIOpen ops")
+                    help="backbone BatchNorm2d/add/ReLU glue on the hand-written NHWC kernels (needs "
+                         "--channels-last 1; fp32 or bf16 activations); 0 = stock PyTorch/MIOpen ops")
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--miopen-find", type=int, default=0,
                     help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find; tens of minutes of kernel "
@@ -222,7 +222,7 @@ def main():
     model = build_model(args, device, args.pairs)
     if args.channels_last:
         model.encoder = model.encoder.to(memory_format=torch.channels_last)
-    fused_bn = bool(args.fused_bn and args.channels_last and args.dtype == "fp32")
+    fused_bn = bool(args.fused_bn and args.channels_last)
     if fused_bn:
         from peclr_amd.bn2d import enable_hip_batchnorm
 

@@ -183,36 +183,41 @@ int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* sizes, int n_t
  * Replaces nn.BatchNorm2d + `out += identity` + nn.ReLU between the convolutions of the
  * torchvision ResNet blocks the reference builds (resnet_model.py:15, norm_layer=nn.BatchNorm2d).
  * Activations are NHWC (torch.channels_last): x, residual, y, dy, dx, d_residual are row-major
- * [R = N*H*W][C] with C % 4 == 0 and C/4 either <= 256 and a divisor of 256, or a multiple of 256
- * (every ResNet width).  One entry point = one launch:
- *   forward (training): peclr_bn2d_stats_f32 -> peclr_bn2d_finalize_f32 -> peclr_bn2d_apply_f32
- *   forward (eval)    :                          peclr_bn2d_finalize_f32 -> peclr_bn2d_apply_f32
- *   backward          : peclr_bn2d_bwd_reduce_f32 -> peclr_bn2d_bwd_finalize_f32 -> peclr_bn2d_bwd_apply_f32
- * partial: [n_split][2][C] row-slice partial sums (n_split from peclr_bn2d_n_split or any >= 1);
+ * [R = N*H*W][C] of io_dtype (PECLR_DTYPE_F32, or PECLR_DTYPE_BF16 for autocast backbones);
+ * statistics, parameters and arithmetic are fp32.  With W = 4 (fp32) / 8 (bf16) channels per
+ * 16-byte word, C/W must divide 256 or be a multiple of it (every ResNet width).
+ * One entry point = one launch:
+ *   forward (training): peclr_bn2d_stats -> peclr_bn2d_finalize_f32 -> peclr_bn2d_apply
+ *   forward (eval)    :                     peclr_bn2d_finalize_f32 -> peclr_bn2d_apply
+ *   backward          : peclr_bn2d_bwd_reduce -> peclr_bn2d_bwd_finalize_f32 -> peclr_bn2d_bwd_apply
+ * partial (forward): [n_split*2 + 1][C] floats = row-slice partial sums + one row holding the
+ * shift; partial (backward): [n_split*2][C].  n_split from peclr_bn2d_n_split, or any >= 1.
  * scale_shift: [2][C] = {gamma*invstd, beta - mean*gamma*invstd}; coef: [2][C] scratch for dx.
  * y (nullable in the backward): pass the forward output when a residual was added (the ReLU mask
  * cannot be recomputed from x alone); d_residual (nullable) receives the masked dy.          */
-int peclr_bn2d_n_split(int R, int C);
-int peclr_bn2d_stats_f32(const float* x, int R, int C, float* partial, int n_split,
-                         peclr_stream_t stream);
-int peclr_bn2d_finalize_f32(const float* x, const float* partial, int n_split, int R, int C,
-                            int training, float eps, float momentum, const float* gamma,
-                            const float* beta, float* running_mean, float* running_var,
+#define PECLR_DTYPE_F32 0
+#define PECLR_DTYPE_BF16 1
+int peclr_bn2d_n_split(int R, int C, int io_dtype);
+int peclr_bn2d_stats(const void* x, int io_dtype, int R, int C, float* partial, int n_split,
+                     peclr_stream_t stream);
+int peclr_bn2d_finalize_f32(const float* partial, int n_split, int R, int C, int training,
+                            float eps, float momentum, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var,
                             int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
                             float* scale_shift, peclr_stream_t stream);
-int peclr_bn2d_apply_f32(const float* x, const float* residual, int R, int C,
-                         const float* scale_shift, int relu, float* y, peclr_stream_t stream);
-int peclr_bn2d_bwd_reduce_f32(const float* dy, const float* x, const float* y, int R, int C,
-                              int relu, const float* save_mean, const float* save_invstd,
-                              const float* scale_shift, float* partial, int n_split,
-                              peclr_stream_t stream);
+int peclr_bn2d_apply(const void* x, const void* residual, int io_dtype, int R, int C,
+                     const float* scale_shift, int relu, void* y, peclr_stream_t stream);
+int peclr_bn2d_bwd_reduce(const void* dy, const void* x, const void* y, int io_dtype, int R, int C,
+                          int relu, const float* save_mean, const float* save_invstd,
+                          const float* scale_shift, float* partial, int n_split,
+                          peclr_stream_t stream);
 int peclr_bn2d_bwd_finalize_f32(const float* partial, int n_split, int R, int C, int training,
                                 const float* scale_shift, float* dgamma, float* dbeta,
                                 float* coef, peclr_stream_t stream);
-int peclr_bn2d_bwd_apply_f32(const float* dy, const float* x, const float* y, int R, int C,
-                             int relu, const float* save_mean, const float* save_invstd,
-                             const float* scale_shift, const float* coef, float* dx,
-                             float* d_residual, peclr_stream_t stream);
+int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y, int io_dtype, int R, int C,
+                         int relu, const float* save_mean, const float* save_invstd,
+                         const float* scale_shift, const float* coef, void* dx,
+                         void* d_residual, peclr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -40,14 +40,14 @@ SIGNATURES = {
     "peclr_ntxent_finalize_f32": (c_int, [_P, c_int, _P, c_int, c_float, _P, _P, c_int, _P, _P]),
     "peclr_ntxent_bwd_f32": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, c_float, _P, _P, c_float, _P,
                                      c_int, _P]),
-    "peclr_bn2d_n_split": (c_int, [c_int, c_int]),
-    "peclr_bn2d_stats_f32": (c_int, [_P, c_int, c_int, _P, c_int, _P]),
-    "peclr_bn2d_finalize_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P,
-                                        _P, _P, _P, _P]),
-    "peclr_bn2d_apply_f32": (c_int, [_P, _P, c_int, c_int, _P, c_int, _P, _P]),
-    "peclr_bn2d_bwd_reduce_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "peclr_bn2d_n_split": (c_int, [c_int, c_int, c_int]),
+    "peclr_bn2d_stats": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
+    "peclr_bn2d_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P,
+                                        _P, _P, _P]),
+    "peclr_bn2d_apply": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P]),
+    "peclr_bn2d_bwd_reduce": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "peclr_bn2d_bwd_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
-    "peclr_bn2d_bwd_apply_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "peclr_bn2d_bwd_apply": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
@@ -301,18 +301,22 @@ def lars_adam_step(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_ch
 
 
 # ------------------------------------------------------------------ backbone glue: BN2d (+add) (+ReLU), NHWC
-def _nhwc_ptr(t: torch.Tensor, what: str):
+DTYPE_F32, DTYPE_BF16 = 0, 1
+_IO = {torch.float32: (DTYPE_F32, 4), torch.bfloat16: (DTYPE_BF16, 2)}
+
+
+def _nhwc_ptr(t: torch.Tensor, what: str, dtype=None):
     if not t.is_cuda:
         raise PeclrHipError(f"{what}: expected a HIP device tensor (peclr_amd has no CPU path)")
-    if t.dtype != torch.float32 or t.dim() != 4:
-        raise PeclrHipError(f"{what}: expected a 4-D fp32 tensor, got {t.dtype} {tuple(t.shape)}")
+    if t.dtype not in _IO or t.dim() != 4 or (dtype is not None and t.dtype != dtype):
+        raise PeclrHipError(f"{what}: expected a 4-D {dtype or 'fp32/bf16'} tensor, got {t.dtype} {tuple(t.shape)}")
     if not t.is_contiguous(memory_format=torch.channels_last):
         raise PeclrHipError(f"{what}: tensor must be channels_last (NHWC) contiguous")
     return t.data_ptr()
 
 
-def bn2d_n_split(r: int, c: int) -> int:
-    n = lib().peclr_bn2d_n_split(r, c)
+def bn2d_n_split(r: int, c: int, io: int) -> int:
+    n = lib().peclr_bn2d_n_split(r, c, io)
     if n < 1:
         raise PeclrHipError(f"fused BatchNorm2d: unsupported shape R={r} C={c} (C must be a ResNet width)")
     return n
@@ -322,28 +326,29 @@ def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training,
     n, c, h, w = x.shape
     r = n * h * w
     dev = x.device
+    xp = _nhwc_ptr(x, "bn2d x")
+    io, e = _IO[x.dtype]
     y = torch.empty_like(x, memory_format=torch.channels_last)
     save = torch.empty((2, c), device=dev, dtype=torch.float32)
     ss = torch.empty((2, c), device=dev, dtype=torch.float32)
-    xp = _nhwc_ptr(x, "bn2d x")
     part_ptr, ns = None, 0
     if training:
-        ns = bn2d_n_split(r, c)
-        partial = torch.empty((ns, 2, c), device=dev, dtype=torch.float32)
+        ns = bn2d_n_split(r, c, io)
+        partial = torch.empty((2 * ns + 1, c), device=dev, dtype=torch.float32)
         part_ptr = partial.data_ptr()
-        with _timed("bn2d_stats", 4 * r * c):
-            rc = lib().peclr_bn2d_stats_f32(xp, r, c, part_ptr, ns, _stream())
-        _check(rc, "peclr_bn2d_stats_f32")
+        with _timed("bn2d_stats", e * r * c):
+            rc = lib().peclr_bn2d_stats(xp, io, r, c, part_ptr, ns, _stream())
+        _check(rc, "peclr_bn2d_stats")
     with _timed("bn2d_finalize", 8 * ns * c):
-        rc = lib().peclr_bn2d_finalize_f32(xp, part_ptr, ns, r, c, int(training), eps, momentum, _ptr(gamma),
-                                           _ptr(beta), _ptr(running_mean), _ptr(running_var),
+        rc = lib().peclr_bn2d_finalize_f32(part_ptr, ns, r, c, int(training), eps, momentum, _ptr(gamma), _ptr(beta),
+                                           _ptr(running_mean), _ptr(running_var),
                                            _ptr(nbt, torch.int64, "num_batches_tracked") if training else None,
                                            save[0].data_ptr(), save[1].data_ptr(), ss.data_ptr(), _stream())
     _check(rc, "peclr_bn2d_finalize_f32")
-    with _timed("bn2d_apply", (12 if residual is not None else 8) * r * c):
-        rc = lib().peclr_bn2d_apply_f32(xp, _nhwc_ptr(residual, "bn2d residual") if residual is not None else None,
-                                        r, c, ss.data_ptr(), int(relu), y.data_ptr(), _stream())
-    _check(rc, "peclr_bn2d_apply_f32")
+    with _timed("bn2d_apply", (3 if residual is not None else 2) * e * r * c):
+        rc = lib().peclr_bn2d_apply(xp, _nhwc_ptr(residual, "bn2d residual", x.dtype) if residual is not None else None,
+                                    io, r, c, ss.data_ptr(), int(relu), y.data_ptr(), _stream())
+    _check(rc, "peclr_bn2d_apply")
     return y, save, ss
 
 
@@ -351,26 +356,27 @@ def bn2d_bwd(dy, x, y, save, ss, training, relu, want_dres):
     n, c, h, w = x.shape
     r = n * h * w
     dev = x.device
-    ns = bn2d_n_split(r, c)
-    partial = torch.empty((ns, 2, c), device=dev, dtype=torch.float32)
+    io, e = _IO[x.dtype]
+    ns = bn2d_n_split(r, c, io)
+    partial = torch.empty((2 * ns, c), device=dev, dtype=torch.float32)
     dparams = torch.empty((2, c), device=dev, dtype=torch.float32)  # dgamma, dbeta
     coef = torch.empty((2, c), device=dev, dtype=torch.float32)
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     dres = torch.empty_like(x, memory_format=torch.channels_last) if want_dres else None
-    dyp, xp = _nhwc_ptr(dy, "bn2d dy"), _nhwc_ptr(x, "bn2d x")
-    yp = _nhwc_ptr(y, "bn2d y") if y is not None else None
-    with _timed("bn2d_bwd_reduce", (12 if y is not None else 8) * r * c):
-        rc = lib().peclr_bn2d_bwd_reduce_f32(dyp, xp, yp, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
-                                             ss.data_ptr(), partial.data_ptr(), ns, _stream())
-    _check(rc, "peclr_bn2d_bwd_reduce_f32")
+    dyp, xp = _nhwc_ptr(dy, "bn2d dy", x.dtype), _nhwc_ptr(x, "bn2d x")
+    yp = _nhwc_ptr(y, "bn2d y", x.dtype) if y is not None else None
+    with _timed("bn2d_bwd_reduce", (3 if y is not None else 2) * e * r * c):
+        rc = lib().peclr_bn2d_bwd_reduce(dyp, xp, yp, io, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
+                                         ss.data_ptr(), partial.data_ptr(), ns, _stream())
+    _check(rc, "peclr_bn2d_bwd_reduce")
     with _timed("bn2d_bwd_finalize", 8 * ns * c):
         rc = lib().peclr_bn2d_bwd_finalize_f32(partial.data_ptr(), ns, r, c, int(training), ss.data_ptr(),
                                                dparams[0].data_ptr(), dparams[1].data_ptr(), coef.data_ptr(),
                                                _stream())
     _check(rc, "peclr_bn2d_bwd_finalize_f32")
-    with _timed("bn2d_bwd_apply", (12 + (4 if y is not None else 0) + (4 if want_dres else 0)) * r * c):
-        rc = lib().peclr_bn2d_bwd_apply_f32(dyp, xp, yp, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
-                                            ss.data_ptr(), coef.data_ptr(), dx.data_ptr(),
-                                            dres.data_ptr() if dres is not None else None, _stream())
-    _check(rc, "peclr_bn2d_bwd_apply_f32")
+    with _timed("bn2d_bwd_apply", (3 + (1 if y is not None else 0) + (1 if want_dres else 0)) * e * r * c):
+        rc = lib().peclr_bn2d_bwd_apply(dyp, xp, yp, io, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
+                                        ss.data_ptr(), coef.data_ptr(), dx.data_ptr(),
+                                        dres.data_ptr() if dres is not None else None, _stream())
+    _check(rc, "peclr_bn2d_bwd_apply")
     return dx, dparams[0], dparams[1], dres

@@ -8,8 +8,8 @@ takes the block's residual and a ReLU flag, so a ResNet block can hand the whole
 Two execution modes, chosen EXPLICITLY (no silent dispatch):
   hip = False (default)  stock PyTorch ops: F.batch_norm, add, relu -- any device / layout / dtype;
                          this is the PyTorch-ROCm backbone BASELINE.json:north_star describes.
-  hip = True             the hand-written HIP kernels; requires fp32 channels_last HIP tensors and
-                         raises otherwise.  Turn it on with `enable_hip_batchnorm(module)`.
+  hip = True             the hand-written HIP kernels; requires fp32 or bf16 (autocast) channels_last
+                         HIP tensors and raises otherwise.  Turn it on with `enable_hip_batchnorm`.
 """
 from __future__ import annotations
 
@@ -40,7 +40,7 @@ class _BN2dAct(torch.autograd.Function):
         training, relu, has_res, has_y = ctx.cfg
         x, save, ss = ctx.saved_tensors[:3]
         y = ctx.saved_tensors[3] if has_y else None
-        dy = dy.contiguous(memory_format=torch.channels_last)
+        dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         dx, dgamma, dbeta, dres = _capi.bn2d_bwd(dy, x, y, save, ss, training, relu,
                                                  has_res and ctx.needs_input_grad[3])
         if has_res and dres is None and ctx.needs_input_grad[3]:

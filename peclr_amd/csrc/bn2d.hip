@@ -1,4 +1,5 @@
-// Fused BatchNorm2d (+ residual add) (+ ReLU) for the NHWC ResNet backbone, forward and backward.
+// Fused BatchNorm2d (+ residual add) (+ ReLU) for the NHWC ResNet backbone, forward and backward,
+// fp32 or bf16 activations (statistics, parameters and all arithmetic in fp32).
 //
 // Scope: SURVEY.md section 8f rank 4 ("fused ... backbone epilogue").  The convolutions stay on
 // PyTorch-ROCm/MIOpen; what moves here is everything BETWEEN them: nn.BatchNorm2d (train/eval),
@@ -9,10 +10,10 @@
 //
 // Layout: activations are NHWC (torch.channels_last), i.e. a row-major [R = N*H*W, C] matrix with
 // the channel contiguous, so a channel is a COLUMN: the same "column statistics over rows" shape as
-// the head's BatchNorm1d.  Threads own one float4 of 4 channels for the whole kernel
-// (tid -> (row lane, column group) with the column group fastest, so consecutive lanes read
-// consecutive 16-byte words: every wave-instruction is a 1 KiB contiguous burst) and walk rows with
-// 8 independent loads in flight.
+// the head's BatchNorm1d.  A thread owns one 16-byte word of channels (4 fp32 / 8 bf16) for the whole
+// kernel (tid -> (row lane, column group) with the column group fastest, so consecutive lanes read
+// consecutive 16-byte words: every wave-instruction is a 1 KiB contiguous burst) and walks rows with
+// U independent loads per stream in flight.
 //
 //   forward  = stats (partial sum / sum-of-squares per row slice, shifted by row 0 to avoid
 //              cancellation)  ->  finalize (fixed-order combine in float64, running stats)
@@ -20,94 +21,148 @@
 //   backward = reduce (partial dbeta, dgamma with the ReLU mask recomputed from x, or read from y
 //              when a residual was added)  ->  finalize  ->  apply: dx (and d_residual = masked dy)
 //
-// Algorithmic bytes per element (fp32): fwd 4 (stats) + 8 (apply) [+4 residual];
-// bwd 8 (reduce) + 12 (apply) [+4 y, twice, and +4 d_residual when a residual was added].
-// The stock path moves 8+12 (BN) + 8 (ReLU) + 12 (add) forward and 12 (ReLU) + 20 (BN) backward.
+// Algorithmic bytes per element (e = 4 fp32 / 2 bf16): fwd e (stats) + 2e (apply) [+e residual];
+// bwd 2e (reduce) + 3e (apply) [+e for y, twice, and +e d_residual when a residual was added].
+// The stock path moves 2e+3e (BN) + 2e (ReLU) + 3e (add) forward and 3e (ReLU) + 5e (BN) backward.
 // Everything is bit-reproducible (no atomics; fixed combine order).
+#include <initializer_list>
+
 #include "common.hpp"
 
 namespace peclr {
 namespace {
 
 constexpr int T = 256;
-constexpr int UNROLL = 8;
 
-__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
-__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
-    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+// ---- W floats held in registers + the 16-byte global word they travel as
+template <int W> struct Fv { float v[W]; };
+
+template <typename IO> struct Word;
+template <> struct Word<float> {
+    static constexpr int W = 4, U = 8;  // U = rows in flight per stream
+    static __device__ __forceinline__ Fv<4> load(const float* p) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        return {{t.x, t.y, t.z, t.w}};
+    }
+    static __device__ __forceinline__ void store(float* p, const Fv<4>& a) {
+        *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    }
+};
+typedef uint16_t bf16_t;
+template <> struct Word<bf16_t> {
+    static constexpr int W = 8, U = 4;
+    static __device__ __forceinline__ Fv<8> load(const bf16_t* p) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+        Fv<8> r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r.v[2 * k] = __uint_as_float(w[k] << 16);
+            r.v[2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u);
+        }
+        return r;
+    }
+    static __device__ __forceinline__ unsigned rne(float f) {  // fp32 -> bf16, round to nearest even
+        const unsigned u = __float_as_uint(f);
+        return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const Fv<8>& a) {
+        unsigned w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = rne(a.v[2 * k]) | (rne(a.v[2 * k + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+// per-channel fp32 parameters: W consecutive floats
+template <int W> __device__ __forceinline__ Fv<W> loadp(const float* p) {
+    Fv<W> r;
+#pragma unroll
+    for (int k = 0; k < W; k += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p + k);
+        r.v[k] = t.x; r.v[k + 1] = t.y; r.v[k + 2] = t.z; r.v[k + 3] = t.w;
+    }
+    return r;
 }
-__device__ __forceinline__ float4 relu4(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
-__device__ __forceinline__ float4 mask4(float4 y, float4 d) {
-    return make_float4(y.x > 0.f ? d.x : 0.f, y.y > 0.f ? d.y : 0.f, y.z > 0.f ? d.z : 0.f, y.w > 0.f ? d.w : 0.f);
+template <int W> __device__ __forceinline__ void storep(float* p, const Fv<W>& a) {
+#pragma unroll
+    for (int k = 0; k < W; k += 4) *reinterpret_cast<float4*>(p + k) = make_float4(a.v[k], a.v[k + 1], a.v[k + 2], a.v[k + 3]);
 }
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_stream(float* p, float4 x) {  // written once, read by a later kernel
-    *reinterpret_cast<float4*>(p) = x;
+template <int W> __device__ __forceinline__ Fv<W> zero() {
+    Fv<W> r;
+#pragma unroll
+    for (int k = 0; k < W; ++k) r.v[k] = 0.f;
+    return r;
 }
 
-// Geometry shared by every kernel: C4 = C/4 column groups; a block covers CGB = min(C4, 256) of them
+// Geometry shared by every kernel: CW = C/W column groups; a block covers CGB = min(CW, 256) of them
 // (blockIdx.x = column block) and RPP = 256/CGB rows per pass; blockIdx.y = row slice.
 struct Geo {
     int R, C, CGB, RPP, rows_per_block;
 };
+template <int W>
 __device__ __forceinline__ void thread_geo(const Geo& g, int& col, int& r_begin, int& r_end, int& rl) {
     const int cgl = threadIdx.x % g.CGB;
     rl = threadIdx.x / g.CGB;
-    col = (blockIdx.x * g.CGB + cgl) * 4;
+    col = (blockIdx.x * g.CGB + cgl) * W;
     r_begin = blockIdx.y * g.rows_per_block;
     r_end = min(g.R, r_begin + g.rows_per_block);
 }
 
 // Sum over the block's row lanes (threads with equal column group); valid in row lane 0.
-__device__ __forceinline__ float4 lane_reduce(float4 v, float4* red, const Geo& g, int rl) {
+template <int W>
+__device__ __forceinline__ Fv<W> lane_reduce(Fv<W> v, float* red, const Geo& g, int rl) {
     if (g.RPP == 1) return v;
     __syncthreads();
-    red[threadIdx.x] = v;
+#pragma unroll
+    for (int k = 0; k < W; ++k) red[k * T + threadIdx.x] = v.v[k];
     __syncthreads();
-    float4 t = f4(0.f);
+    Fv<W> t = zero<W>();
     if (rl == 0)
-        for (int k = 0; k < g.RPP; ++k) t = t + red[k * g.CGB + threadIdx.x];
+        for (int l = 0; l < g.RPP; ++l)
+#pragma unroll
+            for (int k = 0; k < W; ++k) t.v[k] += red[k * T + l * g.CGB + threadIdx.x];
     return t;
 }
 
 // ------------------------------------------------------------------ forward: statistics
-__global__ __launch_bounds__(T) void bn2d_stats_kernel(const float* __restrict__ x, Geo g, float* __restrict__ partial) {
-    __shared__ float4 red[T];
+// partial: [n_split][2][C] sums, followed by one extra row [C] = the shift (row 0 of x as fp32).
+template <typename IO>
+__global__ __launch_bounds__(T) void bn2d_stats_kernel(const IO* __restrict__ x, Geo g, int n_split, float* __restrict__ partial) {
+    constexpr int W = Word<IO>::W, U = Word<IO>::U;
+    __shared__ float red[W * T];
     int col, r0, r1, rl;
-    thread_geo(g, col, r0, r1, rl);
-    const float4 k0 = *reinterpret_cast<const float4*>(x + col);  // shift = row 0 (same for every block)
-    float4 s = f4(0.f), q = f4(0.f);
-    int r = r0 + rl;
-    for (; r + (UNROLL - 1) * g.RPP < r1; r += UNROLL * g.RPP) {
-        float4 v[UNROLL];
+    thread_geo<W>(g, col, r0, r1, rl);
+    const Fv<W> k0 = Word<IO>::load(x + col);  // shift = row 0 (same for every block)
+    Fv<W> s = zero<W>(), q = zero<W>();
+    auto acc = [&](const Fv<W>& v) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) v[u] = *reinterpret_cast<const float4*>(x + (size_t)(r + u * g.RPP) * g.C + col);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const float4 d = v[u] - k0;
-            s = s + d;
-            q = fma4(d, d, q);
+        for (int k = 0; k < W; ++k) {
+            const float d = v.v[k] - k0.v[k];
+            s.v[k] += d;
+            q.v[k] = fmaf(d, d, q.v[k]);
         }
+    };
+    int r = r0 + rl;
+    for (; r + (U - 1) * g.RPP < r1; r += U * g.RPP) {
+        Fv<W> v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = Word<IO>::load(x + (size_t)(r + u * g.RPP) * g.C + col);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc(v[u]);
     }
-    for (; r < r1; r += g.RPP) {
-        const float4 d = *reinterpret_cast<const float4*>(x + (size_t)r * g.C + col) - k0;
-        s = s + d;
-        q = fma4(d, d, q);
-    }
-    s = lane_reduce(s, red, g, rl);
-    q = lane_reduce(q, red, g, rl);
+    for (; r < r1; r += g.RPP) acc(Word<IO>::load(x + (size_t)r * g.C + col));
+    s = lane_reduce<W>(s, red, g, rl);
+    q = lane_reduce<W>(q, red, g, rl);
     if (rl == 0) {
         float* o = partial + (size_t)blockIdx.y * 2 * g.C;
-        *reinterpret_cast<float4*>(o + col) = s;
-        *reinterpret_cast<float4*>(o + g.C + col) = q;
+        storep<W>(o + col, s);
+        storep<W>(o + g.C + col, q);
+        if (blockIdx.y == 0) storep<W>(partial + (size_t)n_split * 2 * g.C + col, k0);
     }
 }
 
-// Finalize kernels: a 1024-thread workgroup owns 32 channels; its 32 row lanes each combine every 32nd row-slice
-// partial in float64 (coalesced 128-byte reads), then lane 0 adds the 32 lane sums in a fixed order.
+// Finalize kernels: a 1024-thread workgroup owns 32 channels; its 32 row lanes each combine every 32nd
+// row-slice partial in float64 (coalesced 128-byte reads), then lane 0 adds the 32 lane sums in a fixed order.
 constexpr int FT = 1024, FC = 32, FL = FT / FC;
 __device__ __forceinline__ void combine_partials(const float* __restrict__ partial, int n_split, int C, int c, int lane,
                                                  double (*red)[2][FC], double& a, double& b) {
@@ -138,19 +193,18 @@ __device__ __forceinline__ void combine_partials(const float* __restrict__ parti
         }
 }
 
-__global__ __launch_bounds__(FT) void bn2d_stats_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial,
-                                                                int n_split, int R, int C, float eps, float momentum,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                float* running_mean, float* running_var, int64_t* nbt,
-                                                                float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                                float* __restrict__ scale_shift) {
+__global__ __launch_bounds__(FT) void bn2d_stats_finalize_kernel(const float* __restrict__ partial, int n_split, int R, int C,
+                                                                 float eps, float momentum, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* running_mean,
+                                                                 float* running_var, int64_t* nbt, float* __restrict__ save_mean,
+                                                                 float* __restrict__ save_invstd, float* __restrict__ scale_shift) {
     __shared__ double red[FL][2][FC];
     const int c = blockIdx.x * FC + threadIdx.x % FC, lane = threadIdx.x / FC;
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
     double s, q;
     combine_partials(partial, n_split, C, c, lane, red, s, q);
     if (lane != 0 || c >= C) return;
-    const double k0 = (double)x[c];
+    const double k0 = (double)partial[(size_t)n_split * 2 * C + c];
     const double ms = s / R;                 // mean of (x - k0)
     double var = q / R - ms * ms;            // biased variance
     if (var < 0.0) var = 0.0;
@@ -184,84 +238,101 @@ __global__ __launch_bounds__(T) void bn2d_eval_params_kernel(int C, float eps, c
 }
 
 // ------------------------------------------------------------------ forward: apply
-template <bool RES, bool RELU>
-__global__ __launch_bounds__(T) void bn2d_apply_kernel(const float* __restrict__ x, const float* __restrict__ res, Geo g,
-                                                       const float* __restrict__ scale_shift, float* __restrict__ y) {
+template <typename IO, bool RES, bool RELU>
+__global__ __launch_bounds__(T) void bn2d_apply_kernel(const IO* __restrict__ x, const IO* __restrict__ res, Geo g,
+                                                       const float* __restrict__ scale_shift, IO* __restrict__ y) {
+    constexpr int W = Word<IO>::W, U = Word<IO>::U;
     int col, r0, r1, rl;
-    thread_geo(g, col, r0, r1, rl);
-    const float4 sc = *reinterpret_cast<const float4*>(scale_shift + col);
-    const float4 sh = *reinterpret_cast<const float4*>(scale_shift + g.C + col);
+    thread_geo<W>(g, col, r0, r1, rl);
+    const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
+    auto emit = [&](size_t o, const Fv<W>& v, const Fv<W>& w) {
+        Fv<W> t;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            float a = fmaf(v.v[k], sc.v[k], sh.v[k]);
+            if (RES) a += w.v[k];
+            t.v[k] = RELU ? fmaxf(a, 0.f) : a;
+        }
+        Word<IO>::store(y + o, t);
+    };
     int r = r0 + rl;
-    for (; r + (UNROLL - 1) * g.RPP < r1; r += UNROLL * g.RPP) {
-        float4 v[UNROLL], w[UNROLL];
+    for (; r + (U - 1) * g.RPP < r1; r += U * g.RPP) {
+        Fv<W> v[U], w[RES ? U : 1];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
+        for (int u = 0; u < U; ++u) {
             const size_t o = (size_t)(r + u * g.RPP) * g.C + col;
-            v[u] = *reinterpret_cast<const float4*>(x + o);
-            if (RES) w[u] = *reinterpret_cast<const float4*>(res + o);
+            v[u] = Word<IO>::load(x + o);
+            if (RES) w[u] = Word<IO>::load(res + o);
         }
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            float4 t = fma4(v[u], sc, sh);
-            if (RES) t = t + w[u];
-            if (RELU) t = relu4(t);
-            store_stream(y + (size_t)(r + u * g.RPP) * g.C + col, t);
-        }
+        for (int u = 0; u < U; ++u) emit((size_t)(r + u * g.RPP) * g.C + col, v[u], RES ? w[RES ? u : 0] : v[u]);
     }
     for (; r < r1; r += g.RPP) {
         const size_t o = (size_t)r * g.C + col;
-        float4 t = fma4(*reinterpret_cast<const float4*>(x + o), sc, sh);
-        if (RES) t = t + *reinterpret_cast<const float4*>(res + o);
-        if (RELU) t = relu4(t);
-        store_stream(y + o, t);
+        const Fv<W> v = Word<IO>::load(x + o);
+        emit(o, v, RES ? Word<IO>::load(res + o) : v);
     }
 }
 
-// ------------------------------------------------------------------ backward: reduce
+// ------------------------------------------------------------------ backward
 // MASK: 0 = no ReLU, 1 = ReLU mask recomputed from x (no residual), 2 = ReLU mask read from y.
-template <int MASK>
-__global__ __launch_bounds__(T) void bn2d_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                            const float* __restrict__ y, Geo g,
+template <int W, int MASK>
+__device__ __forceinline__ Fv<W> masked(const Fv<W>& d, const Fv<W>& xv, const Fv<W>& yv, const Fv<W>& sc, const Fv<W>& sh) {
+    Fv<W> r;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        bool on = true;
+        if (MASK == 1) on = fmaf(xv.v[k], sc.v[k], sh.v[k]) > 0.f;
+        if (MASK == 2) on = yv.v[k] > 0.f;
+        r.v[k] = on ? d.v[k] : 0.f;
+    }
+    return r;
+}
+
+template <typename IO, int MASK>
+__global__ __launch_bounds__(T) void bn2d_bwd_reduce_kernel(const IO* __restrict__ dy, const IO* __restrict__ x,
+                                                            const IO* __restrict__ y, Geo g,
                                                             const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                             const float* __restrict__ scale_shift, float* __restrict__ partial) {
-    __shared__ float4 red[T];
+    constexpr int W = Word<IO>::W, U = Word<IO>::U;
+    __shared__ float red[W * T];
     int col, r0, r1, rl;
-    thread_geo(g, col, r0, r1, rl);
-    const float4 mean = *reinterpret_cast<const float4*>(save_mean + col);
-    const float4 invstd = *reinterpret_cast<const float4*>(save_invstd + col);
-    const float4 sc = *reinterpret_cast<const float4*>(scale_shift + col);
-    const float4 sh = *reinterpret_cast<const float4*>(scale_shift + g.C + col);
-    float4 sb = f4(0.f), sg = f4(0.f);
-    int r = r0 + rl;
-    auto acc = [&](float4 d, float4 xv, float4 yv) {
-        if (MASK == 1) d = mask4(fma4(xv, sc, sh), d);
-        if (MASK == 2) d = mask4(yv, d);
-        sb = sb + d;
-        sg = fma4(d, (xv - mean) * invstd, sg);
-    };
-    for (; r + (UNROLL - 1) * g.RPP < r1; r += UNROLL * g.RPP) {
-        float4 d[UNROLL], xv[UNROLL], yv[UNROLL];
+    thread_geo<W>(g, col, r0, r1, rl);
+    const Fv<W> mean = loadp<W>(save_mean + col), invstd = loadp<W>(save_invstd + col);
+    const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
+    Fv<W> sb = zero<W>(), sg = zero<W>();
+    auto acc = [&](const Fv<W>& d0, const Fv<W>& xv, const Fv<W>& yv) {
+        const Fv<W> d = masked<W, MASK>(d0, xv, yv, sc, sh);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
+        for (int k = 0; k < W; ++k) {
+            sb.v[k] += d.v[k];
+            sg.v[k] = fmaf(d.v[k], (xv.v[k] - mean.v[k]) * invstd.v[k], sg.v[k]);
+        }
+    };
+    int r = r0 + rl;
+    for (; r + (U - 1) * g.RPP < r1; r += U * g.RPP) {
+        Fv<W> d[U], xv[U], yv[MASK == 2 ? U : 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             const size_t o = (size_t)(r + u * g.RPP) * g.C + col;
-            d[u] = *reinterpret_cast<const float4*>(dy + o);
-            xv[u] = *reinterpret_cast<const float4*>(x + o);
-            if (MASK == 2) yv[u] = *reinterpret_cast<const float4*>(y + o);
+            d[u] = Word<IO>::load(dy + o);
+            xv[u] = Word<IO>::load(x + o);
+            if (MASK == 2) yv[u] = Word<IO>::load(y + o);
         }
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) acc(d[u], xv[u], MASK == 2 ? yv[u] : f4(0.f));
+        for (int u = 0; u < U; ++u) acc(d[u], xv[u], MASK == 2 ? yv[MASK == 2 ? u : 0] : xv[u]);
     }
     for (; r < r1; r += g.RPP) {
         const size_t o = (size_t)r * g.C + col;
-        acc(*reinterpret_cast<const float4*>(dy + o), *reinterpret_cast<const float4*>(x + o),
-            MASK == 2 ? *reinterpret_cast<const float4*>(y + o) : f4(0.f));
+        const Fv<W> xv = Word<IO>::load(x + o);
+        acc(Word<IO>::load(dy + o), xv, MASK == 2 ? Word<IO>::load(y + o) : xv);
     }
-    sb = lane_reduce(sb, red, g, rl);
-    sg = lane_reduce(sg, red, g, rl);
+    sb = lane_reduce<W>(sb, red, g, rl);
+    sg = lane_reduce<W>(sg, red, g, rl);
     if (rl == 0) {
         float* o = partial + (size_t)blockIdx.y * 2 * g.C;
-        *reinterpret_cast<float4*>(o + col) = sb;
-        *reinterpret_cast<float4*>(o + g.C + col) = sg;
+        storep<W>(o + col, sb);
+        storep<W>(o + g.C + col, sg);
     }
 }
 
@@ -269,9 +340,9 @@ __global__ __launch_bounds__(T) void bn2d_bwd_reduce_kernel(const float* __restr
 //   training: dx = k1*dy' + (k2 + k3*xhat)  with k1 = gamma*invstd, k2 = -k1*dbeta/R, k3 = -k1*dgamma/R
 //   eval    : dx = k1*dy'
 __global__ __launch_bounds__(FT) void bn2d_bwd_finalize_kernel(const float* __restrict__ partial, int n_split, int R, int C,
-                                                              int training, const float* __restrict__ scale_shift,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ coef) {
+                                                               int training, const float* __restrict__ scale_shift,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ coef) {
     __shared__ double red[FL][2][FC];
     const int c = blockIdx.x * FC + threadIdx.x % FC, lane = threadIdx.x / FC;
     double sb, sg;
@@ -284,44 +355,46 @@ __global__ __launch_bounds__(FT) void bn2d_bwd_finalize_kernel(const float* __re
     coef[C + c] = training ? (float)(-k1 * sg / R) : 0.f;
 }
 
-template <int MASK, bool DRES>
-__global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           const float* __restrict__ y, Geo g,
+template <typename IO, int MASK, bool DRES>
+__global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict__ dy, const IO* __restrict__ x,
+                                                           const IO* __restrict__ y, Geo g,
                                                            const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                            const float* __restrict__ scale_shift, const float* __restrict__ coef,
-                                                           float* __restrict__ dx, float* __restrict__ dres) {
+                                                           IO* __restrict__ dx, IO* __restrict__ dres) {
+    constexpr int W = Word<IO>::W, U = Word<IO>::U;
     int col, r0, r1, rl;
-    thread_geo(g, col, r0, r1, rl);
-    const float4 mean = *reinterpret_cast<const float4*>(save_mean + col);
-    const float4 invstd = *reinterpret_cast<const float4*>(save_invstd + col);
-    const float4 sc = *reinterpret_cast<const float4*>(scale_shift + col);
-    const float4 sh = *reinterpret_cast<const float4*>(scale_shift + g.C + col);
-    const float4 k2 = *reinterpret_cast<const float4*>(coef + col);
-    const float4 k3 = *reinterpret_cast<const float4*>(coef + g.C + col);
-    auto emit = [&](size_t o, float4 d, float4 xv, float4 yv) {
-        if (MASK == 1) d = mask4(fma4(xv, sc, sh), d);
-        if (MASK == 2) d = mask4(yv, d);
-        if (DRES) store_stream(dres + o, d);
-        const float4 xh = (xv - mean) * invstd;
-        store_stream(dx + o, fma4(d, sc, fma4(xh, k3, k2)));
+    thread_geo<W>(g, col, r0, r1, rl);
+    const Fv<W> mean = loadp<W>(save_mean + col), invstd = loadp<W>(save_invstd + col);
+    const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
+    const Fv<W> k2 = loadp<W>(coef + col), k3 = loadp<W>(coef + g.C + col);
+    auto emit = [&](size_t o, const Fv<W>& d0, const Fv<W>& xv, const Fv<W>& yv) {
+        const Fv<W> d = masked<W, MASK>(d0, xv, yv, sc, sh);
+        if (DRES) Word<IO>::store(dres + o, d);
+        Fv<W> t;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const float xh = (xv.v[k] - mean.v[k]) * invstd.v[k];
+            t.v[k] = fmaf(d.v[k], sc.v[k], fmaf(xh, k3.v[k], k2.v[k]));
+        }
+        Word<IO>::store(dx + o, t);
     };
     int r = r0 + rl;
-    for (; r + (UNROLL - 1) * g.RPP < r1; r += UNROLL * g.RPP) {
-        float4 d[UNROLL], xv[UNROLL], yv[UNROLL];
+    for (; r + (U - 1) * g.RPP < r1; r += U * g.RPP) {
+        Fv<W> d[U], xv[U], yv[MASK == 2 ? U : 1];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
+        for (int u = 0; u < U; ++u) {
             const size_t o = (size_t)(r + u * g.RPP) * g.C + col;
-            d[u] = *reinterpret_cast<const float4*>(dy + o);
-            xv[u] = *reinterpret_cast<const float4*>(x + o);
-            if (MASK == 2) yv[u] = *reinterpret_cast<const float4*>(y + o);
+            d[u] = Word<IO>::load(dy + o);
+            xv[u] = Word<IO>::load(x + o);
+            if (MASK == 2) yv[u] = Word<IO>::load(y + o);
         }
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) emit((size_t)(r + u * g.RPP) * g.C + col, d[u], xv[u], MASK == 2 ? yv[u] : f4(0.f));
+        for (int u = 0; u < U; ++u) emit((size_t)(r + u * g.RPP) * g.C + col, d[u], xv[u], MASK == 2 ? yv[MASK == 2 ? u : 0] : xv[u]);
     }
     for (; r < r1; r += g.RPP) {
         const size_t o = (size_t)r * g.C + col;
-        emit(o, *reinterpret_cast<const float4*>(dy + o), *reinterpret_cast<const float4*>(x + o),
-             MASK == 2 ? *reinterpret_cast<const float4*>(y + o) : f4(0.f));
+        const Fv<W> xv = Word<IO>::load(x + o);
+        emit(o, Word<IO>::load(dy + o), xv, MASK == 2 ? Word<IO>::load(y + o) : xv);
     }
 }
 
@@ -331,20 +404,20 @@ struct Plan {
     dim3 grid;
     int n_split;
 };
-inline bool make_plan(int R, int C, int want_split, Plan& p) {
-    if (R <= 0 || C <= 0 || C % 4) return false;
-    const int c4 = C / 4;
-    int cgb = c4 < T ? c4 : T;
-    if (T % cgb || c4 % cgb) return false;  // C/4 must be a power-of-two-ish divisor layout (true for every ResNet width)
+inline bool make_plan(int R, int C, int W, int U, int want_split, Plan& p) {
+    if (R <= 0 || C <= 0 || C % W) return false;
+    const int cw = C / W;
+    const int cgb = cw < T ? cw : T;
+    if (T % cgb || cw % cgb) return false;  // C/W a divisor of 256 or a multiple of it (every ResNet width)
     const int rpp = T / cgb;
-    const int ncb = c4 / cgb;
+    const int ncb = cw / cgb;
     int split, rows;
     if (want_split > 0) {  // caller-fixed (partials buffer already sized): trailing blocks may be empty
         split = want_split;
         rows = ((R + split - 1) / split + rpp - 1) / rpp * rpp;
     } else {               // aim for ~1024 workgroups (4 per CU), at least one unrolled pass per block
         split = 1024 / ncb;
-        const int max_split = (R + rpp * UNROLL - 1) / (rpp * UNROLL);
+        const int max_split = (R + rpp * U - 1) / (rpp * U);
         if (split > max_split) split = max_split;
         if (split < 1) split = 1;
         rows = ((R + split - 1) / split + rpp - 1) / rpp * rpp;
@@ -355,36 +428,87 @@ inline bool make_plan(int R, int C, int want_split, Plan& p) {
     p.n_split = split;
     return true;
 }
+inline bool plan_for(int io_dtype, int R, int C, int want_split, Plan& p) {
+    if (io_dtype == PECLR_DTYPE_F32) return make_plan(R, C, Word<float>::W, Word<float>::U, want_split, p);
+    if (io_dtype == PECLR_DTYPE_BF16) return make_plan(R, C, Word<bf16_t>::W, Word<bf16_t>::U, want_split, p);
+    return false;
+}
+inline bool all_aligned(std::initializer_list<const void*> ps) {
+    for (const void* q : ps)
+        if (q && !aligned16(q)) return false;
+    return true;
+}
+
+template <typename IO>
+void launch_apply(const Plan& p, hipStream_t s, const void* x, const void* res, const float* ss, int relu, void* y) {
+    const IO* xp = static_cast<const IO*>(x);
+    const IO* rp = static_cast<const IO*>(res);
+    IO* yp = static_cast<IO*>(y);
+    if (res && relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, true, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp);
+    else if (res) hipLaunchKernelGGL((bn2d_apply_kernel<IO, true, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp);
+    else if (relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, false, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp);
+    else hipLaunchKernelGGL((bn2d_apply_kernel<IO, false, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp);
+}
+
+inline int mask_mode(int relu, const void* y) { return !relu ? 0 : (y ? 2 : 1); }
+
+template <typename IO>
+void launch_reduce(const Plan& p, hipStream_t s, int mm, const void* dy, const void* x, const void* y, const float* mean,
+                   const float* invstd, const float* ss, float* partial) {
+    const IO *d = static_cast<const IO*>(dy), *xp = static_cast<const IO*>(x), *yp = static_cast<const IO*>(y);
+    if (mm == 0) hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<IO, 0>), p.grid, dim3(T), 0, s, d, xp, yp, p.g, mean, invstd, ss, partial);
+    else if (mm == 1) hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<IO, 1>), p.grid, dim3(T), 0, s, d, xp, yp, p.g, mean, invstd, ss, partial);
+    else hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<IO, 2>), p.grid, dim3(T), 0, s, d, xp, yp, p.g, mean, invstd, ss, partial);
+}
+
+template <typename IO>
+void launch_bwd_apply(const Plan& p, hipStream_t s, int mm, const void* dy, const void* x, const void* y, const float* mean,
+                      const float* invstd, const float* ss, const float* coef, void* dx, void* dres) {
+    const IO *d = static_cast<const IO*>(dy), *xp = static_cast<const IO*>(x), *yp = static_cast<const IO*>(y);
+    IO *o = static_cast<IO*>(dx), *r = static_cast<IO*>(dres);
+#define PECLR_LAUNCH(M, D) hipLaunchKernelGGL((bn2d_bwd_apply_kernel<IO, M, D>), p.grid, dim3(T), 0, s, d, xp, yp, p.g, mean, invstd, ss, coef, o, r)
+    if (dres) {
+        if (mm == 0) PECLR_LAUNCH(0, true); else if (mm == 1) PECLR_LAUNCH(1, true); else PECLR_LAUNCH(2, true);
+    } else {
+        if (mm == 0) PECLR_LAUNCH(0, false); else if (mm == 1) PECLR_LAUNCH(1, false); else PECLR_LAUNCH(2, false);
+    }
+#undef PECLR_LAUNCH
+}
 
 }  // namespace
 }  // namespace peclr
 
 using namespace peclr;
 
-extern "C" int peclr_bn2d_n_split(int R, int C) {
+extern "C" int peclr_bn2d_n_split(int R, int C, int io_dtype) {
     Plan p;
-    return make_plan(R, C, 0, p) ? p.n_split : 0;
+    return plan_for(io_dtype, R, C, 0, p) ? p.n_split : 0;
 }
 
-extern "C" int peclr_bn2d_stats_f32(const float* x, int R, int C, float* partial, int n_split, peclr_stream_t stream) {
+extern "C" int peclr_bn2d_stats(const void* x, int io_dtype, int R, int C, float* partial, int n_split,
+                                peclr_stream_t stream) {
     if (!x || !partial) return PECLR_ERR_NULL;
     Plan p;
-    if (n_split < 1 || !make_plan(R, C, n_split, p)) return PECLR_ERR_SHAPE;
-    if (!aligned16(x) || !aligned16(partial)) return PECLR_ERR_ALIGN;
-    hipLaunchKernelGGL(bn2d_stats_kernel, p.grid, dim3(T), 0, static_cast<hipStream_t>(stream), x, p.g, partial);
+    if (n_split < 1 || !plan_for(io_dtype, R, C, n_split, p)) return PECLR_ERR_SHAPE;
+    if (!all_aligned({x, partial})) return PECLR_ERR_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (io_dtype == PECLR_DTYPE_F32)
+        hipLaunchKernelGGL((bn2d_stats_kernel<float>), p.grid, dim3(T), 0, s, static_cast<const float*>(x), p.g, n_split, partial);
+    else
+        hipLaunchKernelGGL((bn2d_stats_kernel<bf16_t>), p.grid, dim3(T), 0, s, static_cast<const bf16_t*>(x), p.g, n_split, partial);
     return launch_status();
 }
 
-extern "C" int peclr_bn2d_finalize_f32(const float* x, const float* partial, int n_split, int R, int C, int training,
-                                       float eps, float momentum, const float* gamma, const float* beta,
-                                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                       float* save_mean, float* save_invstd, float* scale_shift, peclr_stream_t stream) {
+extern "C" int peclr_bn2d_finalize_f32(const float* partial, int n_split, int R, int C, int training, float eps,
+                                       float momentum, const float* gamma, const float* beta, float* running_mean,
+                                       float* running_var, int64_t* num_batches_tracked, float* save_mean,
+                                       float* save_invstd, float* scale_shift, peclr_stream_t stream) {
     if (!gamma || !beta || !save_mean || !save_invstd || !scale_shift) return PECLR_ERR_NULL;
     if (R <= 0 || C <= 0) return PECLR_ERR_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (training) {
-        if (!x || !partial || n_split < 1) return PECLR_ERR_NULL;
-        hipLaunchKernelGGL(bn2d_stats_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FT), 0, s, x, partial, n_split, R, C, eps,
+        if (!partial || n_split < 1) return PECLR_ERR_NULL;
+        hipLaunchKernelGGL(bn2d_stats_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FT), 0, s, partial, n_split, R, C, eps,
                            momentum, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd,
                            scale_shift);
     } else {
@@ -395,35 +519,29 @@ extern "C" int peclr_bn2d_finalize_f32(const float* x, const float* partial, int
     return launch_status();
 }
 
-extern "C" int peclr_bn2d_apply_f32(const float* x, const float* residual, int R, int C, const float* scale_shift,
-                                    int relu, float* y, peclr_stream_t stream) {
+extern "C" int peclr_bn2d_apply(const void* x, const void* residual, int io_dtype, int R, int C,
+                                const float* scale_shift, int relu, void* y, peclr_stream_t stream) {
     if (!x || !scale_shift || !y) return PECLR_ERR_NULL;
     Plan p;
-    if (!make_plan(R, C, 0, p)) return PECLR_ERR_SHAPE;
-    if (!aligned16(x) || !aligned16(y) || !aligned16(scale_shift) || (residual && !aligned16(residual))) return PECLR_ERR_ALIGN;
+    if (!plan_for(io_dtype, R, C, 0, p)) return PECLR_ERR_SHAPE;
+    if (!all_aligned({x, y, scale_shift, residual})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (residual && relu) hipLaunchKernelGGL((bn2d_apply_kernel<true, true>), p.grid, dim3(T), 0, s, x, residual, p.g, scale_shift, y);
-    else if (residual) hipLaunchKernelGGL((bn2d_apply_kernel<true, false>), p.grid, dim3(T), 0, s, x, residual, p.g, scale_shift, y);
-    else if (relu) hipLaunchKernelGGL((bn2d_apply_kernel<false, true>), p.grid, dim3(T), 0, s, x, residual, p.g, scale_shift, y);
-    else hipLaunchKernelGGL((bn2d_apply_kernel<false, false>), p.grid, dim3(T), 0, s, x, residual, p.g, scale_shift, y);
+    if (io_dtype == PECLR_DTYPE_F32) launch_apply<float>(p, s, x, residual, scale_shift, relu, y);
+    else launch_apply<bf16_t>(p, s, x, residual, scale_shift, relu, y);
     return launch_status();
 }
 
-static int mask_mode(int relu, const float* y) { return !relu ? 0 : (y ? 2 : 1); }
-
-extern "C" int peclr_bn2d_bwd_reduce_f32(const float* dy, const float* x, const float* y, int R, int C, int relu,
-                                         const float* save_mean, const float* save_invstd, const float* scale_shift,
-                                         float* partial, int n_split, peclr_stream_t stream) {
+extern "C" int peclr_bn2d_bwd_reduce(const void* dy, const void* x, const void* y, int io_dtype, int R, int C,
+                                     int relu, const float* save_mean, const float* save_invstd,
+                                     const float* scale_shift, float* partial, int n_split, peclr_stream_t stream) {
     if (!dy || !x || !save_mean || !save_invstd || !scale_shift || !partial) return PECLR_ERR_NULL;
     Plan p;
-    if (n_split < 1 || !make_plan(R, C, n_split, p)) return PECLR_ERR_SHAPE;
-    if (!aligned16(dy) || !aligned16(x) || (y && !aligned16(y)) || !aligned16(partial)) return PECLR_ERR_ALIGN;
+    if (n_split < 1 || !plan_for(io_dtype, R, C, n_split, p)) return PECLR_ERR_SHAPE;
+    if (!all_aligned({dy, x, y, partial})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (mask_mode(relu, y)) {
-        case 0: hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<0>), p.grid, dim3(T), 0, s, dy, x, y, p.g, save_mean, save_invstd, scale_shift, partial); break;
-        case 1: hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<1>), p.grid, dim3(T), 0, s, dy, x, y, p.g, save_mean, save_invstd, scale_shift, partial); break;
-        default: hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<2>), p.grid, dim3(T), 0, s, dy, x, y, p.g, save_mean, save_invstd, scale_shift, partial); break;
-    }
+    const int mm = mask_mode(relu, y);
+    if (io_dtype == PECLR_DTYPE_F32) launch_reduce<float>(p, s, mm, dy, x, y, save_mean, save_invstd, scale_shift, partial);
+    else launch_reduce<bf16_t>(p, s, mm, dy, x, y, save_mean, save_invstd, scale_shift, partial);
     return launch_status();
 }
 
@@ -432,27 +550,23 @@ extern "C" int peclr_bn2d_bwd_finalize_f32(const float* partial, int n_split, in
                                            peclr_stream_t stream) {
     if (!partial || !scale_shift || !dgamma || !dbeta || !coef) return PECLR_ERR_NULL;
     if (n_split < 1 || R <= 0 || C <= 0) return PECLR_ERR_SHAPE;
-    hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FT), 0, static_cast<hipStream_t>(stream), partial,
-                       n_split, R, C, training, scale_shift, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FT), 0, static_cast<hipStream_t>(stream),
+                       partial, n_split, R, C, training, scale_shift, dgamma, dbeta, coef);
     return launch_status();
 }
 
-extern "C" int peclr_bn2d_bwd_apply_f32(const float* dy, const float* x, const float* y, int R, int C, int relu,
-                                        const float* save_mean, const float* save_invstd, const float* scale_shift,
-                                        const float* coef, float* dx, float* d_residual, peclr_stream_t stream) {
+extern "C" int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y, int io_dtype, int R, int C, int relu,
+                                    const float* save_mean, const float* save_invstd, const float* scale_shift,
+                                    const float* coef, void* dx, void* d_residual, peclr_stream_t stream) {
     if (!dy || !x || !save_mean || !save_invstd || !scale_shift || !coef || !dx) return PECLR_ERR_NULL;
     Plan p;
-    if (!make_plan(R, C, 0, p)) return PECLR_ERR_SHAPE;
-    if (!aligned16(dy) || !aligned16(x) || (y && !aligned16(y)) || !aligned16(dx) || (d_residual && !aligned16(d_residual)))
-        return PECLR_ERR_ALIGN;
+    if (!plan_for(io_dtype, R, C, 0, p)) return PECLR_ERR_SHAPE;
+    if (!all_aligned({dy, x, y, dx, d_residual})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int mm = mask_mode(relu, y);
-#define LAUNCH(M, D) hipLaunchKernelGGL((bn2d_bwd_apply_kernel<M, D>), p.grid, dim3(T), 0, s, dy, x, y, p.g, save_mean, save_invstd, scale_shift, coef, dx, d_residual)
-    if (d_residual) {
-        if (mm == 0) LAUNCH(0, true); else if (mm == 1) LAUNCH(1, true); else LAUNCH(2, true);
-    } else {
-        if (mm == 0) LAUNCH(0, false); else if (mm == 1) LAUNCH(1, false); else LAUNCH(2, false);
-    }
-#undef LAUNCH
+    if (io_dtype == PECLR_DTYPE_F32)
+        launch_bwd_apply<float>(p, s, mm, dy, x, y, save_mean, save_invstd, scale_shift, coef, dx, d_residual);
+    else
+        launch_bwd_apply<bf16_t>(p, s, mm, dy, x, y, save_mean, save_invstd, scale_shift, coef, dx, d_residual);
     return launch_status();
 }

@@ -556,3 +556,89 @@ def test_training_step_with_flat_grad_buckets_matches_plain():
     # MIOpen's split-K weight-gradient kernels accumulate with atomics: run-to-run noise ~1e-6 relative
     for a, b in zip(g0, g1):
         assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-7  # (head bias grad is ~0)
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 8, 8), (2, 256, 5, 7), (3, 2048, 2, 2), (16, 64, 56, 56), (5, 1024, 1, 1),
+                                   (6, 128, 9, 9)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
+def test_bn2d_fused_bf16_io(shape, relu, res):
+    """bf16 activations (autocast backbones), fp32 statistics/parameters.  Reference: float64 torch on
+    the SAME bf16-rounded inputs; outputs are bf16, so they agree to one bf16 ulp (2^-8 relative)."""
+    from peclr_amd.bn2d import FusedBatchNormAct2d
+
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h + 1)
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.7).bfloat16()
+    r = torch.randn(shape, generator=g).bfloat16() if res else None
+    dy = torch.randn(shape, generator=g).bfloat16()
+    bn = FusedBatchNormAct2d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g)
+        bn.bias.uniform_(-0.3, 0.3, generator=g)
+    ref = torch.nn.BatchNorm2d(c).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    xr = x.double().requires_grad_()
+    rr = r.double().requires_grad_() if res else None
+    yr = ref(xr)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy.double())
+
+    bn = bn.to(DEV).train()
+    bn.hip = True
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    rd = r.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_() if res else None
+    yd = bn(xd, rd, relu)
+    assert yd.dtype == torch.bfloat16 and yd.is_contiguous(memory_format=torch.channels_last)
+    yd.backward(dy.to(DEV).contiguous(memory_format=torch.channels_last))
+    ulp = 2.0 ** -8
+    yref = yr.detach().numpy()
+    np.testing.assert_allclose(host(yd.float()), yref, atol=ulp * np.abs(yref).max() + 1e-6, rtol=ulp)
+    dxr = xr.grad.numpy()
+    np.testing.assert_allclose(host(xd.grad.float()), dxr, atol=2 * ulp * max(1.0, np.abs(dxr).max()), rtol=2 * ulp)
+    if res:
+        np.testing.assert_allclose(host(rd.grad.float()), rr.grad.numpy(), atol=1e-6)  # masked dy: exact
+    gs = max(1.0, float(ref.weight.grad.abs().max()))
+    np.testing.assert_allclose(host(bn.weight.grad), ref.weight.grad.numpy(), atol=2e-3 * gs, rtol=1e-3)
+    np.testing.assert_allclose(host(bn.bias.grad), ref.bias.grad.numpy(), atol=2e-3 * gs, rtol=1e-3)
+    np.testing.assert_allclose(host(bn.running_mean), ref.running_mean.numpy(), atol=1e-5)
+    np.testing.assert_allclose(host(bn.running_var), ref.running_var.numpy(), atol=1e-5)
+
+
+def test_bf16_autocast_step_runs_on_fused_glue():
+    """bf16 autocast backbone (configs C3/C5) through the fused NHWC glue; the head, logits and loss
+    stay fp32.  Checked against the same model on the stock PyTorch ops."""
+    import copy
+    import warnings
+
+    from peclr_amd import Hybrid2Model, hybrid2_config
+    from peclr_amd.bn2d import enable_hip_batchnorm
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(1)
+    n = 8
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, augmentation=["crop", "rotate"],
+                         batch_size=n, num_samples=64, pretrained=False)
+    stock = Hybrid2Model(cfg).to(DEV).train()
+    stock.encoder = stock.encoder.to(memory_format=torch.channels_last)
+    fused = copy.deepcopy(stock)
+    enable_hip_batchnorm(fused.encoder)
+    g = torch.Generator().manual_seed(2)
+    batch = {"transformed_image1": torch.randn(n, 3, 64, 64, generator=g), "transformed_image2": torch.randn(n, 3, 64, 64, generator=g),
+             "jitter_x_1": torch.randint(-14, 1, (n,), generator=g), "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+             "jitter_y_1": torch.randint(-14, 1, (n,), generator=g), "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+             "angle_1": torch.randint(-45, 46, (n,), generator=g).double(), "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    for k in ("transformed_image1", "transformed_image2"):
+        batch[k] = batch[k].contiguous(memory_format=torch.channels_last)
+    losses = []
+    for m in (stock, fused):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m.training_step(batch, 0)
+        assert out["loss"].dtype == torch.float32
+        out["loss"].backward()
+        losses.append(float(out["loss"]))
+        assert all(torch.isfinite(p.grad).all() for n_, p in m.named_parameters() if "final_layer" not in n_)
+    assert abs(losses[0] - losses[1]) < 5e-2   # two bf16 pipelines of an 18-layer net
