@@ -47,11 +47,15 @@ def init_from_env(backend: Optional[str] = None) -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
+        # PECLR_SHARE_DEVICE=1 (tests only): every rank on GPU 0, to rehearse the N > 1 path on a
+        # single-GPU box -- RCCL refuses two ranks per device, so pair it with PECLR_DIST_BACKEND=gloo
+        local = 0 if os.environ.get("PECLR_SHARE_DEVICE") == "1" else local
         torch.cuda.set_device(local)
     if world > 1 and not is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("PECLR_DIST_BACKEND") or \
+            ("nccl" if torch.cuda.is_available() else "gloo")
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", local)
@@ -67,7 +71,10 @@ def all_gather_cat(t: Tensor, group=None) -> Tensor:
         return t
     t = t.contiguous()
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
-    dist.all_gather_into_tensor(out, t, group=group)
+    if dist.get_backend(group) == "gloo" and t.is_cuda:  # gloo has no fused all-gather for device tensors
+        dist.all_gather(list(out.chunk(world)), t, group=group)
+    else:
+        dist.all_gather_into_tensor(out, t, group=group)
     return out
 
 

@@ -1,0 +1,106 @@
+"""N > 1 on the REAL kernels with one GPU: two processes share cuda:0 and talk over gloo (RCCL refuses
+two ranks per device).  Everything except the transport is the production multi-GPU path: rank offsets
+in the NT-Xent kernels, the packed lse/loss gather, gradients accumulated into the flat buckets with
+stride-preserving views, SUM all-reduce from autograd hooks, the fused optimiser on bucket views."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r"""
+import os, sys, warnings
+sys.path.insert(0, os.environ["PECLR_ROOT"])
+warnings.simplefilter("ignore")
+import torch
+from peclr_amd import Hybrid2Model, Trainer, hybrid2_config
+from peclr_amd import dist as pdist
+from peclr_amd.bn2d import enable_hip_batchnorm
+
+N_LOCAL = 4
+def make_model():
+    torch.manual_seed(21)
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, augmentation=["crop", "rotate"],
+                         batch_size=N_LOCAL, num_samples=64, pretrained=False)
+    m = Hybrid2Model(cfg).cuda().train()
+    m.encoder = m.encoder.to(memory_format=torch.channels_last)
+    enable_hip_batchnorm(m.encoder)
+    for mod in m.modules():          # batch-independent normalisation: isolates the collective logic
+        if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            mod.eval()
+    return m
+def make_batch(world):
+    g = torch.Generator().manual_seed(7)
+    n = world * N_LOCAL
+    b = {"transformed_image1": torch.randn(n, 3, 32, 32, generator=g), "transformed_image2": torch.randn(n, 3, 32, 32, generator=g),
+         "jitter_x_1": torch.randint(-14, 1, (n,), generator=g), "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+         "jitter_y_1": torch.randint(-14, 1, (n,), generator=g), "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+         "angle_1": torch.randint(-45, 46, (n,), generator=g).double(), "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+    return b
+def to_dev(b):
+    b = {k: v.cuda() for k, v in b.items()}
+    for k in ("transformed_image1", "transformed_image2"):
+        b[k] = b[k].contiguous(memory_format=torch.channels_last)
+    return b
+world = int(os.environ.get("WORLD_SIZE", "1"))
+pdist.init_from_env()
+rank = pdist.rank()
+model = make_model()
+tr = Trainer(max_epochs=1, bucket_bytes=4 << 20).attach(model)
+tr.zero_grad()
+full = make_batch(max(world, 2))
+if world > 1:
+    sl = slice(rank * N_LOCAL, (rank + 1) * N_LOCAL)
+    batch = to_dev({k: v[sl].contiguous() for k, v in full.items()})
+    tr.reducer.prepare(tr._unused)
+else:
+    batch = to_dev(full)
+out = model.training_step(batch, 0)
+out["loss"].backward()
+if world > 1:
+    tr.reducer.finish()
+grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None and "final_layer" not in n}
+torch.save({"loss": out["loss"].detach().cpu(), "grads": grads}, os.environ["PECLR_OUT"] + f".r{rank}")
+tr.optimizer.step()                      # fused LARS/Adam straight out of the flat buckets
+torch.cuda.synchronize()
+if world > 1:
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+"""
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, PECLR_ROOT=ROOT, PECLR_DIST_BACKEND="gloo", PECLR_SHARE_DEVICE="1")
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, str(script)],
+                              env=dict(env, PECLR_OUT=str(tmp_path / "two"), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=500)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    subprocess.run([sys.executable, str(script)], env=dict(env, PECLR_OUT=str(tmp_path / "one"), WORLD_SIZE="1"), check=True,
+                   timeout=500)
+    r0, r1 = torch.load(str(tmp_path / "two") + ".r0"), torch.load(str(tmp_path / "two") + ".r1")
+    one = torch.load(str(tmp_path / "one") + ".r0")
+    assert torch.equal(r0["loss"], r1["loss"])
+    assert abs(float(r0["loss"]) - float(one["loss"])) < 2e-6
+    for n, g1 in one["grads"].items():
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), n      # SUM-reduced: identical on both ranks
+        a, b = r0["grads"][n].numpy(), g1.numpy()
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-4 * max(1e-6, float(np.abs(b).max())) + 1e-7, err_msg=n)
