@@ -258,6 +258,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     loss = float(out["loss"])
+    table_steps = args.steps
 
     if rank == 0:
         images = world * 2 * args.pairs * args.accum * args.steps
@@ -268,7 +269,7 @@ def main():
         dominant = max(kernels, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
         roof = {k: kernels[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
         roof.update(kernel=dominant, avg_us=kernels[dominant]["avg_us"],
-                    launches_per_step=kernels[dominant]["launches"] // (args.steps * args.accum),
+                    launches_per_step=kernels[dominant]["launches"] // (table_steps * args.accum),
                     traffic=pmc_traffic(dominant),
                     algorithmic_bytes=kernels[dominant]["bytes"], algorithmic_flops=kernels[dominant]["flops"])
         flops_img = conv_flops_per_image(model.encoder.features, (args.size, args.size))
@@ -292,7 +293,7 @@ def main():
             "backbone": {"note": "PyTorch-ROCm/MIOpen encoder (not hand-written); 3x forward conv FLOPs",
                          "flops_per_step_per_gpu": step_flops, "achieved": round(ach_tf, 2), "peak": peak_tf,
                          "unit": "TFLOP/s", "frac": round(ach_tf / peak_tf, 4)},
-            "hand_written_us_per_step": round(sum(k["avg_us"] * k["launches"] / args.steps
+            "hand_written_us_per_step": round(sum(k["avg_us"] * k["launches"] / table_steps
                                                   for k in kernels.values()), 1),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -163,6 +163,9 @@ int peclr_ntxent_bwd_f32(const float* z_rows, int Mr, int row_offset, const floa
  * the tensor's entry of the HOST arrays group_lr / group_weight_decay (n_groups <= 8, copied into
  * the kernel arguments).  It combines a tensor's chunk sums in a fixed order (bit-reproducible),
  * applies the LARS trust ratio + weight decay and the Adam update.
+ * device_hyper (nullable): DEVICE float[18] = {lr[8], weight_decay[8], bias_corr1, bias_corr2}; when
+ * given it overrides the by-value scalars, so a hipGraph that captured the launch can be replayed
+ * with new per-step values.
  * use_lars == 0: plain Adam with L2 weight decay (torch.optim.Adam semantics; norms_ws unused).
  * bias_corr1/2 = 1 - beta^step, computed by the host.  The LARS-scaled gradient is consumed in
  * registers and NOT written back to grad.                                                   */
@@ -173,8 +176,9 @@ int peclr_lars_sumsq_f32(float* const* ptrs, const int64_t* sizes, int n_tensors
 int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* sizes, int n_tensors,
                                const int32_t* chunk_tensor, const int64_t* chunk_offset,
                                const int32_t* tensor_chunk_begin, const int32_t* tensor_group,
-                               int n_chunks, const float* norms_ws, const float* group_lr,
-                               const float* group_weight_decay, int n_groups, float beta1,
+                               int n_chunks, const float* norms_ws, const float* device_hyper,
+                               const float* group_lr, const float* group_weight_decay, int n_groups,
+                               float beta1,
                                float beta2, float adam_eps, float bias_corr1, float bias_corr2,
                                int use_lars, float lars_eta, float lars_eps, int lars_clip,
                                peclr_stream_t stream);
@@ -193,8 +197,10 @@ int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* sizes, int n_t
  * partial (forward): [n_split*2 + 1][C] floats = row-slice partial sums + one row holding the
  * shift; partial (backward): [n_split*2][C].  n_split from peclr_bn2d_n_split, or any >= 1.
  * scale_shift: [2][C] = {gamma*invstd, beta - mean*gamma*invstd}; coef: [2][C] scratch for dx.
- * y (nullable in the backward): pass the forward output when a residual was added (the ReLU mask
- * cannot be recomputed from x alone); d_residual (nullable) receives the masked dy.          */
+ * ReLU mask in the backward: recomputed from x when neither y nor relu_mask is given (valid only
+ * if no residual was added); read from relu_mask ([R][C/32] uint32, 1 bit per element, written by
+ * peclr_bn2d_apply when its relu_mask argument is non-null; needs C % 32 == 0) or, failing that,
+ * from the forward output y.  d_residual (nullable) receives the masked dy.                  */
 #define PECLR_DTYPE_F32 0
 #define PECLR_DTYPE_BF16 1
 int peclr_bn2d_n_split(int R, int C, int io_dtype);
@@ -206,18 +212,19 @@ int peclr_bn2d_finalize_f32(const float* partial, int n_split, int R, int C, int
                             int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
                             float* scale_shift, peclr_stream_t stream);
 int peclr_bn2d_apply(const void* x, const void* residual, int io_dtype, int R, int C,
-                     const float* scale_shift, int relu, void* y, peclr_stream_t stream);
-int peclr_bn2d_bwd_reduce(const void* dy, const void* x, const void* y, int io_dtype, int R, int C,
-                          int relu, const float* save_mean, const float* save_invstd,
-                          const float* scale_shift, float* partial, int n_split,
-                          peclr_stream_t stream);
+                     const float* scale_shift, int relu, void* y, uint32_t* relu_mask,
+                     peclr_stream_t stream);
+int peclr_bn2d_bwd_reduce(const void* dy, const void* x, const void* y, const uint32_t* relu_mask,
+                          int io_dtype, int R, int C, int relu, const float* save_mean,
+                          const float* save_invstd, const float* scale_shift, float* partial,
+                          int n_split, peclr_stream_t stream);
 int peclr_bn2d_bwd_finalize_f32(const float* partial, int n_split, int R, int C, int training,
                                 const float* scale_shift, float* dgamma, float* dbeta,
                                 float* coef, peclr_stream_t stream);
-int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y, int io_dtype, int R, int C,
-                         int relu, const float* save_mean, const float* save_invstd,
-                         const float* scale_shift, const float* coef, void* dx,
-                         void* d_residual, peclr_stream_t stream);
+int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y, const uint32_t* relu_mask,
+                         int io_dtype, int R, int C, int relu, const float* save_mean,
+                         const float* save_invstd, const float* scale_shift, const float* coef,
+                         void* dx, void* d_residual, peclr_stream_t stream);
 
 #ifdef __cplusplus
 }

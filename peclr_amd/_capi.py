@@ -44,12 +44,12 @@ SIGNATURES = {
     "peclr_bn2d_stats": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
     "peclr_bn2d_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P,
                                         _P, _P, _P]),
-    "peclr_bn2d_apply": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P]),
-    "peclr_bn2d_bwd_reduce": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "peclr_bn2d_apply": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
+    "peclr_bn2d_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "peclr_bn2d_bwd_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
-    "peclr_bn2d_bwd_apply": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "peclr_bn2d_bwd_apply": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
-    "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_float,
+    "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
                                            _P]),
 }
@@ -278,8 +278,9 @@ def ntxent_bwd(z_rows, row_offset, z_all, n_half, inv_tau, lse_all, dloss, grad_
 # ------------------------------------------------------------------ optimiser
 def lars_adam_step(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_chunk_begin, tensor_group, n_chunks,
                    norms_ws, group_lr, group_wd, beta1, beta2, adam_eps, bias_corr1, bias_corr2, use_lars,
-                   lars_eta, lars_eps, lars_clip):
-    """group_lr / group_wd: Python float lists, one entry per parameter group (host arrays)."""
+                   lars_eta, lars_eps, lars_clip, device_hyper=None):
+    """group_lr / group_wd: Python float lists, one entry per parameter group (host arrays).
+    device_hyper: optional device float[18] that overrides lr / wd / bias corrections (graph replay)."""
     p = _ptr(ptrs, torch.int64, "ptrs")
     sz = _ptr(sizes, torch.int64, "sizes")
     ct = _ptr(chunk_tensor, torch.int32, "chunk_tensor")
@@ -294,7 +295,7 @@ def lars_adam_step(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_ch
     with _timed("lars_adam_update"):
         rc = lib().peclr_lars_adam_update_f32(
             p, sz, n_tensors, ct, co, _ptr(tensor_chunk_begin, torch.int32, "tensor_chunk_begin"),
-            _ptr(tensor_group, torch.int32, "tensor_group"), n_chunks, _ptr(norms_ws),
+            _ptr(tensor_group, torch.int32, "tensor_group"), n_chunks, _ptr(norms_ws), _ptr(device_hyper),
             ctypes.cast(lr_arr, c_void_p), ctypes.cast(wd_arr, c_void_p), ng, beta1, beta2, adam_eps, bias_corr1,
             bias_corr2, int(use_lars), lars_eta, lars_eps, int(lars_clip), _stream())
     _check(rc, "peclr_lars_adam_update_f32")
@@ -322,7 +323,9 @@ def bn2d_n_split(r: int, c: int, io: int) -> int:
     return n
 
 
-def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, relu):
+def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, relu,
+             want_mask=False):
+    """want_mask: also write the 1-bit ReLU mask ([R, C/32] int32) the backward reads instead of y."""
     n, c, h, w = x.shape
     r = n * h * w
     dev = x.device
@@ -345,14 +348,17 @@ def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training,
                                            _ptr(nbt, torch.int64, "num_batches_tracked") if training else None,
                                            save[0].data_ptr(), save[1].data_ptr(), ss.data_ptr(), _stream())
     _check(rc, "peclr_bn2d_finalize_f32")
-    with _timed("bn2d_apply", (3 if residual is not None else 2) * e * r * c):
+    mask = torch.empty((r, c // 32), device=dev, dtype=torch.int32) if (want_mask and relu and c % 32 == 0) else None
+    with _timed("bn2d_apply", (3 if residual is not None else 2) * e * r * c + (r * c // 8 if mask is not None else 0)):
         rc = lib().peclr_bn2d_apply(xp, _nhwc_ptr(residual, "bn2d residual", x.dtype) if residual is not None else None,
-                                    io, r, c, ss.data_ptr(), int(relu), y.data_ptr(), _stream())
+                                    io, r, c, ss.data_ptr(), int(relu), y.data_ptr(),
+                                    mask.data_ptr() if mask is not None else None, _stream())
     _check(rc, "peclr_bn2d_apply")
-    return y, save, ss
+    return y, save, ss, mask
 
 
-def bn2d_bwd(dy, x, y, save, ss, training, relu, want_dres):
+def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres):
+    """ReLU mask source: `mask` (bit mask from the forward) > `y` (forward output) > recomputed from x."""
     n, c, h, w = x.shape
     r = n * h * w
     dev = x.device
@@ -364,9 +370,11 @@ def bn2d_bwd(dy, x, y, save, ss, training, relu, want_dres):
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     dres = torch.empty_like(x, memory_format=torch.channels_last) if want_dres else None
     dyp, xp = _nhwc_ptr(dy, "bn2d dy", x.dtype), _nhwc_ptr(x, "bn2d x")
-    yp = _nhwc_ptr(y, "bn2d y", x.dtype) if y is not None else None
-    with _timed("bn2d_bwd_reduce", (3 if y is not None else 2) * e * r * c):
-        rc = lib().peclr_bn2d_bwd_reduce(dyp, xp, yp, io, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
+    yp = _nhwc_ptr(y, "bn2d y", x.dtype) if (y is not None and mask is None) else None
+    mp = _ptr(mask, torch.int32, "relu mask")
+    extra = (r * c // 8) if mask is not None else (e * r * c if yp is not None else 0)
+    with _timed("bn2d_bwd_reduce", 2 * e * r * c + extra):
+        rc = lib().peclr_bn2d_bwd_reduce(dyp, xp, yp, mp, io, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
                                          ss.data_ptr(), partial.data_ptr(), ns, _stream())
     _check(rc, "peclr_bn2d_bwd_reduce")
     with _timed("bn2d_bwd_finalize", 8 * ns * c):
@@ -374,8 +382,8 @@ def bn2d_bwd(dy, x, y, save, ss, training, relu, want_dres):
                                                dparams[0].data_ptr(), dparams[1].data_ptr(), coef.data_ptr(),
                                                _stream())
     _check(rc, "peclr_bn2d_bwd_finalize_f32")
-    with _timed("bn2d_bwd_apply", (3 + (1 if y is not None else 0) + (1 if want_dres else 0)) * e * r * c):
-        rc = lib().peclr_bn2d_bwd_apply(dyp, xp, yp, io, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
+    with _timed("bn2d_bwd_apply", (3 + (1 if want_dres else 0)) * e * r * c + extra):
+        rc = lib().peclr_bn2d_bwd_apply(dyp, xp, yp, mp, io, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
                                         ss.data_ptr(), coef.data_ptr(), dx.data_ptr(),
                                         dres.data_ptr() if dres is not None else None, _stream())
     _check(rc, "peclr_bn2d_bwd_apply")

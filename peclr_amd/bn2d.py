@@ -26,22 +26,25 @@ class _BN2dAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool):
         training = bn.training or not bn.track_running_stats
-        y, save, ss = _capi.bn2d_fwd(x, residual, weight, bias, bn.running_mean, bn.running_var,
-                                     bn.num_batches_tracked, training, bn.eps,
-                                     bn.momentum if bn.momentum is not None else 0.1, relu)
-        # the ReLU mask can be recomputed from x unless a residual was added before it
-        keep_y = y if (relu and residual is not None) else None
-        ctx.save_for_backward(x, save, ss, *([keep_y] if keep_y is not None else []))
-        ctx.cfg = (training, relu, residual is not None, keep_y is not None)
+        # the ReLU mask can be recomputed from x unless a residual was added before it; then the
+        # forward writes a 1-bit mask (or, for C % 32 != 0, the backward re-reads y)
+        need_mask = relu and residual is not None
+        y, save, ss, mask = _capi.bn2d_fwd(x, residual, weight, bias, bn.running_mean, bn.running_var,
+                                           bn.num_batches_tracked, training, bn.eps,
+                                           bn.momentum if bn.momentum is not None else 0.1, relu, want_mask=need_mask)
+        keep = mask if mask is not None else (y if need_mask else None)
+        ctx.save_for_backward(x, save, ss, *([keep] if keep is not None else []))
+        ctx.cfg = (training, relu, residual is not None, keep is not None, mask is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        training, relu, has_res, has_y = ctx.cfg
+        training, relu, has_res, has_keep, is_mask = ctx.cfg
         x, save, ss = ctx.saved_tensors[:3]
-        y = ctx.saved_tensors[3] if has_y else None
+        keep = ctx.saved_tensors[3] if has_keep else None
+        y, mask = (None, keep) if is_mask else (keep, None)
         dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
-        dx, dgamma, dbeta, dres = _capi.bn2d_bwd(dy, x, y, save, ss, training, relu,
+        dx, dgamma, dbeta, dres = _capi.bn2d_bwd(dy, x, y, mask, save, ss, training, relu,
                                                  has_res and ctx.needs_input_grad[3])
         if has_res and dres is None and ctx.needs_input_grad[3]:
             dres = dy

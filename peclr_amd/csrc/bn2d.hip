@@ -21,8 +21,11 @@
 //   backward = reduce (partial dbeta, dgamma with the ReLU mask recomputed from x, or read from y
 //              when a residual was added)  ->  finalize  ->  apply: dx (and d_residual = masked dy)
 //
+// When a residual is added before the ReLU the mask cannot be recomputed from x: the forward then
+// writes a 1-bit-per-element mask ([R][C/32] words, 1/8 byte per element) that both backward passes read
+// instead of re-reading y.
 // Algorithmic bytes per element (e = 4 fp32 / 2 bf16): fwd e (stats) + 2e (apply) [+e residual];
-// bwd 2e (reduce) + 3e (apply) [+e for y, twice, and +e d_residual when a residual was added].
+// bwd 2e (reduce) + 3e (apply) [+1/8 for the mask, twice, and +e d_residual when a residual was added].
 // The stock path moves 2e+3e (BN) + 2e (ReLU) + 3e (add) forward and 3e (ReLU) + 5e (BN) backward.
 // Everything is bit-reproducible (no atomics; fixed combine order).
 #include <initializer_list>
@@ -238,22 +241,44 @@ __global__ __launch_bounds__(T) void bn2d_eval_params_kernel(int C, float eps, c
 }
 
 // ------------------------------------------------------------------ forward: apply
+// ReLU bit mask, 1 bit per element, layout [R][C/32] uint32 (bit c%32 of word (r, c/32)): independent
+// of the launch geometry.  The 32/W lanes that own one word are adjacent lanes of one wave in the same
+// row (column group is the fastest thread index and CGB is a multiple of 32/W).
+template <int W>
+__device__ __forceinline__ void mask_store(unsigned* __restrict__ mask, int row, int col, int C, unsigned bits) {
+    constexpr int LPW = 32 / W;  // lanes per word
+    unsigned word = bits << ((threadIdx.x % LPW) * W);
+#pragma unroll
+    for (int o = 1; o < LPW; o <<= 1) word |= __shfl_xor(word, o, kWave);
+    if (threadIdx.x % LPW == 0) mask[(size_t)row * (C / 32) + col / 32] = word;
+}
+template <int W>
+__device__ __forceinline__ unsigned mask_load(const unsigned* __restrict__ mask, int row, int col, int C) {
+    constexpr int LPW = 32 / W;
+    return (mask[(size_t)row * (C / 32) + col / 32] >> ((threadIdx.x % LPW) * W)) & ((1u << W) - 1u);
+}
+
 template <typename IO, bool RES, bool RELU>
 __global__ __launch_bounds__(T) void bn2d_apply_kernel(const IO* __restrict__ x, const IO* __restrict__ res, Geo g,
-                                                       const float* __restrict__ scale_shift, IO* __restrict__ y) {
+                                                       const float* __restrict__ scale_shift, IO* __restrict__ y,
+                                                       unsigned* __restrict__ relu_mask) {
     constexpr int W = Word<IO>::W, U = Word<IO>::U;
     int col, r0, r1, rl;
     thread_geo<W>(g, col, r0, r1, rl);
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
-    auto emit = [&](size_t o, const Fv<W>& v, const Fv<W>& w) {
+    auto emit = [&](int row, const Fv<W>& v, const Fv<W>& w) {
+        const size_t o = (size_t)row * g.C + col;
         Fv<W> t;
+        unsigned bits = 0;
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             float a = fmaf(v.v[k], sc.v[k], sh.v[k]);
             if (RES) a += w.v[k];
+            if (RELU) bits |= (a > 0.f ? 1u : 0u) << k;
             t.v[k] = RELU ? fmaxf(a, 0.f) : a;
         }
         Word<IO>::store(y + o, t);
+        if (RELU && relu_mask) mask_store<W>(relu_mask, row, col, g.C, bits);  // the word's lanes share `row`
     };
     int r = r0 + rl;
     for (; r + (U - 1) * g.RPP < r1; r += U * g.RPP) {
@@ -265,25 +290,28 @@ __global__ __launch_bounds__(T) void bn2d_apply_kernel(const IO* __restrict__ x,
             if (RES) w[u] = Word<IO>::load(res + o);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) emit((size_t)(r + u * g.RPP) * g.C + col, v[u], RES ? w[RES ? u : 0] : v[u]);
+        for (int u = 0; u < U; ++u) emit(r + u * g.RPP, v[u], RES ? w[RES ? u : 0] : v[u]);
     }
     for (; r < r1; r += g.RPP) {
         const size_t o = (size_t)r * g.C + col;
         const Fv<W> v = Word<IO>::load(x + o);
-        emit(o, v, RES ? Word<IO>::load(res + o) : v);
+        emit(r, v, RES ? Word<IO>::load(res + o) : v);
     }
 }
 
 // ------------------------------------------------------------------ backward
-// MASK: 0 = no ReLU, 1 = ReLU mask recomputed from x (no residual), 2 = ReLU mask read from y.
+// MASK: 0 = no ReLU, 1 = ReLU mask recomputed from x (no residual), 2 = ReLU mask read from y,
+//       3 = ReLU mask read from the 1-bit-per-element mask the forward wrote.
 template <int W, int MASK>
-__device__ __forceinline__ Fv<W> masked(const Fv<W>& d, const Fv<W>& xv, const Fv<W>& yv, const Fv<W>& sc, const Fv<W>& sh) {
+__device__ __forceinline__ Fv<W> masked(const Fv<W>& d, const Fv<W>& xv, const Fv<W>& yv, unsigned bits, const Fv<W>& sc,
+                                        const Fv<W>& sh) {
     Fv<W> r;
 #pragma unroll
     for (int k = 0; k < W; ++k) {
         bool on = true;
         if (MASK == 1) on = fmaf(xv.v[k], sc.v[k], sh.v[k]) > 0.f;
         if (MASK == 2) on = yv.v[k] > 0.f;
+        if (MASK == 3) on = (bits >> k) & 1u;
         r.v[k] = on ? d.v[k] : 0.f;
     }
     return r;
@@ -291,7 +319,7 @@ __device__ __forceinline__ Fv<W> masked(const Fv<W>& d, const Fv<W>& xv, const F
 
 template <typename IO, int MASK>
 __global__ __launch_bounds__(T) void bn2d_bwd_reduce_kernel(const IO* __restrict__ dy, const IO* __restrict__ x,
-                                                            const IO* __restrict__ y, Geo g,
+                                                            const IO* __restrict__ y, const unsigned* __restrict__ relu_mask, Geo g,
                                                             const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                             const float* __restrict__ scale_shift, float* __restrict__ partial) {
     constexpr int W = Word<IO>::W, U = Word<IO>::U;
@@ -301,8 +329,8 @@ __global__ __launch_bounds__(T) void bn2d_bwd_reduce_kernel(const IO* __restrict
     const Fv<W> mean = loadp<W>(save_mean + col), invstd = loadp<W>(save_invstd + col);
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
     Fv<W> sb = zero<W>(), sg = zero<W>();
-    auto acc = [&](const Fv<W>& d0, const Fv<W>& xv, const Fv<W>& yv) {
-        const Fv<W> d = masked<W, MASK>(d0, xv, yv, sc, sh);
+    auto acc = [&](const Fv<W>& d0, const Fv<W>& xv, const Fv<W>& yv, unsigned bits) {
+        const Fv<W> d = masked<W, MASK>(d0, xv, yv, bits, sc, sh);
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             sb.v[k] += d.v[k];
@@ -312,20 +340,23 @@ __global__ __launch_bounds__(T) void bn2d_bwd_reduce_kernel(const IO* __restrict
     int r = r0 + rl;
     for (; r + (U - 1) * g.RPP < r1; r += U * g.RPP) {
         Fv<W> d[U], xv[U], yv[MASK == 2 ? U : 1];
+        unsigned mb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t o = (size_t)(r + u * g.RPP) * g.C + col;
             d[u] = Word<IO>::load(dy + o);
             xv[u] = Word<IO>::load(x + o);
             if (MASK == 2) yv[u] = Word<IO>::load(y + o);
+            mb[u] = MASK == 3 ? mask_load<W>(relu_mask, r + u * g.RPP, col, g.C) : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc(d[u], xv[u], MASK == 2 ? yv[MASK == 2 ? u : 0] : xv[u]);
+        for (int u = 0; u < U; ++u) acc(d[u], xv[u], MASK == 2 ? yv[MASK == 2 ? u : 0] : xv[u], mb[u]);
     }
     for (; r < r1; r += g.RPP) {
         const size_t o = (size_t)r * g.C + col;
         const Fv<W> xv = Word<IO>::load(x + o);
-        acc(Word<IO>::load(dy + o), xv, MASK == 2 ? Word<IO>::load(y + o) : xv);
+        acc(Word<IO>::load(dy + o), xv, MASK == 2 ? Word<IO>::load(y + o) : xv,
+            MASK == 3 ? mask_load<W>(relu_mask, r, col, g.C) : 0u);
     }
     sb = lane_reduce<W>(sb, red, g, rl);
     sg = lane_reduce<W>(sg, red, g, rl);
@@ -357,7 +388,7 @@ __global__ __launch_bounds__(FT) void bn2d_bwd_finalize_kernel(const float* __re
 
 template <typename IO, int MASK, bool DRES>
 __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict__ dy, const IO* __restrict__ x,
-                                                           const IO* __restrict__ y, Geo g,
+                                                           const IO* __restrict__ y, const unsigned* __restrict__ relu_mask, Geo g,
                                                            const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                            const float* __restrict__ scale_shift, const float* __restrict__ coef,
                                                            IO* __restrict__ dx, IO* __restrict__ dres) {
@@ -367,8 +398,8 @@ __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict_
     const Fv<W> mean = loadp<W>(save_mean + col), invstd = loadp<W>(save_invstd + col);
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
     const Fv<W> k2 = loadp<W>(coef + col), k3 = loadp<W>(coef + g.C + col);
-    auto emit = [&](size_t o, const Fv<W>& d0, const Fv<W>& xv, const Fv<W>& yv) {
-        const Fv<W> d = masked<W, MASK>(d0, xv, yv, sc, sh);
+    auto emit = [&](size_t o, const Fv<W>& d0, const Fv<W>& xv, const Fv<W>& yv, unsigned bits) {
+        const Fv<W> d = masked<W, MASK>(d0, xv, yv, bits, sc, sh);
         if (DRES) Word<IO>::store(dres + o, d);
         Fv<W> t;
 #pragma unroll
@@ -381,20 +412,24 @@ __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict_
     int r = r0 + rl;
     for (; r + (U - 1) * g.RPP < r1; r += U * g.RPP) {
         Fv<W> d[U], xv[U], yv[MASK == 2 ? U : 1];
+        unsigned mb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t o = (size_t)(r + u * g.RPP) * g.C + col;
             d[u] = Word<IO>::load(dy + o);
             xv[u] = Word<IO>::load(x + o);
             if (MASK == 2) yv[u] = Word<IO>::load(y + o);
+            mb[u] = MASK == 3 ? mask_load<W>(relu_mask, r + u * g.RPP, col, g.C) : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) emit((size_t)(r + u * g.RPP) * g.C + col, d[u], xv[u], MASK == 2 ? yv[MASK == 2 ? u : 0] : xv[u]);
+        for (int u = 0; u < U; ++u)
+            emit((size_t)(r + u * g.RPP) * g.C + col, d[u], xv[u], MASK == 2 ? yv[MASK == 2 ? u : 0] : xv[u], mb[u]);
     }
     for (; r < r1; r += g.RPP) {
         const size_t o = (size_t)r * g.C + col;
         const Fv<W> xv = Word<IO>::load(x + o);
-        emit(o, Word<IO>::load(dy + o), xv, MASK == 2 ? Word<IO>::load(y + o) : xv);
+        emit(o, Word<IO>::load(dy + o), xv, MASK == 2 ? Word<IO>::load(y + o) : xv,
+             MASK == 3 ? mask_load<W>(relu_mask, r, col, g.C) : 0u);
     }
 }
 
@@ -440,37 +475,38 @@ inline bool all_aligned(std::initializer_list<const void*> ps) {
 }
 
 template <typename IO>
-void launch_apply(const Plan& p, hipStream_t s, const void* x, const void* res, const float* ss, int relu, void* y) {
+void launch_apply(const Plan& p, hipStream_t s, const void* x, const void* res, const float* ss, int relu, void* y,
+                  unsigned* mask) {
     const IO* xp = static_cast<const IO*>(x);
     const IO* rp = static_cast<const IO*>(res);
     IO* yp = static_cast<IO*>(y);
-    if (res && relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, true, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp);
-    else if (res) hipLaunchKernelGGL((bn2d_apply_kernel<IO, true, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp);
-    else if (relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, false, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp);
-    else hipLaunchKernelGGL((bn2d_apply_kernel<IO, false, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp);
+    if (res && relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, true, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask);
+    else if (res) hipLaunchKernelGGL((bn2d_apply_kernel<IO, true, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask);
+    else if (relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, false, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask);
+    else hipLaunchKernelGGL((bn2d_apply_kernel<IO, false, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask);
 }
 
-inline int mask_mode(int relu, const void* y) { return !relu ? 0 : (y ? 2 : 1); }
+inline int mask_mode(int relu, const void* y, const void* mask) { return !relu ? 0 : (mask ? 3 : (y ? 2 : 1)); }
 
 template <typename IO>
-void launch_reduce(const Plan& p, hipStream_t s, int mm, const void* dy, const void* x, const void* y, const float* mean,
-                   const float* invstd, const float* ss, float* partial) {
+void launch_reduce(const Plan& p, hipStream_t s, int mm, const void* dy, const void* x, const void* y, const unsigned* mask,
+                   const float* mean, const float* invstd, const float* ss, float* partial) {
     const IO *d = static_cast<const IO*>(dy), *xp = static_cast<const IO*>(x), *yp = static_cast<const IO*>(y);
-    if (mm == 0) hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<IO, 0>), p.grid, dim3(T), 0, s, d, xp, yp, p.g, mean, invstd, ss, partial);
-    else if (mm == 1) hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<IO, 1>), p.grid, dim3(T), 0, s, d, xp, yp, p.g, mean, invstd, ss, partial);
-    else hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<IO, 2>), p.grid, dim3(T), 0, s, d, xp, yp, p.g, mean, invstd, ss, partial);
+#define PECLR_LAUNCH(M) hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<IO, M>), p.grid, dim3(T), 0, s, d, xp, yp, mask, p.g, mean, invstd, ss, partial)
+    if (mm == 0) PECLR_LAUNCH(0); else if (mm == 1) PECLR_LAUNCH(1); else if (mm == 2) PECLR_LAUNCH(2); else PECLR_LAUNCH(3);
+#undef PECLR_LAUNCH
 }
 
 template <typename IO>
-void launch_bwd_apply(const Plan& p, hipStream_t s, int mm, const void* dy, const void* x, const void* y, const float* mean,
-                      const float* invstd, const float* ss, const float* coef, void* dx, void* dres) {
+void launch_bwd_apply(const Plan& p, hipStream_t s, int mm, const void* dy, const void* x, const void* y, const unsigned* mask,
+                      const float* mean, const float* invstd, const float* ss, const float* coef, void* dx, void* dres) {
     const IO *d = static_cast<const IO*>(dy), *xp = static_cast<const IO*>(x), *yp = static_cast<const IO*>(y);
     IO *o = static_cast<IO*>(dx), *r = static_cast<IO*>(dres);
-#define PECLR_LAUNCH(M, D) hipLaunchKernelGGL((bn2d_bwd_apply_kernel<IO, M, D>), p.grid, dim3(T), 0, s, d, xp, yp, p.g, mean, invstd, ss, coef, o, r)
+#define PECLR_LAUNCH(M, D) hipLaunchKernelGGL((bn2d_bwd_apply_kernel<IO, M, D>), p.grid, dim3(T), 0, s, d, xp, yp, mask, p.g, mean, invstd, ss, coef, o, r)
     if (dres) {
-        if (mm == 0) PECLR_LAUNCH(0, true); else if (mm == 1) PECLR_LAUNCH(1, true); else PECLR_LAUNCH(2, true);
+        if (mm == 0) PECLR_LAUNCH(0, true); else if (mm == 1) PECLR_LAUNCH(1, true); else if (mm == 2) PECLR_LAUNCH(2, true); else PECLR_LAUNCH(3, true);
     } else {
-        if (mm == 0) PECLR_LAUNCH(0, false); else if (mm == 1) PECLR_LAUNCH(1, false); else PECLR_LAUNCH(2, false);
+        if (mm == 0) PECLR_LAUNCH(0, false); else if (mm == 1) PECLR_LAUNCH(1, false); else if (mm == 2) PECLR_LAUNCH(2, false); else PECLR_LAUNCH(3, false);
     }
 #undef PECLR_LAUNCH
 }
@@ -520,28 +556,31 @@ extern "C" int peclr_bn2d_finalize_f32(const float* partial, int n_split, int R,
 }
 
 extern "C" int peclr_bn2d_apply(const void* x, const void* residual, int io_dtype, int R, int C,
-                                const float* scale_shift, int relu, void* y, peclr_stream_t stream) {
+                                const float* scale_shift, int relu, void* y, uint32_t* relu_mask,
+                                peclr_stream_t stream) {
     if (!x || !scale_shift || !y) return PECLR_ERR_NULL;
     Plan p;
     if (!plan_for(io_dtype, R, C, 0, p)) return PECLR_ERR_SHAPE;
+    if (relu_mask && (C % 32 || !relu)) return PECLR_ERR_SHAPE;
     if (!all_aligned({x, y, scale_shift, residual})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (io_dtype == PECLR_DTYPE_F32) launch_apply<float>(p, s, x, residual, scale_shift, relu, y);
-    else launch_apply<bf16_t>(p, s, x, residual, scale_shift, relu, y);
+    if (io_dtype == PECLR_DTYPE_F32) launch_apply<float>(p, s, x, residual, scale_shift, relu, y, relu_mask);
+    else launch_apply<bf16_t>(p, s, x, residual, scale_shift, relu, y, relu_mask);
     return launch_status();
 }
 
-extern "C" int peclr_bn2d_bwd_reduce(const void* dy, const void* x, const void* y, int io_dtype, int R, int C,
-                                     int relu, const float* save_mean, const float* save_invstd,
+extern "C" int peclr_bn2d_bwd_reduce(const void* dy, const void* x, const void* y, const uint32_t* relu_mask,
+                                     int io_dtype, int R, int C, int relu, const float* save_mean, const float* save_invstd,
                                      const float* scale_shift, float* partial, int n_split, peclr_stream_t stream) {
     if (!dy || !x || !save_mean || !save_invstd || !scale_shift || !partial) return PECLR_ERR_NULL;
     Plan p;
     if (n_split < 1 || !plan_for(io_dtype, R, C, n_split, p)) return PECLR_ERR_SHAPE;
     if (!all_aligned({dy, x, y, partial})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int mm = mask_mode(relu, y);
-    if (io_dtype == PECLR_DTYPE_F32) launch_reduce<float>(p, s, mm, dy, x, y, save_mean, save_invstd, scale_shift, partial);
-    else launch_reduce<bf16_t>(p, s, mm, dy, x, y, save_mean, save_invstd, scale_shift, partial);
+    if (relu_mask && C % 32) return PECLR_ERR_SHAPE;
+    const int mm = mask_mode(relu, y, relu_mask);
+    if (io_dtype == PECLR_DTYPE_F32) launch_reduce<float>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, partial);
+    else launch_reduce<bf16_t>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, partial);
     return launch_status();
 }
 
@@ -555,7 +594,8 @@ extern "C" int peclr_bn2d_bwd_finalize_f32(const float* partial, int n_split, in
     return launch_status();
 }
 
-extern "C" int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y, int io_dtype, int R, int C, int relu,
+extern "C" int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y, const uint32_t* relu_mask, int io_dtype,
+                                    int R, int C, int relu,
                                     const float* save_mean, const float* save_invstd, const float* scale_shift,
                                     const float* coef, void* dx, void* d_residual, peclr_stream_t stream) {
     if (!dy || !x || !save_mean || !save_invstd || !scale_shift || !coef || !dx) return PECLR_ERR_NULL;
@@ -563,10 +603,11 @@ extern "C" int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y
     if (!plan_for(io_dtype, R, C, 0, p)) return PECLR_ERR_SHAPE;
     if (!all_aligned({dy, x, y, dx, d_residual})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int mm = mask_mode(relu, y);
+    if (relu_mask && C % 32) return PECLR_ERR_SHAPE;
+    const int mm = mask_mode(relu, y, relu_mask);
     if (io_dtype == PECLR_DTYPE_F32)
-        launch_bwd_apply<float>(p, s, mm, dy, x, y, save_mean, save_invstd, scale_shift, coef, dx, d_residual);
+        launch_bwd_apply<float>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, coef, dx, d_residual);
     else
-        launch_bwd_apply<bf16_t>(p, s, mm, dy, x, y, save_mean, save_invstd, scale_shift, coef, dx, d_residual);
+        launch_bwd_apply<bf16_t>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, coef, dx, d_residual);
     return launch_status();
 }

@@ -90,11 +90,17 @@ __global__ __launch_bounds__(256) void lars_adam_kernel(float* const* __restrict
                                                         const int32_t* __restrict__ tensor_chunk_begin,
                                                         const int32_t* __restrict__ tensor_group,
                                                         int n_chunks, const float* __restrict__ norms_ws,
-                                                        OptArgs a) {
+                                                        const float* __restrict__ device_hyper, OptArgs a) {
     const int c = blockIdx.x;
     const int t = chunk_tensor[c];
     const int grp = tensor_group ? tensor_group[t] : 0;
-    const float lr = a.lr[grp];
+    // per-step scalars either by value (kernel arguments) or from device memory, so that a captured
+    // hipGraph can be replayed with a new learning rate / bias correction every step
+    // (read into locals: writing the by-value argument struct would demote it to scratch memory)
+    const float lr = device_hyper ? device_hyper[grp] : a.lr[grp];
+    const float wd_group = device_hyper ? device_hyper[MAX_GROUPS + grp] : a.weight_decay[grp];
+    const float bias_corr1 = device_hyper ? device_hyper[2 * MAX_GROUPS] : a.bias_corr1;
+    const float bias_corr2 = device_hyper ? device_hyper[2 * MAX_GROUPS + 1] : a.bias_corr2;
     const int64_t off = chunk_offset[c];
     const int64_t n = min((int64_t)CHUNK, sizes[t] - off);
     float* p = ptrs[t] + off;
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) void lars_adam_kernel(float* const* __restrict
     float* m = ptrs[2 * n_tensors + t] + off;
     float* v = ptrs[3 * n_tensors + t] + off;
 
-    float trust = 1.f, wd = a.weight_decay[grp];
+    float trust = 1.f, wd = wd_group;
     if (a.use_lars) {
         // the workgroup combines the tensor's chunk sums cooperatively, always in the same tree order
         // (every chunk of a tensor gets bit-identical norms); a serial per-thread loop over up to
@@ -123,8 +129,8 @@ __global__ __launch_bounds__(256) void lars_adam_kernel(float* const* __restrict
             wd = 0.f;  // update_p leaves the gradient untouched
         }
     }
-    const float step_size = lr / a.bias_corr1;
-    const float inv_bc2_sqrt = 1.f / sqrtf(a.bias_corr2);
+    const float step_size = lr / bias_corr1;
+    const float inv_bc2_sqrt = 1.f / sqrtf(bias_corr2);
     const float b1 = a.beta1, b2 = a.beta2, eps = a.adam_eps;
     auto upd = [&](float& pk, float gk, float& mk, float& vk) {
         gk = (gk + wd * pk) * trust;
@@ -184,20 +190,20 @@ extern "C" int peclr_lars_sumsq_f32(float* const* ptrs, const int64_t* sizes, in
 extern "C" int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* sizes, int n_tensors,
                                           const int32_t* chunk_tensor, const int64_t* chunk_offset,
                                           const int32_t* tensor_chunk_begin, const int32_t* tensor_group,
-                                          int n_chunks, const float* norms_ws, const float* group_lr,
-                                          const float* group_weight_decay, int n_groups, float beta1,
+                                          int n_chunks, const float* norms_ws, const float* device_hyper,
+                                          const float* group_lr, const float* group_weight_decay, int n_groups,
+                                          float beta1,
                                           float beta2, float adam_eps, float bias_corr1, float bias_corr2,
                                           int use_lars, float lars_eta, float lars_eps, int lars_clip,
                                           peclr_stream_t stream) {
-    if (!ptrs || !sizes || !chunk_tensor || !chunk_offset || !tensor_chunk_begin || !group_lr ||
-        !group_weight_decay)
-        return PECLR_ERR_NULL;
+    if (!ptrs || !sizes || !chunk_tensor || !chunk_offset || !tensor_chunk_begin) return PECLR_ERR_NULL;
+    if (!device_hyper && (!group_lr || !group_weight_decay)) return PECLR_ERR_NULL;
     if (use_lars && !norms_ws) return PECLR_ERR_NULL;
     if (n_tensors <= 0 || n_chunks <= 0 || n_groups < 1 || n_groups > MAX_GROUPS) return PECLR_ERR_SHAPE;
     if (n_groups > 1 && !tensor_group) return PECLR_ERR_NULL;
-    if (!(bias_corr1 > 0.f) || !(bias_corr2 > 0.f)) return PECLR_ERR_SHAPE;
+    if (!device_hyper && (!(bias_corr1 > 0.f) || !(bias_corr2 > 0.f))) return PECLR_ERR_SHAPE;
     OptArgs a = {};
-    for (int g = 0; g < n_groups; ++g) {
+    for (int g = 0; g < n_groups && !device_hyper; ++g) {
         a.lr[g] = group_lr[g];
         a.weight_decay[g] = group_weight_decay[g];
     }
@@ -205,6 +211,6 @@ extern "C" int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* siz
     a.lars_eta = lars_eta; a.lars_eps = lars_eps; a.use_lars = use_lars; a.lars_clip = lars_clip;
     hipLaunchKernelGGL(lars_adam_kernel, dim3(n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream), ptrs, sizes,
                        n_tensors, chunk_tensor, chunk_offset, tensor_chunk_begin, tensor_group, n_chunks, norms_ws,
-                       a);
+                       device_hyper, a);
     return launch_status();
 }

@@ -15,7 +15,9 @@ Exchange steps per optimisation step:
      RCCL all-gathers (`ops.ntxent`).
   2. SUM all-reduce of the parameter gradients (RN-50: ~94 MB fp32), in a few LARGE flat buckets:
      xGMI is point-to-point (7 links x ~153 GB/s per GPU), ring collectives are bound by one link
-     and RCCL needs big messages to stripe across links, so the bucket size defaults to 64 MiB and
+     and RCCL needs big messages to stripe across links, so the bucket size defaults to 32 MiB
+     (ResNet-50: head + layer4 in two buckets, layer3 in one, and a last 6 MB bucket for layer2 /
+     layer1 / stem -- the only one whose all-reduce cannot hide behind remaining backward work) and
      buckets are launched from autograd hooks as soon as their last gradient lands (overlap with the
      rest of the backward).  `encoder.final_layer.*` never receives a gradient and is skipped.
 """
@@ -104,7 +106,7 @@ class GradReducer:
     the optimiser step, and `zero_grad()` instead of `optimizer.zero_grad()`.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 32 << 20):
         self.group = group
         self.world = world_size(group)
         params = [p for p in params if p.requires_grad]

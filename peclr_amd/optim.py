@@ -87,6 +87,10 @@ class LARSAdam(Optimizer):
         if self.fused and not first.is_cuda:
             raise _capi.PeclrHipError("LARSAdam(fused=True) needs HIP device parameters")
         self._fused_cache = {}
+        # hipGraph support: per-step scalars live in device memory (`_hyper`), refreshed by
+        # `prepare_step()` OUTSIDE the graph; the captured launch (`launch_only()`) only reads them
+        self._hyper = self._hyper_host = None
+        self._prepared = None
 
     def _prepare(self, group):
         """Lazy state init + step count for one group; returns (params, grads, m, v, step)."""
@@ -102,6 +106,37 @@ class LARSAdam(Optimizer):
         m = [self.state[p]["exp_avg"] for p in params]
         v = [self.state[p]["exp_avg_sq"] for p in params]
         return params, grads, m, v, (self.state[params[0]]["step"] if params else 0)
+
+    # ---- hipGraph-capturable split of step(): host part / device part
+    @torch.no_grad()
+    def prepare_step(self):
+        """Host side of one fused step: advance the step counters and stage lr / weight decay / bias
+        corrections into device memory.  Call before every graph replay (and before capturing)."""
+        if not self.fused:
+            raise _capi.PeclrHipError("prepare_step()/launch_only() need the fused HIP optimiser")
+        prepared = [(g, *self._prepare(g)) for g in self.param_groups]
+        prepared = [t for t in prepared if t[1]]
+        if len(prepared) > 8 or len({(tuple(g["betas"]), g["eps"], st) for g, _, _, _, _, st in prepared}) != 1:
+            raise _capi.PeclrHipError("graph mode needs <= 8 parameter groups with common betas / eps / step")
+        g0, step = prepared[0][0], prepared[0][5]
+        b1, b2 = g0["betas"]
+        vals = [0.0] * 18
+        for i, t in enumerate(prepared):
+            vals[i], vals[8 + i] = float(t[0]["lr"]), float(t[0]["weight_decay"])
+        vals[16], vals[17] = 1.0 - b1 ** step, 1.0 - b2 ** step
+        if self._hyper is None:
+            dev = prepared[0][1][0].device
+            self._hyper = torch.zeros(18, dtype=torch.float32, device=dev)
+            self._hyper_host = torch.zeros(18, dtype=torch.float32).pin_memory()
+        self._hyper_host.copy_(torch.tensor(vals, dtype=torch.float32))
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        self._prepared = prepared
+
+    @torch.no_grad()
+    def launch_only(self):
+        """Device side of the step prepared by `prepare_step()`: the two kernel launches, with every
+        per-step scalar read from device memory -- safe to capture in a hipGraph and replay."""
+        self._step_fused(self._prepared, device_hyper=self._hyper)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -128,7 +163,7 @@ class LARSAdam(Optimizer):
         return loss
 
     # ---- HIP: two launches per optimiser step (sum of squares; update), all groups at once
-    def _step_fused(self, prepared):
+    def _step_fused(self, prepared, device_hyper=None):
         params = [p for t in prepared for p in t[1]]
         grads = [x for t in prepared for x in t[2]]
         m = [x for t in prepared for x in t[3]]
@@ -153,7 +188,8 @@ class LARSAdam(Optimizer):
         _capi.lars_adam_step(wl.ptrs, wl.sizes, wl.n_tensors, wl.chunk_tensor, wl.chunk_offset, wl.begin, wl.group,
                              wl.n_chunks, wl.norms_ws, [float(t[0]["lr"]) for t in prepared],
                              [float(t[0]["weight_decay"]) for t in prepared], b1, b2, g0["eps"], 1.0 - b1 ** step,
-                             1.0 - b2 ** step, self.lars, self.eta, self.lars_eps, self.clip)
+                             1.0 - b2 ** step, self.lars, self.eta, self.lars_eps, self.clip,
+                             device_hyper=device_hyper)
 
     # ---- torch foreach restatement (any device)
     def _step_foreach(self, params, grads, m, v, lr, b1, b2, eps, wd, bc1, bc2):

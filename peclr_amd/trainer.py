@@ -21,7 +21,7 @@ from .port import save_checkpoint
 class Trainer:
     def __init__(self, max_epochs: int = 1, accumulate_grad_batches: int = 1, precision: str = "fp32",
                  checkpoint_dir: Optional[str] = None, save_top_k: int = 1, process_group=None,
-                 bucket_bytes: int = 64 << 20, channels_last: bool = False, grad_buckets=None):
+                 bucket_bytes: int = 32 << 20, channels_last: bool = False, grad_buckets=None):
         self.max_epochs = max_epochs
         self.accumulate_grad_batches = accumulate_grad_batches
         self.precision = precision

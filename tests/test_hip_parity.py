@@ -642,3 +642,52 @@ def test_bf16_autocast_step_runs_on_fused_glue():
         losses.append(float(out["loss"]))
         assert all(torch.isfinite(p.grad).all() for n_, p in m.named_parameters() if "final_layer" not in n_)
     assert abs(losses[0] - losses[1]) < 5e-2   # two bf16 pipelines of an 18-layer net
+
+
+def test_bn2d_relu_bitmask_equals_reading_y(capi):
+    """Residual + ReLU: the backward with the 1-bit mask written by the forward is bit-identical to the
+    backward that re-reads y (both through the C ABI), fp32 and bf16."""
+    for dtype in (torch.float32, torch.bfloat16):
+        n, c, h, w = 6, 256, 7, 5
+        g = torch.Generator().manual_seed(9)
+        mk = lambda: torch.randn(n, c, h, w, generator=g).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+        x, res, dy = mk(), mk(), mk()
+        gamma = torch.rand(c, generator=g).to(DEV) + 0.5
+        beta = torch.randn(c, generator=g).to(DEV) * 0.2
+        y, save, ss, mask = capi.bn2d_fwd(x, res, gamma, beta, None, None, None, True, 1e-5, 0.1, True, want_mask=True)
+        assert mask is not None and mask.shape == (n * h * w, c // 32)
+        # mask bits == (y > 0)
+        bits = (y.permute(0, 2, 3, 1).reshape(-1, c // 32, 32) > 0).to(torch.int64)
+        words = (bits << torch.arange(32, device=DEV)).sum(-1)
+        assert torch.equal(words, mask.to(torch.int64) & 0xFFFFFFFF)
+        a = capi.bn2d_bwd(dy, x, None, mask, save, ss, True, True, True)
+        b = capi.bn2d_bwd(dy, x, y, None, save, ss, True, True, True)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+
+
+def test_lars_adam_device_hyperparameters_match_by_value():
+    """prepare_step() + launch_only() (per-step scalars staged in DEVICE memory -- what a captured hipGraph
+    needs to be replayable with a changing lr) is bit-identical to step() (scalars by value)."""
+    from peclr_amd.optim import LARSAdam
+
+    shapes = [(64, 3, 7, 7), (64,), (5000,), (512, 2048)]
+    p0 = [torch.randn(s, generator=torch.Generator().manual_seed(i)) for i, s in enumerate(shapes)]
+
+    def run(split):
+        ps = [torch.nn.Parameter(p.clone().to(DEV)) for p in p0]
+        opt = LARSAdam([{"params": ps[:2], "weight_decay": 1e-6}, {"params": ps[2:], "weight_decay": 0.0}], lr=1e-3)
+        g = torch.Generator().manual_seed(1)
+        for step in range(4):
+            opt.param_groups[0]["lr"] = opt.param_groups[1]["lr"] = 1e-3 * (step + 1)
+            for p in ps:
+                p.grad = torch.randn(p.shape, generator=g).to(DEV)
+            if split:
+                opt.prepare_step()
+                opt.launch_only()
+            else:
+                opt.step()
+        return [p.detach().clone() for p in ps]
+
+    for a, b in zip(run(False), run(True)):
+        assert torch.equal(a, b)
