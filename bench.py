@@ -252,14 +252,13 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    loss = float(out["loss"])
+    table_steps = args.steps
     event_log, _capi.EVENT_LOG = _capi.EVENT_LOG, None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
-    loss = float(out["loss"])
-    table_steps = args.steps
-
     if rank == 0:
         images = world * 2 * args.pairs * args.accum * args.steps
         n_params = sum(p.numel() for n, p in model.named_parameters() if "final_layer" not in n)

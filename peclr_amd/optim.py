@@ -125,18 +125,36 @@ class LARSAdam(Optimizer):
             vals[i], vals[8 + i] = float(t[0]["lr"]), float(t[0]["weight_decay"])
         vals[16], vals[17] = 1.0 - b1 ** step, 1.0 - b2 ** step
         if self._hyper is None:
-            dev = prepared[0][1][0].device
-            self._hyper = torch.zeros(18, dtype=torch.float32, device=dev)
-            self._hyper_host = torch.zeros(18, dtype=torch.float32).pin_memory()
-        self._hyper_host.copy_(torch.tensor(vals, dtype=torch.float32))
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
+            self._hyper = torch.zeros(18, dtype=torch.float32, device=prepared[0][1][0].device)
+        # pageable source: the values are staged before copy_ returns, so the host may run ahead of
+        # the GPU by any number of steps without racing on a shared pinned buffer
+        self._hyper.copy_(torch.tensor(vals, dtype=torch.float32))
         self._prepared = prepared
 
     @torch.no_grad()
-    def launch_only(self):
+    def launch_only(self, reuse_worklist: bool = False):
         """Device side of the step prepared by `prepare_step()`: the two kernel launches, with every
-        per-step scalar read from device memory -- safe to capture in a hipGraph and replay."""
-        self._step_fused(self._prepared, device_hyper=self._hyper)
+        per-step scalar read from device memory -- safe to capture in a hipGraph and replay.
+        reuse_worklist: launch with the existing device-side pointer table as is (inside a capture the
+        gradients live at new addresses that are only known afterwards -> `repoint_worklist()`)."""
+        self._step_fused(self._prepared, device_hyper=self._hyper, reuse=reuse_worklist)
+
+    @torch.no_grad()
+    def repoint_worklist(self):
+        """Rewrite the device-side pointer table from the CURRENT param / grad / moment addresses (same
+        tensors, same order, same sizes as when the work list was built)."""
+        wl = self._fused_cache["all"]
+        groups = [[p for p in g["params"] if p.grad is not None] for g in self.param_groups]
+        params = [p for ps in groups for p in ps]
+        if len(params) != wl.n_tensors:
+            raise _capi.PeclrHipError("repoint_worklist: the set of parameters with gradients changed")
+        seqs = (params, [p.grad for p in params], [self.state[p]["exp_avg"] for p in params],
+                [self.state[p]["exp_avg_sq"] for p in params])
+        for p_, g_ in zip(params, seqs[1]):
+            if g_.stride() != p_.stride() or g_.dtype != torch.float32:
+                raise _capi.PeclrHipError("repoint_worklist: grad layout differs from the parameter's")
+        wl.ptrs.copy_(torch.tensor([t.data_ptr() for seq in seqs for t in seq], dtype=torch.int64))
+        wl.key = tuple(t.data_ptr() for t in (*params, *seqs[1]))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -163,7 +181,16 @@ class LARSAdam(Optimizer):
         return loss
 
     # ---- HIP: two launches per optimiser step (sum of squares; update), all groups at once
-    def _step_fused(self, prepared, device_hyper=None):
+    def _step_fused(self, prepared, device_hyper=None, reuse=False):
+        if reuse:
+            wl = self._fused_cache["all"]
+            g0, step = prepared[0][0], prepared[0][5]
+            b1, b2 = g0["betas"]
+            _capi.lars_adam_step(wl.ptrs, wl.sizes, wl.n_tensors, wl.chunk_tensor, wl.chunk_offset, wl.begin,
+                                 wl.group, wl.n_chunks, wl.norms_ws, [0.0] * len(prepared), [0.0] * len(prepared), b1,
+                                 b2, g0["eps"], 1.0, 1.0, self.lars, self.eta, self.lars_eps, self.clip,
+                                 device_hyper=device_hyper)
+            return
         params = [p for t in prepared for p in t[1]]
         grads = [x for t in prepared for x in t[2]]
         m = [x for t in prepared for x in t[3]]

@@ -82,6 +82,54 @@ class Trainer:
             self.global_step += 1
         return {key: v.detach() for key, v in out.items()}
 
+    # ---- whole-step hipGraph (single process): forward + backward + fused optimiser captured once and
+    # replayed per step -- for launch-bound configurations (bf16 backbones: ~35 ms of kernels per 40 ms
+    # step).  Per-step scalars reach the captured optimiser kernel through device memory
+    # (`LARSAdam.prepare_step`); gradients are allocated INSIDE the capture (pre-existing .grad views
+    # into all-reduce buckets do not replay correctly, tools/exp/graph_capture_bisect.py) and the
+    # optimiser's device-side pointer table is patched to their addresses afterwards.
+    def capture_step_graph(self, example_batch: Dict[str, torch.Tensor], warmup: int = 3):
+        if self.world_size > 1 or self.reducer is not None:
+            raise RuntimeError("capture_step_graph is single-process only (no gradient buckets)")
+        if self.accumulate_grad_batches != 1:
+            raise RuntimeError("capture_step_graph needs accumulate_grad_batches=1")
+        self._static_batch = {k: v.clone() for k, v in example_batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(warmup):
+                self.training_micro_step(self._static_batch, i)
+            # one eager forward/backward so every parameter that trains has a gradient: build the
+            # optimiser's work list and stage the scalars of the step the graph will perform first
+            with self._autocast():
+                self.model.training_step(self._static_batch, 0)["loss"].backward()
+            self.optimizer.prepare_step()
+            self.optimizer.launch_only()          # performs that step eagerly (and builds the work list)
+            self.scheduler.step()
+            self.global_step += 1
+            self.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            with self._autocast():
+                out = self.model.training_step(self._static_batch, 0)
+            out["loss"].backward()
+            self.optimizer.launch_only(reuse_worklist=True)
+        self.optimizer.repoint_worklist()         # gradients now live in the graph's private pool
+        self._static_out = out
+        return self
+
+    def replay_step(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        if batch is not None and batch is not self._static_batch:
+            for k, v in batch.items():
+                self._static_batch[k].copy_(v, non_blocking=True)
+        self.optimizer.prepare_step()
+        self._graph.replay()
+        self.scheduler.step()
+        self.global_step += 1
+        return self._static_out
+
     def fit(self, model, train_batches: Callable[[int], Iterable[Dict[str, torch.Tensor]]],
             val_batches: Optional[Callable[[int], Iterable[Dict[str, torch.Tensor]]]] = None):
         """`train_batches(epoch)` yields batch dicts already on the model's device."""
