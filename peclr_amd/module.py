@@ -24,7 +24,6 @@ import torch
 from torch import Tensor, nn
 from torch.optim.lr_scheduler import CosineAnnealingLR
 
-from . import dist as pdist
 from . import ops
 from .encoder import get_wrapper_model
 from .optim import LARSAdam, LinearWarmupCosineAnnealingLR

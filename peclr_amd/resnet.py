@@ -10,7 +10,7 @@ importable here); pinned by state_dict key/shape lists (tests/test_resnet.py).
 """
 from __future__ import annotations
 
-from typing import List, Optional, Type, Union
+from typing import List, Type, Union
 
 import torch
 from torch import Tensor, nn
