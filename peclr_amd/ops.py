@@ -50,6 +50,9 @@ class BNState:
     num_batches_tracked: Optional[Tensor]
 
 
+_REGISTER_BN_MAX_ROWS = 1024  # bn_relu kernels hold <= 16 rows per thread x 64 row slices in registers
+
+
 def _as_slabs(t: Tensor) -> Tensor:
     return t if t.dim() == 3 else t.unsqueeze(0)
 
@@ -60,15 +63,29 @@ class _HeadAlign(torch.autograd.Function):
         h = h.contiguous()
         m, din = h.shape
         hid, d = w1.shape[0], w2.shape[0]
-        # K1: a = h W1^T  (split-K slabs; bias and the slab reduction are fused into the BN kernel)
-        a_slabs = _as_slabs(_capi.gemm(_capi.GEMM_NT, h, w1, split_k=_capi.pick_split_k(m, hid, din), tag="gemm_k1_fwd"))
-        a_pre, a, save = _capi.bn_relu_fwd(a_slabs, b1, gamma, beta, bn.eps, bn.momentum, bn.training,
-                                           bn.running_mean, bn.running_var, bn.num_batches_tracked)
+        ss = None
+        if m <= _REGISTER_BN_MAX_ROWS:
+            # K1: a = h W1^T  (split-K slabs; bias and the slab reduction are fused into the BN kernel,
+            # which keeps its rows in registers)
+            a_slabs = _as_slabs(_capi.gemm(_capi.GEMM_NT, h, w1, split_k=_capi.pick_split_k(m, hid, din),
+                                           tag="gemm_k1_fwd"))
+            a_pre, a, save = _capi.bn_relu_fwd(a_slabs, b1, gamma, beta, bn.eps, bn.momentum, bn.training,
+                                               bn.running_mean, bn.running_var, bn.num_batches_tracked)
+        else:
+            # large batches: enough tiles without split-K (bias in the GEMM epilogue), and the [M, H]
+            # activation matrix IS an NHWC tensor with 1x1 spatial extent -> the streaming
+            # stats / finalize / apply kernels of the backbone glue (4.5-5.5 TB/s) instead of the
+            # register-resident kernel, which only scales to 1024 rows
+            a_pre = _capi.gemm(_capi.GEMM_NT, h, w1, bias=b1, tag="gemm_k1_fwd")
+            a4, save, ss, _ = _capi.bn2d_fwd(a_pre.view(m, hid, 1, 1), None, gamma, beta, bn.running_mean,
+                                            bn.running_var, bn.num_batches_tracked, bn.training, bn.eps,
+                                            bn.momentum, relu=True)
+            a = a4.view(m, hid)
         # K2: p = relu(bn(a)) W2^T  (slabs reduced inside the align kernel)
         p_slabs = _as_slabs(_capi.gemm(_capi.GEMM_NT, a, w2, split_k=_capi.pick_split_k(m, d, hid), tag="gemm_k2_fwd"))
         p, z, norms, row_stats = _capi.align_fwd(p_slabs, spec.n_pairs, spec.flags, spec.jitter, spec.extents,
                                                  spec.angles, spec.want_stats)
-        ctx.save_for_backward(h, w1, gamma, beta, w2, a_pre, a, save, p, z, norms)
+        ctx.save_for_backward(h, w1, gamma, beta, w2, a_pre, a, save, p, z, norms, *([ss] if ss is not None else []))
         ctx.spec, ctx.bn_training = spec, bn.training
         if row_stats is None:
             row_stats = torch.empty(0, device=h.device)
@@ -77,12 +94,21 @@ class _HeadAlign(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz, _d_stats):
-        h, w1, gamma, beta, w2, a_pre, a, save, p, z, norms = ctx.saved_tensors
+        h, w1, gamma, beta, w2, a_pre, a, save, p, z, norms = ctx.saved_tensors[:11]
+        ss = ctx.saved_tensors[11] if len(ctx.saved_tensors) > 11 else None
         spec = ctx.spec
         dp = _capi.align_bwd(dz.contiguous(), p, z, norms, spec.n_pairs, spec.flags, spec.angles)
         dw2 = _capi.gemm(_capi.GEMM_TN, dp, a, tag="gemm_dw2")            # [D,H]   = dp^T a
         da = _capi.gemm(_capi.GEMM_NN, dp, w2, tag="gemm_da")            # [M,H]   = dp W2
-        d_a_pre, dgamma, dbeta, db1 = _capi.bn_relu_bwd(da, a_pre, save, gamma, beta, ctx.bn_training)
+        if ss is None:
+            d_a_pre, dgamma, dbeta, db1 = _capi.bn_relu_bwd(da, a_pre, save, gamma, beta, ctx.bn_training)
+        else:
+            m, hid = a_pre.shape
+            dx4, dgamma, dbeta, _ = _capi.bn2d_bwd(da.view(m, hid, 1, 1), a_pre.view(m, hid, 1, 1), None, None, save,
+                                                   ss, ctx.bn_training, True, False)
+            d_a_pre = dx4.view(m, hid)
+            # column sum of d_a_pre in closed form: 0 through batch statistics, scale*dbeta through frozen ones
+            db1 = torch.zeros_like(dbeta) if ctx.bn_training else ss[0] * dbeta
         dw1 = _capi.gemm(_capi.GEMM_TN, d_a_pre, h, tag="gemm_dw1")       # [H,Din] = dA^T h
         dh = _capi.gemm(_capi.GEMM_NN, d_a_pre, w1, tag="gemm_dh") if ctx.needs_input_grad[0] else None
         return dh, dw1, db1, dgamma, dbeta, dw2, None, None

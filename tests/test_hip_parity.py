@@ -734,3 +734,29 @@ def test_whole_step_hip_graph_matches_eager():
     # MIOpen's atomically-accumulated weight gradients + Adam's early-step sensitivity: curves agree loosely
     assert graph == pytest.approx(eager[4:], rel=5e-2)
     assert graph[-1] < 0.8 * eager[3]                # and it keeps learning under replay
+
+
+def test_head_large_batch_streaming_bn_matches_oracle():
+    """M > 1024 rows routes the head's BatchNorm1d+ReLU through the streaming (backbone-glue) kernels."""
+    from peclr_amd import ops
+
+    n, din, hid = 700, 64, 128   # M = 1400
+    m = 2 * n
+    h, w1, b1 = rnd((m, din), 80), rnd((hid, din), 81, 0.2), rnd((hid,), 82, 0.1)
+    gamma, beta, w2 = 0.5 + np.abs(rnd((hid,), 83)), rnd((hid,), 84, 0.2), rnd((128, hid), 85, 0.2)
+    ref = O.head_loss_fwd_bwd(h, w1, b1, gamma, beta, w2, n, crop=False, rotate=False)
+    t = {k: dev(v).requires_grad_() for k, v in dict(h=h, w1=w1, b1=b1, gamma=gamma, beta=beta, w2=w2).items()}
+    rm, rv, nbt = torch.zeros(hid, device=DEV), torch.ones(hid, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    z, rs = ops.head_align(t["h"], t["w1"], t["b1"], t["gamma"], t["beta"], t["w2"],
+                           ops.BNState(True, 1e-5, 0.1, rm, rv, nbt), ops.AlignSpec(n_pairs=n))
+    loss, _, _ = ops.ntxent(z, n, 0.5, rs)
+    loss.backward()
+    assert abs(float(loss) - float(ref["loss"])) < 1e-5
+    for k, r in (("h", "dh"), ("w1", "dw1"), ("gamma", "dgamma"), ("beta", "dbeta"), ("w2", "dw2")):
+        scale = max(1.0, float(np.abs(ref[r]).max()))
+        np.testing.assert_allclose(host(t[k].grad), ref[r], atol=5e-5 * scale, err_msg=r)
+    assert float(t["b1"].grad.abs().max()) == 0.0 and int(nbt) == 1
+    rm_ref, rv_ref = O.bn1d_running_update(np.zeros(hid, np.float32), np.ones(hid, np.float32), ref["bn_mean"],
+                                           ref["bn_var"], m)
+    np.testing.assert_allclose(host(rm), rm_ref, atol=1e-5)
+    np.testing.assert_allclose(host(rv), rv_ref, atol=1e-5)

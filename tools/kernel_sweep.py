@@ -66,6 +66,19 @@ def main():
                                              one.data_ptr(), 1.0 / m, slabs.data_ptr(), jb, st())
         us = timed(bwd)
         out.append(row("ntxent_bwd", f"M={m} jsplit={jb}", us, 4 * m * m * 128, 512 * 2 * m + 512 * m * jb))
+    # ---- NT-Xent at the 8-GPU config C3: 256 local rows against the 2048 gathered rows
+    z = torch.nn.functional.normalize(torch.randn(2048, 128, device=DEV))
+    zr = z[512:768].contiguous()
+    jf, jb = _capi.ntxent_jsplit(256, 2048, False), _capi.ntxent_jsplit(256, 2048, True)
+    part = torch.empty(jf, 256, device=DEV); pos = torch.empty(256, device=DEV); lse = torch.zeros(2048, device=DEV)
+    one = torch.ones(1, device=DEV); slabs = torch.empty(jb, 256, 128, device=DEV)
+    us = timed(lambda: L.peclr_ntxent_fwd_f32(zr.data_ptr(), 256, 512, z.data_ptr(), 2048, 128, 128, 2.0, None,
+                                              part.data_ptr(), pos.data_ptr(), jf, st()))
+    out.append(row("ntxent_fwd", f"Mr=256 x Mg=2048 (C3 per rank) jsplit={jf}", us, 2 * 256 * 2048 * 128, 512 * (256 + 2048)))
+    us = timed(lambda: L.peclr_ntxent_bwd_f32(zr.data_ptr(), 256, 512, z.data_ptr(), 2048, 128, 128, 2.0, lse.data_ptr(),
+                                              one.data_ptr(), 1.0 / 2048, slabs.data_ptr(), jb, st()))
+    out.append(row("ntxent_bwd", f"Mr=256 x Mg=2048 (C3 per rank) jsplit={jb}", us, 4 * 256 * 2048 * 128,
+                   512 * (256 + 2048) + 512 * 256 * jb))
     # ---- GEMM (NT: the K1 forward shape family, then square)
     for (m, n, k) in ((256, 512, 2048), (2048, 512, 2048), (4096, 4096, 4096), (8192, 2048, 2048)):
         a = torch.randn(m, k, device=DEV); b = torch.randn(n, k, device=DEV)
