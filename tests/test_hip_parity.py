@@ -760,3 +760,30 @@ def test_head_large_batch_streaming_bn_matches_oracle():
                                            ref["bn_var"], m)
     np.testing.assert_allclose(host(rm), rm_ref, atol=1e-5)
     np.testing.assert_allclose(host(rv), rv_ref, atol=1e-5)
+
+
+@pytest.mark.parametrize("n", [16384, 70000])
+def test_align_large_m_variants_match_small_variant(capi, n):
+    """The 16- and 64-rows-per-workgroup variants (shared float64 sin/cos) against the oracle on a
+    sample of rows and against the invariants on all rows."""
+    m = 2 * n
+    g = torch.Generator().manual_seed(n)
+    p = torch.randn(1, m, 128, generator=g).to(DEV)
+    jit = tuple(torch.randint(-14, 1, (n,), generator=g).to(DEV) for _ in range(4))
+    ang = tuple(torch.randint(-45, 46, (n,), generator=g).double().to(DEV) for _ in range(2))
+    _, z, norms, stats = capi.align_fwd(p, n, capi.ALIGN_CROP | capi.ALIGN_ROTATE, jit, (224, 224), ang)
+    assert torch.allclose(z.norm(dim=1), torch.ones(m, device=DEV), atol=1e-5)
+    rows = torch.cat([torch.arange(0, 40), torch.arange(n - 20, n + 20), torch.arange(m - 40, m)])
+    # oracle on the sampled rows: build a small two-view problem out of matching view-1 / view-2 rows
+    idx1 = torch.cat([torch.arange(0, 40), torch.arange(n - 20, n)])
+    idx2 = idx1 + n
+    sel = torch.cat([idx1, idx2]).to(DEV)
+    ps = host(p[0][sel])
+    jx = np.concatenate([host(jit[0][idx1.to(DEV)]), host(jit[1][idx1.to(DEV)])])
+    jy = np.concatenate([host(jit[2][idx1.to(DEV)]), host(jit[3][idx1.to(DEV)])])
+    an = np.concatenate([host(ang[0][idx1.to(DEV)]), host(ang[1][idx1.to(DEV)])])
+    z_ref, stats_ref, _ = O.align_fwd(ps, len(idx1), crop=True, rotate=True, jitter_x=jx, jitter_y=jy, angle=an,
+                                      image_hw=(224, 224))
+    np.testing.assert_allclose(host(z[sel]), z_ref, atol=2e-6)
+    got = host(stats[sel]).reshape(2, len(idx1), 8).mean(1).reshape(16)
+    np.testing.assert_allclose(got, stats_ref, atol=2e-6)

@@ -108,6 +108,10 @@ def main():
         ang = tuple(torch.randint(-45, 46, (n,), device=DEV).double() for _ in range(2))
         us = timed(lambda: _capi.align_fwd(p, n, 3, jit, (224, 224), ang))
         out.append(row("align_fwd", f"M={m}", us, 0, m * (512 * 3 + 48)))
+        pp, zz, nn_, _ = _capi.align_fwd(p, n, 3, jit, (224, 224), ang)
+        dz = torch.randn(m, 128, device=DEV)
+        us = timed(lambda: _capi.align_bwd(dz, pp, zz, nn_, n, 3, ang))
+        out.append(row("align_bwd", f"M={m}", us, 0, m * (512 * 4 + 16)))
     # ---- LARS/Adam over one big tensor list (ResNet-50 sized: 23.5 M parameters)
     from peclr_amd.optim import LARSAdam
     ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in (2048 * 512 * 9, 1024 * 2048, 512 * 512 * 9, 64 * 147,
