@@ -65,6 +65,9 @@ def parse():
                     help="backbone BatchNorm2d/add/ReLU glue on the hand-written NHWC kernels (needs "
                          "--channels-last 1; fp32 or bf16 activations); 0 = stock PyTorch/MIOpen ops")
     ap.add_argument("--accum", type=int, default=1)
+    ap.add_argument("--sync-bn", type=int, default=0,
+                    help="1: BatchNorm statistics over the global batch (exact N-rank == 1-device semantics, two small "
+                         "all-reduces per BN layer); 0: per-rank statistics, like DDP without SyncBatchNorm")
     ap.add_argument("--miopen-find", type=int, default=0,
                     help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find; tens of minutes of kernel "
                          "JIT on a box without a populated user find-db)")
@@ -227,7 +230,8 @@ def main():
         from peclr_amd.bn2d import enable_hip_batchnorm
 
         enable_hip_batchnorm(model.encoder)
-    trainer = Trainer(max_epochs=100, accumulate_grad_batches=args.accum, precision=args.dtype).attach(model)
+    trainer = Trainer(max_epochs=100, accumulate_grad_batches=args.accum, precision=args.dtype,
+                      sync_batchnorm=bool(args.sync_bn)).attach(model)
     trainer.zero_grad()
     batch = synthetic_batch(args.pairs, args.size, 5 + rank, device)
     if args.channels_last:
@@ -285,7 +289,8 @@ def main():
                                    f"LARS(Adam) step, {args.dtype}",
                        "global_batch": world * 2 * args.pairs * args.accum, "parallelism": f"dp{world}",
                        "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn,
-                       "bn": "per-rank batch statistics"},
+                       "bn": "global-batch statistics (synchronised)" if (args.sync_bn and world > 1)
+                       else "per-rank batch statistics"},
             "loss": round(loss, 6),
             "roofline": roof,
             "kernels": kernels,

@@ -194,8 +194,15 @@ int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* sizes, int n_t
  *   forward (training): peclr_bn2d_stats -> peclr_bn2d_finalize_f32 -> peclr_bn2d_apply
  *   forward (eval)    :                     peclr_bn2d_finalize_f32 -> peclr_bn2d_apply
  *   backward          : peclr_bn2d_bwd_reduce -> peclr_bn2d_bwd_finalize_f32 -> peclr_bn2d_bwd_apply
- * partial (forward): [n_split*2 + 1][C] floats = row-slice partial sums + one row holding the
- * shift; partial (backward): [n_split*2][C].  n_split from peclr_bn2d_n_split, or any >= 1.
+ * partial (forward): [n_split*2 + 1][C] floats = row-slice partial sums (of x - shift and its
+ * square) + one row holding the shift; shift (nullable): [C] vector to subtract, default = row 0
+ * of x.  partial (backward): [n_split*2][C].  n_split from peclr_bn2d_n_split, or any >= 1.
+ * Synchronised statistics across data-parallel ranks (optional; every rank passes the SAME shift,
+ * e.g. running_mean): peclr_bn2d_stats -> peclr_bn2d_combine_f64 (totals: double [2*C+1]; the
+ * caller stores its row count in the last element) -> the caller SUM-all-reduces totals -> peclr_bn2d_finalize_totals_f32; backward:
+ * peclr_bn2d_bwd_reduce -> peclr_bn2d_combine_f64 -> all-reduce ->
+ * peclr_bn2d_bwd_finalize_totals_f32 (dgamma/dbeta from the LOCAL totals, dx coefficients from the
+ * GLOBAL ones).
  * scale_shift: [2][C] = {gamma*invstd, beta - mean*gamma*invstd}; coef: [2][C] scratch for dx.
  * ReLU mask in the backward: recomputed from x when neither y nor relu_mask is given (valid only
  * if no residual was added); read from relu_mask ([R][C/32] uint32, 1 bit per element, written by
@@ -204,13 +211,24 @@ int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* sizes, int n_t
 #define PECLR_DTYPE_F32 0
 #define PECLR_DTYPE_BF16 1
 int peclr_bn2d_n_split(int R, int C, int io_dtype);
-int peclr_bn2d_stats(const void* x, int io_dtype, int R, int C, float* partial, int n_split,
-                     peclr_stream_t stream);
+int peclr_bn2d_stats(const void* x, int io_dtype, int R, int C, const float* shift,
+                     float* partial, int n_split, peclr_stream_t stream);
 int peclr_bn2d_finalize_f32(const float* partial, int n_split, int R, int C, int training,
                             float eps, float momentum, const float* gamma, const float* beta,
                             float* running_mean, float* running_var,
                             int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
                             float* scale_shift, peclr_stream_t stream);
+int peclr_bn2d_combine_f64(const float* partial, int n_split, int C, double* totals,
+                           peclr_stream_t stream);
+int peclr_bn2d_finalize_totals_f32(const double* totals, const float* shift, int C,
+                                   float eps, float momentum, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, float* save_mean,
+                                   float* save_invstd, float* scale_shift, peclr_stream_t stream);
+int peclr_bn2d_bwd_finalize_totals_f32(const double* local_totals, const double* global_totals,
+                                       int C, int training, const float* scale_shift,
+                                       float* dgamma, float* dbeta, float* coef,
+                                       peclr_stream_t stream);
 int peclr_bn2d_apply(const void* x, const void* residual, int io_dtype, int R, int C,
                      const float* scale_shift, int relu, void* y, uint32_t* relu_mask,
                      peclr_stream_t stream);

@@ -41,7 +41,11 @@ SIGNATURES = {
     "peclr_ntxent_bwd_f32": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, c_float, _P, _P, c_float, _P,
                                      c_int, _P]),
     "peclr_bn2d_n_split": (c_int, [c_int, c_int, c_int]),
-    "peclr_bn2d_stats": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
+    "peclr_bn2d_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P]),
+    "peclr_bn2d_combine_f64": (c_int, [_P, c_int, c_int, _P, _P]),
+    "peclr_bn2d_finalize_totals_f32": (c_int, [_P, _P, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P,
+                                               _P]),
+    "peclr_bn2d_bwd_finalize_totals_f32": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_bn2d_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P,
                                         _P, _P, _P]),
     "peclr_bn2d_apply": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
@@ -323,9 +327,26 @@ def bn2d_n_split(r: int, c: int, io: int) -> int:
     return n
 
 
+def _sync_totals(partial, ns, c, rows, group):
+    """Synchronised BatchNorm: combine this rank's slice partials into double [2][C] totals, append the
+    row count and SUM-all-reduce over `group`.  Returns (local totals, global totals, global rows)."""
+    import torch.distributed as td
+
+    local = torch.empty(2 * c + 1, device=partial.device, dtype=torch.float64)
+    with _timed("bn2d_combine", 8 * ns * c):
+        rc = lib().peclr_bn2d_combine_f64(partial.data_ptr(), ns, c, local.data_ptr(), _stream())
+    _check(rc, "peclr_bn2d_combine_f64")
+    local[2 * c] = float(rows)
+    total = local.clone()
+    td.all_reduce(total, op=td.ReduceOp.SUM, group=group)
+    return local, total
+
+
 def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, relu,
-             want_mask=False):
-    """want_mask: also write the 1-bit ReLU mask ([R, C/32] int32) the backward reads instead of y."""
+             want_mask=False, sync_group=None):
+    """want_mask: also write the 1-bit ReLU mask ([R, C/32] int32) the backward reads instead of y.
+    sync_group: a process group -> training statistics are those of the rows of ALL its ranks
+    (mean/var of the global batch, as one device holding the concatenated batch would compute)."""
     n, c, h, w = x.shape
     r = n * h * w
     dev = x.device
@@ -339,15 +360,29 @@ def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training,
         ns = bn2d_n_split(r, c, io)
         partial = torch.empty((2 * ns + 1, c), device=dev, dtype=torch.float32)
         part_ptr = partial.data_ptr()
+        sync = sync_group is not None
+        if sync and running_mean is None:
+            raise PeclrHipError("synchronised BatchNorm needs running statistics (their mean is the common shift)")
+        # synchronised: every rank must subtract the SAME shift before summing -> the (replicated) running mean
+        shift = running_mean.detach().clone() if sync else None
         with _timed("bn2d_stats", e * r * c):
-            rc = lib().peclr_bn2d_stats(xp, io, r, c, part_ptr, ns, _stream())
+            rc = lib().peclr_bn2d_stats(xp, io, r, c, _ptr(shift), part_ptr, ns, _stream())
         _check(rc, "peclr_bn2d_stats")
-    with _timed("bn2d_finalize", 8 * ns * c):
-        rc = lib().peclr_bn2d_finalize_f32(part_ptr, ns, r, c, int(training), eps, momentum, _ptr(gamma), _ptr(beta),
-                                           _ptr(running_mean), _ptr(running_var),
-                                           _ptr(nbt, torch.int64, "num_batches_tracked") if training else None,
-                                           save[0].data_ptr(), save[1].data_ptr(), ss.data_ptr(), _stream())
-    _check(rc, "peclr_bn2d_finalize_f32")
+    if training and sync:
+        _, total = _sync_totals(partial, ns, c, r, sync_group)
+        with _timed("bn2d_finalize", 16 * c):
+            rc = lib().peclr_bn2d_finalize_totals_f32(total.data_ptr(), shift.data_ptr(), c, eps, momentum,
+                                                      _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                                      _ptr(nbt, torch.int64, "num_batches_tracked"),
+                                                      save[0].data_ptr(), save[1].data_ptr(), ss.data_ptr(), _stream())
+        _check(rc, "peclr_bn2d_finalize_totals_f32")
+    else:
+        with _timed("bn2d_finalize", 8 * ns * c):
+            rc = lib().peclr_bn2d_finalize_f32(part_ptr, ns, r, c, int(training), eps, momentum, _ptr(gamma), _ptr(beta),
+                                               _ptr(running_mean), _ptr(running_var),
+                                               _ptr(nbt, torch.int64, "num_batches_tracked") if training else None,
+                                               save[0].data_ptr(), save[1].data_ptr(), ss.data_ptr(), _stream())
+        _check(rc, "peclr_bn2d_finalize_f32")
     mask = torch.empty((r, c // 32), device=dev, dtype=torch.int32) if (want_mask and relu and c % 32 == 0) else None
     with _timed("bn2d_apply", (3 if residual is not None else 2) * e * r * c + (r * c // 8 if mask is not None else 0)):
         rc = lib().peclr_bn2d_apply(xp, _nhwc_ptr(residual, "bn2d residual", x.dtype) if residual is not None else None,
@@ -357,8 +392,10 @@ def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training,
     return y, save, ss, mask
 
 
-def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres):
-    """ReLU mask source: `mask` (bit mask from the forward) > `y` (forward output) > recomputed from x."""
+def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres, sync_group=None):
+    """ReLU mask source: `mask` (bit mask from the forward) > `y` (forward output) > recomputed from x.
+    sync_group: as in bn2d_fwd; dgamma/dbeta stay this rank's local sums (the gradient all-reduce sums
+    them later), dx uses the global sums."""
     n, c, h, w = x.shape
     r = n * h * w
     dev = x.device
@@ -377,11 +414,19 @@ def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres):
         rc = lib().peclr_bn2d_bwd_reduce(dyp, xp, yp, mp, io, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
                                          ss.data_ptr(), partial.data_ptr(), ns, _stream())
     _check(rc, "peclr_bn2d_bwd_reduce")
-    with _timed("bn2d_bwd_finalize", 8 * ns * c):
-        rc = lib().peclr_bn2d_bwd_finalize_f32(partial.data_ptr(), ns, r, c, int(training), ss.data_ptr(),
-                                               dparams[0].data_ptr(), dparams[1].data_ptr(), coef.data_ptr(),
-                                               _stream())
-    _check(rc, "peclr_bn2d_bwd_finalize_f32")
+    if training and sync_group is not None:
+        local, total = _sync_totals(partial, ns, c, r, sync_group)
+        with _timed("bn2d_bwd_finalize", 32 * c):
+            rc = lib().peclr_bn2d_bwd_finalize_totals_f32(local.data_ptr(), total.data_ptr(), c, 1, ss.data_ptr(),
+                                                          dparams[0].data_ptr(), dparams[1].data_ptr(), coef.data_ptr(),
+                                                          _stream())
+        _check(rc, "peclr_bn2d_bwd_finalize_totals_f32")
+    else:
+        with _timed("bn2d_bwd_finalize", 8 * ns * c):
+            rc = lib().peclr_bn2d_bwd_finalize_f32(partial.data_ptr(), ns, r, c, int(training), ss.data_ptr(),
+                                                   dparams[0].data_ptr(), dparams[1].data_ptr(), coef.data_ptr(),
+                                                   _stream())
+        _check(rc, "peclr_bn2d_bwd_finalize_f32")
     with _timed("bn2d_bwd_apply", (3 + (1 if want_dres else 0)) * e * r * c + extra):
         rc = lib().peclr_bn2d_bwd_apply(dyp, xp, yp, mp, io, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
                                         ss.data_ptr(), coef.data_ptr(), dx.data_ptr(),

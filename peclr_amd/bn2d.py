@@ -31,10 +31,12 @@ class _BN2dAct(torch.autograd.Function):
         need_mask = relu and residual is not None
         y, save, ss, mask = _capi.bn2d_fwd(x, residual, weight, bias, bn.running_mean, bn.running_var,
                                            bn.num_batches_tracked, training, bn.eps,
-                                           bn.momentum if bn.momentum is not None else 0.1, relu, want_mask=need_mask)
+                                           bn.momentum if bn.momentum is not None else 0.1, relu, want_mask=need_mask,
+                                           sync_group=bn.sync_group if training else None)
         keep = mask if mask is not None else (y if need_mask else None)
         ctx.save_for_backward(x, save, ss, *([keep] if keep is not None else []))
         ctx.cfg = (training, relu, residual is not None, keep is not None, mask is not None)
+        ctx.sync_group = bn.sync_group if training else None
         return y
 
     @staticmethod
@@ -45,7 +47,7 @@ class _BN2dAct(torch.autograd.Function):
         y, mask = (None, keep) if is_mask else (keep, None)
         dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         dx, dgamma, dbeta, dres = _capi.bn2d_bwd(dy, x, y, mask, save, ss, training, relu,
-                                                 has_res and ctx.needs_input_grad[3])
+                                                 has_res and ctx.needs_input_grad[3], sync_group=ctx.sync_group)
         if has_res and dres is None and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dgamma, dbeta, dres, None, None
@@ -57,6 +59,9 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
                          track_running_stats=track_running_stats, **kw)
         self.hip = False
         self.default_relu = False  # stem BN inside an nn.Sequential: fuse the ReLU that follows it
+        # data parallel: a process group -> training statistics over the rows of ALL its ranks (what one
+        # device holding the concatenated batch computes); None -> per-rank statistics (DDP's default)
+        self.sync_group = None
 
     def forward(self, x: Tensor, residual: Optional[Tensor] = None, relu: Optional[bool] = None) -> Tensor:
         relu = self.default_relu if relu is None else relu
@@ -64,18 +69,22 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
             if not self.affine or (self.training and self.momentum is None):
                 raise _capi.PeclrHipError("fused BatchNorm2d needs affine=True and a fixed momentum")
             return _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu)
+        if self.sync_group is not None and self.training:
+            raise _capi.PeclrHipError("synchronised statistics are implemented by the HIP kernels only (hip=True)")
         y = super().forward(x)
         if residual is not None:
             y = y + residual
         return F.relu(y) if relu else y
 
 
-def enable_hip_batchnorm(module: nn.Module, enabled: bool = True) -> int:
+def enable_hip_batchnorm(module: nn.Module, enabled: bool = True, sync_group=None) -> int:
     """Switch every FusedBatchNormAct2d under `module` to the HIP kernels (or back).  The caller is
-    responsible for feeding fp32 channels_last HIP tensors; anything else raises."""
+    responsible for feeding fp32 channels_last HIP tensors; anything else raises.
+    sync_group: process group whose ranks share their batch statistics (None = per-rank)."""
     n = 0
     for m in module.modules():
         if isinstance(m, FusedBatchNormAct2d):
             m.hip = enabled
+            m.sync_group = sync_group if enabled else None
             n += 1
     return n

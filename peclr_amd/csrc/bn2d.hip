@@ -130,12 +130,15 @@ __device__ __forceinline__ Fv<W> lane_reduce(Fv<W> v, float* red, const Geo& g, 
 // ------------------------------------------------------------------ forward: statistics
 // partial: [n_split][2][C] sums, followed by one extra row [C] = the shift (row 0 of x as fp32).
 template <typename IO>
-__global__ __launch_bounds__(T) void bn2d_stats_kernel(const IO* __restrict__ x, Geo g, int n_split, float* __restrict__ partial) {
+__global__ __launch_bounds__(T) void bn2d_stats_kernel(const IO* __restrict__ x, const float* __restrict__ shift, Geo g,
+                                                       int n_split, float* __restrict__ partial) {
     constexpr int W = Word<IO>::W, U = Word<IO>::U;
     __shared__ float red[W * T];
     int col, r0, r1, rl;
     thread_geo<W>(g, col, r0, r1, rl);
-    const Fv<W> k0 = Word<IO>::load(x + col);  // shift = row 0 (same for every block)
+    // shift: row 0 of x (same for every block), or a caller-provided vector that is identical on every
+    // rank (synchronised statistics: partial sums of different ranks must share their shift)
+    const Fv<W> k0 = shift ? loadp<W>(shift + col) : Word<IO>::load(x + col);
     Fv<W> s = zero<W>(), q = zero<W>();
     auto acc = [&](const Fv<W>& v) {
 #pragma unroll
@@ -223,6 +226,63 @@ __global__ __launch_bounds__(FT) void bn2d_stats_finalize_kernel(const float* __
         const float unbiased = (float)(var * ((double)R / (double)(R > 1 ? R - 1 : 1)));
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
     }
+}
+
+// ---- synchronised statistics (data parallel): combine -> [all-reduce on the host side] -> finalize
+// totals: double [2*C + 1] = per-channel sums, then the row count (set by the host before the all-reduce)
+__global__ __launch_bounds__(FT) void bn2d_combine_kernel(const float* __restrict__ partial, int n_split, int C,
+                                                          double* __restrict__ totals) {
+    __shared__ double red[FL][2][FC];
+    const int c = blockIdx.x * FC + threadIdx.x % FC, lane = threadIdx.x / FC;
+    double a, b;
+    combine_partials(partial, n_split, C, c, lane, red, a, b);
+    if (lane != 0 || c >= C) return;
+    totals[c] = a;
+    totals[C + c] = b;
+}
+
+__global__ __launch_bounds__(T) void bn2d_finalize_totals_kernel(const double* __restrict__ totals, const float* __restrict__ shift,
+                                                                 int C, float eps, float momentum,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* running_mean, float* running_var, int64_t* nbt,
+                                                                 float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                                 float* __restrict__ scale_shift) {
+    const int c = blockIdx.x * T + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    const double count = totals[2 * C];
+    const double ms = totals[c] / count;
+    double var = totals[C + c] / count - ms * ms;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)(ms + (double)shift[c]);
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    const float sc = gamma[c] * invstd;
+    scale_shift[c] = sc;
+    scale_shift[C + c] = beta[c] - mean * sc;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    if (running_var) {
+        const float unbiased = (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// dgamma / dbeta are this rank's LOCAL sums (parameter gradients are summed across ranks later by the
+// gradient all-reduce); the dx coefficients use the GLOBAL sums and the global row count.
+__global__ __launch_bounds__(T) void bn2d_bwd_finalize_totals_kernel(const double* __restrict__ local_totals,
+                                                                     const double* __restrict__ global_totals,
+                                                                     int C, int training, const float* __restrict__ scale_shift,
+                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                     float* __restrict__ coef) {
+    const int c = blockIdx.x * T + threadIdx.x;
+    if (c >= C) return;
+    const double count = global_totals[2 * C];
+    dbeta[c] = (float)local_totals[c];
+    dgamma[c] = (float)local_totals[C + c];
+    const double k1 = (double)scale_shift[c];
+    coef[c] = training ? (float)(-k1 * global_totals[c] / count) : 0.f;
+    coef[C + c] = training ? (float)(-k1 * global_totals[C + c] / count) : 0.f;
 }
 
 // eval mode: scale/shift from the running statistics
@@ -521,17 +581,47 @@ extern "C" int peclr_bn2d_n_split(int R, int C, int io_dtype) {
     return plan_for(io_dtype, R, C, 0, p) ? p.n_split : 0;
 }
 
-extern "C" int peclr_bn2d_stats(const void* x, int io_dtype, int R, int C, float* partial, int n_split,
-                                peclr_stream_t stream) {
+extern "C" int peclr_bn2d_stats(const void* x, int io_dtype, int R, int C, const float* shift, float* partial,
+                                int n_split, peclr_stream_t stream) {
     if (!x || !partial) return PECLR_ERR_NULL;
     Plan p;
     if (n_split < 1 || !plan_for(io_dtype, R, C, n_split, p)) return PECLR_ERR_SHAPE;
-    if (!all_aligned({x, partial})) return PECLR_ERR_ALIGN;
+    if (!all_aligned({x, partial, shift})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (io_dtype == PECLR_DTYPE_F32)
-        hipLaunchKernelGGL((bn2d_stats_kernel<float>), p.grid, dim3(T), 0, s, static_cast<const float*>(x), p.g, n_split, partial);
+        hipLaunchKernelGGL((bn2d_stats_kernel<float>), p.grid, dim3(T), 0, s, static_cast<const float*>(x), shift, p.g, n_split, partial);
     else
-        hipLaunchKernelGGL((bn2d_stats_kernel<bf16_t>), p.grid, dim3(T), 0, s, static_cast<const bf16_t*>(x), p.g, n_split, partial);
+        hipLaunchKernelGGL((bn2d_stats_kernel<bf16_t>), p.grid, dim3(T), 0, s, static_cast<const bf16_t*>(x), shift, p.g, n_split, partial);
+    return launch_status();
+}
+
+extern "C" int peclr_bn2d_combine_f64(const float* partial, int n_split, int C, double* totals, peclr_stream_t stream) {
+    if (!partial || !totals) return PECLR_ERR_NULL;
+    if (n_split < 1 || C <= 0) return PECLR_ERR_SHAPE;
+    hipLaunchKernelGGL(bn2d_combine_kernel, dim3((C + FC - 1) / FC), dim3(FT), 0, static_cast<hipStream_t>(stream), partial,
+                       n_split, C, totals);
+    return launch_status();
+}
+
+extern "C" int peclr_bn2d_finalize_totals_f32(const double* totals, const float* shift, int C, float eps,
+                                              float momentum, const float* gamma, const float* beta, float* running_mean,
+                                              float* running_var, int64_t* num_batches_tracked, float* save_mean,
+                                              float* save_invstd, float* scale_shift, peclr_stream_t stream) {
+    if (!totals || !shift || !gamma || !beta || !save_mean || !save_invstd || !scale_shift) return PECLR_ERR_NULL;
+    if (C <= 0) return PECLR_ERR_SHAPE;
+    hipLaunchKernelGGL(bn2d_finalize_totals_kernel, dim3((C + T - 1) / T), dim3(T), 0, static_cast<hipStream_t>(stream), totals,
+                       shift, C, eps, momentum, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean,
+                       save_invstd, scale_shift);
+    return launch_status();
+}
+
+extern "C" int peclr_bn2d_bwd_finalize_totals_f32(const double* local_totals, const double* global_totals,
+                                                  int C, int training, const float* scale_shift, float* dgamma,
+                                                  float* dbeta, float* coef, peclr_stream_t stream) {
+    if (!local_totals || !global_totals || !scale_shift || !dgamma || !dbeta || !coef) return PECLR_ERR_NULL;
+    if (C <= 0) return PECLR_ERR_SHAPE;
+    hipLaunchKernelGGL(bn2d_bwd_finalize_totals_kernel, dim3((C + T - 1) / T), dim3(T), 0, static_cast<hipStream_t>(stream),
+                       local_totals, global_totals, C, training, scale_shift, dgamma, dbeta, coef);
     return launch_status();
 }
 

@@ -137,7 +137,8 @@ class SimCLR(BaseModel):
         state = ops.BNState(training=bn.training or not bn.track_running_stats, eps=bn.eps,
                             momentum=bn.momentum if bn.momentum is not None else 0.1,
                             running_mean=bn.running_mean, running_var=bn.running_var,
-                            num_batches_tracked=bn.num_batches_tracked)
+                            num_batches_tracked=bn.num_batches_tracked,
+                            sync_group=getattr(self, "sync_bn_group", None))
         return ops.head_align(encodings, lin1.weight, lin1.bias, bn.weight, bn.bias, lin2.weight, state, spec)
 
     def _loss(self, z: Tensor, n_pairs: int, row_stats=None):

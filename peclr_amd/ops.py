@@ -48,6 +48,7 @@ class BNState:
     running_mean: Optional[Tensor]
     running_var: Optional[Tensor]
     num_batches_tracked: Optional[Tensor]
+    sync_group: object = None  # process group sharing the batch statistics (None = per-rank)
 
 
 _REGISTER_BN_MAX_ROWS = 1024  # bn_relu kernels hold <= 16 rows per thread x 64 row slices in registers
@@ -64,7 +65,8 @@ class _HeadAlign(torch.autograd.Function):
         m, din = h.shape
         hid, d = w1.shape[0], w2.shape[0]
         ss = None
-        if m <= _REGISTER_BN_MAX_ROWS:
+        sync = bn.sync_group if bn.training else None
+        if m <= _REGISTER_BN_MAX_ROWS and sync is None:
             # K1: a = h W1^T  (split-K slabs; bias and the slab reduction are fused into the BN kernel,
             # which keeps its rows in registers)
             a_slabs = _as_slabs(_capi.gemm(_capi.GEMM_NT, h, w1, split_k=_capi.pick_split_k(m, hid, din),
@@ -75,18 +77,19 @@ class _HeadAlign(torch.autograd.Function):
             # large batches: enough tiles without split-K (bias in the GEMM epilogue), and the [M, H]
             # activation matrix IS an NHWC tensor with 1x1 spatial extent -> the streaming
             # stats / finalize / apply kernels of the backbone glue (4.5-5.5 TB/s) instead of the
-            # register-resident kernel, which only scales to 1024 rows
+            # register-resident kernel, which only scales to 1024 rows.  Synchronised statistics
+            # (all-reduce between stats and finalize) also take this three-phase route.
             a_pre = _capi.gemm(_capi.GEMM_NT, h, w1, bias=b1, tag="gemm_k1_fwd")
             a4, save, ss, _ = _capi.bn2d_fwd(a_pre.view(m, hid, 1, 1), None, gamma, beta, bn.running_mean,
                                             bn.running_var, bn.num_batches_tracked, bn.training, bn.eps,
-                                            bn.momentum, relu=True)
+                                            bn.momentum, relu=True, sync_group=sync)
             a = a4.view(m, hid)
         # K2: p = relu(bn(a)) W2^T  (slabs reduced inside the align kernel)
         p_slabs = _as_slabs(_capi.gemm(_capi.GEMM_NT, a, w2, split_k=_capi.pick_split_k(m, d, hid), tag="gemm_k2_fwd"))
         p, z, norms, row_stats = _capi.align_fwd(p_slabs, spec.n_pairs, spec.flags, spec.jitter, spec.extents,
                                                  spec.angles, spec.want_stats)
         ctx.save_for_backward(h, w1, gamma, beta, w2, a_pre, a, save, p, z, norms, *([ss] if ss is not None else []))
-        ctx.spec, ctx.bn_training = spec, bn.training
+        ctx.spec, ctx.bn_training, ctx.sync_group = spec, bn.training, sync
         if row_stats is None:
             row_stats = torch.empty(0, device=h.device)
         ctx.mark_non_differentiable(row_stats)
@@ -105,9 +108,11 @@ class _HeadAlign(torch.autograd.Function):
         else:
             m, hid = a_pre.shape
             dx4, dgamma, dbeta, _ = _capi.bn2d_bwd(da.view(m, hid, 1, 1), a_pre.view(m, hid, 1, 1), None, None, save,
-                                                   ss, ctx.bn_training, True, False)
+                                                   ss, ctx.bn_training, True, False, sync_group=ctx.sync_group)
             d_a_pre = dx4.view(m, hid)
-            # column sum of d_a_pre in closed form: 0 through batch statistics, scale*dbeta through frozen ones
+            # column sum of d_a_pre in closed form: 0 through batch statistics (with synchronised
+            # statistics: 0 once summed over the ranks, which the gradient all-reduce does),
+            # scale*dbeta through frozen ones
             db1 = torch.zeros_like(dbeta) if ctx.bn_training else ss[0] * dbeta
         dw1 = _capi.gemm(_capi.GEMM_TN, d_a_pre, h, tag="gemm_dw1")       # [H,Din] = dA^T h
         dh = _capi.gemm(_capi.GEMM_NN, d_a_pre, w1, tag="gemm_dh") if ctx.needs_input_grad[0] else None

@@ -21,7 +21,8 @@ from .port import save_checkpoint
 class Trainer:
     def __init__(self, max_epochs: int = 1, accumulate_grad_batches: int = 1, precision: str = "fp32",
                  checkpoint_dir: Optional[str] = None, save_top_k: int = 1, process_group=None,
-                 bucket_bytes: int = 32 << 20, channels_last: bool = False, grad_buckets=None):
+                 bucket_bytes: int = 32 << 20, channels_last: bool = False, grad_buckets=None,
+                 sync_batchnorm: bool = False):
         self.max_epochs = max_epochs
         self.accumulate_grad_batches = accumulate_grad_batches
         self.precision = precision
@@ -31,6 +32,10 @@ class Trainer:
         self.bucket_bytes = bucket_bytes
         self.channels_last = channels_last
         self.grad_buckets = grad_buckets  # None: only when world_size > 1; True: always (flat grad buffers)
+        # True: BatchNorm statistics (backbone and head) are those of the GLOBAL batch, so N ranks x B
+        # samples compute exactly what one device with N*B samples computes (costs two small
+        # all-reduces per BN layer per step).  False: per-rank statistics, like DDP without SyncBatchNorm.
+        self.sync_batchnorm = sync_batchnorm
         self.world_size = pdist.world_size(process_group)
         self.global_step = 0
         self.current_epoch = 0
@@ -44,12 +49,31 @@ class Trainer:
         model.setup("fit")
         pdist.broadcast_module_state(model, 0, self.process_group)
         self.model = model
+        if self.sync_batchnorm and self.world_size > 1:
+            self._enable_sync_batchnorm(model)
         if self.world_size > 1 or self.grad_buckets:
             self.reducer = pdist.GradReducer(model.parameters(), self.process_group, self.bucket_bytes)
         (self.optimizer,), (sched,) = model.configure_optimizers()
         self.scheduler = sched["scheduler"]
         self._unused = [p for n, p in model.named_parameters() if "final_layer" in n]
         return self
+
+    def _enable_sync_batchnorm(self, model):
+        import torch.distributed as td
+
+        from .bn2d import FusedBatchNormAct2d
+
+        group = self.process_group if self.process_group is not None else td.group.WORLD
+        for name, m in model.named_modules():
+            if isinstance(m, FusedBatchNormAct2d):
+                if not m.hip:
+                    raise RuntimeError(f"sync_batchnorm needs the fused HIP BatchNorm ({name}): call "
+                                       "enable_hip_batchnorm(model.encoder) on an NHWC encoder first")
+                m.sync_group = group
+            elif isinstance(m, torch.nn.BatchNorm2d):
+                raise RuntimeError(f"sync_batchnorm: {name} is a stock BatchNorm2d; build the encoder with "
+                                   "peclr_amd.resnet (FusedBatchNormAct2d)")
+        model.sync_bn_group = group  # projection-head BatchNorm1d (ops.head_align)
 
     def _autocast(self):
         if self.precision in ("bf16", "16", 16, "fp16"):

@@ -461,6 +461,67 @@ def test_bn2d_fused_matches_torch(shape, relu, res, training):
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
 
 
+@pytest.fixture(scope="module")
+def solo_group(tmp_path_factory):
+    """A world-size-1 gloo group: drives the synchronised-statistics route (combine -> all-reduce ->
+    finalize-from-totals) in one process; the 2-rank case is tests/test_dist_gpu_rehearsal.py."""
+    import torch.distributed as td
+
+    created = not td.is_initialized()
+    if created:
+        store = td.FileStore(str(tmp_path_factory.mktemp("store") / "rdzv"), 1)
+        td.init_process_group("gloo", store=store, rank=0, world_size=1)
+    yield td.group.WORLD
+    if created:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 8, 8), (3, 2048, 2, 2), (16, 64, 56, 56), (6, 256, 5, 7)])
+@pytest.mark.parametrize("relu,res", [(True, True), (False, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_bn2d_synchronised_route_matches_torch(solo_group, shape, relu, res, dtype):
+    from peclr_amd.bn2d import FusedBatchNormAct2d
+
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h + 1)
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.7).to(dtype)
+    r = torch.randn(shape, generator=g).to(dtype) if res else None
+    dy = torch.randn(shape, generator=g).to(dtype)
+    bn = FusedBatchNormAct2d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g)
+        bn.bias.uniform_(-0.3, 0.3, generator=g)
+        bn.running_mean.uniform_(-0.2, 0.2, generator=g)      # = the shift of the synchronised route
+        bn.running_var.uniform_(0.8, 1.2, generator=g)
+    ref = torch.nn.BatchNorm2d(c).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    xr = x.double().requires_grad_()
+    rr = r.double().requires_grad_() if res else None
+    yr = ref(xr)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy.double())
+
+    bn = bn.to(DEV).train()
+    bn.hip, bn.sync_group = True, solo_group
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    rd = r.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_() if res else None
+    yd = bn(xd, rd, relu)
+    yd.backward(dy.to(DEV).contiguous(memory_format=torch.channels_last))
+    lo = dtype == torch.bfloat16
+    np.testing.assert_allclose(host(yd.float()), yr.detach().numpy(), atol=4e-2 if lo else 2e-5, rtol=1e-2 if lo else 0)
+    scale = max(1.0, float(xr.grad.abs().max()))
+    np.testing.assert_allclose(host(xd.grad.float()), xr.grad.numpy(), atol=(3e-2 if lo else 3e-5) * scale)
+    gs = max(1.0, float(ref.weight.grad.abs().max()))
+    np.testing.assert_allclose(host(bn.weight.grad), ref.weight.grad.numpy(), atol=(2e-2 if lo else 1e-4) * gs, rtol=1e-5)
+    np.testing.assert_allclose(host(bn.bias.grad), ref.bias.grad.numpy(), atol=(2e-2 if lo else 1e-4) * gs, rtol=1e-5)
+    np.testing.assert_allclose(host(bn.running_mean), ref.running_mean.numpy(), atol=1e-5)
+    np.testing.assert_allclose(host(bn.running_var), ref.running_var.numpy(), atol=1e-5)
+    assert int(bn.num_batches_tracked) == 1
+
+
 def test_bn2d_fused_large_mean_is_stable_and_rejects_bad_input():
     from peclr_amd import _capi
     from peclr_amd.bn2d import FusedBatchNormAct2d
