@@ -244,6 +244,34 @@ int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y, const uin
                          const float* save_invstd, const float* scale_shift, const float* coef,
                          void* dx, void* d_residual, peclr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Two-view augmentation, pixel side.
+ * Replaces, for a whole batch and both views at once, what SampleAugmenter.transform_sample does
+ * per sample with OpenCV on CPU workers for the published recipe (reference
+ * src/data_loader/sample_augmenter.py:47-129: rotate_sample :218-247 cv2.warpAffine, crop_sample
+ * :166-186, resize_sample :188-216 cv2.resize INTER_AREA, color_jitter_sample :267-293 cv2 BGR<->HSV)
+ * plus ToTensor + Normalize (src/data_loader/utils.py:283-293).  The parameter side (random draws,
+ * crop box, rotation matrix) stays on the host: peclr_amd/augment.py.
+ *
+ * images : [B][H][W][3] uint8 (the reference's HWC images, one size per batch)
+ * params : [n_views][B][PECLR_AUG_PARAM_DOUBLES] doubles per (view, sample):
+ *            [0..5]  inverse (destination -> source) 2x3 affine of the rotation, row-major
+ *            [6]     != 0: rotate            [7..10] crop window x0, y0, width, height (inside the image)
+ *            [11]    != 0: colour jitter     [12..15] h, s, a, b factors
+ * crops  : [n_views][B][H][W][3] uint8 scratch; only each window (at offset 0,0, row stride W) is written
+ * out    : float32, logical shape [n_views*B][3][out_h][out_w]; channels_last != 0 stores it NHWC
+ * mean/stdv : HOST pointers to 3 floats each (passed to the kernel by value).
+ * 8-bit intermediates sit where the reference has them, so results are bit-identical to the
+ * restatement in oracle/augment_oracle.py (whose pixel arithmetic is itself unpinned: OpenCV is
+ * not available to check against). */
+#define PECLR_AUG_PARAM_DOUBLES 16
+int peclr_augment_warp_crop_u8(const uint8_t* images, int B, int H, int W, int n_views,
+                               const double* params, uint8_t* crops, peclr_stream_t stream);
+int peclr_augment_resize_color_norm(const uint8_t* crops, int B, int H, int W, int n_views,
+                                    const double* params, int out_h, int out_w, const float* mean,
+                                    const float* stdv, int channels_last, float* out,
+                                    peclr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,9 @@ SIGNATURES = {
     "peclr_bn2d_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "peclr_bn2d_bwd_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_bn2d_bwd_apply": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "peclr_augment_warp_crop_u8": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "peclr_augment_resize_color_norm": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, _P,
+                                                _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
@@ -433,3 +436,36 @@ def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres, sync_group=Non
                                         dres.data_ptr() if dres is not None else None, _stream())
     _check(rc, "peclr_bn2d_bwd_apply")
     return dx, dparams[0], dparams[1], dres
+
+
+# ------------------------------------------------------------------ two-view augmentation (pixel side)
+AUG_PARAM_DOUBLES = 16
+
+
+def augment_views(images: torch.Tensor, params: torch.Tensor, out_hw, mean, std, channels_last: bool = True):
+    """images [B,H,W,3] uint8 (HIP), params [V,B,16] float64 (HIP) -> float32 [V*B,3,out_h,out_w]
+    (channels_last storage if asked).  Two launches: rotate+crop window, then resize+colour+normalise."""
+    if not images.is_cuda or images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
+        raise PeclrHipError(f"augment: images must be a [B,H,W,3] uint8 HIP tensor, got {images.dtype} "
+                            f"{tuple(images.shape)} on {images.device} (peclr_amd has no CPU path)")
+    if not images.is_contiguous():
+        raise PeclrHipError("augment: images must be contiguous")
+    b, h, w, _ = images.shape
+    if (params.dtype != torch.float64 or params.dim() != 3 or params.shape[1] != b
+            or params.shape[2] != AUG_PARAM_DOUBLES or not params.is_cuda or not params.is_contiguous()):
+        raise PeclrHipError(f"augment: params must be a contiguous [V,{b},{AUG_PARAM_DOUBLES}] float64 HIP tensor")
+    v = params.shape[0]
+    oh, ow = out_hw
+    crops = torch.empty((v, b, h, w, 3), device=images.device, dtype=torch.uint8)
+    out = torch.empty((v * b, 3, oh, ow), device=images.device, dtype=torch.float32,
+                      memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    mean_arr, std_arr = (c_float * 3)(*mean), (c_float * 3)(*std)
+    with _timed("augment_warp_crop", 2 * v * b * h * w * 3):
+        rc = lib().peclr_augment_warp_crop_u8(images.data_ptr(), b, h, w, v, params.data_ptr(), crops.data_ptr(), _stream())
+    _check(rc, "peclr_augment_warp_crop_u8")
+    with _timed("augment_resize_color_norm", v * b * (h * w * 3 + oh * ow * 12)):
+        rc = lib().peclr_augment_resize_color_norm(crops.data_ptr(), b, h, w, v, params.data_ptr(), oh, ow,
+                                                   ctypes.cast(mean_arr, c_void_p), ctypes.cast(std_arr, c_void_p),
+                                                   int(channels_last), out.data_ptr(), _stream())
+    _check(rc, "peclr_augment_resize_color_norm")
+    return out, crops
