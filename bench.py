@@ -71,6 +71,11 @@ def parse():
     ap.add_argument("--miopen-find", type=int, default=0,
                     help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find; tens of minutes of kernel "
                          "JIT on a box without a populated user find-db)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "0", "1"],
+                    help="1: the timed steps replay ONE hipGraph of the whole step (forward + backward + fused "
+                         "optimiser, Trainer.capture_step_graph); 0: eager launches; auto (default): at N=1 try the "
+                         "graph in a child process and fall back to eager if that process dies (a failed capture is a "
+                         "crash inside the HIP runtime, not an exception); N>1 runs eager (gradient buckets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16, help="pairs in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -206,9 +211,34 @@ def cpu_baseline(args):
                       f"LARS/Adam; {dt:.2f} s"}
 
 
+def try_graph_child():
+    """--graph auto at N=1: run this same command with --graph 1 in a child; returns its JSON line or a reason."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--graph", "1"]
+    try:
+        p = subprocess.run(cmd, env=dict(os.environ, PECLR_BENCH_CHILD="1"), capture_output=True, text=True, timeout=2400)
+    except subprocess.TimeoutExpired:
+        return None, "graph child timed out"
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode == 0 and lines:
+        return lines[-1], None
+    return None, f"graph child exited with {p.returncode}"
+
+
 def main():
     args = parse()
     warnings.simplefilter("ignore")
+    graph_note = None
+    if args.graph == "auto":
+        single = int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1
+        if single and args.accum == 1 and not os.environ.get("PECLR_BENCH_CHILD"):
+            line, graph_note = try_graph_child()
+            if line is not None:
+                print(line, flush=True)
+                return
+        args.graph = "0"
+    use_graph = args.graph == "1"
     from peclr_amd import Trainer, _capi
     from peclr_amd import dist as pdist
     from peclr_amd.resnet import conv_flops_per_image
@@ -243,20 +273,44 @@ def main():
             out = trainer.training_micro_step(batch, i * args.accum + micro)
         return out
 
-    for i in range(args.warmup):
-        out = one_step(i)
-    _capi.EVENT_LOG = {}
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = one_step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    loss = float(out["loss"])
+    if use_graph and (world > 1 or args.accum != 1):
+        raise SystemExit("--graph 1 is single-GPU, accum 1 (the N>1 path keeps gradients in all-reduce buckets)")
+    # Everything runs on ONE non-default stream: hipStreamEndCapture crashes on this ROCm build when the
+    # process has already run the step eagerly on the default stream (tools/exp/graph_capture_sizes.py).
+    stream = torch.cuda.Stream(device)
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        if use_graph:
+            # W untimed eager steps (on a side stream) + the capture, then K timed replays
+            trainer.capture_step_graph(batch, warmup=max(args.warmup, 3))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                out = trainer.replay_step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            loss = float(out["loss"])
+            # per-kernel HIP events cannot sit inside a graph: the SAME K steps once more, eagerly, with an
+            # event pair around every hand-written launch (same kernels, same shapes, same stream)
+            _capi.EVENT_LOG = {}
+            for i in range(args.steps):
+                one_step(args.warmup + args.steps + i)
+            torch.cuda.synchronize()
+        else:
+            for i in range(args.warmup):
+                out = one_step(i)
+            _capi.EVENT_LOG = {}
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                out = one_step(args.warmup + i)
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            dt = time.perf_counter() - t0
+            loss = float(out["loss"])
     table_steps = args.steps
     event_log, _capi.EVENT_LOG = _capi.EVENT_LOG, None
     if world > 1:
@@ -271,6 +325,8 @@ def main():
         # dominant = largest share of the step's hand-written GPU time (avg duration x launches)
         dominant = max(kernels, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
         roof = {k: kernels[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+        if use_graph:
+            roof["events"] = "eager pass of the same K steps right after the timed graph replays"
         roof.update(kernel=dominant, avg_us=kernels[dominant]["avg_us"],
                     launches_per_step=kernels[dominant]["launches"] // (table_steps * args.accum),
                     traffic=pmc_traffic(dominant),
@@ -289,6 +345,8 @@ def main():
                                    f"LARS(Adam) step, {args.dtype}",
                        "global_batch": world * 2 * args.pairs * args.accum, "parallelism": f"dp{world}",
                        "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn,
+                       "launch": ("one hipGraph replay per step (whole step captured)" if use_graph else
+                                  "eager launches" + (f" ({graph_note})" if graph_note else "")),
                        "bn": "global-batch statistics (synchronised)" if (args.sync_bn and world > 1)
                        else "per-rank batch statistics"},
             "loss": round(loss, 6),

@@ -112,6 +112,9 @@ class Trainer:
     # (`LARSAdam.prepare_step`); gradients are allocated INSIDE the capture (pre-existing .grad views
     # into all-reduce buckets do not replay correctly, tools/exp/graph_capture_bisect.py) and the
     # optimiser's device-side pointer table is patched to their addresses afterwards.
+    # Call it BEFORE the process runs the step eagerly on the default stream (or run everything under one
+    # `torch.cuda.stream(side)` like bench.py): on this ROCm build hipStreamEndCapture crashes otherwise
+    # (tools/exp/graph_capture_sizes.py: capture-first works at every size tried, eager-first never).
     def capture_step_graph(self, example_batch: Dict[str, torch.Tensor], warmup: int = 3):
         if self.world_size > 1 or self.reducer is not None:
             raise RuntimeError("capture_step_graph is single-process only (no gradient buckets)")
@@ -141,6 +144,9 @@ class Trainer:
             out["loss"].backward()
             self.optimizer.launch_only(reuse_worklist=True)
         self.optimizer.repoint_worklist()         # gradients now live in the graph's private pool
+        # the captured optimiser launch reads this work list's device tables: keep it alive even if a
+        # later eager step makes the optimiser build a new one
+        self._graph_worklist = self.optimizer._fused_cache.get("all")
         self._static_out = out
         return self
 
