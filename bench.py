@@ -75,7 +75,9 @@ def parse():
                     help="1: the timed steps replay ONE hipGraph of the whole step (forward + backward + fused "
                          "optimiser, Trainer.capture_step_graph); 0: eager launches; auto (default): at N=1 try the "
                          "graph in a child process and fall back to eager if that process dies (a failed capture is a "
-                         "crash inside the HIP runtime, not an exception); N>1 runs eager (gradient buckets)")
+                         "crash inside the HIP runtime, not an exception); at N>1 the step is split into two graphs "
+                         "around its collectives (Trainer.capture_split_graphs), falling back to eager on all ranks "
+                         "if any rank's capture raises")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16, help="pairs in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -155,12 +157,14 @@ def kernel_table(event_log, m_rows, m_global, din, hid, n_params):
     return out
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, args=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, gfx950 corrections applied by tools/pmc_traffic.py) --
     PMC counters cannot be collected from inside the timed run.  None if no profile covers it."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
+    # the committed passes were taken on the default workload; other shapes / dtypes have no PMC figure
+    default = args is None or (args.dtype == "fp32" and args.resnet == "50" and args.pairs == 128 and args.size == 224)
+    if not os.path.exists(path) or not default:
         return None
     with open(path) as f:
         table = json.load(f)
@@ -237,7 +241,9 @@ def main():
             if line is not None:
                 print(line, flush=True)
                 return
-        args.graph = "0"
+            args.graph = "0"
+        else:
+            args.graph = "1" if (not single and args.accum == 1 and not args.sync_bn) else "0"
     use_graph = args.graph == "1"
     from peclr_amd import Trainer, _capi
     from peclr_amd import dist as pdist
@@ -273,21 +279,43 @@ def main():
             out = trainer.training_micro_step(batch, i * args.accum + micro)
         return out
 
-    if use_graph and (world > 1 or args.accum != 1):
-        raise SystemExit("--graph 1 is single-GPU, accum 1 (the N>1 path keeps gradients in all-reduce buckets)")
+    if use_graph and (args.accum != 1 or (world > 1 and args.sync_bn)):
+        raise SystemExit("--graph 1 needs --accum 1 and, at N>1, per-rank BatchNorm statistics")
+    split = use_graph and world > 1
     # Everything runs on ONE non-default stream: hipStreamEndCapture crashes on this ROCm build when the
     # process has already run the step eagerly on the default stream (tools/exp/graph_capture_sizes.py).
     stream = torch.cuda.Stream(device)
     stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(stream):
+        if split:
+            # every rank must take the same path: agree on whether all captures succeeded
+            ok = 1
+            try:
+                trainer.capture_split_graphs(batch, warmup=max(args.warmup, 3))
+            except Exception as exc:  # noqa: BLE001 -- any failure means "run eager"
+                ok, graph_note = 0, f"split-graph capture failed on rank {rank}: {type(exc).__name__}"
+                trainer.reducer.zero_grad()
+            flag = torch.tensor([ok], device=device, dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if int(flag) == 0:
+                use_graph = split = False
+                graph_note = graph_note or "split-graph capture failed on another rank"
         if use_graph:
             # W untimed eager steps (on a side stream) + the capture, then K timed replays
-            trainer.capture_step_graph(batch, warmup=max(args.warmup, 3))
+            if split:
+                replay = trainer.replay_split
+            else:
+                trainer.capture_step_graph(batch, warmup=max(args.warmup, 3))
+                replay = trainer.replay_step
+            if world > 1:
+                torch.distributed.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(args.steps):
-                out = trainer.replay_step()
+                out = replay()
             torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
             dt = time.perf_counter() - t0
             loss = float(out["loss"])
             # per-kernel HIP events cannot sit inside a graph: the SAME K steps once more, eagerly, with an
@@ -329,7 +357,7 @@ def main():
             roof["events"] = "eager pass of the same K steps right after the timed graph replays"
         roof.update(kernel=dominant, avg_us=kernels[dominant]["avg_us"],
                     launches_per_step=kernels[dominant]["launches"] // (table_steps * args.accum),
-                    traffic=pmc_traffic(dominant),
+                    traffic=pmc_traffic(dominant, args),
                     algorithmic_bytes=kernels[dominant]["bytes"], algorithmic_flops=kernels[dominant]["flops"])
         flops_img = conv_flops_per_image(model.encoder.features, (args.size, args.size))
         step_flops = 3 * flops_img * 2 * args.pairs * args.accum
@@ -345,7 +373,9 @@ def main():
                                    f"LARS(Adam) step, {args.dtype}",
                        "global_batch": world * 2 * args.pairs * args.accum, "parallelism": f"dp{world}",
                        "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn,
-                       "launch": ("one hipGraph replay per step (whole step captured)" if use_graph else
+                       "launch": ("two hipGraph replays per step (forward to z | backward from dz), collectives, "
+                                  "NT-Xent and optimiser eager between/after them" if split else
+                                  "one hipGraph replay per step (whole step captured)" if use_graph else
                                   "eager launches" + (f" ({graph_note})" if graph_note else "")),
                        "bn": "global-batch statistics (synchronised)" if (args.sync_bn and world > 1)
                        else "per-rank batch statistics"},

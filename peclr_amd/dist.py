@@ -158,6 +158,14 @@ class GradReducer:
                 b.handle = None
         self._armed = False
 
+    def all_reduce_now(self):
+        """Reduce every bucket (no hooks involved): the path used after a captured backward, whose
+        gradients were copied into the buckets."""
+        if self.world > 1:
+            handles = [dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
+            for h in handles:
+                h.wait()
+
     def zero_grad(self):
         for b in self.buckets:
             b.flat.zero_()

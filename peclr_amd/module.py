@@ -145,14 +145,34 @@ class SimCLR(BaseModel):
         loss, stats16, _ = ops.ntxent(z, n_pairs, TEMPERATURE, row_stats, self.process_group)
         return loss, stats16
 
-    def contrastive_step(self, batch: Dict[str, Tensor]) -> Tensor:
-        """simclr_model.py:37-49: one F.normalize, no alignment, no stats."""
+    def _project(self, batch: Dict[str, Tensor]):
+        """Per-rank part of the step (no collective): images -> unit embeddings z [2N,128] (+ per-row
+        projection statistics, empty here).  simclr_model.py:37-47: one F.normalize, no alignment."""
         batch_size = batch["transformed_image1"].size()[0]
         concat_batch = torch.cat((batch["transformed_image1"], batch["transformed_image2"]), dim=0)
         concat_encoding = self.get_encodings(concat_batch)
-        z, _ = self._head_align(concat_encoding,
-                                ops.AlignSpec(n_pairs=batch_size, single_norm=True, want_stats=False))
-        return self._loss(z, batch_size)[0]
+        z, row_stats = self._head_align(concat_encoding,
+                                        ops.AlignSpec(n_pairs=batch_size, single_norm=True, want_stats=False))
+        return z, row_stats, batch_size
+
+    def _contrast(self, z: Tensor, n_pairs: int, row_stats: Tensor) -> Tensor:
+        """Cross-rank part of the step: NT-Xent over the gathered embeddings (+ the batch means of the
+        projection statistics, which ride in the loss finalize launch)."""
+        if row_stats is None or row_stats.numel() == 0:
+            return self._loss(z, n_pairs)[0]
+        loss, stats16 = self._loss(z, n_pairs, row_stats)
+        self.train_metrics = {**self.train_metrics, **dict(zip(STAT_KEYS, stats16.unbind()))}
+        return loss
+
+    def contrastive_step(self, batch: Dict[str, Tensor]) -> Tensor:
+        z, row_stats, n = self._project(batch)
+        return self._contrast(z, n, row_stats)
+
+    def _step_outputs(self, batch: dict, loss: Tensor) -> Dict[str, Tensor]:
+        self.train_metrics = {**self.train_metrics, **{"loss": loss}}
+        self.plot_params = {"image1": batch["transformed_image1"], "image2": batch["transformed_image2"],
+                            "params": {k: v for k, v in batch.items() if "image" not in k}}
+        return self.train_metrics
 
     def get_encodings(self, batch_images: Tensor) -> Tensor:
         return self.encoder(batch_images)
@@ -165,11 +185,7 @@ class SimCLR(BaseModel):
         return {"embedding": embedding, "projection": projection}
 
     def training_step(self, batch: dict, batch_idx: int) -> Dict[str, Tensor]:
-        loss = self.contrastive_step(batch)
-        self.train_metrics = {**self.train_metrics, **{"loss": loss}}
-        self.plot_params = {"image1": batch["transformed_image1"], "image2": batch["transformed_image2"],
-                            "params": {k: v for k, v in batch.items() if "image" not in k}}
-        return self.train_metrics
+        return self._step_outputs(batch, self.contrastive_step(batch))
 
     def validation_step(self, batch: dict, batch_idx: int) -> Dict[str, Tensor]:
         loss = self.contrastive_step(batch)
@@ -214,12 +230,6 @@ class Hybrid2Model(SimCLR):
         stats16 = row_stats.view(2, n, 8).mean(dim=1).reshape(16)
         self.train_metrics = {**self.train_metrics, **dict(zip(STAT_KEYS, stats16.unbind()))}
         return z[:n], z[n:]
-
-    def contrastive_step(self, batch: Dict[str, Tensor]) -> Tensor:
-        z, row_stats, n = self._project(batch)
-        loss, stats16 = self._loss(z, n, row_stats)  # the batch means ride in the loss finalize launch
-        self.train_metrics = {**self.train_metrics, **dict(zip(STAT_KEYS, stats16.unbind()))}
-        return loss
 
     def get_projection_stats(self, projection: Tensor, name: str) -> dict:
         """hybrid2_model.py:92-106, kept for callers; the training path gets these from the kernel."""

@@ -85,6 +85,54 @@ def free_port():
         return s.getsockname()[1]
 
 
+SPLIT_WORKER = WORKER.split("world = int(os.environ")[0] + r"""
+world = int(os.environ.get("WORLD_SIZE", "1"))
+pdist.init_from_env()
+rank = pdist.rank()
+model = make_model()
+tr = Trainer(max_epochs=10, bucket_bytes=4 << 20, grad_buckets=True).attach(model)
+tr.zero_grad()
+full = make_batch(2)
+sl = slice(rank * N_LOCAL, (rank + 1) * N_LOCAL) if world > 1 else slice(0, 2 * N_LOCAL)
+batch = to_dev({k: v[sl].contiguous() for k, v in full.items()})
+losses = []
+if os.environ["PECLR_MODE"] == "split":
+    tr.capture_split_graphs(batch, warmup=1)
+    losses = [float(tr.replay_split()["loss"]) for _ in range(3)]
+else:
+    losses = [float(tr.training_micro_step(batch, i)["loss"]) for i in range(4)][1:]
+torch.cuda.synchronize()
+torch.save({"losses": losses, "w": model.projection_head[3].weight.detach().cpu()}, os.environ["PECLR_OUT"] + f".r{rank}")
+if world > 1:
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+"""
+
+
+@pytest.mark.timeout(600)
+def test_split_graphs_two_ranks_equal_eager_two_ranks(tmp_path):
+    """capture_split_graphs / replay_split across two ranks (collectives between the graphs, gradients
+    copied from the captured backward into the all-reduce buckets) against the eager two-rank loop."""
+    script = tmp_path / "worker.py"
+    script.write_text(SPLIT_WORKER)
+    env = dict(os.environ, PECLR_ROOT=ROOT, PECLR_DIST_BACKEND="gloo", PECLR_SHARE_DEVICE="1", PECLR_SYNC_BN="0")
+    res = {}
+    for mode in ("eager", "split"):
+        port = free_port()
+        procs = [subprocess.Popen([sys.executable, str(script)],
+                                  env=dict(env, PECLR_MODE=mode, PECLR_OUT=str(tmp_path / mode), RANK=str(r), LOCAL_RANK=str(r),
+                                           WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+        outs = [p.communicate(timeout=500)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        res[mode] = [torch.load(str(tmp_path / mode) + f".r{r}") for r in range(2)]
+    assert res["split"][0]["losses"] == res["split"][1]["losses"]             # global loss: identical on both ranks
+    assert torch.equal(res["split"][0]["w"], res["split"][1]["w"])            # replicas stay in lock-step
+    assert res["split"][0]["losses"][0] == pytest.approx(res["eager"][0]["losses"][0], rel=2e-3)
+    assert res["split"][0]["losses"] == pytest.approx(res["eager"][0]["losses"], rel=6e-2)
+    np.testing.assert_allclose(res["split"][0]["w"].numpy(), res["eager"][0]["w"].numpy(), atol=2e-3)
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("sync_bn", [False, True], ids=["frozen_bn", "sync_bn"])
 def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, sync_bn):

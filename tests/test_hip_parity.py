@@ -797,6 +797,57 @@ def test_whole_step_hip_graph_matches_eager():
     assert graph[-1] < 0.8 * eager[3]                # and it keeps learning under replay
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_split_hip_graphs_match_eager(precision):
+    """The any-world-size variant: graph A (images -> z) | eager NT-Xent (where the collectives are) |
+    graph B (backward from dz) | eager bucket copy + all-reduce + fused optimiser.  Same curve as eager."""
+    import copy
+    import warnings
+
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config
+    from peclr_amd.bn2d import enable_hip_batchnorm
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(13)
+    n = 8
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, augmentation=["crop", "rotate"],
+                         batch_size=n, num_samples=64, warmup_epochs=1, pretrained=False)
+    base = Hybrid2Model(cfg).to(DEV).train()
+    base.encoder = base.encoder.to(memory_format=torch.channels_last)
+    enable_hip_batchnorm(base.encoder)
+    g = torch.Generator().manual_seed(14)
+    batch = {"transformed_image1": torch.randn(n, 3, 64, 64, generator=g), "transformed_image2": torch.randn(n, 3, 64, 64, generator=g),
+             "jitter_x_1": torch.randint(-14, 1, (n,), generator=g), "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+             "jitter_y_1": torch.randint(-14, 1, (n,), generator=g), "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+             "angle_1": torch.randint(-45, 46, (n,), generator=g).double(), "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    for k in ("transformed_image1", "transformed_image2"):
+        batch[k] = batch[k].contiguous(memory_format=torch.channels_last)
+    steps = 7
+    eager_m = copy.deepcopy(base)
+    tr = Trainer(max_epochs=10, precision=precision, grad_buckets=True).attach(eager_m)
+    tr.zero_grad()
+    eager = [tr.training_micro_step(batch, i) for i in range(steps)]
+    graph_m = copy.deepcopy(base)
+    tg = Trainer(max_epochs=10, precision=precision, grad_buckets=True).attach(graph_m)
+    tg.zero_grad()
+    tg.capture_split_graphs(batch, warmup=2)                          # steps 0, 1 eager
+    outs = [tg.replay_split() for _ in range(steps - 2)]              # steps 2..6
+    assert list(outs[0].keys()) == list(eager[2].keys()) and len(outs[0]) == 17
+    assert tg.global_step == tr.global_step == steps
+    tol = 2e-2 if precision == "bf16" else 2e-3
+    assert float(outs[0]["loss"]) == pytest.approx(float(eager[2]["loss"]), rel=tol)     # first replayed step: tight
+    assert float(outs[0]["proj1x_mean"]) == pytest.approx(float(eager[2]["proj1x_mean"]), rel=10 * tol, abs=1e-3)
+    assert [float(o["loss"]) for o in outs] == pytest.approx([float(o["loss"]) for o in eager[2:]], rel=6e-2)
+    assert float(outs[-1]["loss"]) < 0.9 * float(eager[1]["loss"])
+    # new data through the static input buffers
+    g2 = torch.Generator().manual_seed(99)
+    other = dict(batch, transformed_image1=torch.randn(n, 3, 64, 64, generator=g2).to(DEV).contiguous(memory_format=torch.channels_last))
+    assert float(tg.replay_split(other)["loss"]) != float(outs[-1]["loss"])
+    with pytest.raises(RuntimeError, match="grad_buckets"):
+        Trainer(max_epochs=1).attach(copy.deepcopy(base)).capture_split_graphs(batch)
+
+
 def test_head_large_batch_streaming_bn_matches_oracle():
     """M > 1024 rows routes the head's BatchNorm1d+ReLU through the streaming (backbone-glue) kernels."""
     from peclr_amd import ops
