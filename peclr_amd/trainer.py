@@ -22,7 +22,7 @@ class Trainer:
     def __init__(self, max_epochs: int = 1, accumulate_grad_batches: int = 1, precision: str = "fp32",
                  checkpoint_dir: Optional[str] = None, save_top_k: int = 1, process_group=None,
                  bucket_bytes: int = 32 << 20, channels_last: bool = False, grad_buckets=None,
-                 sync_batchnorm: bool = False):
+                 sync_batchnorm: bool = False, hip_graph: bool = False):
         self.max_epochs = max_epochs
         self.accumulate_grad_batches = accumulate_grad_batches
         self.precision = precision
@@ -36,6 +36,11 @@ class Trainer:
         # samples compute exactly what one device with N*B samples computes (costs two small
         # all-reduces per BN layer per step).  False: per-rank statistics, like DDP without SyncBatchNorm.
         self.sync_batchnorm = sync_batchnorm
+        # True: fit() captures the training step on the first batch (one hipGraph; two around the
+        # collectives when gradients live in all-reduce buckets) and replays it for every later batch of
+        # the same shapes; other shapes (a ragged last batch) run eagerly.
+        self.hip_graph = hip_graph
+        self._graph_sig = None
         self.world_size = pdist.world_size(process_group)
         self.global_step = 0
         self.current_epoch = 0
@@ -129,7 +134,9 @@ class Trainer:
             # one eager forward/backward so every parameter that trains has a gradient: build the
             # optimiser's work list and stage the scalars of the step the graph will perform first
             with self._autocast():
-                self.model.training_step(self._static_batch, 0)["loss"].backward()
+                eager_out = self.model.training_step(self._static_batch, 0)
+            eager_out["loss"].backward()
+            self._capture_eager_out = {k: v.detach().clone() for k, v in eager_out.items()}
             self.optimizer.prepare_step()
             self.optimizer.launch_only()          # performs that step eagerly (and builds the work list)
             self.scheduler.step()
@@ -147,6 +154,7 @@ class Trainer:
         # the captured optimiser launch reads this work list's device tables: keep it alive even if a
         # later eager step makes the optimiser build a new one
         self._graph_worklist = self.optimizer._fused_cache.get("all")
+        self._static_grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
         self._static_out = out
         return self
 
@@ -182,9 +190,12 @@ class Trainer:
         self._static_batch = {k: v.clone() for k, v in example_batch.items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        if warmup < 1:
+            raise ValueError("capture_split_graphs needs at least one eager step first (kernel JIT, optimiser state)")
         with torch.cuda.stream(side):
             for i in range(warmup):
-                self.training_micro_step(self._static_batch, i)
+                eager_out = self.training_micro_step(self._static_batch, i)
+            self._capture_eager_out = {k: v.clone() for k, v in eager_out.items()}
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         params = [p for p in model.parameters() if p.requires_grad]
@@ -225,25 +236,58 @@ class Trainer:
         out = model._step_outputs(self._static_batch, loss)
         return {key: v.detach() for key, v in out.items()}
 
+    def _graph_step(self, batch: Dict[str, torch.Tensor], batch_idx: int) -> Dict[str, torch.Tensor]:
+        """fit()'s step when hip_graph is on: capture on the first batch (which is trained on exactly
+        once, by the eager step the capture routine runs), replay for equal shapes, eager otherwise."""
+        sig = tuple((k, tuple(v.shape), v.dtype) for k, v in batch.items())
+        if self._graph_sig is None:
+            self._graph_sig = sig
+            if self.reducer is None:
+                self.capture_step_graph(batch, warmup=0)
+            else:
+                self.capture_split_graphs(batch, warmup=1)
+            return self._capture_eager_out
+        if sig != self._graph_sig:
+            out = self.training_micro_step(batch, batch_idx)
+            if self.reducer is None:          # the eager step dropped .grad: hand the graph's buffers back
+                for p, g in self._static_grads:
+                    p.grad = g
+            return out
+        out = self.replay_step(batch) if self.reducer is None else self.replay_split(batch)
+        return {k: v.detach().clone() for k, v in out.items()}   # the graph's outputs are static buffers
+
     def fit(self, model, train_batches: Callable[[int], Iterable[Dict[str, torch.Tensor]]],
             val_batches: Optional[Callable[[int], Iterable[Dict[str, torch.Tensor]]]] = None):
         """`train_batches(epoch)` yields batch dicts already on the model's device."""
         if self.model is not model:
             self.attach(model)
         self.zero_grad()
-        for epoch in range(self.max_epochs):
-            self.current_epoch = epoch
-            model.train()
-            outputs = [self.training_micro_step(b, i) for i, b in enumerate(train_batches(epoch))]
-            if val_batches is not None:
-                model.eval()
-                with torch.no_grad():
-                    vouts = [model.validation_step(b, i) for i, b in enumerate(val_batches(epoch))]
-                if vouts:
-                    model.validation_epoch_end(vouts)
-            if outputs:
-                model.training_epoch_end(outputs)
-                self._checkpoint(model, epoch)
+        use_graph = (self.hip_graph and self.accumulate_grad_batches == 1
+                     and not (self.sync_batchnorm and self.world_size > 1))
+        step = self._graph_step if use_graph else self.training_micro_step
+        # with graphs the whole loop lives on one side stream: a backward on the default stream before the
+        # capture would pull the legacy stream into it (see capture_step_graph)
+        stream_ctx = contextlib.nullcontext()
+        if use_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            stream_ctx = torch.cuda.stream(side)
+        with stream_ctx:
+            for epoch in range(self.max_epochs):
+                self.current_epoch = epoch
+                model.train()
+                outputs = [step(b, i) for i, b in enumerate(train_batches(epoch))]
+                if val_batches is not None:
+                    model.eval()
+                    with torch.no_grad():
+                        vouts = [model.validation_step(b, i) for i, b in enumerate(val_batches(epoch))]
+                    if vouts:
+                        model.validation_epoch_end(vouts)
+                if outputs:
+                    model.training_epoch_end(outputs)
+                    self._checkpoint(model, epoch)
+        if use_graph:
+            torch.cuda.current_stream().wait_stream(side)
         return model
 
     def _checkpoint(self, model, epoch):

@@ -4,6 +4,8 @@ Every test needs a real MI355X (`-m gpu`).  Tolerance: BASELINE.json:north_star 
 on the loss and the per-pair similarities; the kernels are held to tighter bounds where fp32
 round-off allows (stated per assertion).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -846,6 +848,55 @@ def test_split_hip_graphs_match_eager(precision):
     assert float(tg.replay_split(other)["loss"]) != float(outs[-1]["loss"])
     with pytest.raises(RuntimeError, match="grad_buckets"):
         Trainer(max_epochs=1).attach(copy.deepcopy(base)).capture_split_graphs(batch)
+
+
+@pytest.mark.parametrize("buckets", [False, True], ids=["one_graph", "split_graphs"])
+def test_fit_with_hip_graph_matches_eager_fit(tmp_path, buckets):
+    """Trainer(hip_graph=True).fit: capture on the first batch, replay equal shapes, eager for the ragged
+    last batch; epoch metrics, step count, schedule and checkpoints as the eager loop."""
+    import copy
+    import warnings
+
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config
+    from peclr_amd.bn2d import enable_hip_batchnorm
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(17)
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, augmentation=["crop", "rotate"],
+                         batch_size=8, num_samples=38, warmup_epochs=1, pretrained=False)
+    base = Hybrid2Model(cfg).to(DEV).train()
+    base.encoder = base.encoder.to(memory_format=torch.channels_last)
+    enable_hip_batchnorm(base.encoder)
+
+    def batches(epoch):
+        g = torch.Generator().manual_seed(100 + epoch)
+        for n in (8, 8, 8, 8, 6):                                      # ragged tail
+            b = {"transformed_image1": torch.randn(n, 3, 64, 64, generator=g), "transformed_image2": torch.randn(n, 3, 64, 64, generator=g),
+                 "jitter_x_1": torch.randint(-14, 1, (n,), generator=g), "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+                 "jitter_y_1": torch.randint(-14, 1, (n,), generator=g), "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+                 "angle_1": torch.randint(-45, 46, (n,), generator=g).double(), "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+            b = {k: v.to(DEV) for k, v in b.items()}
+            for k in ("transformed_image1", "transformed_image2"):
+                b[k] = b[k].contiguous(memory_format=torch.channels_last)
+            yield b
+
+    runs = {}
+    for graph in (False, True):
+        m = copy.deepcopy(base)
+        tr = Trainer(max_epochs=2, checkpoint_dir=str(tmp_path / f"ck{int(graph)}"), hip_graph=graph,
+                     grad_buckets=True if buckets else None)
+        os.makedirs(tr.checkpoint_dir, exist_ok=True)
+        tr.fit(m, batches, batches)
+        torch.cuda.synchronize()
+        runs[graph] = (tr, m)
+    (te, me), (tg, mg) = runs[False], runs[True]
+    assert tg.global_step == te.global_step == 10
+    assert tg.optimizer.param_groups[0]["lr"] == pytest.approx(te.optimizer.param_groups[0]["lr"], rel=1e-12)
+    assert set(mg.train_metrics_epoch) == set(me.train_metrics_epoch) and len(mg.train_metrics_epoch) == 17
+    assert float(mg.train_metrics_epoch["loss"]) == pytest.approx(float(me.train_metrics_epoch["loss"]), rel=6e-2)
+    assert float(mg.validation_metrics_epoch["loss"]) == pytest.approx(float(me.validation_metrics_epoch["loss"]), rel=1e-1)
+    assert int(mg.projection_head[1].num_batches_tracked) == int(me.projection_head[1].num_batches_tracked) == 10
+    assert len(os.listdir(tg.checkpoint_dir)) == 1
 
 
 def test_head_large_batch_streaming_bn_matches_oracle():
