@@ -52,6 +52,10 @@ SIGNATURES = {
     "peclr_bn2d_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "peclr_bn2d_bwd_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_bn2d_bwd_apply": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "peclr_bn2d_pool_n_split": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "peclr_bn2d_pool_apply": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "peclr_bn2d_pool_bwd_reduce": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "peclr_bn2d_pool_bwd_apply": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "peclr_augment_warp_crop_u8": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "peclr_augment_resize_color_norm": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, _P,
                                                 _P]),
@@ -345,17 +349,14 @@ def _sync_totals(partial, ns, c, rows, group):
     return local, total
 
 
-def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, relu,
-             want_mask=False, sync_group=None):
-    """want_mask: also write the 1-bit ReLU mask ([R, C/32] int32) the backward reads instead of y.
-    sync_group: a process group -> training statistics are those of the rows of ALL its ranks
-    (mean/var of the global batch, as one device holding the concatenated batch would compute)."""
+def _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group=None):
+    """stats -> finalize: (save [mean, invstd], scale_shift) for x [N,C,H,W] NHWC; updates the running
+    statistics in training mode."""
     n, c, h, w = x.shape
     r = n * h * w
     dev = x.device
     xp = _nhwc_ptr(x, "bn2d x")
     io, e = _IO[x.dtype]
-    y = torch.empty_like(x, memory_format=torch.channels_last)
     save = torch.empty((2, c), device=dev, dtype=torch.float32)
     ss = torch.empty((2, c), device=dev, dtype=torch.float32)
     part_ptr, ns = None, 0
@@ -386,6 +387,21 @@ def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training,
                                                _ptr(nbt, torch.int64, "num_batches_tracked") if training else None,
                                                save[0].data_ptr(), save[1].data_ptr(), ss.data_ptr(), _stream())
         _check(rc, "peclr_bn2d_finalize_f32")
+    return save, ss
+
+
+def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, relu,
+             want_mask=False, sync_group=None):
+    """want_mask: also write the 1-bit ReLU mask ([R, C/32] int32) the backward reads instead of y.
+    sync_group: a process group -> training statistics are those of the rows of ALL its ranks
+    (mean/var of the global batch, as one device holding the concatenated batch would compute)."""
+    n, c, h, w = x.shape
+    r = n * h * w
+    dev = x.device
+    xp = _nhwc_ptr(x, "bn2d x")
+    io, e = _IO[x.dtype]
+    save, ss = _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group)
+    y = torch.empty_like(x, memory_format=torch.channels_last)
     mask = torch.empty((r, c // 32), device=dev, dtype=torch.int32) if (want_mask and relu and c % 32 == 0) else None
     with _timed("bn2d_apply", (3 if residual is not None else 2) * e * r * c + (r * c // 8 if mask is not None else 0)):
         rc = lib().peclr_bn2d_apply(xp, _nhwc_ptr(residual, "bn2d residual", x.dtype) if residual is not None else None,
@@ -436,6 +452,60 @@ def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres, sync_group=Non
                                         dres.data_ptr() if dres is not None else None, _stream())
     _check(rc, "peclr_bn2d_bwd_apply")
     return dx, dparams[0], dparams[1], dres
+
+
+def bn2d_pool_fwd(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group=None):
+    """Stem: y = maxpool3x3/2(relu(bn(x))) in one pass; returns (y, tap codes, save, scale_shift)."""
+    n, c, h, w = x.shape
+    io, e = _IO[x.dtype]
+    save, ss = _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group)
+    ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((n, c, ph, pw), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    code = torch.empty((n, ph, pw, c), device=x.device, dtype=torch.uint8)
+    with _timed("bn2d_pool_apply", e * n * c * (h * w + ph * pw) + n * c * ph * pw):
+        rc = lib().peclr_bn2d_pool_apply(_nhwc_ptr(x, "bn2d x"), io, n, h, w, c, ss.data_ptr(), y.data_ptr(),
+                                         code.data_ptr(), _stream())
+    _check(rc, "peclr_bn2d_pool_apply")
+    return y, code, save, ss
+
+
+def bn2d_pool_bwd(dy, x, code, save, ss, training, sync_group=None):
+    n, c, h, w = x.shape
+    r = n * h * w
+    ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    io, e = _IO[x.dtype]
+    dev = x.device
+    ns = lib().peclr_bn2d_pool_n_split(n, h, w, c, io)
+    if ns < 1:
+        raise PeclrHipError(f"fused stem BN+ReLU+max-pool: unsupported shape {tuple(x.shape)}")
+    partial = torch.empty((2 * ns, c), device=dev, dtype=torch.float32)
+    dparams = torch.empty((2, c), device=dev, dtype=torch.float32)
+    coef = torch.empty((2, c), device=dev, dtype=torch.float32)
+    dx = torch.empty_like(x, memory_format=torch.channels_last)
+    dyp, xp = _nhwc_ptr(dy, "pooled dy", x.dtype), _nhwc_ptr(x, "bn2d x")
+    pooled = n * c * ph * pw
+    with _timed("bn2d_pool_bwd_reduce", (e + 1) * pooled + e * r * c):
+        rc = lib().peclr_bn2d_pool_bwd_reduce(dyp, xp, code.data_ptr(), io, n, h, w, c, save[0].data_ptr(),
+                                              save[1].data_ptr(), ss.data_ptr(), partial.data_ptr(), ns, _stream())
+    _check(rc, "peclr_bn2d_pool_bwd_reduce")
+    if training and sync_group is not None:
+        local, total = _sync_totals(partial, ns, c, r, sync_group)
+        with _timed("bn2d_bwd_finalize", 32 * c):
+            rc = lib().peclr_bn2d_bwd_finalize_totals_f32(local.data_ptr(), total.data_ptr(), c, 1, ss.data_ptr(),
+                                                          dparams[0].data_ptr(), dparams[1].data_ptr(), coef.data_ptr(),
+                                                          _stream())
+        _check(rc, "peclr_bn2d_bwd_finalize_totals_f32")
+    else:
+        with _timed("bn2d_bwd_finalize", 8 * ns * c):
+            rc = lib().peclr_bn2d_bwd_finalize_f32(partial.data_ptr(), ns, r, c, int(training), ss.data_ptr(),
+                                                   dparams[0].data_ptr(), dparams[1].data_ptr(), coef.data_ptr(),
+                                                   _stream())
+        _check(rc, "peclr_bn2d_bwd_finalize_f32")
+    with _timed("bn2d_pool_bwd_apply", (e + 1) * pooled + 2 * e * r * c):
+        rc = lib().peclr_bn2d_pool_bwd_apply(dyp, xp, code.data_ptr(), io, n, h, w, c, save[0].data_ptr(),
+                                             save[1].data_ptr(), ss.data_ptr(), coef.data_ptr(), dx.data_ptr(), _stream())
+    _check(rc, "peclr_bn2d_pool_bwd_apply")
+    return dx, dparams[0], dparams[1]
 
 
 # ------------------------------------------------------------------ two-view augmentation (pixel side)

@@ -53,28 +53,56 @@ class _BN2dAct(torch.autograd.Function):
         return dx, dgamma, dbeta, dres, None, None
 
 
+class _BN2dReluPool(torch.autograd.Function):
+    """Stem: BatchNorm2d -> ReLU -> MaxPool2d(3, 2, 1) without ever writing the un-pooled activation."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn: "FusedBatchNormAct2d"):
+        training = bn.training or not bn.track_running_stats
+        sync = bn.sync_group if training else None
+        y, code, save, ss = _capi.bn2d_pool_fwd(x, weight, bias, bn.running_mean, bn.running_var,
+                                                bn.num_batches_tracked, training, bn.eps,
+                                                bn.momentum if bn.momentum is not None else 0.1, sync_group=sync)
+        ctx.save_for_backward(x, code, save, ss)
+        ctx.cfg = (training, sync)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, code, save, ss = ctx.saved_tensors
+        training, sync = ctx.cfg
+        dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        dx, dgamma, dbeta = _capi.bn2d_pool_bwd(dy, x, code, save, ss, training, sync_group=sync)
+        return dx, dgamma, dbeta, None
+
+
 class FusedBatchNormAct2d(nn.BatchNorm2d):
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, **kw):
         super().__init__(num_features, eps=eps, momentum=momentum, affine=affine,
                          track_running_stats=track_running_stats, **kw)
         self.hip = False
         self.default_relu = False  # stem BN inside an nn.Sequential: fuse the ReLU that follows it
+        self.default_pool = False  # ... and the MaxPool2d(3, 2, 1) after that (the encoder's stem)
         # data parallel: a process group -> training statistics over the rows of ALL its ranks (what one
         # device holding the concatenated batch computes); None -> per-rank statistics (DDP's default)
         self.sync_group = None
 
     def forward(self, x: Tensor, residual: Optional[Tensor] = None, relu: Optional[bool] = None) -> Tensor:
         relu = self.default_relu if relu is None else relu
+        pool = self.default_pool and relu and residual is None
         if self.hip:
             if not self.affine or (self.training and self.momentum is None):
                 raise _capi.PeclrHipError("fused BatchNorm2d needs affine=True and a fixed momentum")
+            if pool:
+                return _BN2dReluPool.apply(x, self.weight, self.bias, self)
             return _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu)
         if self.sync_group is not None and self.training:
             raise _capi.PeclrHipError("synchronised statistics are implemented by the HIP kernels only (hip=True)")
         y = super().forward(x)
         if residual is not None:
             y = y + residual
-        return F.relu(y) if relu else y
+        y = F.relu(y) if relu else y
+        return F.max_pool2d(y, 3, stride=2, padding=1) if pool else y
 
 
 def enable_hip_batchnorm(module: nn.Module, enabled: bool = True, sync_group=None) -> int:

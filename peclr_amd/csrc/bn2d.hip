@@ -494,6 +494,164 @@ __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict_
 }
 
 // ------------------------------------------------------------------ host
+
+// ------------------------------------------------------------------ stem: BN + ReLU + 3x3/2 max-pool in one pass
+// torchvision's stem is conv7x7/2 -> BatchNorm2d -> ReLU -> MaxPool2d(3, stride 2, padding 1)
+// (resnet_model.py:15 wraps it as features[0..3]).  Normalising, rectifying and pooling in ONE pass never
+// materialises the 112x112 activation (822 MB at 2x128 views): forward reads x (L2 absorbs the 2.25x
+// window overlap) and writes the pooled tensor plus a 1-byte tap code per pooled element; backward
+// rebuilds the sparse pre-pool gradient from the codes on the fly, in the reduce pass (over pooled
+// elements) and in the apply pass (every pre-pool element gathers from the <= 4 windows that hold it).
+// Tap code = 3*dh + dw of the FIRST maximum in row-major window order (strict >), torch's rule.
+struct PoolGeo {
+    int N, H, Wd, C, PH, PW, CW, PPB;  // CW = C / W column groups, PPB = 256 / CW pixels per block pass
+};
+
+template <typename IO>
+__global__ __launch_bounds__(T) void bn2d_pool_apply_kernel(const IO* __restrict__ x, PoolGeo g,
+                                                            const float* __restrict__ scale_shift, IO* __restrict__ y,
+                                                            uint8_t* __restrict__ code) {
+    constexpr int W = Word<IO>::W;
+    const int cg = threadIdx.x % g.CW, pl = threadIdx.x / g.CW, col = cg * W;
+    const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
+    const long long P = (long long)g.N * g.PH * g.PW;
+    for (long long p = (long long)blockIdx.x * g.PPB + pl; p < P; p += (long long)gridDim.x * g.PPB) {
+        const int pw = (int)(p % g.PW), ph = (int)((p / g.PW) % g.PH), n = (int)(p / ((long long)g.PW * g.PH));
+        Fv<W> best;
+        unsigned char bc[W];
+        bool first = true;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int h = 2 * ph - 1 + dh;
+            if (h < 0 || h >= g.H) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int w = 2 * pw - 1 + dw;
+                if (w < 0 || w >= g.Wd) continue;
+                const Fv<W> v = Word<IO>::load(x + (((size_t)n * g.H + h) * g.Wd + w) * g.C + col);
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    const float t = fmaxf(fmaf(v.v[k], sc.v[k], sh.v[k]), 0.f);
+                    if (first || t > best.v[k]) best.v[k] = t, bc[k] = (unsigned char)(3 * dh + dw);
+                }
+                first = false;
+            }
+        }
+        Word<IO>::store(y + (size_t)p * g.C + col, best);
+        unsigned packed[W / 4];
+#pragma unroll
+        for (int k = 0; k < W; k += 4) packed[k / 4] = bc[k] | (bc[k + 1] << 8) | (bc[k + 2] << 16) | ((unsigned)bc[k + 3] << 24);
+#pragma unroll
+        for (int k = 0; k < W / 4; ++k) reinterpret_cast<unsigned*>(code + (size_t)p * g.C + col)[k] = packed[k];
+    }
+}
+
+// partial: [gridDim.x][2][C] = (sum of masked dy, sum of masked dy * xhat) over the block's pooled pixels
+template <typename IO>
+__global__ __launch_bounds__(T) void bn2d_pool_bwd_reduce_kernel(const IO* __restrict__ dyp, const IO* __restrict__ x,
+                                                                 const uint8_t* __restrict__ code, PoolGeo g,
+                                                                 const float* __restrict__ save_mean,
+                                                                 const float* __restrict__ save_invstd,
+                                                                 const float* __restrict__ scale_shift,
+                                                                 float* __restrict__ partial) {
+    constexpr int W = Word<IO>::W;
+    __shared__ float red[2 * W * T];
+    const int cg = threadIdx.x % g.CW, pl = threadIdx.x / g.CW, col = cg * W;
+    const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
+    const Fv<W> mean = loadp<W>(save_mean + col), inv = loadp<W>(save_invstd + col);
+    Fv<W> s = zero<W>(), q = zero<W>();
+    const long long P = (long long)g.N * g.PH * g.PW;
+    for (long long p = (long long)blockIdx.x * g.PPB + pl; p < P; p += (long long)gridDim.x * g.PPB) {
+        const int pw = (int)(p % g.PW), ph = (int)((p / g.PW) % g.PH), n = (int)(p / ((long long)g.PW * g.PH));
+        const Fv<W> gy = Word<IO>::load(dyp + (size_t)p * g.C + col);
+        unsigned char bc[W];
+#pragma unroll
+        for (int k = 0; k < W / 4; ++k) {
+            const unsigned u = reinterpret_cast<const unsigned*>(code + (size_t)p * g.C + col)[k];
+            bc[4 * k] = u & 255u, bc[4 * k + 1] = (u >> 8) & 255u, bc[4 * k + 2] = (u >> 16) & 255u, bc[4 * k + 3] = u >> 24;
+        }
+        // visit only the taps some channel of this word points at (neighbouring channels mostly agree)
+        unsigned want = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) want |= 1u << bc[k];
+        for (int tap = 0; tap < 9; ++tap) {
+            if (!((want >> tap) & 1u)) continue;
+            const int h = 2 * ph - 1 + tap / 3, w = 2 * pw - 1 + tap % 3;
+            const Fv<W> v = Word<IO>::load(x + (((size_t)n * g.H + h) * g.Wd + w) * g.C + col);
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const bool on = bc[k] == tap && fmaf(v.v[k], sc.v[k], sh.v[k]) > 0.f;
+                const float d = on ? gy.v[k] : 0.f;
+                s.v[k] += d;
+                q.v[k] += d * ((v.v[k] - mean.v[k]) * inv.v[k]);
+            }
+        }
+    }
+    // block reduction over the pixel lanes that share a column group (fixed order)
+#pragma unroll
+    for (int k = 0; k < W; ++k) red[k * T + threadIdx.x] = s.v[k], red[(W + k) * T + threadIdx.x] = q.v[k];
+    __syncthreads();
+    if (pl == 0) {
+        Fv<W> ts = zero<W>(), tq = zero<W>();
+        for (int l = 0; l < g.PPB; ++l)
+#pragma unroll
+            for (int k = 0; k < W; ++k) ts.v[k] += red[k * T + l * g.CW + cg], tq.v[k] += red[(W + k) * T + l * g.CW + cg];
+        storep<W>(partial + (size_t)blockIdx.x * 2 * g.C + col, ts);
+        storep<W>(partial + (size_t)blockIdx.x * 2 * g.C + g.C + col, tq);
+    }
+}
+
+template <typename IO>
+__global__ __launch_bounds__(T) void bn2d_pool_bwd_apply_kernel(const IO* __restrict__ dyp, const IO* __restrict__ x,
+                                                                const uint8_t* __restrict__ code, PoolGeo g,
+                                                                const float* __restrict__ save_mean,
+                                                                const float* __restrict__ save_invstd,
+                                                                const float* __restrict__ scale_shift,
+                                                                const float* __restrict__ coef, IO* __restrict__ dx) {
+    constexpr int W = Word<IO>::W;
+    const int cg = threadIdx.x % g.CW, pl = threadIdx.x / g.CW, col = cg * W;
+    const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
+    const Fv<W> mean = loadp<W>(save_mean + col), inv = loadp<W>(save_invstd + col);
+    const Fv<W> c0 = loadp<W>(coef + col), c1 = loadp<W>(coef + g.C + col);
+    const long long R = (long long)g.N * g.H * g.Wd;
+    for (long long r = (long long)blockIdx.x * g.PPB + pl; r < R; r += (long long)gridDim.x * g.PPB) {
+        const int w = (int)(r % g.Wd), h = (int)((r / g.Wd) % g.H), n = (int)(r / ((long long)g.Wd * g.H));
+        const Fv<W> v = Word<IO>::load(x + (size_t)r * g.C + col);
+        Fv<W> d = zero<W>();
+        // windows holding (h, w): ph in {h/2, (h+1)/2}, pw in {w/2, (w+1)/2} (one or two each); all four
+        // candidates are loaded together (predicated) so the loads overlap
+        const int phs[2] = {h >> 1, (h + 1) >> 1}, pws[2] = {w >> 1, (w + 1) >> 1};
+        Fv<W> gy[4];
+        unsigned cw[4][W / 4];
+        bool on[4];
+        unsigned char mine[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ph = phs[i >> 1], pw = pws[i & 1];
+            on[i] = ph < g.PH && pw < g.PW && !((i >> 1) && phs[1] == phs[0]) && !((i & 1) && pws[1] == pws[0]);
+            mine[i] = (unsigned char)(3 * (h - (2 * ph - 1)) + (w - (2 * pw - 1)));
+            const size_t p = on[i] ? (((size_t)n * g.PH + ph) * g.PW + pw) * g.C + col : 0;
+            gy[i] = on[i] ? Word<IO>::load(dyp + p) : zero<W>();
+#pragma unroll
+            for (int k = 0; k < W / 4; ++k) cw[i][k] = on[i] ? reinterpret_cast<const unsigned*>(code + p)[k] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < W / 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (((cw[i][k] >> (8 * j)) & 255u) == mine[i]) d.v[4 * k + j] += gy[i].v[4 * k + j];
+        Fv<W> o;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const float dy = fmaf(v.v[k], sc.v[k], sh.v[k]) > 0.f ? d.v[k] : 0.f;
+            o.v[k] = fmaf(dy, sc.v[k], fmaf((v.v[k] - mean.v[k]) * inv.v[k], c1.v[k], c0.v[k]));
+        }
+        Word<IO>::store(dx + (size_t)r * g.C + col, o);
+    }
+}
+
 struct Plan {
     Geo g;
     dim3 grid;
@@ -699,5 +857,81 @@ extern "C" int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y
         launch_bwd_apply<float>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, coef, dx, d_residual);
     else
         launch_bwd_apply<bf16_t>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, coef, dx, d_residual);
+    return launch_status();
+}
+
+// ---- stem: BN + ReLU + max-pool(3, 2, 1)
+namespace {
+bool pool_geo(int io_dtype, int N, int H, int W_, int C, peclr::PoolGeo& g) {
+    const int w = io_dtype == PECLR_DTYPE_F32 ? 4 : io_dtype == PECLR_DTYPE_BF16 ? 8 : 0;
+    if (!w || N <= 0 || H <= 0 || W_ <= 0 || C <= 0 || C % w) return false;
+    const int cw = C / w;
+    if (cw > T || T % cw) return false;
+    g = {N, H, W_, C, (H - 1) / 2 + 1, (W_ - 1) / 2 + 1, cw, T / cw};
+    return true;
+}
+int pool_blocks(const peclr::PoolGeo& g, long long pixels, int cap) {
+    const long long b = (pixels + g.PPB - 1) / g.PPB;
+    return (int)(b < cap ? b : cap);
+}
+}  // namespace
+
+extern "C" int peclr_bn2d_pool_n_split(int N, int H, int W, int C, int io_dtype) {
+    PoolGeo g;
+    if (!pool_geo(io_dtype, N, H, W, C, g)) return PECLR_ERR_SHAPE;
+    return pool_blocks(g, (long long)N * g.PH * g.PW, 4096);
+}
+
+extern "C" int peclr_bn2d_pool_apply(const void* x, int io_dtype, int N, int H, int W, int C, const float* scale_shift,
+                                     void* y, uint8_t* code, peclr_stream_t stream) {
+    if (!x || !scale_shift || !y || !code) return PECLR_ERR_NULL;
+    PoolGeo g;
+    if (!pool_geo(io_dtype, N, H, W, C, g)) return PECLR_ERR_SHAPE;
+    if (!all_aligned({x, y, code, scale_shift})) return PECLR_ERR_ALIGN;
+    const int blocks = pool_blocks(g, (long long)N * g.PH * g.PW, 1 << 16);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (io_dtype == PECLR_DTYPE_F32)
+        hipLaunchKernelGGL((bn2d_pool_apply_kernel<float>), dim3(blocks), dim3(T), 0, s, static_cast<const float*>(x), g,
+                           scale_shift, static_cast<float*>(y), code);
+    else
+        hipLaunchKernelGGL((bn2d_pool_apply_kernel<bf16_t>), dim3(blocks), dim3(T), 0, s, static_cast<const bf16_t*>(x), g,
+                           scale_shift, static_cast<bf16_t*>(y), code);
+    return launch_status();
+}
+
+extern "C" int peclr_bn2d_pool_bwd_reduce(const void* dy_pool, const void* x, const uint8_t* code, int io_dtype, int N, int H,
+                                          int W, int C, const float* save_mean, const float* save_invstd,
+                                          const float* scale_shift, float* partial, int n_split, peclr_stream_t stream) {
+    if (!dy_pool || !x || !code || !save_mean || !save_invstd || !scale_shift || !partial) return PECLR_ERR_NULL;
+    PoolGeo g;
+    if (!pool_geo(io_dtype, N, H, W, C, g) || n_split < 1) return PECLR_ERR_SHAPE;
+    if (!all_aligned({dy_pool, x, code, partial})) return PECLR_ERR_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (io_dtype == PECLR_DTYPE_F32)
+        hipLaunchKernelGGL((bn2d_pool_bwd_reduce_kernel<float>), dim3(n_split), dim3(T), 0, s, static_cast<const float*>(dy_pool),
+                           static_cast<const float*>(x), code, g, save_mean, save_invstd, scale_shift, partial);
+    else
+        hipLaunchKernelGGL((bn2d_pool_bwd_reduce_kernel<bf16_t>), dim3(n_split), dim3(T), 0, s, static_cast<const bf16_t*>(dy_pool),
+                           static_cast<const bf16_t*>(x), code, g, save_mean, save_invstd, scale_shift, partial);
+    return launch_status();
+}
+
+extern "C" int peclr_bn2d_pool_bwd_apply(const void* dy_pool, const void* x, const uint8_t* code, int io_dtype, int N, int H,
+                                         int W, int C, const float* save_mean, const float* save_invstd,
+                                         const float* scale_shift, const float* coef, void* dx, peclr_stream_t stream) {
+    if (!dy_pool || !x || !code || !save_mean || !save_invstd || !scale_shift || !coef || !dx) return PECLR_ERR_NULL;
+    PoolGeo g;
+    if (!pool_geo(io_dtype, N, H, W, C, g)) return PECLR_ERR_SHAPE;
+    if (!all_aligned({dy_pool, x, code, dx})) return PECLR_ERR_ALIGN;
+    const int blocks = pool_blocks(g, (long long)N * H * W, 1 << 16);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (io_dtype == PECLR_DTYPE_F32)
+        hipLaunchKernelGGL((bn2d_pool_bwd_apply_kernel<float>), dim3(blocks), dim3(T), 0, s, static_cast<const float*>(dy_pool),
+                           static_cast<const float*>(x), code, g, save_mean, save_invstd, scale_shift, coef,
+                           static_cast<float*>(dx));
+    else
+        hipLaunchKernelGGL((bn2d_pool_bwd_apply_kernel<bf16_t>), dim3(blocks), dim3(T), 0, s, static_cast<const bf16_t*>(dy_pool),
+                           static_cast<const bf16_t*>(x), code, g, save_mean, save_invstd, scale_shift, coef,
+                           static_cast<bf16_t*>(dx));
     return launch_status();
 }

@@ -27,10 +27,13 @@ class ResNetModel(nn.Module):
         # FusedBatchNormAct2d IS an nn.BatchNorm2d (the reference passes norm_layer=nn.BatchNorm2d):
         # identical parameters/buffers/state_dict; it can additionally run as one fused HIP pass
         model = model_function(pretrained=config.model.pretrained, norm_layer=FusedBatchNormAct2d)
-        # features.2 (the stem ReLU) is fused into features.1; an Identity keeps the Sequential indices
-        # (and therefore every state_dict key) where the reference has them
+        # features.2 (the stem ReLU) and features.3 (MaxPool2d(3, 2, 1)) are folded into features.1;
+        # Identity modules keep the Sequential indices (and therefore every state_dict key) where the
+        # reference has them.  Stock mode: F.batch_norm / relu / max_pool2d; HIP mode: one pass that never
+        # writes the 112x112 activation.
         model.bn1.default_relu = True
-        self.features = nn.Sequential(model.conv1, model.bn1, nn.Identity(), model.maxpool, model.layer1,
+        model.bn1.default_pool = True
+        self.features = nn.Sequential(model.conv1, model.bn1, nn.Identity(), nn.Identity(), model.layer1,
                                       model.layer2, model.layer3, model.layer4,
                                       nn.AdaptiveAvgPool2d(output_size=(1, 1)))
         self.final_layer = nn.Sequential(nn.Linear(model.fc.in_features, 21 * 3 + 1))

@@ -463,6 +463,57 @@ def test_bn2d_fused_matches_torch(shape, relu, res, training):
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize("shape", [(4, 64, 16, 16), (3, 64, 15, 17), (2, 64, 112, 112), (2, 128, 9, 9), (1, 64, 1, 5)])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_stem_bn_relu_maxpool_fused_matches_torch(shape, training, dtype):
+    """features[1..3] of the encoder in one pass (the un-pooled activation is never written) against
+    torch's BatchNorm2d -> ReLU -> MaxPool2d(3, 2, 1) in float64, forward and backward."""
+    from peclr_amd.bn2d import FusedBatchNormAct2d
+
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h * 3 + w)
+    x = (torch.randn(shape, generator=g) * 1.3 + 0.2).to(dtype)
+    bn = FusedBatchNormAct2d(c)
+    bn.default_relu = bn.default_pool = True
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g)
+        bn.bias.uniform_(-0.3, 0.3, generator=g)
+        bn.running_mean.uniform_(-0.2, 0.2, generator=g)
+        bn.running_var.uniform_(0.8, 1.2, generator=g)
+    ref = torch.nn.BatchNorm2d(c).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    bn.train(training)
+    ref.train(training)
+    xr = x.double().requires_grad_()
+    yr = torch.nn.functional.max_pool2d(torch.relu(ref(xr)), 3, stride=2, padding=1)
+    dy = torch.randn(yr.shape, generator=g).to(dtype)
+    yr.backward(dy.double())
+
+    import copy
+
+    stock = copy.deepcopy(bn)(x.float())                              # stock mode runs the same three ops (CPU)
+    assert stock.shape == yr.shape
+    hip = copy.deepcopy(bn).to(DEV).train(training)
+    hip.hip = True
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    yd = hip(xd)
+    assert yd.shape == yr.shape and yd.is_contiguous(memory_format=torch.channels_last)
+    yd.backward(dy.to(DEV).contiguous(memory_format=torch.channels_last))
+    lo = dtype == torch.bfloat16
+    np.testing.assert_allclose(host(yd.float()), yr.detach().numpy(), atol=4e-2 if lo else 2e-5, rtol=1e-2 if lo else 0)
+    scale = max(1.0, float(xr.grad.abs().max()))
+    bad = np.abs(host(xd.grad.float()) - xr.grad.numpy()) > (3e-2 if lo else 3e-5) * scale
+    assert bad.mean() <= (2e-3 if lo else 0.0), f"{bad.sum()} of {bad.size} gradient elements differ"
+    gs = max(1.0, float(ref.weight.grad.abs().max()))
+    np.testing.assert_allclose(host(hip.weight.grad), ref.weight.grad.numpy(), atol=(3e-2 if lo else 1e-4) * gs, rtol=1e-5)
+    np.testing.assert_allclose(host(hip.bias.grad), ref.bias.grad.numpy(), atol=(3e-2 if lo else 1e-4) * gs, rtol=1e-5)
+    np.testing.assert_allclose(host(stock.detach()), yr.detach().numpy(), atol=4e-2 if lo else 2e-5, rtol=1e-2 if lo else 0)
+    if training:
+        np.testing.assert_allclose(host(hip.running_mean), ref.running_mean.numpy(), atol=1e-5)
+        np.testing.assert_allclose(host(hip.running_var), ref.running_var.numpy(), atol=1e-5)
+
+
 @pytest.fixture(scope="module")
 def solo_group(tmp_path_factory):
     """A world-size-1 gloo group: drives the synchronised-statistics route (combine -> all-reduce ->
@@ -559,6 +610,37 @@ def test_resnet_fused_bn_equals_stock_on_gpu():
     for (n, ps), (_, pf) in zip(stock.named_parameters(), fused.named_parameters()):
         scale = max(1e-3, float(ps.grad.abs().max()))
         assert float((ps.grad - pf.grad).abs().max()) <= 2e-3 * scale, n
+    for (n, bs), (_, bf) in zip(stock.named_buffers(), fused.named_buffers()):
+        np.testing.assert_allclose(host(bf.float()), host(bs.float()), atol=1e-4, rtol=1e-4, err_msg=n)
+
+
+def test_encoder_wrapper_fused_stem_equals_stock_on_gpu():
+    """The reference-shaped encoder (features.0..8, stem ReLU and max-pool folded into features.1):
+    HIP glue incl. the one-pass BN+ReLU+max-pool stem vs the same module on PyTorch's stock ops."""
+    import copy
+
+    from peclr_amd import hybrid2_config
+    from peclr_amd.bn2d import enable_hip_batchnorm
+    from peclr_amd.encoder import get_wrapper_model
+
+    torch.manual_seed(1)
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, pretrained=False)
+    stock = get_wrapper_model(cfg, False).to(DEV).to(memory_format=torch.channels_last).train()
+    assert isinstance(stock.features[2], torch.nn.Identity) and isinstance(stock.features[3], torch.nn.Identity)
+    fused = copy.deepcopy(stock)
+    assert enable_hip_batchnorm(fused) == 20
+    x = torch.randn(8, 3, 96, 96, device=DEV).contiguous(memory_format=torch.channels_last)
+    ys, yf = stock(x), fused(x)
+    assert ys.shape == (8, 512)
+    np.testing.assert_allclose(host(yf), host(ys), atol=2e-4, rtol=1e-4)
+    ys.square().mean().backward()
+    yf.square().mean().backward()
+    for (n, ps), (_, pf) in zip(stock.named_parameters(), fused.named_parameters()):
+        if ps.grad is None:
+            assert pf.grad is None and "final_layer" in n
+            continue
+        scale = max(1e-3, float(ps.grad.abs().max()))
+        assert float((ps.grad - pf.grad).abs().max()) <= 5e-3 * scale, n   # BN-weight grads: sums of cancelling terms
     for (n, bs), (_, bf) in zip(stock.named_buffers(), fused.named_buffers()):
         np.testing.assert_allclose(host(bf.float()), host(bs.float()), atol=1e-4, rtol=1e-4, err_msg=n)
 
