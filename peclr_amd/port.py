@@ -65,6 +65,14 @@ def get_encoder_state_dict(saved_model_path: str) -> OrderedDict:
     return out
 
 
+def restore_model(model: torch.nn.Module, checkpoint_dir: str, checkpoint: str = ""):
+    """experiments/utils.py:535-546: load the newest (or the named) checkpoint's `state_dict`."""
+    path = get_latest_checkpoint(checkpoint_dir, checkpoint)
+    print(f"Restoring {path}")
+    model.load_state_dict(torch.load(path, map_location="cpu")["state_dict"])
+    return model
+
+
 def save_checkpoint(path: str, model: torch.nn.Module, optimizer=None, scheduler=None, epoch: int = 0,
                     global_step: int = 0, monitor: float = None):
     """Lightning-shaped checkpoint ({"state_dict", "epoch", "global_step", ...}) so files

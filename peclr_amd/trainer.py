@@ -273,7 +273,7 @@ class Trainer:
             side.wait_stream(torch.cuda.current_stream())
             stream_ctx = torch.cuda.stream(side)
         with stream_ctx:
-            for epoch in range(self.max_epochs):
+            for epoch in range(getattr(self, "_start_epoch", 0), self.max_epochs):
                 self.current_epoch = epoch
                 model.train()
                 outputs = [step(b, i) for i, b in enumerate(train_batches(epoch))]
@@ -289,6 +289,22 @@ class Trainer:
         if use_graph:
             torch.cuda.current_stream().wait_stream(side)
         return model
+
+    def resume(self, path: str):
+        """Continue a run from a checkpoint written by `_checkpoint` / `save_checkpoint` (what Lightning's
+        `resume_from_checkpoint` restores): weights and buffers, optimiser moments and step counts,
+        scheduler position, epoch and global step.  Call after `attach(model)`; `fit` then starts at the
+        epoch after the saved one."""
+        ckpt = torch.load(path, map_location="cpu")
+        self.model.load_state_dict(ckpt["state_dict"])
+        if "optimizer_states" in ckpt:
+            self.optimizer.load_state_dict(ckpt["optimizer_states"][0])
+        if "lr_schedulers" in ckpt:
+            self.scheduler.load_state_dict(ckpt["lr_schedulers"][0])
+        self.global_step = int(ckpt.get("global_step", 0))
+        self.current_epoch = int(ckpt.get("epoch", -1)) + 1
+        self._start_epoch = self.current_epoch
+        return self
 
     def _checkpoint(self, model, epoch):
         if self.checkpoint_dir is None or pdist.rank(self.process_group) != 0:

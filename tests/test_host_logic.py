@@ -234,6 +234,52 @@ def test_trainer_accumulation_and_checkpoint_roundtrip(tmp_path):
         peclr_to_torchvision(torch.nn.Linear(2, 2), path)
 
 
+def test_resume_continues_the_run_exactly(tmp_path):
+    """Trainer.resume: weights, optimiser moments/step counts, schedule position, epoch and global step;
+    a run resumed after epoch 0 ends where the uninterrupted run ends.  restore_model: weights only
+    (experiments/utils.py:535-546)."""
+    import copy
+    import warnings
+
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config, restore_model
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(3)
+    n = 2
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, augmentation=["crop", "rotate"],
+                         batch_size=n, num_samples=6, warmup_epochs=1, pretrained=False)
+    base = Hybrid2Model(cfg)
+
+    def batches(epoch):
+        g = torch.Generator().manual_seed(50 + epoch)
+        for _ in range(3):
+            yield {"transformed_image1": torch.randn(n, 3, 32, 32, generator=g),
+                   "transformed_image2": torch.randn(n, 3, 32, 32, generator=g),
+                   "jitter_x_1": torch.randint(-14, 1, (n,), generator=g), "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+                   "jitter_y_1": torch.randint(-14, 1, (n,), generator=g), "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+                   "angle_1": torch.randint(-45, 46, (n,), generator=g).double(),
+                   "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+
+    straight = copy.deepcopy(base)
+    ts = Trainer(max_epochs=2, checkpoint_dir=str(tmp_path / "a"), save_top_k=5)
+    ts.fit(straight, batches)
+    # the "interrupted" run is the same run cut after epoch 0: its checkpoint is a/epoch=0.ckpt
+    resumed = copy.deepcopy(base)
+    tr = Trainer(max_epochs=2, checkpoint_dir=str(tmp_path / "b"), save_top_k=5).attach(resumed)
+    tr.resume(os.path.join(tmp_path / "a", "epoch=0.ckpt"))
+    assert tr.global_step == 3 and tr.current_epoch == 1
+    tr.fit(resumed, batches)
+    assert tr.global_step == ts.global_step == 6
+    assert tr.scheduler.last_epoch == ts.scheduler.last_epoch
+    for (k, a), (_, b) in zip(straight.state_dict().items(), resumed.state_dict().items()):
+        assert torch.equal(a, b), k
+    fresh = restore_model(copy.deepcopy(base), str(tmp_path / "b"))          # newest checkpoint: epoch=1
+    assert torch.equal(fresh.projection_head[3].weight, resumed.projection_head[3].weight)
+    again = restore_model(copy.deepcopy(base), str(tmp_path / "a"), "epoch=0.ckpt")
+    assert not torch.equal(again.projection_head[3].weight, resumed.projection_head[3].weight)
+    assert not torch.equal(again.projection_head[3].weight, base.projection_head[3].weight)
+
+
 def test_resnet_state_dict_layout():
     from peclr_amd import resnet
 
