@@ -30,6 +30,8 @@ BENCH_KERNELS = {
     "bn2d_stats": "bn2d_stats_kernel", "bn2d_finalize": "bn2d_stats_finalize_kernel", "bn2d_apply": "bn2d_apply_kernel",
     "bn2d_bwd_reduce": "bn2d_bwd_reduce_kernel", "bn2d_bwd_finalize": "bn2d_bwd_finalize_kernel",
     "bn2d_bwd_apply": "bn2d_bwd_apply_kernel",
+    "bn2d_pool_apply": "bn2d_pool_apply_kernel", "bn2d_pool_bwd_reduce": "bn2d_pool_bwd_reduce_kernel",
+    "bn2d_pool_bwd_apply": "bn2d_pool_bwd_apply_kernel",
 }
 
 
