@@ -248,17 +248,20 @@ int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y, const uin
  * torchvision ResNet the reference wraps, resnet_model.py:15-26); x is [N][H][W][C] NHWC, the pooled
  * output [N][PH][PW][C] with PH = (H-1)/2 + 1.  The un-pooled activation is never written.  Forward:
  * peclr_bn2d_stats -> peclr_bn2d_finalize_f32 (as above, on x) -> peclr_bn2d_pool_apply, which also
- * writes a 1-byte tap code (3*dh+dw of the first maximum, row-major, torch's rule) per pooled
- * element.  Backward: peclr_bn2d_pool_bwd_reduce (partial [n_split][2][C], n_split from
- * peclr_bn2d_pool_n_split) -> peclr_bn2d_bwd_finalize_f32 with R = N*H*W ->
- * peclr_bn2d_pool_bwd_apply (dx on the un-pooled grid).  C/4 (fp32) or C/8 (bf16) must divide 256. */
+ * writes, per pooled element, a 1-byte tap code (3*dh+dw of the first maximum, row-major, torch's
+ * rule) and the x value at that maximum (x_at_max, same dtype/shape as y).  Backward:
+ * peclr_bn2d_pool_bwd_reduce (a streaming reduction over dy and x_at_max; partial [n_split][2][C],
+ * n_split from peclr_bn2d_pool_n_split or any >= 1) -> peclr_bn2d_bwd_finalize_f32 with R = N*H*W
+ * -> peclr_bn2d_pool_bwd_apply (dx on the un-pooled grid: every element gathers from the <= 4
+ * windows that hold it).  C/4 (fp32) or C/8 (bf16) must divide 256. */
 int peclr_bn2d_pool_n_split(int N, int H, int W, int C, int io_dtype);
 int peclr_bn2d_pool_apply(const void* x, int io_dtype, int N, int H, int W, int C,
-                          const float* scale_shift, void* y, uint8_t* code, peclr_stream_t stream);
-int peclr_bn2d_pool_bwd_reduce(const void* dy_pool, const void* x, const uint8_t* code, int io_dtype,
-                               int N, int H, int W, int C, const float* save_mean,
-                               const float* save_invstd, const float* scale_shift, float* partial,
-                               int n_split, peclr_stream_t stream);
+                          const float* scale_shift, void* y, void* x_at_max, uint8_t* code,
+                          peclr_stream_t stream);
+int peclr_bn2d_pool_bwd_reduce(const void* dy_pool, const void* x_at_max, int io_dtype, int N, int H,
+                               int W, int C, const float* save_mean, const float* save_invstd,
+                               const float* scale_shift, float* partial, int n_split,
+                               peclr_stream_t stream);
 int peclr_bn2d_pool_bwd_apply(const void* dy_pool, const void* x, const uint8_t* code, int io_dtype,
                               int N, int H, int W, int C, const float* save_mean,
                               const float* save_invstd, const float* scale_shift, const float* coef,

@@ -53,8 +53,8 @@ SIGNATURES = {
     "peclr_bn2d_bwd_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_bn2d_bwd_apply": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "peclr_bn2d_pool_n_split": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "peclr_bn2d_pool_apply": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
-    "peclr_bn2d_pool_bwd_reduce": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "peclr_bn2d_pool_apply": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "peclr_bn2d_pool_bwd_reduce": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "peclr_bn2d_pool_bwd_apply": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "peclr_augment_warp_crop_u8": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "peclr_augment_resize_color_norm": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, _P,
@@ -461,15 +461,16 @@ def bn2d_pool_fwd(x, gamma, beta, running_mean, running_var, nbt, training, eps,
     save, ss = _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group)
     ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     y = torch.empty((n, c, ph, pw), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    x_at_max = torch.empty_like(y)
     code = torch.empty((n, ph, pw, c), device=x.device, dtype=torch.uint8)
-    with _timed("bn2d_pool_apply", e * n * c * (h * w + ph * pw) + n * c * ph * pw):
+    with _timed("bn2d_pool_apply", e * n * c * (h * w + 2 * ph * pw) + n * c * ph * pw):
         rc = lib().peclr_bn2d_pool_apply(_nhwc_ptr(x, "bn2d x"), io, n, h, w, c, ss.data_ptr(), y.data_ptr(),
-                                         code.data_ptr(), _stream())
+                                         x_at_max.data_ptr(), code.data_ptr(), _stream())
     _check(rc, "peclr_bn2d_pool_apply")
-    return y, code, save, ss
+    return y, x_at_max, code, save, ss
 
 
-def bn2d_pool_bwd(dy, x, code, save, ss, training, sync_group=None):
+def bn2d_pool_bwd(dy, x, x_at_max, code, save, ss, training, sync_group=None):
     n, c, h, w = x.shape
     r = n * h * w
     ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
@@ -484,9 +485,10 @@ def bn2d_pool_bwd(dy, x, code, save, ss, training, sync_group=None):
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     dyp, xp = _nhwc_ptr(dy, "pooled dy", x.dtype), _nhwc_ptr(x, "bn2d x")
     pooled = n * c * ph * pw
-    with _timed("bn2d_pool_bwd_reduce", (e + 1) * pooled + e * r * c):
-        rc = lib().peclr_bn2d_pool_bwd_reduce(dyp, xp, code.data_ptr(), io, n, h, w, c, save[0].data_ptr(),
-                                              save[1].data_ptr(), ss.data_ptr(), partial.data_ptr(), ns, _stream())
+    with _timed("bn2d_pool_bwd_reduce", 2 * e * pooled):
+        rc = lib().peclr_bn2d_pool_bwd_reduce(dyp, _nhwc_ptr(x_at_max, "x at the maximum", x.dtype), io, n, h, w, c,
+                                              save[0].data_ptr(), save[1].data_ptr(), ss.data_ptr(), partial.data_ptr(),
+                                              ns, _stream())
     _check(rc, "peclr_bn2d_pool_bwd_reduce")
     if training and sync_group is not None:
         local, total = _sync_totals(partial, ns, c, r, sync_group)

@@ -60,19 +60,19 @@ class _BN2dReluPool(torch.autograd.Function):
     def forward(ctx, x, weight, bias, bn: "FusedBatchNormAct2d"):
         training = bn.training or not bn.track_running_stats
         sync = bn.sync_group if training else None
-        y, code, save, ss = _capi.bn2d_pool_fwd(x, weight, bias, bn.running_mean, bn.running_var,
+        y, x_at_max, code, save, ss = _capi.bn2d_pool_fwd(x, weight, bias, bn.running_mean, bn.running_var,
                                                 bn.num_batches_tracked, training, bn.eps,
                                                 bn.momentum if bn.momentum is not None else 0.1, sync_group=sync)
-        ctx.save_for_backward(x, code, save, ss)
+        ctx.save_for_backward(x, x_at_max, code, save, ss)
         ctx.cfg = (training, sync)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, code, save, ss = ctx.saved_tensors
+        x, x_at_max, code, save, ss = ctx.saved_tensors
         training, sync = ctx.cfg
         dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
-        dx, dgamma, dbeta = _capi.bn2d_pool_bwd(dy, x, code, save, ss, training, sync_group=sync)
+        dx, dgamma, dbeta = _capi.bn2d_pool_bwd(dy, x, x_at_max, code, save, ss, training, sync_group=sync)
         return dx, dgamma, dbeta, None
 
 

@@ -506,18 +506,40 @@ __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict_
 struct PoolGeo {
     int N, H, Wd, C, PH, PW, CW, PPB;  // CW = C / W column groups, PPB = 256 / CW pixels per block pass
 };
+// Workgroups are handed to the 8 XCDs round-robin and every XCD has its own L2.  The 3x3/2 windows of
+// neighbouring pixels overlap, so the pixels of ONE image should meet in ONE L2: hardware block b works on
+// image n = 8 * (j / bpi) + b % 8 and on run j % bpi of that image's pixels, with j = b / 8 and bpi = runs
+// per image.  At any moment the 8 XCDs walk 8 consecutive images in step (a few MB apart, so their streams
+// spread over the HBM channels; handing each XCD a contiguous EIGHTH of the tensor instead put all eight
+// streams on the same channels and ran 20 % slower).  Images past N idle.
+constexpr int kXcd = 8;
+struct XcdSlot {
+    int n, run;
+};
+__device__ __forceinline__ XcdSlot xcd_slot(int runs_per_image) {
+    const int j = blockIdx.x / kXcd;
+    return {kXcd * (j / runs_per_image) + (int)(blockIdx.x % kXcd), j % runs_per_image};
+}
+
+constexpr int kPoolIter = 4;  // pixels per thread in the two apply kernels (fewer, longer workgroups)
 
 template <typename IO>
 __global__ __launch_bounds__(T) void bn2d_pool_apply_kernel(const IO* __restrict__ x, PoolGeo g,
                                                             const float* __restrict__ scale_shift, IO* __restrict__ y,
-                                                            uint8_t* __restrict__ code) {
+                                                            IO* __restrict__ x_at_max, uint8_t* __restrict__ code) {
     constexpr int W = Word<IO>::W;
     const int cg = threadIdx.x % g.CW, pl = threadIdx.x / g.CW, col = cg * W;
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
-    const long long P = (long long)g.N * g.PH * g.PW;
-    for (long long p = (long long)blockIdx.x * g.PPB + pl; p < P; p += (long long)gridDim.x * g.PPB) {
-        const int pw = (int)(p % g.PW), ph = (int)((p / g.PW) % g.PH), n = (int)(p / ((long long)g.PW * g.PH));
-        Fv<W> best;
+    const int per_image = g.PH * g.PW, span = g.PPB * kPoolIter;
+    const XcdSlot slot = xcd_slot((per_image + span - 1) / span);
+    if (slot.n >= g.N) return;
+    const int n = slot.n;
+    for (int it = 0; it < kPoolIter; ++it) {
+        const int q = slot.run * span + it * g.PPB + pl;
+        if (q >= per_image) break;
+        const int pw = q % g.PW, ph = q / g.PW;
+        const long long p = (long long)n * per_image + q;
+        Fv<W> best, xb;
         unsigned char bc[W];
         bool first = true;
 #pragma unroll
@@ -532,12 +554,13 @@ __global__ __launch_bounds__(T) void bn2d_pool_apply_kernel(const IO* __restrict
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
                     const float t = fmaxf(fmaf(v.v[k], sc.v[k], sh.v[k]), 0.f);
-                    if (first || t > best.v[k]) best.v[k] = t, bc[k] = (unsigned char)(3 * dh + dw);
+                    if (first || t > best.v[k]) best.v[k] = t, xb.v[k] = v.v[k], bc[k] = (unsigned char)(3 * dh + dw);
                 }
                 first = false;
             }
         }
         Word<IO>::store(y + (size_t)p * g.C + col, best);
+        Word<IO>::store(x_at_max + (size_t)p * g.C + col, xb);   // exact: x is an IO value already
         unsigned packed[W / 4];
 #pragma unroll
         for (int k = 0; k < W; k += 4) packed[k / 4] = bc[k] | (bc[k + 1] << 8) | (bc[k + 2] << 16) | ((unsigned)bc[k + 3] << 24);
@@ -548,9 +571,8 @@ __global__ __launch_bounds__(T) void bn2d_pool_apply_kernel(const IO* __restrict
 
 // partial: [gridDim.x][2][C] = (sum of masked dy, sum of masked dy * xhat) over the block's pooled pixels
 template <typename IO>
-__global__ __launch_bounds__(T) void bn2d_pool_bwd_reduce_kernel(const IO* __restrict__ dyp, const IO* __restrict__ x,
-                                                                 const uint8_t* __restrict__ code, PoolGeo g,
-                                                                 const float* __restrict__ save_mean,
+__global__ __launch_bounds__(T) void bn2d_pool_bwd_reduce_kernel(const IO* __restrict__ dyp, const IO* __restrict__ x_at_max,
+                                                                 PoolGeo g, const float* __restrict__ save_mean,
                                                                  const float* __restrict__ save_invstd,
                                                                  const float* __restrict__ scale_shift,
                                                                  float* __restrict__ partial) {
@@ -560,33 +582,32 @@ __global__ __launch_bounds__(T) void bn2d_pool_bwd_reduce_kernel(const IO* __res
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
     const Fv<W> mean = loadp<W>(save_mean + col), inv = loadp<W>(save_invstd + col);
     Fv<W> s = zero<W>(), q = zero<W>();
+    // every pooled element's gradient lands on ONE un-pooled element, whose x the forward kept: a plain
+    // streaming reduction over the pooled grid.  gridDim.x blocks, contiguous chunks, 4 loads in flight.
     const long long P = (long long)g.N * g.PH * g.PW;
-    for (long long p = (long long)blockIdx.x * g.PPB + pl; p < P; p += (long long)gridDim.x * g.PPB) {
-        const int pw = (int)(p % g.PW), ph = (int)((p / g.PW) % g.PH), n = (int)(p / ((long long)g.PW * g.PH));
-        const Fv<W> gy = Word<IO>::load(dyp + (size_t)p * g.C + col);
-        unsigned char bc[W];
+    const long long chunk = ((P + gridDim.x - 1) / gridDim.x + g.PPB - 1) / g.PPB * g.PPB;
+    const long long p_begin = (long long)blockIdx.x * chunk, p_end = p_begin + chunk < P ? p_begin + chunk : P;
+    auto acc = [&](const Fv<W>& gy, const Fv<W>& xv) {
 #pragma unroll
-        for (int k = 0; k < W / 4; ++k) {
-            const unsigned u = reinterpret_cast<const unsigned*>(code + (size_t)p * g.C + col)[k];
-            bc[4 * k] = u & 255u, bc[4 * k + 1] = (u >> 8) & 255u, bc[4 * k + 2] = (u >> 16) & 255u, bc[4 * k + 3] = u >> 24;
+        for (int k = 0; k < W; ++k) {
+            const float d = fmaf(xv.v[k], sc.v[k], sh.v[k]) > 0.f ? gy.v[k] : 0.f;
+            s.v[k] += d;
+            q.v[k] += d * ((xv.v[k] - mean.v[k]) * inv.v[k]);
         }
-        // visit only the taps some channel of this word points at (neighbouring channels mostly agree)
-        unsigned want = 0;
+    };
+    long long p = p_begin + pl;
+    for (; p + 3 * g.PPB < p_end; p += 4 * g.PPB) {
+        Fv<W> gy[4], xv[4];
 #pragma unroll
-        for (int k = 0; k < W; ++k) want |= 1u << bc[k];
-        for (int tap = 0; tap < 9; ++tap) {
-            if (!((want >> tap) & 1u)) continue;
-            const int h = 2 * ph - 1 + tap / 3, w = 2 * pw - 1 + tap % 3;
-            const Fv<W> v = Word<IO>::load(x + (((size_t)n * g.H + h) * g.Wd + w) * g.C + col);
-#pragma unroll
-            for (int k = 0; k < W; ++k) {
-                const bool on = bc[k] == tap && fmaf(v.v[k], sc.v[k], sh.v[k]) > 0.f;
-                const float d = on ? gy.v[k] : 0.f;
-                s.v[k] += d;
-                q.v[k] += d * ((v.v[k] - mean.v[k]) * inv.v[k]);
-            }
+        for (int u = 0; u < 4; ++u) {
+            gy[u] = Word<IO>::load(dyp + (size_t)(p + u * g.PPB) * g.C + col);
+            xv[u] = Word<IO>::load(x_at_max + (size_t)(p + u * g.PPB) * g.C + col);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc(gy[u], xv[u]);
     }
+    for (; p < p_end; p += g.PPB)
+        acc(Word<IO>::load(dyp + (size_t)p * g.C + col), Word<IO>::load(x_at_max + (size_t)p * g.C + col));
     // block reduction over the pixel lanes that share a column group (fixed order)
 #pragma unroll
     for (int k = 0; k < W; ++k) red[k * T + threadIdx.x] = s.v[k], red[(W + k) * T + threadIdx.x] = q.v[k];
@@ -596,8 +617,8 @@ __global__ __launch_bounds__(T) void bn2d_pool_bwd_reduce_kernel(const IO* __res
         for (int l = 0; l < g.PPB; ++l)
 #pragma unroll
             for (int k = 0; k < W; ++k) ts.v[k] += red[k * T + l * g.CW + cg], tq.v[k] += red[(W + k) * T + l * g.CW + cg];
-        storep<W>(partial + (size_t)blockIdx.x * 2 * g.C + col, ts);
-        storep<W>(partial + (size_t)blockIdx.x * 2 * g.C + g.C + col, tq);
+        storep<W>(partial + (size_t)blockIdx.x * 2 * g.C + col, ts);      // slot order is irrelevant to the
+        storep<W>(partial + (size_t)blockIdx.x * 2 * g.C + g.C + col, tq);  // fixed-order combine that follows
     }
 }
 
@@ -613,9 +634,15 @@ __global__ __launch_bounds__(T) void bn2d_pool_bwd_apply_kernel(const IO* __rest
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
     const Fv<W> mean = loadp<W>(save_mean + col), inv = loadp<W>(save_invstd + col);
     const Fv<W> c0 = loadp<W>(coef + col), c1 = loadp<W>(coef + g.C + col);
-    const long long R = (long long)g.N * g.H * g.Wd;
-    for (long long r = (long long)blockIdx.x * g.PPB + pl; r < R; r += (long long)gridDim.x * g.PPB) {
-        const int w = (int)(r % g.Wd), h = (int)((r / g.Wd) % g.H), n = (int)(r / ((long long)g.Wd * g.H));
+    const int per_image = g.H * g.Wd, span = g.PPB * 2 * kPoolIter;
+    const XcdSlot slot = xcd_slot((per_image + span - 1) / span);
+    if (slot.n >= g.N) return;
+    const int n = slot.n;
+    for (int it = 0; it < 2 * kPoolIter; ++it) {
+        const int q = slot.run * span + it * g.PPB + pl;
+        if (q >= per_image) break;
+        const int w = q % g.Wd, h = q / g.Wd;
+        const long long r = (long long)n * per_image + q;
         const Fv<W> v = Word<IO>::load(x + (size_t)r * g.C + col);
         Fv<W> d = zero<W>();
         // windows holding (h, w): ph in {h/2, (h+1)/2}, pw in {w/2, (w+1)/2} (one or two each); all four
@@ -870,49 +897,54 @@ bool pool_geo(int io_dtype, int N, int H, int W_, int C, peclr::PoolGeo& g) {
     g = {N, H, W_, C, (H - 1) / 2 + 1, (W_ - 1) / 2 + 1, cw, T / cw};
     return true;
 }
-int pool_blocks(const peclr::PoolGeo& g, long long pixels, int cap) {
-    const long long b = (pixels + g.PPB - 1) / g.PPB;
-    return (int)(b < cap ? b : cap);
+// grid = 8 * ceil(N / 8) * runs-per-image (see xcd_slot); cap > 0 bounds the total (the reduce's partials)
+int pool_blocks(const peclr::PoolGeo& g, int pixels_per_image, int iters) {
+    const int span = g.PPB * iters;
+    return 8 * ((g.N + 7) / 8) * ((pixels_per_image + span - 1) / span);
 }
 }  // namespace
 
 extern "C" int peclr_bn2d_pool_n_split(int N, int H, int W, int C, int io_dtype) {
     PoolGeo g;
     if (!pool_geo(io_dtype, N, H, W, C, g)) return PECLR_ERR_SHAPE;
-    return pool_blocks(g, (long long)N * g.PH * g.PW, 4096);
+    // ~2048 workgroups, at least four passes (one unrolled batch of loads) each
+    const long long pixels = (long long)N * g.PH * g.PW;
+    long long n = (pixels + 4LL * g.PPB - 1) / (4LL * g.PPB);
+    if (n > 2048) n = 2048;
+    return (int)(n < 1 ? 1 : n);
 }
 
 extern "C" int peclr_bn2d_pool_apply(const void* x, int io_dtype, int N, int H, int W, int C, const float* scale_shift,
-                                     void* y, uint8_t* code, peclr_stream_t stream) {
-    if (!x || !scale_shift || !y || !code) return PECLR_ERR_NULL;
+                                     void* y, void* x_at_max, uint8_t* code, peclr_stream_t stream) {
+    if (!x || !scale_shift || !y || !x_at_max || !code) return PECLR_ERR_NULL;
     PoolGeo g;
     if (!pool_geo(io_dtype, N, H, W, C, g)) return PECLR_ERR_SHAPE;
-    if (!all_aligned({x, y, code, scale_shift})) return PECLR_ERR_ALIGN;
-    const int blocks = pool_blocks(g, (long long)N * g.PH * g.PW, 1 << 16);
+    if (!all_aligned({x, y, x_at_max, code, scale_shift})) return PECLR_ERR_ALIGN;
+    const int blocks = pool_blocks(g, g.PH * g.PW, kPoolIter);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (io_dtype == PECLR_DTYPE_F32)
         hipLaunchKernelGGL((bn2d_pool_apply_kernel<float>), dim3(blocks), dim3(T), 0, s, static_cast<const float*>(x), g,
-                           scale_shift, static_cast<float*>(y), code);
+                           scale_shift, static_cast<float*>(y), static_cast<float*>(x_at_max), code);
     else
         hipLaunchKernelGGL((bn2d_pool_apply_kernel<bf16_t>), dim3(blocks), dim3(T), 0, s, static_cast<const bf16_t*>(x), g,
-                           scale_shift, static_cast<bf16_t*>(y), code);
+                           scale_shift, static_cast<bf16_t*>(y), static_cast<bf16_t*>(x_at_max), code);
     return launch_status();
 }
 
-extern "C" int peclr_bn2d_pool_bwd_reduce(const void* dy_pool, const void* x, const uint8_t* code, int io_dtype, int N, int H,
-                                          int W, int C, const float* save_mean, const float* save_invstd,
-                                          const float* scale_shift, float* partial, int n_split, peclr_stream_t stream) {
-    if (!dy_pool || !x || !code || !save_mean || !save_invstd || !scale_shift || !partial) return PECLR_ERR_NULL;
+extern "C" int peclr_bn2d_pool_bwd_reduce(const void* dy_pool, const void* x_at_max, int io_dtype, int N, int H, int W, int C,
+                                          const float* save_mean, const float* save_invstd, const float* scale_shift,
+                                          float* partial, int n_split, peclr_stream_t stream) {
+    if (!dy_pool || !x_at_max || !save_mean || !save_invstd || !scale_shift || !partial) return PECLR_ERR_NULL;
     PoolGeo g;
     if (!pool_geo(io_dtype, N, H, W, C, g) || n_split < 1) return PECLR_ERR_SHAPE;
-    if (!all_aligned({dy_pool, x, code, partial})) return PECLR_ERR_ALIGN;
+    if (!all_aligned({dy_pool, x_at_max, partial})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (io_dtype == PECLR_DTYPE_F32)
         hipLaunchKernelGGL((bn2d_pool_bwd_reduce_kernel<float>), dim3(n_split), dim3(T), 0, s, static_cast<const float*>(dy_pool),
-                           static_cast<const float*>(x), code, g, save_mean, save_invstd, scale_shift, partial);
+                           static_cast<const float*>(x_at_max), g, save_mean, save_invstd, scale_shift, partial);
     else
         hipLaunchKernelGGL((bn2d_pool_bwd_reduce_kernel<bf16_t>), dim3(n_split), dim3(T), 0, s, static_cast<const bf16_t*>(dy_pool),
-                           static_cast<const bf16_t*>(x), code, g, save_mean, save_invstd, scale_shift, partial);
+                           static_cast<const bf16_t*>(x_at_max), g, save_mean, save_invstd, scale_shift, partial);
     return launch_status();
 }
 
@@ -923,7 +955,7 @@ extern "C" int peclr_bn2d_pool_bwd_apply(const void* dy_pool, const void* x, con
     PoolGeo g;
     if (!pool_geo(io_dtype, N, H, W, C, g)) return PECLR_ERR_SHAPE;
     if (!all_aligned({dy_pool, x, code, dx})) return PECLR_ERR_ALIGN;
-    const int blocks = pool_blocks(g, (long long)N * H * W, 1 << 16);
+    const int blocks = pool_blocks(g, H * W, 2 * kPoolIter);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (io_dtype == PECLR_DTYPE_F32)
         hipLaunchKernelGGL((bn2d_pool_bwd_apply_kernel<float>), dim3(blocks), dim3(T), 0, s, static_cast<const float*>(dy_pool),

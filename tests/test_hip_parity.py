@@ -639,8 +639,12 @@ def test_encoder_wrapper_fused_stem_equals_stock_on_gpu():
         if ps.grad is None:
             assert pf.grad is None and "final_layer" in n
             continue
-        scale = max(1e-3, float(ps.grad.abs().max()))
-        assert float((ps.grad - pf.grad).abs().max()) <= 5e-3 * scale, n   # BN-weight grads: sums of cancelling terms
+        # Norm-wise: two IDENTICAL stock runs already differ by 3.4e-3 of the largest element here (MIOpen's
+        # atomically accumulated weight gradients through small-batch BN, tools/exp/stem_diag.py), and a
+        # pre-activation within rounding of zero may land on the other side of a ReLU in the other
+        # implementation, which shows up as an isolated outlier element.
+        err = float((ps.grad - pf.grad).norm()) / max(1e-6, float(ps.grad.norm()))
+        assert err <= 2e-2, (n, err)
     for (n, bs), (_, bf) in zip(stock.named_buffers(), fused.named_buffers()):
         np.testing.assert_allclose(host(bf.float()), host(bs.float()), atol=1e-4, rtol=1e-4, err_msg=n)
 
