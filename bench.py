@@ -143,8 +143,10 @@ def kernel_table(event_log, m_rows, m_global, din, hid, n_params):
         avg_us = 1e3 * sum(ms) / len(ms)
         if name in work:
             bound, flops, nbytes = work[name]
-        else:  # shape-dependent launches (bn2d_*): the wrapper recorded each launch's algorithmic work
-            bound, flops, nbytes = "hbm", 0, sum(r[2] for r in recs) / len(recs)
+        else:  # shape-dependent launches (bn2d_*, conv1x1_dgrad_add): the wrapper recorded each launch's
+            # algorithmic work; the roof that takes longer at its peak is the one that bounds the kernel
+            nbytes, flops = sum(r[2] for r in recs) / len(recs), sum(r[3] for r in recs) / len(recs)
+            bound = "mfma" if flops / (MFMA_F32_PEAK_TF * 1e12) > nbytes / (HBM_PEAK_GBS * 1e9) else "hbm"
         entry = {"bound": bound, "launches": len(ms), "avg_us": round(avg_us, 3), "bytes": nbytes, "flops": flops}
         if bound == "hbm":
             ach = nbytes / (avg_us * 1e-6) / 1e9

@@ -69,6 +69,13 @@ int peclr_gemm_f32(int layout, int M, int N, int K, const float* A, int lda, con
                    int ldb, float* C, int ldc, const float* bias, int split_k, float* slabs,
                    peclr_stream_t stream);
 /* The library's own split-K policy for a given problem (>= 1). */
+/* C = op(A) op(B) + addend (same layouts as peclr_gemm_f32, no split-K): the 1x1-convolution input
+ * gradient of a bottleneck's first conv with the residual branch's gradient added in the epilogue,
+ * dX[R,Cin] = dY[R,Cmid] W[Cmid,Cin] + dRes[R,Cin] -- what autograd otherwise does as MIOpen dgrad +
+ * a separate elementwise add over the block input (torchvision Bottleneck, resnet_model.py:15). */
+int peclr_gemm_add_f32(int layout, int M, int N, int K, const float* A, int lda, const float* B,
+                       int ldb, float* C, int ldc, const float* addend, int ldd,
+                       peclr_stream_t stream);
 int peclr_gemm_pick_split_k(int M, int N, int K);
 
 /* out[i] = sum_s slabs[s][i] (+ bias[i % cols] if non-null), i < rows*cols. */

@@ -27,6 +27,7 @@ SIGNATURES = {
     "peclr_version": (c_int, []),
     "peclr_error_string": (c_char_p, [c_int]),
     "peclr_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P]),
+    "peclr_gemm_add_f32": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
     "peclr_gemm_pick_split_k": (c_int, [c_int, c_int, c_int]),
     "peclr_slab_reduce_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "peclr_bn_relu_fwd_f32": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, c_float, c_float, c_int, _P, _P,
@@ -310,6 +311,24 @@ def lars_adam_step(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_ch
             ctypes.cast(lr_arr, c_void_p), ctypes.cast(wd_arr, c_void_p), ng, beta1, beta2, adam_eps, bias_corr1,
             bias_corr2, int(use_lars), lars_eta, lars_eps, int(lars_clip), _stream())
     _check(rc, "peclr_lars_adam_update_f32")
+
+
+def gemm_add(layout: int, a: torch.Tensor, b: torch.Tensor, addend: torch.Tensor, tag: str = "gemm_add") -> torch.Tensor:
+    """C = op(A) op(B) + addend, all fp32 row-major contiguous 2-D HIP tensors."""
+    if layout == GEMM_NT:
+        (m, k), (n, k2) = a.shape, b.shape
+    elif layout == GEMM_NN:
+        (m, k), (k2, n) = a.shape, b.shape
+    else:
+        (k, m), (k2, n) = a.shape, b.shape
+    if k != k2 or tuple(addend.shape) != (m, n):
+        raise PeclrHipError(f"gemm_add: shapes {tuple(a.shape)} x {tuple(b.shape)} + {tuple(addend.shape)} (layout {layout})")
+    out = torch.empty((m, n), device=a.device, dtype=torch.float32)
+    with _timed(tag, 4 * (m * k + k * n + 2 * m * n), 2 * m * n * k):
+        rc = lib().peclr_gemm_add_f32(layout, m, n, k, _ptr(a), a.shape[1], _ptr(b), b.shape[1], out.data_ptr(), n,
+                                      _ptr(addend), n, _stream())
+    _check(rc, "peclr_gemm_add_f32")
+    return out
 
 
 # ------------------------------------------------------------------ backbone glue: BN2d (+add) (+ReLU), NHWC

@@ -76,6 +76,52 @@ class _BN2dReluPool(torch.autograd.Function):
         return dx, dgamma, dbeta, None
 
 
+class _ForkConv1x1(torch.autograd.Function):
+    """Bottleneck entry: (x, W) -> (conv1x1(x, W), x).  The block input feeds both the first convolution and
+    the identity branch, so its gradient is dY W + d_identity: autograd runs MIOpen's dgrad and then an
+    elementwise add over the block input (3.6 % of the fp32 step); here both are ONE fp32 GEMM with the
+    identity gradient added in the epilogue.  Forward and the weight gradient stay on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return F.conv2d(x, weight), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, gid):
+        x, weight = ctx.saved_tensors
+        n, cin, h, w = x.shape
+        cmid = weight.shape[0]
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            gy = gy.contiguous(memory_format=torch.channels_last)
+            gid = gid.contiguous(memory_format=torch.channels_last)
+            r = n * h * w
+            a = gy.permute(0, 2, 3, 1).reshape(r, cmid)           # NHWC storage seen as [R, Cmid]: a view
+            d = gid.permute(0, 2, 3, 1).reshape(r, cin)
+            out = _capi.gemm_add(_capi.GEMM_NN, a, weight.reshape(cmid, cin), d, tag="conv1x1_dgrad_add")
+            dx = out.view(n, h, w, cin).permute(0, 3, 1, 2)       # back to a channels_last NCHW tensor
+        return dx, dw
+
+
+def fork_conv1x1(conv: nn.Conv2d, x: Tensor):
+    """`(conv(x), x)` with the fused input gradient when `conv.hip_fork` is set (enable_hip_batchnorm does
+    it for the bottlenecks' first 1x1 convolution) and the tensors are fp32 channels_last on a HIP
+    device; the stock ops otherwise (bf16 autocast, CPU)."""
+    ok = (getattr(conv, "hip_fork", False) and x.is_cuda and x.dtype == torch.float32
+          and not torch.is_autocast_enabled() and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+          and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and x.requires_grad
+          and x.is_contiguous(memory_format=torch.channels_last)
+          and conv.weight.shape[0] % 4 == 0 and conv.weight.shape[1] % 4 == 0)
+    if ok:
+        return _ForkConv1x1.apply(x, conv.weight)
+    return conv(x), x
+
+
 class FusedBatchNormAct2d(nn.BatchNorm2d):
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, **kw):
         super().__init__(num_features, eps=eps, momentum=momentum, affine=affine,
@@ -115,4 +161,6 @@ def enable_hip_batchnorm(module: nn.Module, enabled: bool = True, sync_group=Non
             m.hip = enabled
             m.sync_group = sync_group if enabled else None
             n += 1
+        elif getattr(m, "fork_entry", False):   # bottleneck conv1 (resnet.Bottleneck marks it)
+            m.hip_fork = enabled
     return n

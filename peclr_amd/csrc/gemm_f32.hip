@@ -32,7 +32,8 @@ struct GemmArgs {
     const float* B;
     float* out;
     const float* bias;
-    int M, N, K, lda, ldb, ldo, kchunk;
+    const float* addend;  // optional [M][N] matrix added in the epilogue (row stride ldd)
+    int M, N, K, lda, ldb, ldo, ldd, kchunk;
     size_t slab_stride;  // 0 when writing C directly
 };
 
@@ -82,7 +83,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, kh = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: the grid is 1-D (x), 8 * ceil(row blocks / 8) * column tiles.  Workgroups go to
+    // the 8 XCDs round-robin, so hardware block b runs row block 8 * (j / nct) + b % 8, column tile j % nct
+    // with j = b / 8: every column tile of a row block lands on the SAME XCD, one after the other, and the
+    // 64 x K operand tile they share is read from HBM once and from that XCD's L2 afterwards.
+    const int nct = (g.N + BN - 1) / BN;
+    const int j = blockIdx.x / 8;
+    const int row_block = 8 * (j / nct) + (int)(blockIdx.x % 8);
+    if (row_block * BM >= g.M) return;
+    const int m0 = row_block * BM, n0 = (j % nct) * BN;
     const int kbeg = blockIdx.z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + mfma32_row(r, kh);
-            if (m < g.M) out[(size_t)m * g.ldo + n] = acc[r] + bv;
+            if (m < g.M) out[(size_t)m * g.ldo + n] = acc[r] + bv + (g.addend ? g.addend[(size_t)m * g.ldd + n] : 0.f);
         }
     }
 }
@@ -178,9 +187,27 @@ extern "C" int peclr_gemm_pick_split_k(int M, int N, int K) {
     return (K + kc - 1) / kc;           // effective number of non-empty slabs
 }
 
+namespace {
+int gemm_launch(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, const float* addend, int ldd, int split_k, float* slabs, peclr_stream_t stream);
+}
+
 extern "C" int peclr_gemm_f32(int layout, int M, int N, int K, const float* A, int lda, const float* B,
                               int ldb, float* C, int ldc, const float* bias, int split_k, float* slabs,
                               peclr_stream_t stream) {
+    return gemm_launch(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, 0, split_k, slabs, stream);
+}
+
+extern "C" int peclr_gemm_add_f32(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                                  float* C, int ldc, const float* addend, int ldd, peclr_stream_t stream) {
+    if (!addend) return PECLR_ERR_NULL;
+    if (ldd < N || !aligned16(addend)) return PECLR_ERR_SHAPE;
+    return gemm_launch(layout, M, N, K, A, lda, B, ldb, C, ldc, nullptr, addend, ldd, 1, nullptr, stream);
+}
+
+namespace {
+int gemm_launch(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, const float* addend, int ldd, int split_k, float* slabs, peclr_stream_t stream) {
     if (!A || !B) return PECLR_ERR_NULL;
     if (split_k < 1) return PECLR_ERR_SHAPE;
     if (split_k == 1 && !C) return PECLR_ERR_NULL;
@@ -197,15 +224,19 @@ extern "C" int peclr_gemm_f32(int layout, int M, int N, int K, const float* A, i
     GemmArgs g;
     g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.kchunk = kchunk_for(K, split_k);
+    g.addend = addend;
+    g.ldd = ldd;
     if (split_k == 1) { g.out = C; g.ldo = ldc; g.bias = bias; g.slab_stride = 0; }
     else { g.out = slabs; g.ldo = N; g.bias = nullptr; g.slab_stride = (size_t)M * N; }
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, split_k), block(256);
+    const int nrb = (M + BM - 1) / BM, nct = (N + BN - 1) / BN;
+    dim3 grid(8 * ((nrb + 7) / 8) * nct, 1, split_k), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g);
     else if (a_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, g);
     return launch_status();
 }
+}  // namespace
 
 extern "C" int peclr_slab_reduce_f32(const float* slabs, int n_slabs, int rows, int cols, const float* bias,
                                      float* out, peclr_stream_t stream) {

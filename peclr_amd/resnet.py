@@ -15,7 +15,7 @@ from typing import List, Type, Union
 import torch
 from torch import Tensor, nn
 
-from .bn2d import FusedBatchNormAct2d
+from .bn2d import FusedBatchNormAct2d, fork_conv1x1
 
 
 def conv3x3(cin, cout, stride=1):
@@ -62,6 +62,7 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None, norm_layer=nn.BatchNorm2d):
         super().__init__()
         self.conv1 = conv1x1(inplanes, planes)
+        self.conv1.fork_entry = downsample is None  # identity blocks: x feeds conv1 AND the residual add
         self.bn1 = norm_layer(planes)
         self.conv2 = conv3x3(planes, planes, stride)  # v1.5: stride on the 3x3
         self.bn2 = norm_layer(planes)
@@ -72,8 +73,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x: Tensor) -> Tensor:
-        identity = x if self.downsample is None else self.downsample(x)
-        out = _bn(self.bn1, self.conv1(x), relu=True)
+        if self.downsample is None:
+            out, identity = fork_conv1x1(self.conv1, x)   # one GEMM for "dgrad + residual gradient" in backward
+        else:
+            out, identity = self.conv1(x), self.downsample(x)
+        out = _bn(self.bn1, out, relu=True)
         out = _bn(self.bn2, self.conv2(out), relu=True)
         return _bn(self.bn3, self.conv3(out), identity, relu=True)
 

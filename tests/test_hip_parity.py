@@ -614,6 +614,39 @@ def test_resnet_fused_bn_equals_stock_on_gpu():
         np.testing.assert_allclose(host(bf.float()), host(bs.float()), atol=1e-4, rtol=1e-4, err_msg=n)
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 56, 56, 64), (3, 512, 9, 7, 128), (1, 64, 5, 5, 16), (4, 2048, 7, 7, 512)])
+def test_fork_conv1x1_fused_input_gradient(shape):
+    """Bottleneck entry: conv1x1(x) and the identity branch share x; d x = dY W + d_identity as ONE GEMM
+    (peclr_gemm_add_f32) against autograd's MIOpen dgrad + add, and against float64."""
+    from peclr_amd.bn2d import fork_conv1x1
+
+    n, cin, h, w, cmid = shape
+    g = torch.Generator().manual_seed(cin + h)
+    conv = torch.nn.Conv2d(cin, cmid, 1, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    x = torch.randn(n, cin, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, cmid, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    gid = torch.randn(n, cin, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    outs = {}
+    for fused in (False, True):
+        conv.hip_fork = fused
+        conv.weight.grad = None
+        xx = x.clone().requires_grad_()
+        y, ident = fork_conv1x1(conv, xx)
+        torch.autograd.backward((y, ident), (gy, gid))
+        outs[fused] = (y.detach(), xx.grad.clone(), conv.weight.grad.clone())
+    np.testing.assert_allclose(host(outs[True][0]), host(outs[False][0]), atol=1e-4)   # both MIOpen; solver may differ
+    assert outs[True][1].is_contiguous(memory_format=torch.channels_last)
+    ref = torch.einsum("nmhw,mc->nchw", gy.double().cpu(), conv.weight.detach().double().cpu().view(cmid, cin)) + gid.double().cpu()
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(host(outs[True][1]), ref.numpy(), atol=2e-5 * scale * max(1.0, cmid / 64) ** 0.5)
+    np.testing.assert_allclose(host(outs[True][1]), host(outs[False][1]), atol=4e-5 * scale * max(1.0, cmid / 64) ** 0.5)
+    np.testing.assert_allclose(host(outs[True][2]), host(outs[False][2]), rtol=1e-3, atol=1e-3 * float(outs[False][2].abs().max()))
+    with torch.autocast("cuda", dtype=torch.bfloat16):                   # bf16 autocast: stock path, no error
+        conv.hip_fork = True
+        y, ident = fork_conv1x1(conv, x.clone().requires_grad_())
+        assert y.dtype == torch.bfloat16
+
+
 def test_encoder_wrapper_fused_stem_equals_stock_on_gpu():
     """The reference-shaped encoder (features.0..8, stem ReLU and max-pool folded into features.1):
     HIP glue incl. the one-pass BN+ReLU+max-pool stem vs the same module on PyTorch's stock ops."""
