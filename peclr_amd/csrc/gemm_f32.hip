@@ -34,6 +34,7 @@ struct GemmArgs {
     const float* bias;
     const float* addend;  // optional [M][N] matrix added in the epilogue (row stride ldd)
     int M, N, K, lda, ldb, ldo, ldd, kchunk;
+    int stream_out;       // output (and addend) larger than the caches: non-temporal epilogue
     size_t slab_stride;  // 0 when writing C directly
 };
 
@@ -138,10 +139,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int n = n0 + wn * 32 + i;
     if (n < g.N) {
         const float bv = g.bias ? g.bias[n] : 0.f;
+        if (g.stream_out) {  // tall outputs (1x1-convolution gradients): read the addend / write C past the caches
+            float dv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 32 + mfma32_row(r, kh);
-            if (m < g.M) out[(size_t)m * g.ldo + n] = acc[r] + bv + (g.addend ? g.addend[(size_t)m * g.ldd + n] : 0.f);
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + mfma32_row(r, kh);
+                dv[r] = (g.addend && m < g.M) ? __builtin_nontemporal_load(g.addend + (size_t)m * g.ldd + n) : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + mfma32_row(r, kh);
+                if (m < g.M) __builtin_nontemporal_store(acc[r] + bv + dv[r], out + (size_t)m * g.ldo + n);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + mfma32_row(r, kh);
+                if (m < g.M) out[(size_t)m * g.ldo + n] = acc[r] + bv + (g.addend ? g.addend[(size_t)m * g.ldd + n] : 0.f);
+            }
         }
     }
 }
@@ -226,6 +241,7 @@ int gemm_launch(int layout, int M, int N, int K, const float* A, int lda, const 
     g.kchunk = kchunk_for(K, split_k);
     g.addend = addend;
     g.ldd = ldd;
+    g.stream_out = split_k == 1 && (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
     if (split_k == 1) { g.out = C; g.ldo = ldc; g.bias = bias; g.slab_stride = 0; }
     else { g.out = slabs; g.ldo = N; g.bias = nullptr; g.slab_stride = (size_t)M * N; }
     const int nrb = (M + BM - 1) / BM, nct = (N + BN - 1) / BN;

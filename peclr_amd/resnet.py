@@ -62,7 +62,7 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None, norm_layer=nn.BatchNorm2d):
         super().__init__()
         self.conv1 = conv1x1(inplanes, planes)
-        self.conv1.fork_entry = downsample is None  # identity blocks: x feeds conv1 AND the residual add
+        self.conv1.fork_entry = True  # x feeds conv1 AND the residual branch (identity or downsample)
         self.bn1 = norm_layer(planes)
         self.conv2 = conv3x3(planes, planes, stride)  # v1.5: stride on the 3x3
         self.bn2 = norm_layer(planes)
@@ -73,10 +73,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x: Tensor) -> Tensor:
-        if self.downsample is None:
-            out, identity = fork_conv1x1(self.conv1, x)   # one GEMM for "dgrad + residual gradient" in backward
-        else:
-            out, identity = self.conv1(x), self.downsample(x)
+        # x has two consumers; in backward "conv1's input gradient + the residual branch's gradient" is one GEMM
+        out, identity = fork_conv1x1(self.conv1, x)
+        if self.downsample is not None:
+            identity = self.downsample(identity)
         out = _bn(self.bn1, out, relu=True)
         out = _bn(self.bn2, self.conv2(out), relu=True)
         return _bn(self.bn3, self.conv3(out), identity, relu=True)

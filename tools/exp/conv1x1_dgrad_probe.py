@@ -30,3 +30,11 @@ for (n, hw, cmid, cin) in ((256, 56, 64, 256), (256, 28, 128, 512), (256, 14, 25
     ref = f().permute(0, 2, 3, 1).reshape(r, cin)
     err = float((_capi.gemm(_capi.GEMM_NN, a, b) - ref).abs().max())
     print(f"R={r} Cmid={cmid} Cin={cin}: miopen dgrad {t_dgrad:.0f} us + add {t_add:.0f} us = {t_dgrad + t_add:.0f} us | peclr gemm NN {t_gemm:.0f} us (max |d| {err:.1e})", flush=True)
+
+print("with the residual gradient added in the epilogue (peclr_gemm_add_f32):")
+for (n, hw, cmid, cin) in ((256, 56, 64, 256), (256, 28, 128, 512), (256, 14, 256, 1024), (256, 7, 512, 2048)):
+    r = n * hw * hw
+    a, b, d = torch.randn(r, cmid, device="cuda"), torch.randn(cmid, cin, device="cuda"), torch.randn(r, cin, device="cuda")
+    t = timed(lambda: _capi.gemm_add(_capi.GEMM_NN, a, b, d))
+    fl, by = 2 * r * cmid * cin, 4 * (r * cmid + 2 * r * cin)
+    print(f"R={r} Cmid={cmid} Cin={cin}: {t:.0f} us  {fl / t / 1e6:.1f} TFLOP/s  {by / t / 1e3:.0f} GB/s", flush=True)
