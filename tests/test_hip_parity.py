@@ -608,8 +608,10 @@ def test_resnet_fused_bn_equals_stock_on_gpu():
     ys.square().mean().backward()
     yf.square().mean().backward()
     for (n, ps), (_, pf) in zip(stock.named_parameters(), fused.named_parameters()):
-        scale = max(1e-3, float(ps.grad.abs().max()))
-        assert float((ps.grad - pf.grad).abs().max()) <= 2e-3 * scale, n
+        # norm-wise (see test_encoder_wrapper_fused_stem_equals_stock_on_gpu): MIOpen's weight gradients are
+        # accumulated atomically, and a ReLU input within rounding of zero may flip between implementations
+        err = float((ps.grad - pf.grad).norm()) / max(1e-6, float(ps.grad.norm()))
+        assert err <= 2e-2, (n, err)
     for (n, bs), (_, bf) in zip(stock.named_buffers(), fused.named_buffers()):
         np.testing.assert_allclose(host(bf.float()), host(bs.float()), atol=1e-4, rtol=1e-4, err_msg=n)
 
