@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--fused-bn", type=int, default=1,
                     help="backbone BatchNorm2d/add/ReLU glue on the hand-written NHWC kernels (needs "
                          "--channels-last 1; fp32 or bf16 activations); 0 = stock PyTorch/MIOpen ops")
+    ap.add_argument("--fork-gemm", type=int, default=1,
+                    help="bottleneck entry: conv1's input gradient + the residual branch's gradient as ONE hand-written "
+                         "GEMM (needs --fused-bn 1, fp32); 0 = MIOpen dgrad + autograd's elementwise add")
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--sync-bn", type=int, default=0,
                     help="1: BatchNorm statistics over the global batch (exact N-rank == 1-device semantics, two small "
@@ -268,6 +271,10 @@ def main():
         from peclr_amd.bn2d import enable_hip_batchnorm
 
         enable_hip_batchnorm(model.encoder)
+        if not args.fork_gemm:
+            for m in model.encoder.modules():
+                if getattr(m, "hip_fork", False):
+                    m.hip_fork = False
     trainer = Trainer(max_epochs=100, accumulate_grad_batches=args.accum, precision=args.dtype,
                       sync_batchnorm=bool(args.sync_bn)).attach(model)
     trainer.zero_grad()
@@ -374,7 +381,7 @@ def main():
                                    f"views per GPU, crop+rotate equivariance alignment, NT-Xent tau=0.5, "
                                    f"LARS(Adam) step, {args.dtype}",
                        "global_batch": world * 2 * args.pairs * args.accum, "parallelism": f"dp{world}",
-                       "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn,
+                       "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn, "fork_gemm": bool(fused_bn and args.fork_gemm and args.dtype == "fp32"),
                        "launch": ("two hipGraph replays per step (forward to z | backward from dz), collectives, "
                                   "NT-Xent and optimiser eager between/after them" if split else
                                   "one hipGraph replay per step (whole step captured)" if use_graph else
