@@ -109,6 +109,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         tile_store<B_KC>(lds[0][1], tid, rb);
     }
     __syncthreads();
+    // epilogue addend (conv1x1 dgrad + residual gradient): fetched while the LAST K-tile is being multiplied,
+    // so the round trip to HBM is not exposed between the last MFMA and the first store
+    float dv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv[r] = 0.f;
+    const int n_out = n0 + wn * 32 + i;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
@@ -116,6 +122,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             const int k0 = kbeg + (kt + 1) * BK;
             tile_load<A_KC>(g.A, g.lda, m0, g.M, k0, kend, tid, ra);
             tile_load<B_KC>(g.B, g.ldb, n0, g.N, k0, kend, tid, rb);
+        } else if (g.addend && n_out < g.N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + mfma32_row(r, kh);
+                if (m < g.M) dv[r] = __builtin_nontemporal_load(g.addend + (size_t)m * g.ldd + n_out);
+            }
         }
         const float* ta = lds[cur][0];
         const float* tb = lds[cur][1];
@@ -136,16 +148,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
 
     float* out = g.out + (size_t)blockIdx.z * g.slab_stride;
-    const int n = n0 + wn * 32 + i;
+    const int n = n_out;
     if (n < g.N) {
         const float bv = g.bias ? g.bias[n] : 0.f;
-        if (g.stream_out) {  // tall outputs (1x1-convolution gradients): read the addend / write C past the caches
-            float dv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 32 + mfma32_row(r, kh);
-                dv[r] = (g.addend && m < g.M) ? __builtin_nontemporal_load(g.addend + (size_t)m * g.ldd + n) : 0.f;
-            }
+        if (g.stream_out) {  // tall outputs (1x1-convolution gradients): write C past the caches
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 + mfma32_row(r, kh);
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 + mfma32_row(r, kh);
-                if (m < g.M) out[(size_t)m * g.ldo + n] = acc[r] + bv + (g.addend ? g.addend[(size_t)m * g.ldd + n] : 0.f);
+                if (m < g.M) out[(size_t)m * g.ldo + n] = acc[r] + bv + dv[r];
             }
         }
     }
@@ -244,9 +250,9 @@ int gemm_launch(int layout, int M, int N, int K, const float* A, int lda, const 
     g.stream_out = split_k == 1 && (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
     if (split_k == 1) { g.out = C; g.ldo = ldc; g.bias = bias; g.slab_stride = 0; }
     else { g.out = slabs; g.ldo = N; g.bias = nullptr; g.slab_stride = (size_t)M * N; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const int nrb = (M + BM - 1) / BM, nct = (N + BN - 1) / BN;
     dim3 grid(8 * ((nrb + 7) / 8) * nct, 1, split_k), block(256);
-    hipStream_t s = static_cast<hipStream_t>(stream);
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g);
     else if (a_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, g);

@@ -68,6 +68,28 @@ def test_gemm_nn_tn(capi, m, n, k):
                                    atol=1e-5 * np.sqrt(kk))
 
 
+@pytest.mark.parametrize("m,n,k", [(8200, 1100, 100), (16384, 1024, 64), (4096, 2048, 260)])
+def test_gemm_large_shapes(capi, m, n, k):
+    """Thousands of tiles (XCD-aware tile order, non-temporal epilogue for outputs past the caches): all
+    three layouts, ragged edges, bias, and the addend epilogue, against float64."""
+    a, b, bias = rnd((m, k), 21), rnd((n, k), 22), rnd((n,), 23)
+    tol = 2e-5 * np.sqrt(k)
+    got = host(capi.gemm(capi.GEMM_NT, dev(a), dev(b), dev(bias)))
+    np.testing.assert_allclose(got, a.astype(np.float64) @ b.astype(np.float64).T + bias, rtol=0, atol=tol)
+    bn, d = rnd((k, n), 24), rnd((m, n), 25)
+    got = host(capi.gemm_add(capi.GEMM_NN, dev(a), dev(bn), dev(d)))
+    np.testing.assert_allclose(got, a.astype(np.float64) @ bn.astype(np.float64) + d, rtol=0, atol=tol)
+    at = rnd((k, m), 26)
+    got = host(capi.gemm(capi.GEMM_TN, dev(at), dev(bn)))
+    np.testing.assert_allclose(got, at.astype(np.float64).T @ bn.astype(np.float64), rtol=0, atol=tol)
+    eye = np.zeros((m, k), np.float32)
+    eye[np.arange(k), np.arange(k)] = 1.0                                  # row/column swaps would show
+    asym = (np.arange(k * n, dtype=np.float32).reshape(k, n) % 977) / 7.0
+    got = host(capi.gemm(capi.GEMM_NN, dev(eye), dev(asym)))
+    np.testing.assert_array_equal(got[:k], asym)
+    assert not got[k:].any()
+
+
 def test_gemm_transpose_detecting(capi):
     """A = I against an ASYMMETRIC B: catches a row/col swap in the accumulator write-out."""
     n = 64
@@ -616,7 +638,8 @@ def test_resnet_fused_bn_equals_stock_on_gpu():
         np.testing.assert_allclose(host(bf.float()), host(bs.float()), atol=1e-4, rtol=1e-4, err_msg=n)
 
 
-@pytest.mark.parametrize("shape", [(2, 256, 56, 56, 64), (3, 512, 9, 7, 128), (1, 64, 5, 5, 16), (4, 2048, 7, 7, 512)])
+@pytest.mark.parametrize("shape", [(2, 256, 56, 56, 64), (3, 512, 9, 7, 128), (1, 64, 5, 5, 16), (4, 2048, 7, 7, 512),
+                                   (16, 1024, 32, 32, 256)])
 def test_fork_conv1x1_fused_input_gradient(shape):
     """Bottleneck entry: conv1x1(x) and the identity branch share x; d x = dY W + d_identity as ONE GEMM
     (peclr_gemm_add_f32) against autograd's MIOpen dgrad + add, and against float64."""
