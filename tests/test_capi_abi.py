@@ -73,3 +73,23 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_integration_stub_matches_the_abi():
+    """The ctypes stub shown to a reference maintainer in INTEGRATION.md declares the same argument lists
+    as the library's own binding."""
+    import re
+    from ctypes import c_float, c_int, c_void_p
+
+    from peclr_amd import _capi
+    from tests.conftest import ROOT
+
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
+        text = f.read()
+    kinds = {"_P": c_void_p, "_I": c_int, "_F": c_float}
+    stubs = re.findall(r"_L\.(\w+)\.argtypes = \[([^\]]*)\]", text)
+    assert len(stubs) >= 5
+    for name, args in stubs:
+        assert [kinds[a.strip()] for a in args.split(",")] == _capi.SIGNATURES[name][1], name
+    for name in _capi.SIGNATURES:                       # every entry point is documented there
+        assert name in text or name in ("peclr_version", "peclr_error_string"), name
