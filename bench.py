@@ -241,7 +241,7 @@ def main():
     graph_note = None
     if args.graph == "auto":
         single = int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1
-        if single and args.accum == 1 and not os.environ.get("PECLR_BENCH_CHILD"):
+        if single and not os.environ.get("PECLR_BENCH_CHILD"):
             line, graph_note = try_graph_child()
             if line is not None:
                 print(line, flush=True)
@@ -288,8 +288,8 @@ def main():
             out = trainer.training_micro_step(batch, i * args.accum + micro)
         return out
 
-    if use_graph and (args.accum != 1 or (world > 1 and args.sync_bn)):
-        raise SystemExit("--graph 1 needs --accum 1 and, at N>1, per-rank BatchNorm statistics")
+    if use_graph and world > 1 and (args.accum != 1 or args.sync_bn):
+        raise SystemExit("--graph 1 at N>1 needs --accum 1 and per-rank BatchNorm statistics")
     split = use_graph and world > 1
     # Everything runs on ONE non-default stream: hipStreamEndCapture crashes on this ROCm build when the
     # process has already run the step eagerly on the default stream (tools/exp/graph_capture_sizes.py).
@@ -313,6 +313,13 @@ def main():
             # W untimed eager steps (on a side stream) + the capture, then K timed replays
             if split:
                 replay = trainer.replay_split
+            elif args.accum > 1:      # one graph per micro-batch, accumulators + optimiser step every accum-th replay
+                trainer.capture_micro_graph(batch, warmup_windows=max(args.warmup, 1))
+
+                def replay():
+                    for _ in range(args.accum):
+                        out = trainer.replay_micro()
+                    return out
             else:
                 trainer.capture_step_graph(batch, warmup=max(args.warmup, 3))
                 replay = trainer.replay_step
@@ -384,6 +391,8 @@ def main():
                        "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn, "fork_gemm": bool(fused_bn and args.fork_gemm and args.dtype == "fp32"),
                        "launch": ("two hipGraph replays per step (forward to z | backward from dz), collectives, "
                                   "NT-Xent and optimiser eager between/after them" if split else
+                                  f"{args.accum} hipGraph replays (micro-batch forward + backward) + eager accumulate / optimiser per step"
+                                  if use_graph and args.accum > 1 else
                                   "one hipGraph replay per step (whole step captured)" if use_graph else
                                   "eager launches" + (f" ({graph_note})" if graph_note else "")),
                        "bn": "global-batch statistics (synchronised)" if (args.sync_bn and world > 1)

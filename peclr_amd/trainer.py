@@ -236,6 +236,54 @@ class Trainer:
         out = model._step_outputs(self._static_batch, loss)
         return {key: v.detach() for key, v in out.items()}
 
+    # ---- gradient accumulation (accumulate_grad_batches = k > 1, single process): ONE graph of a micro-batch's
+    # forward + backward.  The captured backward writes each gradient into the graph's own buffer (parameters
+    # have no .grad at capture), so a replay OVERWRITES; after each replay the buffers are added, scaled by
+    # 1/k, into accumulators that serve as .grad (one multi-tensor pass over ~100 MB), and every k-th replay is
+    # followed by the eager fused optimiser step on the accumulators.  Negatives are per micro-batch, as in
+    # the reference's Lightning loop.
+    def capture_micro_graph(self, example_batch: Dict[str, torch.Tensor], warmup_windows: int = 1):
+        k = self.accumulate_grad_batches
+        if self.world_size > 1 or self.reducer is not None:
+            raise RuntimeError("capture_micro_graph is single-process only (no gradient buckets)")
+        self._static_batch = {key: v.clone() for key, v in example_batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(max(1, warmup_windows) * k):      # whole windows: ends on an optimiser step
+                self.training_micro_step(self._static_batch, i)
+            self.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            with self._autocast():
+                out = self.model.training_step(self._static_batch, 0)
+            out["loss"].backward()
+        pairs = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
+        self._micro_src = [g for _, g in pairs]
+        self._micro_acc = [torch.zeros_like(g) for g in self._micro_src]
+        for (p, _), a in zip(pairs, self._micro_acc):
+            p.grad = a
+        self._micro_count = 0
+        self._static_out = out
+        return self
+
+    def replay_micro(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        k = self.accumulate_grad_batches
+        if batch is not None and batch is not self._static_batch:
+            for key, v in batch.items():
+                self._static_batch[key].copy_(v, non_blocking=True)
+        self._graph.replay()
+        torch._foreach_add_(self._micro_acc, self._micro_src, alpha=1.0 / k)
+        self._micro_count += 1
+        if self._micro_count % k == 0:
+            self.optimizer.step()
+            torch._foreach_zero_(self._micro_acc)
+            self.scheduler.step()
+            self.global_step += 1
+        return self._static_out
+
     def _graph_step(self, batch: Dict[str, torch.Tensor], batch_idx: int) -> Dict[str, torch.Tensor]:
         """fit()'s step when hip_graph is on: capture on the first batch (which is trained on exactly
         once, by the eager step the capture routine runs), replay for equal shapes, eager otherwise."""

@@ -994,6 +994,46 @@ def test_split_hip_graphs_match_eager(precision):
         Trainer(max_epochs=1).attach(copy.deepcopy(base)).capture_split_graphs(batch)
 
 
+def test_micro_batch_graph_with_accumulation_matches_eager():
+    """accumulate_grad_batches = 2: one hipGraph per micro-batch (forward + backward), gradients added into
+    accumulators after each replay, eager fused optimiser every second replay -- same curve as the eager loop."""
+    import copy
+    import warnings
+
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config
+    from peclr_amd.bn2d import enable_hip_batchnorm
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(19)
+    n = 8
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, augmentation=["crop", "rotate"],
+                         batch_size=n, num_samples=64, num_of_mini_batch=2, warmup_epochs=1, pretrained=False)
+    base = Hybrid2Model(cfg).to(DEV).train()
+    base.encoder = base.encoder.to(memory_format=torch.channels_last)
+    enable_hip_batchnorm(base.encoder)
+    g = torch.Generator().manual_seed(20)
+    batch = {"transformed_image1": torch.randn(n, 3, 64, 64, generator=g), "transformed_image2": torch.randn(n, 3, 64, 64, generator=g),
+             "jitter_x_1": torch.randint(-14, 1, (n,), generator=g), "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+             "jitter_y_1": torch.randint(-14, 1, (n,), generator=g), "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+             "angle_1": torch.randint(-45, 46, (n,), generator=g).double(), "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    for k in ("transformed_image1", "transformed_image2"):
+        batch[k] = batch[k].contiguous(memory_format=torch.channels_last)
+    micro = 10
+    te = Trainer(max_epochs=10, accumulate_grad_batches=2).attach(copy.deepcopy(base))
+    te.zero_grad()
+    eager = [float(te.training_micro_step(batch, i)["loss"]) for i in range(micro)]
+    tg = Trainer(max_epochs=10, accumulate_grad_batches=2).attach(copy.deepcopy(base))
+    tg.zero_grad()
+    tg.capture_micro_graph(batch, warmup_windows=1)                      # micro-batches 0, 1 eager
+    graph = [float(tg.replay_micro()["loss"]) for _ in range(micro - 2)]
+    assert tg.global_step == te.global_step == micro // 2
+    assert graph[0] == pytest.approx(eager[2], rel=2e-3) and graph[1] == pytest.approx(eager[3], rel=2e-3)
+    assert graph == pytest.approx(eager[2:], rel=6e-2)
+    assert graph[0] == pytest.approx(graph[1], rel=2e-2)                  # same window, same weights (BN stats moved only)
+    assert graph[-1] < 0.95 * eager[1]
+
+
 @pytest.mark.parametrize("buckets", [False, True], ids=["one_graph", "split_graphs"])
 def test_fit_with_hip_graph_matches_eager_fit(tmp_path, buckets):
     """Trainer(hip_graph=True).fit: capture on the first batch, replay equal shapes, eager for the ragged
