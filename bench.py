@@ -66,7 +66,7 @@ def parse():
                          "--channels-last 1; fp32 or bf16 activations); 0 = stock PyTorch/MIOpen ops")
     ap.add_argument("--fork-gemm", type=int, default=1,
                     help="bottleneck entry: conv1's input gradient + the residual branch's gradient as ONE hand-written "
-                         "GEMM (needs --fused-bn 1, fp32); 0 = MIOpen dgrad + autograd's elementwise add")
+                         "GEMM (needs --fused-bn 1; fp32 or bf16); 0 = MIOpen dgrad + autograd's elementwise add")
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--sync-bn", type=int, default=0,
                     help="1: BatchNorm statistics over the global batch (exact N-rank == 1-device semantics, two small "
@@ -388,7 +388,7 @@ def main():
                                    f"views per GPU, crop+rotate equivariance alignment, NT-Xent tau=0.5, "
                                    f"LARS(Adam) step, {args.dtype}",
                        "global_batch": world * 2 * args.pairs * args.accum, "parallelism": f"dp{world}",
-                       "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn, "fork_gemm": bool(fused_bn and args.fork_gemm and args.dtype == "fp32"),
+                       "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn, "fork_gemm": bool(fused_bn and args.fork_gemm),
                        "launch": ("two hipGraph replays per step (forward to z | backward from dz), collectives, "
                                   "NT-Xent and optimiser eager between/after them" if split else
                                   f"{args.accum} hipGraph replays (micro-batch forward + backward) + eager accumulate / optimiser per step"

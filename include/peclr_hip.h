@@ -76,6 +76,11 @@ int peclr_gemm_f32(int layout, int M, int N, int K, const float* A, int lda, con
 int peclr_gemm_add_f32(int layout, int M, int N, int K, const float* A, int lda, const float* B,
                        int ldb, float* C, int ldc, const float* addend, int ldd,
                        peclr_stream_t stream);
+/* The same for bf16 (autocast) backbones: C (bf16) = A[M,K] (bf16) . B[N,K]^T (bf16) + addend (bf16,
+ * nullable), fp32 accumulation on v_mfma_f32_32x32x16_bf16; both operands K-contiguous (pass the
+ * 1x1 weight transposed, [Cin][Cmid]); K, lda, ldb multiples of 8. */
+int peclr_gemm_add_bf16(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                        int ldc, const void* addend, int ldd, peclr_stream_t stream);
 int peclr_gemm_pick_split_k(int M, int N, int K);
 
 /* out[i] = sum_s slabs[s][i] (+ bias[i % cols] if non-null), i < rows*cols. */

@@ -28,6 +28,7 @@ SIGNATURES = {
     "peclr_error_string": (c_char_p, [c_int]),
     "peclr_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P]),
     "peclr_gemm_add_f32": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
+    "peclr_gemm_add_bf16": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
     "peclr_gemm_pick_split_k": (c_int, [c_int, c_int, c_int]),
     "peclr_slab_reduce_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "peclr_bn_relu_fwd_f32": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, c_float, c_float, c_int, _P, _P,
@@ -328,6 +329,22 @@ def gemm_add(layout: int, a: torch.Tensor, b: torch.Tensor, addend: torch.Tensor
         rc = lib().peclr_gemm_add_f32(layout, m, n, k, _ptr(a), a.shape[1], _ptr(b), b.shape[1], out.data_ptr(), n,
                                       _ptr(addend), n, _stream())
     _check(rc, "peclr_gemm_add_f32")
+    return out
+
+
+def gemm_add_bf16(a: torch.Tensor, b_t: torch.Tensor, addend: Optional[torch.Tensor], tag: str = "gemm_add") -> torch.Tensor:
+    """C (bf16) = A[M,K] . B_t[N,K]^T + addend, bf16 row-major contiguous 2-D HIP tensors, fp32 accumulate."""
+    (m, k), (n, k2) = a.shape, b_t.shape
+    for t in (a, b_t) + ((addend,) if addend is not None else ()):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
+            raise PeclrHipError("gemm_add_bf16: contiguous bf16 HIP tensors expected (peclr_amd has no CPU path)")
+    if k != k2 or (addend is not None and tuple(addend.shape) != (m, n)):
+        raise PeclrHipError(f"gemm_add_bf16: shapes {tuple(a.shape)} x {tuple(b_t.shape)}^T")
+    out = torch.empty((m, n), device=a.device, dtype=torch.bfloat16)
+    with _timed(tag, 2 * (m * k + k * n + 2 * m * n), 2 * m * n * k):
+        rc = lib().peclr_gemm_add_bf16(m, n, k, a.data_ptr(), k, b_t.data_ptr(), k, out.data_ptr(), n,
+                                       addend.data_ptr() if addend is not None else None, n, _stream())
+    _check(rc, "peclr_gemm_add_bf16")
     return out
 
 

@@ -93,30 +93,38 @@ class _ForkConv1x1(torch.autograd.Function):
         n, cin, h, w = x.shape
         cmid = weight.shape[0]
         dw = None
+        gy = gy.to(x.dtype)
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            dw = torch.ops.aten.convolution_backward(gy, x, weight.to(x.dtype), None, [1, 1], [0, 0], [1, 1], False,
+                                                     [0, 0], 1, [False, True, False])[1].to(weight.dtype)
         dx = None
         if ctx.needs_input_grad[0]:
             gy = gy.contiguous(memory_format=torch.channels_last)
-            gid = gid.contiguous(memory_format=torch.channels_last)
+            gid = gid.to(x.dtype).contiguous(memory_format=torch.channels_last)
             r = n * h * w
             a = gy.permute(0, 2, 3, 1).reshape(r, cmid)           # NHWC storage seen as [R, Cmid]: a view
             d = gid.permute(0, 2, 3, 1).reshape(r, cin)
-            out = _capi.gemm_add(_capi.GEMM_NN, a, weight.reshape(cmid, cin), d, tag="conv1x1_dgrad_add")
+            if x.dtype == torch.bfloat16:                         # autocast backbone: bf16 MFMA, fp32 accumulate
+                wt = weight.detach().reshape(cmid, cin).t().contiguous().to(torch.bfloat16)
+                out = _capi.gemm_add_bf16(a, wt, d, tag="conv1x1_dgrad_add")
+            else:
+                out = _capi.gemm_add(_capi.GEMM_NN, a, weight.reshape(cmid, cin), d, tag="conv1x1_dgrad_add")
             dx = out.view(n, h, w, cin).permute(0, 3, 1, 2)       # back to a channels_last NCHW tensor
         return dx, dw
 
 
 def fork_conv1x1(conv: nn.Conv2d, x: Tensor):
     """`(conv(x), x)` with the fused input gradient when `conv.hip_fork` is set (enable_hip_batchnorm does
-    it for the bottlenecks' first 1x1 convolution) and the tensors are fp32 channels_last on a HIP
-    device; the stock ops otherwise (bf16 autocast, CPU)."""
-    ok = (getattr(conv, "hip_fork", False) and x.is_cuda and x.dtype == torch.float32
-          and not torch.is_autocast_enabled() and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+    it for the bottlenecks' first 1x1 convolution) and the activations are channels_last on a HIP device,
+    fp32 (no autocast) or bf16 (under bf16 autocast); the stock ops otherwise."""
+    autocast = torch.is_autocast_enabled()
+    dtype_ok = ((x.dtype == torch.float32 and not autocast)
+                or (x.dtype == torch.bfloat16 and autocast and torch.get_autocast_gpu_dtype() == torch.bfloat16))
+    ok = (getattr(conv, "hip_fork", False) and x.is_cuda and dtype_ok
+          and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
           and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and x.requires_grad
           and x.is_contiguous(memory_format=torch.channels_last)
-          and conv.weight.shape[0] % 4 == 0 and conv.weight.shape[1] % 4 == 0)
+          and conv.weight.shape[0] % 8 == 0 and conv.weight.shape[1] % 8 == 0)
     if ok:
         return _ForkConv1x1.apply(x, conv.weight)
     return conv(x), x

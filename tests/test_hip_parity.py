@@ -666,10 +666,25 @@ def test_fork_conv1x1_fused_input_gradient(shape):
     np.testing.assert_allclose(host(outs[True][1]), ref.numpy(), atol=2e-5 * scale * max(1.0, cmid / 64) ** 0.5)
     np.testing.assert_allclose(host(outs[True][1]), host(outs[False][1]), atol=4e-5 * scale * max(1.0, cmid / 64) ** 0.5)
     np.testing.assert_allclose(host(outs[True][2]), host(outs[False][2]), rtol=1e-3, atol=1e-3 * float(outs[False][2].abs().max()))
-    with torch.autocast("cuda", dtype=torch.bfloat16):                   # bf16 autocast: stock path, no error
-        conv.hip_fork = True
-        y, ident = fork_conv1x1(conv, x.clone().requires_grad_())
+    # bf16 autocast backbone: bf16 activations / gradients, bf16 MFMA with fp32 accumulation
+    xb, gyb, gidb = (t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for t in (x, gy, gid))
+    refb = (torch.einsum("nmhw,mc->nchw", gyb.double().cpu(), conv.weight.detach().to(torch.bfloat16).double().cpu().view(cmid, cin))
+            + gidb.double().cpu())
+    res = {}
+    for fused in (False, True):
+        conv.hip_fork = fused
+        conv.weight.grad = None
+        xx = xb.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y, ident = fork_conv1x1(conv, xx)
         assert y.dtype == torch.bfloat16
+        torch.autograd.backward((y, ident), (gyb, gidb))
+        assert xx.grad.dtype == torch.bfloat16 and conv.weight.grad.dtype == torch.float32
+        res[fused] = (xx.grad.float(), conv.weight.grad.clone())
+    sb = float(refb.abs().max())
+    np.testing.assert_allclose(host(res[True][0]), refb.numpy(), atol=1.2e-2 * sb)        # one bf16 rounding of the sum
+    np.testing.assert_allclose(host(res[False][0]), refb.numpy(), atol=2.5e-2 * sb)       # stock: rounds dgrad, then the sum
+    np.testing.assert_allclose(host(res[True][1]), host(res[False][1]), rtol=2e-2, atol=2e-2 * float(res[False][1].abs().max()))
 
 
 def test_encoder_wrapper_fused_stem_equals_stock_on_gpu():
