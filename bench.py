@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--fork-gemm", type=int, default=1,
                     help="bottleneck entry: conv1's input gradient + the residual branch's gradient as ONE hand-written "
                          "GEMM (needs --fused-bn 1; fp32 or bf16); 0 = MIOpen dgrad + autograd's elementwise add")
+    ap.add_argument("--augment", type=int, default=0,
+                    help="1: every step draws a fresh batch through the GPU two-view augmentation (uint8 224x224 source "
+                         "images + 2.5D joints resident in HBM -> rotate / crop / resize / colour jitter / normalise "
+                         "kernels -> batch dict) instead of re-using one synthetic batch; the metric's default is 0")
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--sync-bn", type=int, default=0,
                     help="1: BatchNorm statistics over the global batch (exact N-rank == 1-device semantics, two small "
@@ -283,9 +287,26 @@ def main():
         for k in ("transformed_image1", "transformed_image2"):
             batch[k] = batch[k].contiguous(memory_format=torch.channels_last)
 
+    next_batch = lambda: batch  # noqa: E731 -- the metric's default: one synthetic batch, resident in HBM
+    if args.augment:
+        import random
+
+        import numpy as np
+
+        from peclr_amd import TwoViewAugmenter
+
+        rs = np.random.default_rng(5 + rank)
+        raw = torch.from_numpy(rs.integers(0, 256, (args.pairs, 224, 224, 3), dtype=np.uint8)).to(device)
+        joints = torch.from_numpy(np.concatenate([rs.normal((112, 108), 25, (args.pairs, 21, 2)),
+                                                  rs.normal(0, 1, (args.pairs, 21, 1))], axis=2)).float()
+        augmenter = TwoViewAugmenter(params={"resize_shape": [args.size, args.size]}, rng=random.Random(5 + rank),
+                                     channels_last=bool(args.channels_last))
+        next_batch = lambda: augmenter(raw, joints)  # noqa: E731 -- host parameter draws + two HIP launches
+        batch = next_batch()
+
     def one_step(i):
         for micro in range(args.accum):  # one optimiser step = `accum` micro-batches
-            out = trainer.training_micro_step(batch, i * args.accum + micro)
+            out = trainer.training_micro_step(next_batch(), i * args.accum + micro)
         return out
 
     if use_graph and world > 1 and (args.accum != 1 or args.sync_bn):
@@ -312,17 +333,17 @@ def main():
         if use_graph:
             # W untimed eager steps (on a side stream) + the capture, then K timed replays
             if split:
-                replay = trainer.replay_split
+                replay = lambda: trainer.replay_split(next_batch() if args.augment else None)  # noqa: E731
             elif args.accum > 1:      # one graph per micro-batch, accumulators + optimiser step every accum-th replay
                 trainer.capture_micro_graph(batch, warmup_windows=max(args.warmup, 1))
 
                 def replay():
                     for _ in range(args.accum):
-                        out = trainer.replay_micro()
+                        out = trainer.replay_micro(next_batch() if args.augment else None)
                     return out
             else:
                 trainer.capture_step_graph(batch, warmup=max(args.warmup, 3))
-                replay = trainer.replay_step
+                replay = lambda: trainer.replay_step(next_batch() if args.augment else None)  # noqa: E731
             if world > 1:
                 torch.distributed.barrier()
             torch.cuda.synchronize()
@@ -383,7 +404,8 @@ def main():
             "metric": "images/sec (2-view) ResNet-50 bs128 @1/2/4/8 MI355X; NT-Xent loss Δ vs ref",
             "value": round(images / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic" if not args.augment else "synthetic uint8 source images + joints, fresh two-view GPU augmentation per step",
             "config": {"workload": f"ResNet-{args.resnet} encoder, 2x{args.pairs} synthetic {args.size}x{args.size} "
                                    f"views per GPU, crop+rotate equivariance alignment, NT-Xent tau=0.5, "
                                    f"LARS(Adam) step, {args.dtype}",
