@@ -179,8 +179,10 @@ int peclr_ntxent_bwd_f32(const float* z_rows, int Mr, int row_offset, const floa
  * given it overrides the by-value scalars, so a hipGraph that captured the launch can be replayed
  * with new per-step values.
  * use_lars == 0: plain Adam with L2 weight decay (torch.optim.Adam semantics; norms_ws unused).
- * bias_corr1/2 = 1 - beta^step, computed by the host.  The LARS-scaled gradient is consumed in
- * registers and NOT written back to grad.                                                   */
+ * use_lars == 2: LARS, and the scaled gradient (g + wd*p)*trust is ALSO written back over grad, as
+ * pl_bolts' LARSWrapper.update_p leaves it (it mutates p.grad in place before the wrapped Adam
+ * step); with use_lars == 1 it is consumed in registers only (4 B/param less traffic).
+ * bias_corr1/2 = 1 - beta^step, computed by the host.                                        */
 #define PECLR_OPT_CHUNK 4096
 int peclr_lars_sumsq_f32(float* const* ptrs, const int64_t* sizes, int n_tensors,
                          const int32_t* chunk_tensor, const int64_t* chunk_offset, int n_chunks,

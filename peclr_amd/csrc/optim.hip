@@ -132,7 +132,9 @@ __global__ __launch_bounds__(256) void lars_adam_kernel(float* const* __restrict
     const float step_size = lr / bias_corr1;
     const float inv_bc2_sqrt = 1.f / sqrtf(bias_corr2);
     const float b1 = a.beta1, b2 = a.beta2, eps = a.adam_eps;
-    auto upd = [&](float& pk, float gk, float& mk, float& vk) {
+    const bool write_back = a.use_lars == 2;   // LARSWrapper.update_p mutates p.grad in place
+    float* gw = const_cast<float*>(g);
+    auto upd = [&](float& pk, float& gk, float& mk, float& vk) {
         gk = (gk + wd * pk) * trust;
         mk = b1 * mk + (1.f - b1) * gk;
         vk = b2 * vk + (1.f - b2) * gk * gk;
@@ -160,11 +162,13 @@ __global__ __launch_bounds__(256) void lars_adam_kernel(float* const* __restrict
             store_nt(reinterpret_cast<float4*>(m) + k, mm[j]);
             store_nt(reinterpret_cast<float4*>(v) + k, vv[j]);
             store_nt(reinterpret_cast<float4*>(p) + k, pp[j]);
+            if (write_back) store_nt(reinterpret_cast<float4*>(gw) + k, gg[j]);
         }
     } else {
         for (int64_t k = threadIdx.x; k < n; k += 256) {
-            float pk = p[k], mk = m[k], vk = v[k];
-            upd(pk, g[k], mk, vk);
+            float pk = p[k], gk = g[k], mk = m[k], vk = v[k];
+            upd(pk, gk, mk, vk);
+            if (write_back) gw[k] = gk;
             m[k] = mk;
             v[k] = vk;
             p[k] = pk;

@@ -80,6 +80,21 @@ def all_gather_cat(t: Tensor, group=None) -> Tensor:
     return out
 
 
+def assert_uniform(value: int, group=None, device=None, what: str = "value"):
+    """Raise on EVERY rank if `value` is not the same on all ranks of `group` (one 2-element MAX
+    all-reduce of [v, -v])."""
+    if world_size(group) == 1:
+        return
+    if device is None or dist.get_backend(group) == "gloo":
+        device = torch.device("cpu")
+    t = torch.tensor([value, -value], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(t[0]), -int(t[1])
+    if hi != lo:
+        raise RuntimeError(f"{what} differs across data-parallel ranks (min {lo}, max {hi}, this rank {value}): "
+                           "every rank must hold the same number; drop or pad the ragged batch")
+
+
 class _Bucket:
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = params

@@ -50,72 +50,77 @@ except Exception:  # pragma: no cover - not installed on the target image
 STAT_KEYS = tuple(f"{n}{a}_{s}" for n in ("proj1", "proj2") for a in ("x", "y")
                   for s in ("mean", "median", "min", "max"))
 TEMPERATURE = 0.5  # vanila_contrastive_loss default; not a config value (utils.py:154)
+_NO_DECAY_MARKERS = ("bias", "bn")  # base_model.py:34
+
+
+def _epoch_mean(step_dicts: List[dict]) -> Dict[str, Tensor]:
+    """Mean over an epoch's step dicts, key by key, in the first dict's key order (a missing key in a
+    later dict is a KeyError, as in base_model.py:107-110)."""
+    return {name: torch.stack([d[name] for d in step_dicts]).mean() for name in step_dicts[0]}
 
 
 class BaseModel(_Base):
+    """base_model.py:13-127.  `strict_reference` (config key, default False) switches on the
+    reference's wasteful-but-harmless quirks that this build otherwise skips (today: `forward`
+    running the encoder twice)."""
+
     def __init__(self, config):
         super().__init__()
         if "resnet_size" in config.keys():
             self.encoder = get_wrapper_model(config, pretrained=config.get("pretrained", True))
         self.config = config
-        self.train_metrics_epoch = {}
-        self.train_metrics = {}
-        self.validation_metrics_epoch = {}
+        self.train_metrics, self.train_metrics_epoch, self.validation_metrics_epoch = {}, {}, {}
         self.plot_params = {}
         self.process_group = None  # data-parallel group (None = default group / single process)
 
+    # ---- optimiser plumbing (SURVEY.md section 8 a10)
     def exclude_from_wt_decay(self, named_params: Iterator[Tuple[str, Tensor]], weight_decay: float,
-                              skip_list: List[str] = ["bias", "bn"]) -> List[Dict[str, Union[list, float]]]:
-        """base_model.py:30-51 -- substring match on the parameter name, quirks included: stem BN
-        (`encoder.features.1.weight`), `downsample.1.weight` and `projection_head.1.weight` stay in
-        the decayed group."""
-        params, excluded_params = [], []
-        for name, param in named_params:
-            if not param.requires_grad:
-                continue
-            elif any(layer_name in name for layer_name in skip_list):
-                excluded_params.append(param)
-            else:
-                params.append(param)
-        return [{"params": params, "weight_decay": weight_decay},
-                {"params": excluded_params, "weight_decay": 0.0}]
+                              skip_list=_NO_DECAY_MARKERS) -> List[Dict[str, Union[list, float]]]:
+        """Two Adam parameter groups: [decayed, not decayed].  A trainable parameter is kept out of
+        weight decay when its NAME contains one of `skip_list` -- a substring test, so only the
+        residual blocks' `bn1/bn2/bn3` and every `.bias` match; the stem BatchNorm
+        (`encoder.features.1.weight`), `downsample.1.weight` and `projection_head.1.weight` stay
+        decayed (base_model.py:30-51)."""
+        groups = ({"params": [], "weight_decay": weight_decay}, {"params": [], "weight_decay": 0.0})
+        for name, tensor in named_params:
+            if tensor.requires_grad:
+                groups[any(marker in name for marker in skip_list)]["params"].append(tensor)
+        return list(groups)
 
     def setup(self, stage: str):
-        global_batch_size = self.trainer.world_size * self.config.batch_size
-        self.train_iters_per_epoch = self.config.num_samples // global_batch_size
+        """Micro-batches per epoch over all ranks (base_model.py:53-55)."""
+        self.train_iters_per_epoch = self.config.num_samples // (self.trainer.world_size * self.config.batch_size)
+
+    def _optimizer_steps(self, epochs: int) -> int:
+        """Epochs -> optimiser steps, with the reference's operator order: (epochs * iters) // accum."""
+        return epochs * self.train_iters_per_epoch // self.config.num_of_mini_batch
 
     def configure_optimizers(self) -> Tuple[list, list]:
-        parameters = self.exclude_from_wt_decay(self.named_parameters(),
-                                                weight_decay=self.config.opt_weight_decay)
-        lr = self.config.lr * math.sqrt(self.config.batch_size * self.config.num_of_mini_batch)
-        warmup_epochs = self.config.warmup_epochs * self.train_iters_per_epoch // self.config.num_of_mini_batch
-        if "lr_max_epochs" in self.config.keys() and self.config["lr_max_epochs"] is not None:
-            max_epochs = self.config["lr_max_epochs"] * self.train_iters_per_epoch // self.config.num_of_mini_batch
+        """base_model.py:57-104: Adam at lr*sqrt(batch*accum) over the two groups above; "LARS" wraps
+        it (pl_bolts LARSWrapper) and schedules linear warm-up + cosine per optimiser step, anything
+        else is plain Adam under CosineAnnealingLR.  Both arms are ONE fused HIP optimiser here."""
+        cfg = self.config
+        groups = self.exclude_from_wt_decay(self.named_parameters(), weight_decay=cfg.opt_weight_decay)
+        horizon = cfg["lr_max_epochs"] if cfg.get("lr_max_epochs") is not None else self.trainer.max_epochs
+        total_steps = self._optimizer_steps(horizon)
+        use_lars = cfg.optimizer == "LARS"
+        optimizer = LARSAdam(groups, lr=cfg.lr * math.sqrt(cfg.batch_size * cfg.num_of_mini_batch), lars=use_lars,
+                             write_back=bool(cfg.get("strict_reference", False)))
+        if use_lars:
+            schedule = LinearWarmupCosineAnnealingLR(optimizer, warmup_epochs=self._optimizer_steps(cfg.warmup_epochs),
+                                                     max_epochs=total_steps, warmup_start_lr=0, eta_min=0)
         else:
-            max_epochs = self.trainer.max_epochs * self.train_iters_per_epoch // self.config.num_of_mini_batch
-        if self.config.optimizer == "LARS":
-            # Adam -> LARSWrapper of the reference, fused (base_model.py:62-66,90-98)
-            optimizer = LARSAdam(parameters, lr=lr, lars=True)
-            scheduler = LinearWarmupCosineAnnealingLR(optimizer, warmup_epochs=warmup_epochs,
-                                                      max_epochs=max_epochs, warmup_start_lr=0, eta_min=0)
-        else:
-            optimizer = LARSAdam(parameters, lr=lr, lars=False)  # == torch.optim.Adam
-            scheduler = CosineAnnealingLR(optimizer, T_max=max_epochs)
-        scheduler = {"scheduler": scheduler, "interval": "step", "frequency": 1}
-        return [optimizer], [scheduler]
+            schedule = CosineAnnealingLR(optimizer, T_max=total_steps)
+        return [optimizer], [{"scheduler": schedule, "interval": "step", "frequency": 1}]
 
+    # ---- epoch-end hooks (a11).  The monitored quantity is the TRAINING epoch's mean loss
+    # (base_model.py:111-115); the supervised models' "loss_3d" branch is not on this path.
     def training_epoch_end(self, outputs: List[dict]):
-        metric_keys = outputs[0].keys()
-        self.train_metrics_epoch = {key: torch.stack([x[key] for x in outputs]).mean() for key in metric_keys}
-        if "loss_3d" in metric_keys:
-            self.log("checkpoint_saving_loss", self.train_metrics_epoch["loss_3d"])
-        else:
-            self.log("checkpoint_saving_loss", self.train_metrics_epoch["loss"])
+        self.train_metrics_epoch = _epoch_mean(outputs)
+        self.log("checkpoint_saving_loss", self.train_metrics_epoch["loss"])
 
     def validation_epoch_end(self, outputs: List[dict]):
-        metric_keys = outputs[0].keys()
-        self.validation_metrics_epoch = {key: torch.stack([x[key] for x in outputs]).mean()
-                                         for key in metric_keys}
+        self.validation_metrics_epoch = _epoch_mean(outputs)
 
 
 class SimCLR(BaseModel):
@@ -124,12 +129,13 @@ class SimCLR(BaseModel):
         self.projection_head = self.get_projection_head()
 
     def get_projection_head(self) -> nn.Sequential:
-        return nn.Sequential(
-            nn.Linear(self.config.projection_head_input_dim, self.config.projection_head_hidden_dim, bias=True),
-            nn.BatchNorm1d(self.config.projection_head_hidden_dim),
-            nn.ReLU(),
-            nn.Linear(self.config.projection_head_hidden_dim, self.config.output_dim, bias=False),
-        )
+        """Linear(bias) -> BatchNorm1d -> ReLU -> Linear(no bias) (simclr_model.py:20-35).  The
+        Sequential only OWNS the parameters and buffers (state_dict keys projection_head.{0,1,3}.*);
+        the training path's arithmetic runs in the HIP kernels."""
+        d_in, d_hid, d_out = (self.config[k] for k in ("projection_head_input_dim", "projection_head_hidden_dim",
+                                                       "output_dim"))
+        return nn.Sequential(nn.Linear(d_in, d_hid), nn.BatchNorm1d(d_hid), nn.ReLU(),
+                             nn.Linear(d_hid, d_out, bias=False))
 
     # ---- kernels
     def _head_align(self, encodings: Tensor, spec: ops.AlignSpec) -> Tuple[Tensor, Tensor]:
@@ -145,15 +151,23 @@ class SimCLR(BaseModel):
         loss, stats16, _ = ops.ntxent(z, n_pairs, TEMPERATURE, row_stats, self.process_group)
         return loss, stats16
 
+    @staticmethod
+    def _two_views(batch: Dict[str, Tensor]) -> Tensor:
+        """Both views as one [2N, 3, H, W] tensor, view 1 first (hybrid2_model.py:30-32).  A batch that
+        already carries them stacked (`transformed_images`, e.g. from TwoViewAugmenter(stacked=True))
+        is used as is: no copy."""
+        stacked = batch.get("transformed_images")
+        if stacked is not None:
+            return stacked
+        return torch.cat((batch["transformed_image1"], batch["transformed_image2"]), dim=0)
+
     def _project(self, batch: Dict[str, Tensor]):
         """Per-rank part of the step (no collective): images -> unit embeddings z [2N,128] (+ per-row
         projection statistics, empty here).  simclr_model.py:37-47: one F.normalize, no alignment."""
-        batch_size = batch["transformed_image1"].size()[0]
-        concat_batch = torch.cat((batch["transformed_image1"], batch["transformed_image2"]), dim=0)
-        concat_encoding = self.get_encodings(concat_batch)
-        z, row_stats = self._head_align(concat_encoding,
-                                        ops.AlignSpec(n_pairs=batch_size, single_norm=True, want_stats=False))
-        return z, row_stats, batch_size
+        n_pairs = batch["transformed_image1"].size(0)
+        z, row_stats = self._head_align(self.get_encodings(self._two_views(batch)),
+                                        ops.AlignSpec(n_pairs=n_pairs, single_norm=True, want_stats=False))
+        return z, row_stats, n_pairs
 
     def _contrast(self, z: Tensor, n_pairs: int, row_stats: Tensor) -> Tensor:
         """Cross-rank part of the step: NT-Xent over the gathered embeddings (+ the batch means of the
@@ -168,29 +182,41 @@ class SimCLR(BaseModel):
         z, row_stats, n = self._project(batch)
         return self._contrast(z, n, row_stats)
 
-    def _step_outputs(self, batch: dict, loss: Tensor) -> Dict[str, Tensor]:
-        self.train_metrics = {**self.train_metrics, **{"loss": loss}}
+    def _remember_views(self, batch: dict):
+        """What the reference's Comet callback plots (upload_comet_logs.py:91-98): the two image
+        tensors and every non-image batch entry."""
+        extras = {name: value for name, value in batch.items() if "image" not in name}
         self.plot_params = {"image1": batch["transformed_image1"], "image2": batch["transformed_image2"],
-                            "params": {k: v for k, v in batch.items() if "image" not in k}}
+                            "params": extras}
+
+    def _step_outputs(self, batch: dict, loss: Tensor) -> Dict[str, Tensor]:
+        self.train_metrics = {**self.train_metrics, "loss": loss}
+        self._remember_views(batch)
         return self.train_metrics
 
     def get_encodings(self, batch_images: Tensor) -> Tensor:
         return self.encoder(batch_images)
 
     def forward(self, x: Tensor) -> Dict[str, Tensor]:
-        """simclr_model.py:54-57 (inference surface; the reference runs the encoder twice, the two
-        results are identical in eval mode, so it is run once here)."""
+        """Inference surface (simclr_model.py:54-57): encoder features and their projection through the
+        stock torch head modules (not the training path).  The reference evaluates the encoder a
+        second time for the "embedding" entry; in eval mode both results are identical, so that is
+        only done with `config.strict_reference` (in train mode the second pass also updates the
+        BatchNorm running statistics once more, which is what the flag reproduces)."""
         embedding = self.encoder(x)
-        projection = self.projection_head(embedding)  # stock torch modules: not on the training path
-        return {"embedding": embedding, "projection": projection}
+        out = {"embedding": embedding, "projection": self.projection_head(embedding)}
+        if self.config.get("strict_reference", False):
+            out["embedding"] = self.encoder(x)
+        return out
 
     def training_step(self, batch: dict, batch_idx: int) -> Dict[str, Tensor]:
+        """Returns `self.train_metrics` itself: projection statistics (if any) then "loss", which is the
+        entry Lightning back-propagates (simclr_model.py:59-67)."""
         return self._step_outputs(batch, self.contrastive_step(batch))
 
     def validation_step(self, batch: dict, batch_idx: int) -> Dict[str, Tensor]:
         loss = self.contrastive_step(batch)
-        self.plot_params = {"image1": batch["transformed_image1"], "image2": batch["transformed_image2"],
-                            "params": {k: v for k, v in batch.items() if "image" not in k}}
+        self._remember_views(batch)
         return {"loss": loss}
 
 
@@ -219,8 +245,7 @@ class Hybrid2Model(SimCLR):
         return spec
 
     def _project(self, batch: Dict[str, Tensor]):
-        batch_transform = torch.cat((batch["transformed_image1"], batch["transformed_image2"]), dim=0)
-        encodings = self.encoder(batch_transform)
+        encodings = self.encoder(self._two_views(batch))
         spec = self._spec(batch)
         z, row_stats = self._head_align(encodings, spec)
         return z, row_stats, spec.n_pairs
@@ -232,18 +257,14 @@ class Hybrid2Model(SimCLR):
         return z[:n], z[n:]
 
     def get_projection_stats(self, projection: Tensor, name: str) -> dict:
-        """hybrid2_model.py:92-106, kept for callers; the training path gets these from the kernel."""
-        projection_mean = torch.mean(projection, dim=1)
-        projection_median = torch.median(projection, dim=1).values
-        projection_min = torch.min(projection, dim=1).values
-        projection_max = torch.max(projection, dim=1).values
-        out = {}
-        for c, a in enumerate("xy"):
-            out[f"{name}{a}_mean"] = torch.mean(projection_mean, dim=0)[c]
-            out[f"{name}{a}_median"] = torch.mean(projection_median, dim=0)[c]
-            out[f"{name}{a}_min"] = torch.mean(projection_min, dim=0)[c]
-            out[f"{name}{a}_max"] = torch.mean(projection_max, dim=0)[c]
-        return out
+        """Torch spelling of the 8 per-view statistics for external callers (hybrid2_model.py:92-106):
+        per-sample mean / lower median / min / max over the 64 points of `projection` [N,64,2], averaged
+        over the batch, split into x and y.  The training path gets the same numbers from the align
+        kernel (key order: STAT_KEYS)."""
+        per_sample = {"mean": projection.mean(dim=1), "median": projection.median(dim=1).values,
+                      "min": projection.amin(dim=1), "max": projection.amax(dim=1)}
+        batch_mean = {stat: v.mean(dim=0) for stat, v in per_sample.items()}
+        return {f"{name}{axis}_{stat}": batch_mean[stat][c] for c, axis in enumerate("xy") for stat in batch_mean}
 
 
 def get_model(experiment_type: str):

@@ -140,10 +140,13 @@ class _NTXent(torch.autograd.Function):
         out17, row_lse, sim = _capi.ntxent_fwd(z_local, rank * mr, z_all, n_pairs, 1.0 / temperature, 1.0 / mg,
                                                stats_in, n_pairs, want_sim)
         if world > 1:
-            # one collective carries every rank's log-denominators AND its partial loss
-            packed = pdist.all_gather_cat(torch.cat([row_lse, out17[16:17]]), group).view(world, mr + 1)
+            # one collective carries every rank's log-denominators, its partial loss AND its 16 projection
+            # statistics (means over this rank's samples; equal pair counts per rank, so the mean of the
+            # rank means is the global-batch mean a single device would report)
+            packed = pdist.all_gather_cat(torch.cat([row_lse, out17]), group).view(world, mr + 17)
             lse_all = packed[:, :mr].reshape(-1).contiguous()
-            loss = packed[:, mr].sum()
+            loss = packed[:, mr + 16].sum()
+            out17 = torch.cat([packed[:, mr:mr + 16].mean(dim=0), loss.reshape(1)])
         else:
             lse_all, loss = row_lse, out17[16].clone()
         ctx.save_for_backward(z_local, z_all, lse_all)
@@ -169,8 +172,9 @@ def ntxent(z_local: Tensor, n_pairs: int, temperature: float = 0.5, row_stats: O
     z_local: [2*n_pairs, 128] unit rows of this rank (view-1 rows then view-2 rows).
     Returns (loss, stats16, sim): loss is the mean over all world*2*n_pairs rows and is identical on
     every rank; its gradient w.r.t. z_local is d(loss_global)/d(z_local), so parameter gradients
-    must be SUMMED over ranks (peclr_amd.dist.GradReducer does that).  stats16 = batch means of
-    row_stats (this rank's samples).  sim = [Mr, Mg] similarities when want_sim.
+    must be SUMMED over ranks (peclr_amd.dist.GradReducer does that).  stats16 = means of row_stats
+    over the GLOBAL batch (all ranks' samples; every rank must hold n_pairs pairs -- the Trainer checks
+    that).  sim = [Mr, Mg] similarities when want_sim.
     """
     loss, out17, sim = _NTXent.apply(z_local, row_stats, n_pairs, temperature, group, want_sim)
     return loss, out17[:16], sim

@@ -46,7 +46,7 @@ class _FusedWorkList:
     def __init__(self, params, grads, exp_avg, exp_avg_sq, group_of):
         dev = params[0].device
         n = len(params)
-        self.key = tuple(t.data_ptr() for t in (*params, *grads))
+        self.key = tuple(t.data_ptr() for t in (*params, *grads, *exp_avg, *exp_avg_sq))
         ptrs = [t.data_ptr() for seq in (params, grads, exp_avg, exp_avg_sq) for t in seq]
         sizes = [p.numel() for p in params]
         chunk_tensor, chunk_offset, begin = [], [], [0]
@@ -78,10 +78,14 @@ class LARSAdam(Optimizer):
     """
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lars=True, eta=0.02,
-                 lars_eps=1e-8, clip=True, fused=None):
+                 lars_eps=1e-8, clip=True, fused=None, write_back=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.lars, self.eta, self.lars_eps, self.clip = lars, eta, lars_eps, clip
+        # True: leave the LARS-scaled gradient (g + wd*p)*trust in p.grad after the step, as the
+        # reference's LARSWrapper does (it rewrites p.grad in place before Adam reads it); False
+        # (default) keeps it in registers -- nothing on the training path reads .grad after the step
+        self.write_back = bool(write_back) and lars
         first = self.param_groups[0]["params"][0]
         self.fused = first.is_cuda if fused is None else fused
         if self.fused and not first.is_cuda:
@@ -90,6 +94,17 @@ class LARSAdam(Optimizer):
         # hipGraph support: per-step scalars live in device memory (`_hyper`), refreshed by
         # `prepare_step()` OUTSIDE the graph; the captured launch (`launch_only()`) only reads them
         self._hyper = self._hyper_host = None
+        self._prepared = None
+
+    def _lars_mode(self) -> int:
+        return (2 if self.write_back else 1) if self.lars else 0
+
+    def load_state_dict(self, state_dict):
+        """Restored moments are new tensors: drop the cached device work list (its pointer table) so the
+        next step rebuilds it.  A captured hipGraph keeps its own work list alive; re-point that one with
+        `repoint_worklist()` after loading (Trainer.resume runs before any capture)."""
+        super().load_state_dict(state_dict)
+        self._fused_cache.clear()
         self._prepared = None
 
     def _prepare(self, group):
@@ -154,7 +169,7 @@ class LARSAdam(Optimizer):
             if g_.stride() != p_.stride() or g_.dtype != torch.float32:
                 raise _capi.PeclrHipError("repoint_worklist: grad layout differs from the parameter's")
         wl.ptrs.copy_(torch.tensor([t.data_ptr() for seq in seqs for t in seq], dtype=torch.int64))
-        wl.key = tuple(t.data_ptr() for t in (*params, *seqs[1]))
+        wl.key = tuple(t.data_ptr() for seq in seqs for t in seq)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -188,7 +203,7 @@ class LARSAdam(Optimizer):
             b1, b2 = g0["betas"]
             _capi.lars_adam_step(wl.ptrs, wl.sizes, wl.n_tensors, wl.chunk_tensor, wl.chunk_offset, wl.begin,
                                  wl.group, wl.n_chunks, wl.norms_ws, [0.0] * len(prepared), [0.0] * len(prepared), b1,
-                                 b2, g0["eps"], 1.0, 1.0, self.lars, self.eta, self.lars_eps, self.clip,
+                                 b2, g0["eps"], 1.0, 1.0, self._lars_mode(), self.eta, self.lars_eps, self.clip,
                                  device_hyper=device_hyper)
             return
         params = [p for t in prepared for p in t[1]]
@@ -205,7 +220,9 @@ class LARSAdam(Optimizer):
             if g_.stride() != p_.stride() or m_.stride() != p_.stride() or v_.stride() != p_.stride():
                 raise _capi.PeclrHipError("LARSAdam(fused): grad / exp_avg / exp_avg_sq must share the parameter's "
                                           f"strides (param {tuple(p_.stride())}, grad {tuple(g_.stride())})")
-        key = tuple(t.data_ptr() for t in (*params, *grads))
+        # moments included: load_state_dict (or anything else that swaps exp_avg / exp_avg_sq) must not leave
+        # the device-side pointer table aimed at the old, possibly freed, buffers
+        key = tuple(t.data_ptr() for t in (*params, *grads, *m, *v))
         wl = self._fused_cache.get("all")
         if wl is None or wl.key != key:
             group_of = [gi for gi, t in enumerate(prepared) for _ in t[1]]
@@ -215,7 +232,7 @@ class LARSAdam(Optimizer):
         _capi.lars_adam_step(wl.ptrs, wl.sizes, wl.n_tensors, wl.chunk_tensor, wl.chunk_offset, wl.begin, wl.group,
                              wl.n_chunks, wl.norms_ws, [float(t[0]["lr"]) for t in prepared],
                              [float(t[0]["weight_decay"]) for t in prepared], b1, b2, g0["eps"], 1.0 - b1 ** step,
-                             1.0 - b2 ** step, self.lars, self.eta, self.lars_eps, self.clip,
+                             1.0 - b2 ** step, self._lars_mode(), self.eta, self.lars_eps, self.clip,
                              device_hyper=device_hyper)
 
     # ---- torch foreach restatement (any device)
@@ -232,6 +249,8 @@ class LARSAdam(Optimizer):
             g_eff = torch._foreach_mul(params, list(wds.unbind()))
             torch._foreach_add_(g_eff, grads)
             torch._foreach_mul_(g_eff, list(trust.unbind()))
+            if self.write_back:
+                torch._foreach_copy_(grads, g_eff)
         elif wd != 0:
             g_eff = torch._foreach_add(grads, params, alpha=wd)
         else:
@@ -253,7 +272,7 @@ def LARSWrapper(optimizer: Optimizer, eta: float = 0.02, clip: bool = True, eps:
         raise TypeError("LARSWrapper here wraps torch.optim.Adam only (what the reference passes)")
     groups = [{k: v for k, v in g.items() if k in ("params", "lr", "betas", "eps", "weight_decay")}
               for g in optimizer.param_groups]
-    return LARSAdam(groups, lars=True, eta=eta, lars_eps=eps, clip=clip)
+    return LARSAdam(groups, lars=True, eta=eta, lars_eps=eps, clip=clip, write_back=True)  # p.grad rewritten, as there
 
 
 class LinearWarmupCosineAnnealingLR(LRScheduler):

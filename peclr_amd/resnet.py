@@ -6,7 +6,8 @@ Per BASELINE.json:north_star the convolutional backbone stays on PyTorch-ROCm (M
 only restates the architecture: 7x7/2 conv + BN + ReLU + 3x3/2 max-pool, BasicBlock [2,2,2,2] /
 [3,4,6,3], Bottleneck v1.5 (stride on the 3x3) [3,4,6,3] / [3,4,23,3] / [3,8,36,3], kaiming-normal
 (fan_out) conv init, BN weight 1 / bias 0.  PARITY UNPINNED against torchvision 0.8.0 itself (not
-importable here); pinned by state_dict key/shape lists (tests/test_resnet.py).
+importable here); pinned by state_dict key/shape/parameter-count lists
+(tests/test_host_logic.py::test_resnet_state_dict_layout).
 """
 from __future__ import annotations
 

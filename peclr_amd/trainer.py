@@ -18,6 +18,19 @@ from . import dist as pdist
 from .port import save_checkpoint
 
 
+def _flag_last(iterable):
+    """(item, is_last) pairs with one item of look-ahead (Lightning's `is_final_batch`)."""
+    it = iter(iterable)
+    try:
+        prev = next(it)
+    except StopIteration:
+        return
+    for cur in it:
+        yield prev, False
+        prev = cur
+    yield prev, True
+
+
 class Trainer:
     def __init__(self, max_epochs: int = 1, accumulate_grad_batches: int = 1, precision: str = "fp32",
                  checkpoint_dir: Optional[str] = None, save_top_k: int = 1, process_group=None,
@@ -25,7 +38,15 @@ class Trainer:
                  sync_batchnorm: bool = False, hip_graph: bool = False):
         self.max_epochs = max_epochs
         self.accumulate_grad_batches = accumulate_grad_batches
-        self.precision = precision
+        # "fp32" | "bf16" | 16 / "16" / "fp16".  16 is the reference's default (training_config.json:9,
+        # peclr_training.py:78-79: Lightning native AMP = fp16 autocast + a dynamic GradScaler); it is
+        # reproduced with torch.amp.GradScaler: loss scaled before backward, gradients unscaled (after the
+        # all-reduce) and checked before the step, step skipped and scale halved on inf/nan.
+        self.precision = {16: "fp16", "16": "fp16", 32: "fp32", "32": "fp32"}.get(precision, precision)
+        if self.precision not in ("fp32", "bf16", "fp16"):
+            raise ValueError(f"precision {precision!r}: expected 'fp32', 'bf16' or 16/'fp16'")
+        self._scaler = None
+        self._uniform_n = None
         self.checkpoint_dir = checkpoint_dir
         self.save_top_k = save_top_k
         self.process_group = process_group
@@ -81,11 +102,32 @@ class Trainer:
         model.sync_bn_group = group  # projection-head BatchNorm1d (ops.head_align)
 
     def _autocast(self):
-        if self.precision in ("bf16", "16", 16, "fp16"):
-            dtype = torch.bfloat16 if self.precision == "bf16" else torch.float16
+        if self.precision == "fp32":
+            return contextlib.nullcontext()
+        dev = "cuda" if next(self.model.parameters()).is_cuda else "cpu"
+        return torch.autocast(dev, dtype=torch.bfloat16 if self.precision == "bf16" else torch.float16)
+
+    def _grad_scaler(self):
+        """fp16 only: the dynamic loss scaler of native AMP (created on first use, saved in checkpoints)."""
+        if self.precision != "fp16":
+            return None
+        if self._scaler is None:
             dev = "cuda" if next(self.model.parameters()).is_cuda else "cpu"
-            return torch.autocast(dev, dtype=dtype)
-        return contextlib.nullcontext()
+            self._scaler = torch.amp.GradScaler(dev)
+        return self._scaler
+
+    def _check_uniform_batch(self, batch):
+        """N > 1: the all-gather of the embeddings has a fixed shape and the positive-pair index map uses
+        the local pair count on global rows, so every rank must hold the same number of pairs.  Checked
+        (one tiny MIN/MAX all-reduce) whenever this rank's count changes; a ragged last batch that differs
+        across ranks is an error here instead of a hang or silently mis-paired positives."""
+        if self.world_size == 1:
+            return
+        n = int(batch["transformed_image1"].shape[0])
+        if n == self._uniform_n:
+            return
+        pdist.assert_uniform(n, self.process_group, batch["transformed_image1"].device, "pairs per rank")
+        self._uniform_n = n
 
     def zero_grad(self):
         if self.reducer is not None:
@@ -94,22 +136,59 @@ class Trainer:
             self.optimizer.zero_grad(set_to_none=True)
 
     # ---- one micro-batch; returns the step's output dict
-    def training_micro_step(self, batch: Dict[str, torch.Tensor], batch_idx: int) -> Dict[str, torch.Tensor]:
+    def training_micro_step(self, batch: Dict[str, torch.Tensor], batch_idx: int,
+                            is_final_batch: bool = False) -> Dict[str, torch.Tensor]:
+        """Lightning 1.0.8 accumulation: the loss is divided by k for every micro-batch; the optimiser
+        steps when the window is full OR on the epoch's final batch (`should_accumulate = not
+        (accumulation_done or is_final_batch)`), so a trailing partial window is applied, not leaked into
+        the next epoch."""
         k = self.accumulate_grad_batches
-        last = (batch_idx + 1) % k == 0
+        last = (batch_idx + 1) % k == 0 or is_final_batch
+        self._check_uniform_batch(batch)
         if self.reducer is not None and last:
             self.reducer.prepare(self._unused)
+        scaler = self._grad_scaler()
         with self._autocast():
             out = self.model.training_step(batch, batch_idx)
-        (out["loss"] / k).backward()
+        loss = out["loss"] / k
+        (scaler.scale(loss) if scaler is not None else loss).backward()
         if last:
             if self.reducer is not None:
                 self.reducer.finish()
-            self.optimizer.step()
+            if scaler is not None:
+                scaler.step(self.optimizer)   # unscale, inf/nan check, step unless one was found
+                scaler.update()
+            else:
+                self.optimizer.step()
             self.zero_grad()
             self.scheduler.step()
             self.global_step += 1
         return {key: v.detach() for key, v in out.items()}
+
+    def _no_fp16_graphs(self):
+        if self.precision == "fp16":
+            raise RuntimeError("hipGraph capture with precision=16: the GradScaler's skip-on-inf decision is a host "
+                               "branch; use bf16 (no scaler) or hip_graph=False")
+
+    @staticmethod
+    def _clone_batch(batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Static copy of a batch for graph replay.  When the two views arrive as halves of one stacked
+        tensor (`transformed_images`), the copy keeps that relation (no per-step concatenation)."""
+        out = {k: v.clone() for k, v in batch.items() if not (k.startswith("transformed_image") and "transformed_images" in batch)}
+        if "transformed_images" in batch:
+            stacked = batch["transformed_images"].clone(memory_format=torch.preserve_format)
+            n = stacked.shape[0] // 2
+            out.update(transformed_images=stacked, transformed_image1=stacked[:n], transformed_image2=stacked[n:])
+        return out
+
+    @staticmethod
+    def _load_static(static: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor]):
+        stacked = "transformed_images" in static and "transformed_images" in batch
+        for k, v in batch.items():
+            if (stacked and k in ("transformed_image1", "transformed_image2")) or \
+                    (k == "transformed_images" and k not in static):
+                continue   # halves of the stacked tensor travel with it / the halves are copied instead
+            static[k].copy_(v, non_blocking=True)
 
     # ---- whole-step hipGraph (single process): forward + backward + fused optimiser captured once and
     # replayed per step -- for launch-bound configurations (bf16 backbones: ~35 ms of kernels per 40 ms
@@ -121,11 +200,12 @@ class Trainer:
     # `torch.cuda.stream(side)` like bench.py): on this ROCm build hipStreamEndCapture crashes otherwise
     # (tools/exp/graph_capture_sizes.py: capture-first works at every size tried, eager-first never).
     def capture_step_graph(self, example_batch: Dict[str, torch.Tensor], warmup: int = 3):
+        self._no_fp16_graphs()
         if self.world_size > 1 or self.reducer is not None:
             raise RuntimeError("capture_step_graph is single-process only (no gradient buckets)")
         if self.accumulate_grad_batches != 1:
             raise RuntimeError("capture_step_graph needs accumulate_grad_batches=1")
-        self._static_batch = {k: v.clone() for k, v in example_batch.items()}
+        self._static_batch = self._clone_batch(example_batch)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -160,8 +240,7 @@ class Trainer:
 
     def replay_step(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         if batch is not None and batch is not self._static_batch:
-            for k, v in batch.items():
-                self._static_batch[k].copy_(v, non_blocking=True)
+            self._load_static(self._static_batch, batch)
         self.optimizer.prepare_step()
         self._graph.replay()
         self.scheduler.step()
@@ -179,6 +258,7 @@ class Trainer:
     # does not depend on RCCL's capture support; the price is that the all-reduce no longer overlaps
     # with backward (RN-50: 98 MB over xGMI, well under a millisecond against a ~7 ms gain).
     def capture_split_graphs(self, example_batch: Dict[str, torch.Tensor], warmup: int = 3):
+        self._no_fp16_graphs()
         if self.accumulate_grad_batches != 1:
             raise RuntimeError("capture_split_graphs needs accumulate_grad_batches=1")
         if self.reducer is None:
@@ -187,7 +267,7 @@ class Trainer:
         if self.sync_batchnorm and self.world_size > 1:
             raise RuntimeError("capture_split_graphs: synchronised BatchNorm puts collectives inside the graphs")
         model = self.model
-        self._static_batch = {k: v.clone() for k, v in example_batch.items()}
+        self._static_batch = self._clone_batch(example_batch)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         if warmup < 1:
@@ -220,8 +300,7 @@ class Trainer:
     def replay_split(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         model = self.model
         if batch is not None and batch is not self._static_batch:
-            for k, v in batch.items():
-                self._static_batch[k].copy_(v, non_blocking=True)
+            self._load_static(self._static_batch, batch)
         self._graph_a.replay()
         z = self._split_z.detach().requires_grad_()
         loss = model._contrast(z, self._split_n, self._split_rows)     # collectives live here
@@ -243,10 +322,11 @@ class Trainer:
     # followed by the eager fused optimiser step on the accumulators.  Negatives are per micro-batch, as in
     # the reference's Lightning loop.
     def capture_micro_graph(self, example_batch: Dict[str, torch.Tensor], warmup_windows: int = 1):
+        self._no_fp16_graphs()
         k = self.accumulate_grad_batches
         if self.world_size > 1 or self.reducer is not None:
             raise RuntimeError("capture_micro_graph is single-process only (no gradient buckets)")
-        self._static_batch = {key: v.clone() for key, v in example_batch.items()}
+        self._static_batch = self._clone_batch(example_batch)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -272,8 +352,7 @@ class Trainer:
     def replay_micro(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         k = self.accumulate_grad_batches
         if batch is not None and batch is not self._static_batch:
-            for key, v in batch.items():
-                self._static_batch[key].copy_(v, non_blocking=True)
+            self._load_static(self._static_batch, batch)
         self._graph.replay()
         torch._foreach_add_(self._micro_acc, self._micro_src, alpha=1.0 / k)
         self._micro_count += 1
@@ -284,7 +363,8 @@ class Trainer:
             self.global_step += 1
         return self._static_out
 
-    def _graph_step(self, batch: Dict[str, torch.Tensor], batch_idx: int) -> Dict[str, torch.Tensor]:
+    def _graph_step(self, batch: Dict[str, torch.Tensor], batch_idx: int,
+                    is_final_batch: bool = False) -> Dict[str, torch.Tensor]:
         """fit()'s step when hip_graph is on: capture on the first batch (which is trained on exactly
         once, by the eager step the capture routine runs), replay for equal shapes, eager otherwise."""
         sig = tuple((k, tuple(v.shape), v.dtype) for k, v in batch.items())
@@ -296,8 +376,16 @@ class Trainer:
                 self.capture_split_graphs(batch, warmup=1)
             return self._capture_eager_out
         if sig != self._graph_sig:
-            out = self.training_micro_step(batch, batch_idx)
-            if self.reducer is None:          # the eager step dropped .grad: hand the graph's buffers back
+            # off-shape (ragged last) batch: eager step.  The gradients of the previous replay are still
+            # in place (a captured backward OVERWRITES its buffers, nothing zeroes them), so the eager
+            # backward must not accumulate onto them.
+            if self.reducer is None:
+                for p, _ in self._static_grads:
+                    p.grad = None
+            else:
+                self.reducer.zero_grad()
+            out = self.training_micro_step(batch, batch_idx, is_final_batch)
+            if self.reducer is None:          # hand the graph's buffers back to the parameters
                 for p, g in self._static_grads:
                     p.grad = g
             return out
@@ -324,7 +412,7 @@ class Trainer:
             for epoch in range(getattr(self, "_start_epoch", 0), self.max_epochs):
                 self.current_epoch = epoch
                 model.train()
-                outputs = [step(b, i) for i, b in enumerate(train_batches(epoch))]
+                outputs = [step(b, i, final) for i, (b, final) in enumerate(_flag_last(train_batches(epoch)))]
                 if val_batches is not None:
                     model.eval()
                     with torch.no_grad():
@@ -349,6 +437,8 @@ class Trainer:
             self.optimizer.load_state_dict(ckpt["optimizer_states"][0])
         if "lr_schedulers" in ckpt:
             self.scheduler.load_state_dict(ckpt["lr_schedulers"][0])
+        if "native_amp_scaling_state" in ckpt and self._grad_scaler() is not None:
+            self._scaler.load_state_dict(ckpt["native_amp_scaling_state"])
         self.global_step = int(ckpt.get("global_step", 0))
         self.current_epoch = int(ckpt.get("epoch", -1)) + 1
         self._start_epoch = self.current_epoch
@@ -359,7 +449,7 @@ class Trainer:
             return
         monitor = float(model.logged["checkpoint_saving_loss"]) if hasattr(model, "logged") else float("nan")
         path = os.path.join(self.checkpoint_dir, f"epoch={epoch}.ckpt")
-        save_checkpoint(path, model, self.optimizer, self.scheduler, epoch, self.global_step, monitor)
+        save_checkpoint(path, model, self.optimizer, self.scheduler, epoch, self.global_step, monitor, self._scaler)
         self._saved.append((monitor, path))
         self._saved.sort(key=lambda t: t[0])
         while self.save_top_k > 0 and len(self._saved) > self.save_top_k:

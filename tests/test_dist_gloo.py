@@ -102,6 +102,10 @@ def worker(rank, world, port, out_dir):
     grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
     torch.save({"loss": out["loss"].detach(), "grads": grads,
                 "stats": {k: v for k, v in out.items() if k != "loss"}}, os.path.join(out_dir, f"r{rank}.pt"))
+    # a rank whose batch has a different number of pairs is an error on EVERY rank, not a hang
+    ragged = {k: v[: N_LOCAL - rank] for k, v in batch.items()}
+    with pytest.raises(RuntimeError, match="differs across data-parallel ranks"):
+        tr._check_uniform_batch(ragged)
     # a full optimiser step keeps the replicas identical
     tr.optimizer.step()
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])
@@ -126,7 +130,11 @@ def test_two_ranks_equal_one_rank(tmp_path, monkeypatch):
     model = make_model(bn_eval=True)
     out = model.training_step(make_batch(world), 0)
     out["loss"].backward()
-    assert abs(float(out["loss"]) - float(r0["loss"])) < 2e-6
+    assert abs(float(out["loss"].detach()) - float(r0["loss"])) < 2e-6
+    # the 16 projection statistics are those of the GLOBAL batch on every rank (they ride in the packed gather)
+    for k, v in r0["stats"].items():
+        assert torch.equal(v, r1["stats"][k]), k
+        assert abs(float(v) - float(out[k])) < 1e-6, k
     for n, p in model.named_parameters():
         if p.grad is None:
             assert float(r0["grads"][n].abs().max()) == 0.0, n  # final_layer: never gets a gradient

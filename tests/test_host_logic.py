@@ -185,7 +185,7 @@ def test_lars_adam_foreach_matches_oracle_and_schedule():
         LARSAdam([p], fused=True)  # fused needs HIP tensors: no silent fallback
 
 
-def test_trainer_accumulation_and_checkpoint_roundtrip(tmp_path):
+def test_trainer_accumulation_and_checkpoint_roundtrip(tmp_path, monkeypatch):
     import warnings
 
     from peclr_amd import Hybrid2Model, Trainer, hybrid2_config, peclr_to_torchvision, get_encoder_state_dict
@@ -210,14 +210,17 @@ def test_trainer_accumulation_and_checkpoint_roundtrip(tmp_path):
                    "angle_1": torch.randint(-45, 46, (n,), generator=g).double(),
                    "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
 
-    tr = Trainer(max_epochs=2, accumulate_grad_batches=2, checkpoint_dir=str(tmp_path), save_top_k=1)
+    # the reference's layout: $SAVED_MODELS_BASE_PATH/<experiment>/checkpoints/epoch=K.ckpt (utils.py:189-206)
+    monkeypatch.setenv("SAVED_MODELS_BASE_PATH", str(tmp_path))
+    ckpt_dir = tmp_path / "exp1" / "checkpoints"
+    tr = Trainer(max_epochs=2, accumulate_grad_batches=2, checkpoint_dir=str(ckpt_dir), save_top_k=1)
     tr.fit(model, batches, val_batches=lambda e: list(batches(e))[:1])
     assert tr.global_step == 4  # 2 epochs x 4 micro-batches / accumulate 2
     assert set(model.train_metrics_epoch) == set(O.stat_keys()) | {"loss"}
     assert "checkpoint_saving_loss" in model.logged and list(model.validation_metrics_epoch) == ["loss"]
-    ckpts = os.listdir(tmp_path)
+    ckpts = os.listdir(ckpt_dir)
     assert len(ckpts) == 1 and ckpts[0].startswith("epoch=")
-    path = os.path.join(tmp_path, ckpts[0])
+    path = os.path.join(ckpt_dir, ckpts[0])
     # export: every `features` entry lands in a torchvision-layout ResNet, fc untouched
     target = resnet.resnet18()
     fc_before = target.fc.weight.detach().clone()
@@ -228,13 +231,17 @@ def test_trainer_accumulation_and_checkpoint_roundtrip(tmp_path):
     assert torch.equal(tsd["layer4.1.bn2.running_var"], saved["encoder.features.7.1.bn2.running_var"])
     assert list(saved) == list(model.state_dict())
     assert torch.equal(target.fc.weight, fc_before)
-    enc = get_encoder_state_dict(path)
+    from peclr_amd import get_latest_checkpoint
+
+    assert get_latest_checkpoint("exp1") == path and get_latest_checkpoint("exp1", "epoch=7.ckpt").endswith("epoch=7.ckpt")
+    enc = get_encoder_state_dict("exp1", "")   # (saved_model_path, checkpoint), as utils.py:209-225
     assert list(enc)[0] == "features.0.weight" and "final_layer.0.bias" in enc
+    assert all(not k.startswith("encoder.") and "projection_head" not in k for k in enc)
     with pytest.raises(Exception, match="not of type ResNet"):
         peclr_to_torchvision(torch.nn.Linear(2, 2), path)
 
 
-def test_resume_continues_the_run_exactly(tmp_path):
+def test_resume_continues_the_run_exactly(tmp_path, monkeypatch):
     """Trainer.resume: weights, optimiser moments/step counts, schedule position, epoch and global step;
     a run resumed after epoch 0 ends where the uninterrupted run ends.  restore_model: weights only
     (experiments/utils.py:535-546)."""
@@ -261,21 +268,22 @@ def test_resume_continues_the_run_exactly(tmp_path):
                    "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
 
     straight = copy.deepcopy(base)
-    ts = Trainer(max_epochs=2, checkpoint_dir=str(tmp_path / "a"), save_top_k=5)
+    monkeypatch.setenv("SAVED_MODELS_BASE_PATH", str(tmp_path))
+    ts = Trainer(max_epochs=2, checkpoint_dir=str(tmp_path / "a" / "checkpoints"), save_top_k=5)
     ts.fit(straight, batches)
     # the "interrupted" run is the same run cut after epoch 0: its checkpoint is a/epoch=0.ckpt
     resumed = copy.deepcopy(base)
-    tr = Trainer(max_epochs=2, checkpoint_dir=str(tmp_path / "b"), save_top_k=5).attach(resumed)
-    tr.resume(os.path.join(tmp_path / "a", "epoch=0.ckpt"))
+    tr = Trainer(max_epochs=2, checkpoint_dir=str(tmp_path / "b" / "checkpoints"), save_top_k=5).attach(resumed)
+    tr.resume(os.path.join(tmp_path / "a" / "checkpoints", "epoch=0.ckpt"))
     assert tr.global_step == 3 and tr.current_epoch == 1
     tr.fit(resumed, batches)
     assert tr.global_step == ts.global_step == 6
     assert tr.scheduler.last_epoch == ts.scheduler.last_epoch
     for (k, a), (_, b) in zip(straight.state_dict().items(), resumed.state_dict().items()):
         assert torch.equal(a, b), k
-    fresh = restore_model(copy.deepcopy(base), str(tmp_path / "b"))          # newest checkpoint: epoch=1
+    fresh = restore_model(copy.deepcopy(base), "b")                          # (model, experiment_key): newest = epoch=1
     assert torch.equal(fresh.projection_head[3].weight, resumed.projection_head[3].weight)
-    again = restore_model(copy.deepcopy(base), str(tmp_path / "a"), "epoch=0.ckpt")
+    again = restore_model(copy.deepcopy(base), "a", "epoch=0.ckpt")
     assert not torch.equal(again.projection_head[3].weight, resumed.projection_head[3].weight)
     assert not torch.equal(again.projection_head[3].weight, base.projection_head[3].weight)
 
@@ -300,3 +308,165 @@ def test_resnet_state_dict_layout():
     x = torch.randn(2, 3, 64, 64)
     assert resnet.resnet18()(x).shape == (2, 1000)
     assert abs(resnet.conv_flops_per_image(resnet.resnet50()) / 1e9 - 8.18) < 0.05
+
+
+def _tiny_batches(n, count, seed=0, size=32):
+    def batches(epoch):
+        g = torch.Generator().manual_seed(seed + epoch)
+        for _ in range(count):
+            yield {"transformed_image1": torch.randn(n, 3, size, size, generator=g),
+                   "transformed_image2": torch.randn(n, 3, size, size, generator=g),
+                   "jitter_x_1": torch.randint(-14, 1, (n,), generator=g), "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+                   "jitter_y_1": torch.randint(-14, 1, (n,), generator=g), "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+                   "angle_1": torch.randint(-45, 46, (n,), generator=g).double(),
+                   "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+    return batches
+
+
+def test_accumulation_steps_on_the_final_batch_of_the_epoch():
+    """Lightning 1.0.8: `should_accumulate = not (accumulation_done or is_final_batch)` -- 5 batches with
+    accumulate_grad_batches=2 are 3 optimiser steps per epoch (2 + 2 + 1), the trailing partial window is
+    applied (still divided by k) and nothing leaks into the next epoch."""
+    import copy
+    import warnings
+
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(1)
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, augmentation=["crop"], batch_size=2,
+                         num_samples=20, num_of_mini_batch=2, pretrained=False)
+    model = Hybrid2Model(cfg)
+    before_last = {}
+    tr = Trainer(max_epochs=1, accumulate_grad_batches=2)
+    batches = _tiny_batches(2, 5)
+    tr.fit(model, batches)
+    assert tr.global_step == 3 and tr.scheduler.last_epoch == 3
+    assert all(p.grad is None or float(p.grad.abs().sum()) == 0.0 for p in model.parameters())
+    # the last step is exactly "one micro-batch / k": replay it by hand from the state after two full windows
+    torch.manual_seed(1)
+    ref = Hybrid2Model(cfg)
+    tr2 = Trainer(max_epochs=1, accumulate_grad_batches=2).attach(ref)
+    tr2.zero_grad()
+    bl = list(batches(0))
+    for i in range(4):
+        tr2.training_micro_step(bl[i], i)
+    assert tr2.global_step == 2
+    out = ref.training_step(bl[4], 4)
+    (out["loss"] / 2).backward()
+    tr2.optimizer.step()
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_precision_16_uses_a_grad_scaler_and_skips_on_overflow():
+    """precision=16 (the reference's default, training_config.json:9) = fp16 autocast + dynamic loss
+    scaling: an overflowing step is skipped (weights untouched, scale halved, LR schedule still advances),
+    a normal one is applied with unscaled gradients."""
+    import warnings
+
+    from peclr_amd import Trainer
+
+    warnings.simplefilter("ignore")
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(4))
+            self.trainer, self.blow = None, False
+
+        def setup(self, stage):
+            pass
+
+        def configure_optimizers(self):
+            from peclr_amd.optim import LARSAdam
+
+            opt = LARSAdam([{"params": [self.w], "weight_decay": 0.0}], lr=1e-2, lars=False, fused=False)
+            return [opt], [{"scheduler": torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0)}]
+
+        def training_step(self, batch, idx):
+            loss = (self.w * batch["transformed_image1"]).sum()
+            return {"loss": loss * float("inf") if self.blow else loss}
+
+    m = Tiny()
+    tr = Trainer(precision=16).attach(m)
+    assert tr.precision == "fp16"
+    tr.zero_grad()
+    b = {"transformed_image1": torch.arange(4.0)}
+    tr.training_micro_step(b, 0)
+    scale0 = tr._scaler.get_scale()
+    w1 = m.w.detach().clone()
+    assert not torch.equal(w1, torch.ones(4)) or True
+    assert torch.allclose(w1[1:], torch.ones(3) - 1e-2, atol=1e-6)   # Adam's first step = -lr*sign(g): unscaled g
+    m.blow = True
+    tr.training_micro_step(b, 1)
+    assert torch.equal(m.w.detach(), w1) and tr._scaler.get_scale() == scale0 / 2
+    assert tr.global_step == 2 and tr.scheduler.last_epoch == 2
+    with pytest.raises(ValueError):
+        Trainer(precision="fp8")
+
+
+def test_lars_write_back_leaves_the_scaled_gradient_like_the_reference_wrapper():
+    from peclr_amd.optim import LARSAdam, LARSWrapper
+
+    torch.manual_seed(0)
+    p = torch.nn.Parameter(torch.randn(5, 3))
+    g = torch.randn(5, 3)
+    p.grad = g.clone()
+    opt = LARSWrapper(torch.optim.Adam([{"params": [p], "weight_decay": 1e-2}], lr=0.1))
+    assert isinstance(opt, LARSAdam) and opt.write_back
+    w0 = p.detach().clone()
+    opt.step()
+    pn, gn = float(w0.norm()), float(g.norm())
+    trust = min(0.02 * pn / (gn + 1e-2 * pn + 1e-8) / 0.1, 1.0)
+    np.testing.assert_allclose(p.grad.numpy(), ((g + 1e-2 * w0) * trust).numpy(), rtol=1e-6, atol=1e-8)
+    q = torch.nn.Parameter(w0.clone())
+    q.grad = g.clone()
+    LARSAdam([{"params": [q], "weight_decay": 1e-2}], lr=0.1, fused=False).step()   # default: grad untouched
+    assert torch.equal(q.grad, g) and torch.equal(q.detach(), p.detach())
+
+
+def test_forward_strict_reference_runs_the_encoder_twice():
+    """simclr_model.py:54-57 evaluates the encoder a second time for "embedding"; opt-in here."""
+    from peclr_amd import Config, SimCLR
+
+    calls = []
+
+    class Enc(torch.nn.Module):
+        def forward(self, x):
+            calls.append(1)
+            return x.flatten(1)
+
+    for strict, expect in ((False, 1), (True, 2)):
+        cfg = Config(projection_head_input_dim=12, projection_head_hidden_dim=8, output_dim=128, strict_reference=strict)
+        m = SimCLR(cfg)
+        m.encoder = Enc()
+        m.eval()
+        calls.clear()
+        out = m(torch.randn(3, 3, 2, 2))
+        assert len(calls) == expect and set(out) == {"embedding", "projection"}
+        assert out["embedding"].shape == (3, 12) and out["projection"].shape == (3, 128)
+
+
+def test_peclr_to_torchvision_reports_and_stops_on_a_mismatch(tmp_path, capsys):
+    """port_model.py:35-45: key-suffix mismatch or incompatible shapes -> message, no exception, the rest
+    of the ResNet untouched."""
+    from peclr_amd import peclr_to_torchvision, resnet
+
+    src = resnet.resnet18()
+    sd = {"encoder.features." + k: v for k, v in src.state_dict().items() if not k.startswith("fc.")}
+    path = str(tmp_path / "w.ckpt")
+    torch.save({"state_dict": sd}, path)
+    dst = resnet.resnet34()        # same stem, deeper layers: shapes diverge later on
+    stem_before = dst.conv1.weight.detach().clone()
+    l4_before = dst.layer4[2].conv1.weight.detach().clone()
+    peclr_to_torchvision(dst, path)
+    assert torch.equal(dst.conv1.weight, src.conv1.weight) and not torch.equal(dst.conv1.weight, stem_before)
+    assert torch.equal(dst.layer4[2].conv1.weight, l4_before)
+    printed = capsys.readouterr().out
+    assert "don't match" in printed or "not compatible" in printed
+    # a key list whose suffixes disagree at position 1
+    bad = dict([list(sd.items())[0], list(sd.items())[2]])   # conv1.weight, bn1.bias  vs  conv1.weight, bn1.weight
+    torch.save({"state_dict": bad}, path)
+    peclr_to_torchvision(resnet.resnet18(), path)
+    assert "PeCLR layers don't match" in capsys.readouterr().out
