@@ -86,23 +86,32 @@ def parse():
                          "around its collectives (Trainer.capture_split_graphs), falling back to eager on all ranks "
                          "if any rank's capture raises")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=16, help="pairs in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs in the bounded CPU-baseline sample of the workload")
     return ap.parse_args()
 
 
-def synthetic_batch(n, size, seed, device):
+def synthetic_batch(n, size, seed, device, channels_last=False):
     """randn images (post-normalisation ~ N(0,1)), integer-degree float64 angles
-    in [-45,45], int64 jitter in [-14,0]; generator seed = the reference's seed 5 (+ rank)."""
+    in [-45,45], int64 jitter in [-14,0]; generator seed = the reference's seed 5 (+ rank).
+    On a GPU the two views live in ONE [2N,3,S,S] buffer (`transformed_images`) and
+    `transformed_image1/2` are its halves, so the step's `cat(view1, view2)` (hybrid2_model.py:30-32)
+    is a no-op instead of a 154 MB copy per step."""
     g = torch.Generator().manual_seed(seed)
-    b = {"transformed_image1": torch.randn(n, 3, size, size, generator=g),
-         "transformed_image2": torch.randn(n, 3, size, size, generator=g),
-         "jitter_x_1": torch.randint(-14, 1, (n,), generator=g),
+    im1 = torch.randn(n, 3, size, size, generator=g)
+    im2 = torch.randn(n, 3, size, size, generator=g)
+    b = {"jitter_x_1": torch.randint(-14, 1, (n,), generator=g),
          "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
          "jitter_y_1": torch.randint(-14, 1, (n,), generator=g),
          "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
          "angle_1": torch.randint(-45, 46, (n,), generator=g).double(),
          "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
-    return {k: v.to(device) for k, v in b.items()}
+    b = {k: v.to(device) for k, v in b.items()}
+    if device.type == "cpu":
+        return {"transformed_image1": im1, "transformed_image2": im2, **b}
+    stacked = torch.cat([im1, im2]).to(device)
+    if channels_last:
+        stacked = stacked.contiguous(memory_format=torch.channels_last)
+    return {"transformed_images": stacked, "transformed_image1": stacked[:n], "transformed_image2": stacked[n:], **b}
 
 
 def build_model(args, device, pairs):
@@ -181,47 +190,117 @@ def pmc_traffic(kernel, args=None):
     return entry.get("traffic_bytes_per_launch") if entry else None
 
 
+def _physical_cores():
+    try:
+        import psutil
+
+        return psutil.cpu_count(logical=False)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def _median_time(fn, warmup, timed):
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2]), ts
+
+
 def cpu_baseline(args):
-    """The same step on the host: torch-CPU ResNet (same module) + oracle head (NumPy) + foreach
-    LARS/Adam.  Bounded sample: ONE timed step (after one untimed step) of 2 x cpu_pairs views."""
+    """BASELINE.md section 3, on this host's cores (kind "port": the NumPy oracle + the same torch-CPU
+    ResNet module + the foreach LARS/Adam; the reference's own files never run on the GPU box):
+      (i)  head only  -- oracle K1..K8 forward + backward at C2's shape (M = 256, Din = 2048), >= 3 warm-up +
+                         >= 10 timed, median;
+      (ii) full step  -- C1 (ResNet-18, 2x32 @224, Din 512) with the same protocol, and the bench's own
+                         workload on a bounded sample (ResNet-50 at 2 x `--cpu-pairs` views; 1 warm-up + 3
+                         timed, median) -- 2x128 ResNet-50 steps take ~1 min each on host cores.
+    `value` is the bounded sample of the workload the GPU line measures."""
     import numpy as np
 
     from oracle import peclr_oracle as O
     from peclr_amd.optim import LARSAdam
 
-    n = args.cpu_pairs
-    model = build_model(args, torch.device("cpu"), n)
-    params = [p for name, p in model.named_parameters() if "final_layer" not in name]
-    opt = LARSAdam([{"params": params, "weight_decay": 1e-6}], lr=1e-3, lars=True, fused=False)
-    batch = synthetic_batch(n, args.size, 5, torch.device("cpu"))
-    ph = model.projection_head
-    head = [ph[0].weight, ph[0].bias, ph[1].weight, ph[1].bias, ph[3].weight]
+    def make_step(resnet, n, size):
+        a = argparse.Namespace(**vars(args))
+        a.resnet, a.accum = resnet, 1
+        model = build_model(a, torch.device("cpu"), n)
+        params = [p for name, p in model.named_parameters() if "final_layer" not in name]
+        opt = LARSAdam([{"params": params, "weight_decay": 1e-6}], lr=1e-3, lars=True, fused=False)
+        batch = synthetic_batch(n, size, 5, torch.device("cpu"))
+        ph = model.projection_head
+        head = [ph[0].weight, ph[0].bias, ph[1].weight, ph[1].bias, ph[3].weight]
+        jx = torch.cat([batch["jitter_x_1"], batch["jitter_x_2"]]).numpy()
+        jy = torch.cat([batch["jitter_y_1"], batch["jitter_y_2"]]).numpy()
+        ang = torch.cat([batch["angle_1"], batch["angle_2"]]).numpy()
 
-    def step():
-        x = torch.cat([batch["transformed_image1"], batch["transformed_image2"]])
-        h = model.encoder(x)
-        r = O.head_loss_fwd_bwd(h.detach().numpy(), *[t.detach().numpy() for t in head], n, crop=True,
-                                rotate=True,
-                                jitter_x=torch.cat([batch["jitter_x_1"], batch["jitter_x_2"]]).numpy(),
-                                jitter_y=torch.cat([batch["jitter_y_1"], batch["jitter_y_2"]]).numpy(),
-                                angle=torch.cat([batch["angle_1"], batch["angle_2"]]).numpy(),
-                                image_hw=(args.size, args.size))
-        h.backward(torch.from_numpy(np.ascontiguousarray(r["dh"])))
-        for t, k in zip(head, ("dw1", "db1", "dgamma", "dbeta", "dw2")):
-            t.grad = torch.from_numpy(np.ascontiguousarray(r[k].astype(np.float32)))
-        opt.step()
-        opt.zero_grad(set_to_none=True)
-        return float(r["loss"])
+        def step():
+            x = torch.cat([batch["transformed_image1"], batch["transformed_image2"]])
+            h = model.encoder(x)
+            r = O.head_loss_fwd_bwd(h.detach().numpy(), *[t.detach().numpy() for t in head], n, crop=True,
+                                    rotate=True, jitter_x=jx, jitter_y=jy, angle=ang, image_hw=(size, size))
+            h.backward(torch.from_numpy(np.ascontiguousarray(r["dh"])))
+            for t, k in zip(head, ("dw1", "db1", "dgamma", "dbeta", "dw2")):
+                t.grad = torch.from_numpy(np.ascontiguousarray(r[k].astype(np.float32)))
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        return step
 
-    step()
-    t0 = time.perf_counter()
-    step()
-    dt = time.perf_counter() - t0
-    return {"value": round(2 * n / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"1 timed step (after 1 untimed) of ResNet-{args.resnet} on 2x{n} synthetic "
-                      f"{args.size}x{args.size} views, fp32, torch-CPU encoder + NumPy oracle head + foreach "
-                      f"LARS/Adam; {dt:.2f} s"}
+    # (i) head only, C2 shape
+    rng = np.random.default_rng(5)
+    m_rows, din, hid, n = 256, 2048, 512, 128
+    hh = rng.standard_normal((m_rows, din)).astype(np.float32)
+    w1 = (rng.standard_normal((hid, din)) / np.sqrt(din)).astype(np.float32)
+    w2 = (rng.standard_normal((128, hid)) / np.sqrt(hid)).astype(np.float32)
+    b1, gamma, beta = np.zeros(hid, np.float32), np.ones(hid, np.float32), np.zeros(hid, np.float32)
+    jx, jy = rng.integers(-14, 1, m_rows), rng.integers(-14, 1, m_rows)
+    ang = rng.integers(-45, 46, m_rows).astype(np.float64)
+    head_med, head_ts = _median_time(lambda: O.head_loss_fwd_bwd(hh, w1, b1, gamma, beta, w2, n, crop=True, rotate=True,
+                                                                 jitter_x=jx, jitter_y=jy, angle=ang,
+                                                                 image_hw=(224, 224)), 3, 10)
+    # (ii) full step, C1
+    c1_med, c1_ts = _median_time(make_step("18", 32, 224), 3, 10)
+    # (ii) the bench's workload, bounded sample
+    ns = args.cpu_pairs
+    w_med, w_ts = _median_time(make_step(args.resnet, ns, args.size), 1, 3)
+    return {"value": round(2 * ns / w_med, 3), "unit": "images/sec", "cores": _physical_cores() or torch.get_num_threads(),
+            "physical_cores": _physical_cores(), "torch_threads": torch.get_num_threads(), "kind": "port",
+            "sample": f"median of 3 timed steps (after 1 untimed) of ResNet-{args.resnet} on 2x{ns} synthetic "
+                      f"{args.size}x{args.size} views (bounded sample of the 2x{args.pairs} workload), fp32, torch-CPU "
+                      f"encoder + NumPy oracle head + foreach LARS/Adam; {w_med:.2f} s/step",
+            "head_only": {"what": "oracle K1..K8 forward + backward (head, stats, align crop+rotate, NT-Xent), "
+                                  "M=256 rows, Din=2048, float32 inputs", "median_ms": round(1e3 * head_med, 3),
+                          "warmup": 3, "timed": len(head_ts), "min_ms": round(1e3 * head_ts[0], 3),
+                          "max_ms": round(1e3 * head_ts[-1], 3)},
+            "c1_full_step": {"what": "ResNet-18, 2x32 synthetic 224x224 views, Din 512, crop+rotate, fwd + bwd + "
+                                     "LARS/Adam step", "median_s": round(c1_med, 4), "images_per_sec": round(64 / c1_med, 2),
+                             "warmup": 3, "timed": len(c1_ts), "min_s": round(c1_ts[0], 4), "max_s": round(c1_ts[-1], 4)}}
+
+
+def parity_line(model, batch, autocast):
+    """`BASELINE.json:metric`'s second half ("NT-Xent loss delta vs ref"): the HIP head / alignment / loss on
+    the bench batch against the oracle on the same encoder output, computed BEFORE the timed region.
+    Checker only (oracle/step_check.py); nothing it touches is timed."""
+    from oracle import step_check
+
+    d = step_check.step_deltas(model, batch, autocast=autocast)
+    return {k: d[k] for k in ("loss_delta_vs_oracle", "sim_max_abs_delta", "z_max_abs_delta", "stats_max_abs_delta",
+                              "loss_hip", "loss_oracle", "rows") if k in d}
+
+
+def committed_profile(name, args):
+    """Per-kernel figures that cannot be taken from inside the timed run (rocprofv3 kernel-trace durations,
+    SQ MFMA-busy counters): read from the committed summaries under profiles/, default workload only."""
+    path = os.path.join(ROOT, "profiles", name)
+    default = args.dtype == "fp32" and args.resnet == "50" and args.pairs == 128 and args.size == 224
+    if not os.path.exists(path) or not default:
+        return {}
+    with open(path) as f:
+        return json.load(f)
 
 
 def try_graph_child():
@@ -282,10 +361,7 @@ def main():
     trainer = Trainer(max_epochs=100, accumulate_grad_batches=args.accum, precision=args.dtype,
                       sync_batchnorm=bool(args.sync_bn)).attach(model)
     trainer.zero_grad()
-    batch = synthetic_batch(args.pairs, args.size, 5 + rank, device)
-    if args.channels_last:
-        for k in ("transformed_image1", "transformed_image2"):
-            batch[k] = batch[k].contiguous(memory_format=torch.channels_last)
+    batch = synthetic_batch(args.pairs, args.size, 5 + rank, device, channels_last=bool(args.channels_last))
 
     next_batch = lambda: batch  # noqa: E731 -- the metric's default: one synthetic batch, resident in HBM
     if args.augment:
@@ -316,7 +392,10 @@ def main():
     # process has already run the step eagerly on the default stream (tools/exp/graph_capture_sizes.py).
     stream = torch.cuda.Stream(device)
     stream.wait_stream(torch.cuda.current_stream())
+    parity = None
     with torch.cuda.stream(stream):
+        if rank == 0 or world > 1:   # forward-only, untimed; every rank runs it (BatchNorm state stays in step)
+            parity = parity_line(model, batch, trainer._autocast() if args.dtype != "fp32" else None)
         if split:
             # every rank must take the same path: agree on whether all captures succeeded
             ok = 1
@@ -357,14 +436,14 @@ def main():
             loss = float(out["loss"])
             # per-kernel HIP events cannot sit inside a graph: the SAME K steps once more, eagerly, with an
             # event pair around every hand-written launch (same kernels, same shapes, same stream)
-            _capi.EVENT_LOG = {}
+            _capi.EVENT_LOG, _capi.LAUNCH_ORDER = {}, []
             for i in range(args.steps):
                 one_step(args.warmup + args.steps + i)
             torch.cuda.synchronize()
         else:
             for i in range(args.warmup):
                 out = one_step(i)
-            _capi.EVENT_LOG = {}
+            _capi.EVENT_LOG, _capi.LAUNCH_ORDER = {}, []
             if world > 1:
                 torch.distributed.barrier()
             torch.cuda.synchronize()
@@ -378,10 +457,31 @@ def main():
             loss = float(out["loss"])
     table_steps = args.steps
     event_log, _capi.EVENT_LOG = _capi.EVENT_LOG, None
+    launch_order, _capi.LAUNCH_ORDER = _capi.LAUNCH_ORDER, None
+    if rank == 0 and os.environ.get("PECLR_LAUNCH_MANIFEST"):
+        # names of the hand-written launches of the measured pass, in order: the LAST len(order) peclr:: dispatches
+        # of a rocprofv3 trace of this process are exactly these (tools/pmc_mfma.py aligns on that)
+        with open(os.environ["PECLR_LAUNCH_MANIFEST"], "w") as f:
+            json.dump({"order": launch_order, "steps": args.steps, "argv": sys.argv[1:]}, f)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
+    dist_info = None
+    if world > 1:
+        ones = torch.ones(1, device=device)
+        torch.distributed.all_reduce(ones)
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            rccl = None
+        dist_info = {"backend": torch.distributed.get_backend(), "rccl_version": rccl, "ranks_seen": int(ones.item()),
+                     "grad_buckets": [{"params": len(b.params), "bytes": int(b.flat.numel() * b.flat.element_size())}
+                                      for b in trainer.reducer.buckets],
+                     "collectives_per_step": "all_gather z [2N,128] fp32 + all_gather [row_lse | stats16 | loss] + "
+                                             f"{len(trainer.reducer.buckets)} bucket all_reduce(SUM)",
+                     "note": "no scaling curve has been measured by the builder (1 GPU per lease); per-N values "
+                             "are the driver's"}
     if rank == 0:
         images = world * 2 * args.pairs * args.accum * args.steps
         n_params = sum(p.numel() for n, p in model.named_parameters() if "final_layer" not in n)
@@ -428,6 +528,27 @@ def main():
             "hand_written_us_per_step": round(sum(k["avg_us"] * k["launches"] / table_steps
                                                   for k in kernels.values()), 1),
         }
+        if parity is not None:
+            result["parity"] = parity
+            result["loss_delta_vs_oracle"] = parity["loss_delta_vs_oracle"]
+            result["sim_max_abs_delta"] = parity["sim_max_abs_delta"]
+        # figures a run cannot take of itself: rocprofv3 kernel-trace durations (HIP-event pairs add ~4 us, which
+        # matters for the us-scale head kernels) and SQ counters, from the committed profiles of this command
+        prof = committed_profile("r02_bench_mfma.json", args)   # tools/profile_passes.sh + tools/pmc_mfma.py
+        for name, k in kernels.items():
+            p = prof.get(name)
+            if not p:
+                continue
+            k["rocprof_avg_us"] = p["avg_us"]
+            if min(k["avg_us"], p["avg_us"]) < 30.0:
+                work = k["flops"] / 1e12 if k["bound"] == "mfma" else k["bytes"] / 1e9
+                k["achieved_rocprof"] = round(work / (p["avg_us"] * 1e-6), 3)
+                k["frac_rocprof"] = round(k["achieved_rocprof"] / k["peak"], 5)
+            for key in ("mfma_util", "mfma_busy_of_sq_busy", "lds_conflict_share", "occupancy"):
+                if key in p and (k["bound"] == "mfma" or not key.startswith("mfma")):
+                    k[key] = p[key]
+        if world > 1:
+            result["dist"] = dist_info
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(result), flush=True)

@@ -120,6 +120,8 @@ def _stream():
 # ---- optional per-kernel HIP-event timing (bench.py): one entry point = one launch, so an event
 # pair recorded on the launch stream around a call times exactly that kernel.
 EVENT_LOG = None  # None = off; dict name -> list[(start, end)] when bench.py turns it on
+LAUNCH_ORDER = None  # None = off; list of names in launch order (one entry per launch) while EVENT_LOG is on:
+#                      lets tools/pmc_mfma.py align a rocprofv3 dispatch table with the bench's kernel names
 
 
 class _timed:
@@ -134,6 +136,8 @@ class _timed:
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
             self.s.record()  # current stream == the stream the kernel is launched on
+            if LAUNCH_ORDER is not None:
+                LAUNCH_ORDER.append(self.name)
 
     def __exit__(self, *exc):
         if EVENT_LOG is not None:

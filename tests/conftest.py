@@ -9,6 +9,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Same in-tree MIOpen user find-db / kernel cache as bench.py: the PyTorch wheel ships no gfx950 kernel
+# database, so without it every convolution shape is JIT-compiled on first use (minutes for the
+# ResNet-50 @224 / @448 tests on a fresh box).  Only affects the time to the first launch.
+_MIOPEN_DIR = os.path.join(ROOT, ".miopen")
+os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(_MIOPEN_DIR, "db"))
+os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(_MIOPEN_DIR, "cache"))
+for _d in (os.environ["MIOPEN_USER_DB_PATH"], os.environ["MIOPEN_CUSTOM_CACHE_DIR"]):
+    os.makedirs(_d, exist_ok=True)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

@@ -171,3 +171,34 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, sync_bn):
         for n, b1 in one["buffers"].items():
             assert torch.equal(r0["buffers"][n], r1["buffers"][n]), n
             np.testing.assert_allclose(r0["buffers"][n].numpy(), b1.numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("graph", ["auto", "0"], ids=["split_graphs", "eager"])
+def test_bench_two_ranks_on_one_gpu_emits_a_valid_line(graph):
+    """The N > 1 leg of bench.py itself (the command the driver launches for SCALE), as two ranks sharing
+    cuda:0 over gloo: launch mode, aggregate accounting, the parity deltas and the dist record."""
+    import json
+
+    port = free_port()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--resnet", "18",
+           "--pairs", "8", "--size", "64", "--graph", graph]
+    env = dict(os.environ, PECLR_DIST_BACKEND="gloo", PECLR_SHARE_DEVICE="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port))
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, cwd=ROOT) for r in range(2)]
+    outs = [p.communicate(timeout=800) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1].decode()[-3000:] for o in outs)
+    lines = [ln for ln in outs[0][0].decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][0].decode().splitlines() if ln.startswith("{")]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak" and r["unit"] == "images/sec"
+    assert r["config"]["global_batch"] == 2 * 2 * 8 and r["config"]["parallelism"] == "dp2"
+    assert r["value"] == pytest.approx(2 * 2 * 8 * 3 / (r["ms_per_step"] * 3e-3), rel=1e-3)   # whole-job aggregate
+    assert np.isfinite(r["loss"]) and 0 < r["loss"] < 10
+    assert ("two hipGraph replays" in r["config"]["launch"]) == (graph == "auto")
+    assert r["loss_delta_vs_oracle"] <= 1e-4 and r["sim_max_abs_delta"] <= 1e-4
+    d = r["dist"]
+    assert d["ranks_seen"] == 2 and d["backend"] == "gloo" and len(d["grad_buckets"]) >= 1
+    assert "cpu_baseline" not in r           # rank 0 at N = 1 only
+    assert r["roofline"]["kernel"] in r["kernels"]

@@ -1149,3 +1149,110 @@ def test_align_large_m_variants_match_small_variant(capi, n):
     np.testing.assert_allclose(host(z[sel]), z_ref, atol=2e-6)
     got = host(stats[sel]).reshape(2, len(idx1), 8).mean(1).reshape(16)
     np.testing.assert_allclose(got, stats_ref, atol=2e-6)
+
+
+@pytest.mark.parametrize("buckets", [False, True], ids=["one_graph", "split_graphs"])
+def test_ragged_batch_after_a_replay_does_not_accumulate_onto_stale_gradients(buckets):
+    """fit(hip_graph=True): capture on batch 0, replay batch 1, then an off-shape batch runs eagerly.  A captured
+    backward OVERWRITES its gradient buffers and nothing zeroes them, so the eager fallback must start from
+    clean gradients: the gradient the optimiser sees on the ragged step must be the eager run's, not
+    g_previous + g_new (which would be off by ~100 %).  Also: restoring optimiser state after a step makes the
+    fused work list follow the new moment buffers."""
+    import copy
+    import warnings
+
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config
+    from peclr_amd.bn2d import enable_hip_batchnorm
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(23)
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, augmentation=["crop", "rotate"],
+                         batch_size=8, num_samples=38, warmup_epochs=1, pretrained=False)
+    base = Hybrid2Model(cfg).to(DEV).train()
+    base.encoder = base.encoder.to(memory_format=torch.channels_last)
+    enable_hip_batchnorm(base.encoder)
+
+    def make(n, seed):
+        g = torch.Generator().manual_seed(seed)
+        b = {"transformed_image1": torch.randn(n, 3, 64, 64, generator=g), "transformed_image2": torch.randn(n, 3, 64, 64, generator=g),
+             "jitter_x_1": torch.randint(-14, 1, (n,), generator=g), "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+             "jitter_y_1": torch.randint(-14, 1, (n,), generator=g), "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+             "angle_1": torch.randint(-45, 46, (n,), generator=g).double(), "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+        b = {k: v.to(DEV) for k, v in b.items()}
+        for k in ("transformed_image1", "transformed_image2"):
+            b[k] = b[k].contiguous(memory_format=torch.channels_last)
+        return b
+
+    seq = [make(8, 1), make(8, 2), make(6, 3)]
+    seen = {}
+    for graph in (False, True):
+        model = copy.deepcopy(base)
+        tr = Trainer(max_epochs=5, hip_graph=graph, grad_buckets=True if buckets else None).attach(model)
+        tr.zero_grad()
+        real = tr.optimizer.step
+        grabbed = []
+
+        def spy(*a, _real=real, _model=model, _grabbed=grabbed, **kw):
+            _grabbed.append([p.grad.detach().clone() for p in _model.parameters() if p.grad is not None])
+            return _real(*a, **kw)
+
+        tr.optimizer.step = spy
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step = tr._graph_step if graph else tr.training_micro_step
+            for i, b in enumerate(seq):
+                step(b, i, i == len(seq) - 1)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert tr.global_step == 3
+        seen[graph] = grabbed[-1]                        # the ragged step always goes through optimizer.step()
+        if graph and not buckets:
+            # the graph's gradient buffers are back in place for the next replay
+            assert all(p.grad is g for p, g in tr._static_grads)
+    num = sum(float((a - b).double().pow(2).sum()) for a, b in zip(seen[False], seen[True]))
+    den = sum(float(a.double().pow(2).sum()) for a in seen[False])
+    assert len(seen[False]) == len(seen[True]) and (num / den) ** 0.5 <= 3e-2, (num / den) ** 0.5
+
+
+def test_fused_optimizer_follows_moments_restored_by_load_state_dict():
+    """A step, then load_state_dict (new exp_avg / exp_avg_sq tensors), then a step: the fused kernel must
+    update the RESTORED moments (the cached device pointer table used to keep the old addresses)."""
+    from peclr_amd.optim import LARSAdam
+
+    torch.manual_seed(2)
+    ps = [torch.nn.Parameter(torch.randn(300, 70, device=DEV)), torch.nn.Parameter(torch.randn(5000, device=DEV))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    fused = LARSAdam([{"params": ps, "weight_decay": 1e-3}], lr=1e-2, fused=True)
+    ref = LARSAdam([{"params": qs, "weight_decay": 1e-3}], lr=1e-2, fused=False)
+    for step in range(3):
+        gs = [torch.randn_like(p) for p in ps]
+        for p, q, g in zip(ps, qs, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        fused.step()
+        ref.step()
+        if step == 0:      # round-trip both optimisers through their state dicts (fresh moment tensors)
+            fused.load_state_dict(copy_state(fused.state_dict()))
+            ref.load_state_dict(copy_state(ref.state_dict()))
+    for p, q in zip(ps, qs):
+        np.testing.assert_allclose(host(p), host(q), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(host(fused.state[p]["exp_avg_sq"]), host(ref.state[q]["exp_avg_sq"]), rtol=2e-5, atol=1e-9)
+    # write-back mode leaves the LARS-scaled gradient in .grad, like the reference's wrapper
+    wb = LARSAdam([{"params": [torch.nn.Parameter(ps[0].detach().clone())], "weight_decay": 1e-3}], lr=1e-2, fused=True,
+                  write_back=True)
+    wq = LARSAdam([{"params": [torch.nn.Parameter(ps[0].detach().clone())], "weight_decay": 1e-3}], lr=1e-2, fused=False,
+                  write_back=True)
+    g = torch.randn_like(ps[0])
+    for o in (wb, wq):
+        o.param_groups[0]["params"][0].grad = g.clone()
+        o.step()
+    a, b = wb.param_groups[0]["params"][0], wq.param_groups[0]["params"][0]
+    np.testing.assert_allclose(host(a.grad), host(b.grad), rtol=2e-5, atol=1e-8)
+    assert not torch.equal(a.grad, g)
+    np.testing.assert_allclose(host(a), host(b), rtol=2e-5, atol=2e-6)
+
+
+def copy_state(sd):
+    import copy
+
+    return copy.deepcopy(sd)
