@@ -71,6 +71,9 @@ def parse():
                     help="1: every step draws a fresh batch through the GPU two-view augmentation (uint8 224x224 source "
                          "images + 2.5D joints resident in HBM -> rotate / crop / resize / colour jitter / normalise "
                          "kernels -> batch dict) instead of re-using one synthetic batch; the metric's default is 0")
+    ap.add_argument("--checkpoint", type=int, default=0,
+                    help="1: activation checkpointing in the encoder (residual blocks keep only their input for backward "
+                         "and re-run there): for batch sizes / resolutions beyond the activation budget; ~1/3 more compute")
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--sync-bn", type=int, default=0,
                     help="1: BatchNorm statistics over the global batch (exact N-rank == 1-device semantics, two small "
@@ -359,7 +362,7 @@ def main():
                 if getattr(m, "hip_fork", False):
                     m.hip_fork = False
     trainer = Trainer(max_epochs=100, accumulate_grad_batches=args.accum, precision=args.dtype,
-                      sync_batchnorm=bool(args.sync_bn)).attach(model)
+                      sync_batchnorm=bool(args.sync_bn), activation_checkpointing=bool(args.checkpoint)).attach(model)
     trainer.zero_grad()
     batch = synthetic_batch(args.pairs, args.size, 5 + rank, device, channels_last=bool(args.channels_last))
 
@@ -510,7 +513,7 @@ def main():
                                    f"views per GPU, crop+rotate equivariance alignment, NT-Xent tau=0.5, "
                                    f"LARS(Adam) step, {args.dtype}",
                        "global_batch": world * 2 * args.pairs * args.accum, "parallelism": f"dp{world}",
-                       "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn, "fork_gemm": bool(fused_bn and args.fork_gemm),
+                       "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn, "fork_gemm": bool(fused_bn and args.fork_gemm), "activation_checkpointing": bool(args.checkpoint),
                        "launch": ("two hipGraph replays per step (forward to z | backward from dz), collectives, "
                                   "NT-Xent and optimiser eager between/after them" if split else
                                   f"{args.accum} hipGraph replays (micro-batch forward + backward) + eager accumulate / optimiser per step"

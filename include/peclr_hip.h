@@ -258,6 +258,28 @@ int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y, const uin
                          const float* save_invstd, const float* scale_shift, const float* coef,
                          void* dx, void* d_residual, peclr_stream_t stream);
 
+/* Encoder tail: the last residual block's BatchNorm2d + `out += identity` + ReLU, then
+ * AdaptiveAvgPool2d((1,1)) and `.flatten(1)` (features[7][-1].bn*, features[8] and the flatten of
+ * ResNetModel.forward, resnet_model.py:24-26,47), as one pass that never writes the [N][HW][C]
+ * activation: only `pooled` = its per-image channel means, fp32 [N][C] -- the encoder output the
+ * projection head's first GEMM (peclr_gemm_f32, K1) reads directly -- and the 1-bit ReLU mask.
+ * Forward: peclr_bn2d_stats -> peclr_bn2d_finalize_f32 (on x, R = N*HW) -> peclr_bn2d_apply_avgpool.
+ * Backward: the pool's gradient is a broadcast, dy[n][p][c] = d_pooled[n][c] / HW, formed on the fly
+ * (no [R][C] gradient tensor): peclr_bn2d_bwd_reduce_avgpool -> peclr_bn2d_bwd_finalize_f32 ->
+ * peclr_bn2d_bwd_apply_avgpool (dx and d_residual = masked dy, both [R][C] of io_dtype).
+ * Needs C % 32 == 0 and a residual (every ResNet's last block).                                  */
+int peclr_bn2d_apply_avgpool(const void* x, const void* residual, int io_dtype, int N, int HW, int C,
+                             const float* scale_shift, float* pooled, uint32_t* relu_mask,
+                             peclr_stream_t stream);
+int peclr_bn2d_bwd_reduce_avgpool(const float* d_pooled, const void* x, const uint32_t* relu_mask,
+                                  int io_dtype, int N, int HW, int C, const float* save_mean,
+                                  const float* save_invstd, const float* scale_shift, float* partial,
+                                  int n_split, peclr_stream_t stream);
+int peclr_bn2d_bwd_apply_avgpool(const float* d_pooled, const void* x, const uint32_t* relu_mask,
+                                 int io_dtype, int N, int HW, int C, const float* save_mean,
+                                 const float* save_invstd, const float* scale_shift, const float* coef,
+                                 void* dx, void* d_residual, peclr_stream_t stream);
+
 /* Stem: BatchNorm2d + ReLU + MaxPool2d(3, stride 2, padding 1) in one pass (features[1..3] of the
  * torchvision ResNet the reference wraps, resnet_model.py:15-26); x is [N][H][W][C] NHWC, the pooled
  * output [N][PH][PW][C] with PH = (H-1)/2 + 1.  The un-pooled activation is never written.  Forward:

@@ -54,6 +54,9 @@ SIGNATURES = {
     "peclr_bn2d_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "peclr_bn2d_bwd_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_bn2d_bwd_apply": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "peclr_bn2d_apply_avgpool": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "peclr_bn2d_bwd_reduce_avgpool": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "peclr_bn2d_bwd_apply_avgpool": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "peclr_bn2d_pool_n_split": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "peclr_bn2d_pool_apply": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_bn2d_pool_bwd_reduce": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
@@ -491,6 +494,63 @@ def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres, sync_group=Non
                                         ss.data_ptr(), coef.data_ptr(), dx.data_ptr(),
                                         dres.data_ptr() if dres is not None else None, _stream())
     _check(rc, "peclr_bn2d_bwd_apply")
+    return dx, dparams[0], dparams[1], dres
+
+
+def bn2d_avgpool_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group=None):
+    """Encoder tail: mean over H x W of relu(bn(x) + residual) as fp32 [N, C]; the activation itself is not
+    written.  Returns (pooled, relu mask, save, scale_shift)."""
+    n, c, h, w = x.shape
+    r = n * h * w
+    if c % 32 or residual is None:
+        raise PeclrHipError("fused BN + add + ReLU + average pool needs a residual and C % 32 == 0")
+    io, e = _IO[x.dtype]
+    save, ss = _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group)
+    pooled = torch.empty((n, c), device=x.device, dtype=torch.float32)
+    mask = torch.empty((r, c // 32), device=x.device, dtype=torch.int32)
+    with _timed("bn2d_apply_avgpool", 2 * e * r * c + r * c // 8 + 4 * n * c):
+        rc = lib().peclr_bn2d_apply_avgpool(_nhwc_ptr(x, "bn2d x"), _nhwc_ptr(residual, "bn2d residual", x.dtype), io, n,
+                                            h * w, c, ss.data_ptr(), pooled.data_ptr(), mask.data_ptr(), _stream())
+    _check(rc, "peclr_bn2d_apply_avgpool")
+    return pooled, mask, save, ss
+
+
+def bn2d_avgpool_bwd(d_pooled, x, mask, save, ss, training, sync_group=None):
+    """Backward of bn2d_avgpool_fwd from the fp32 [N, C] gradient of the pooled output: (dx, dgamma, dbeta,
+    d_residual)."""
+    n, c, h, w = x.shape
+    r = n * h * w
+    io, e = _IO[x.dtype]
+    dev = x.device
+    ns = bn2d_n_split(r, c, io)
+    partial = torch.empty((2 * ns, c), device=dev, dtype=torch.float32)
+    dparams = torch.empty((2, c), device=dev, dtype=torch.float32)
+    coef = torch.empty((2, c), device=dev, dtype=torch.float32)
+    dx = torch.empty_like(x, memory_format=torch.channels_last)
+    dres = torch.empty_like(x, memory_format=torch.channels_last)
+    dp = _ptr(d_pooled, what="d_pooled")
+    xp, mp = _nhwc_ptr(x, "bn2d x"), _ptr(mask, torch.int32, "relu mask")
+    with _timed("bn2d_bwd_reduce_avgpool", e * r * c + r * c // 8 + 4 * n * c):
+        rc = lib().peclr_bn2d_bwd_reduce_avgpool(dp, xp, mp, io, n, h * w, c, save[0].data_ptr(), save[1].data_ptr(),
+                                                 ss.data_ptr(), partial.data_ptr(), ns, _stream())
+    _check(rc, "peclr_bn2d_bwd_reduce_avgpool")
+    if training and sync_group is not None:
+        local, total = _sync_totals(partial, ns, c, r, sync_group)
+        with _timed("bn2d_bwd_finalize", 32 * c):
+            rc = lib().peclr_bn2d_bwd_finalize_totals_f32(local.data_ptr(), total.data_ptr(), c, 1, ss.data_ptr(),
+                                                          dparams[0].data_ptr(), dparams[1].data_ptr(), coef.data_ptr(),
+                                                          _stream())
+        _check(rc, "peclr_bn2d_bwd_finalize_totals_f32")
+    else:
+        with _timed("bn2d_bwd_finalize", 8 * ns * c):
+            rc = lib().peclr_bn2d_bwd_finalize_f32(partial.data_ptr(), ns, r, c, int(training), ss.data_ptr(),
+                                                   dparams[0].data_ptr(), dparams[1].data_ptr(), coef.data_ptr(),
+                                                   _stream())
+        _check(rc, "peclr_bn2d_bwd_finalize_f32")
+    with _timed("bn2d_bwd_apply_avgpool", 3 * e * r * c + r * c // 8 + 4 * n * c):
+        rc = lib().peclr_bn2d_bwd_apply_avgpool(dp, xp, mp, io, n, h * w, c, save[0].data_ptr(), save[1].data_ptr(),
+                                                ss.data_ptr(), coef.data_ptr(), dx.data_ptr(), dres.data_ptr(), _stream())
+    _check(rc, "peclr_bn2d_bwd_apply_avgpool")
     return dx, dparams[0], dparams[1], dres
 
 

@@ -22,6 +22,50 @@ from torch.nn import functional as F
 from . import _capi
 
 
+# ---- activation checkpointing: a residual block keeps only its INPUT for the
+# backward pass and re-runs its forward there.  While a block is being re-run, BatchNorm layers must not
+# move their running statistics a second time (`_RECOMPUTING`); batch statistics are recomputed and are
+# identical (the kernels are deterministic).
+_RECOMPUTING = False
+
+
+class _CheckpointedBlock(torch.autograd.Function):
+    """y = run(x) without keeping run's intermediate activations; backward re-runs `run` on the saved input
+    under the autocast state of the forward and back-propagates through that second graph (parameter
+    gradients accumulate into `.grad` from inside, so gradient hooks -- the all-reduce buckets -- still fire)."""
+
+    @staticmethod
+    def forward(ctx, run, x):
+        ctx.run = run
+        ctx.autocast = (torch.is_autocast_enabled(x.device.type), torch.get_autocast_dtype(x.device.type))
+        ctx.save_for_backward(x)
+        with torch.no_grad():
+            return run(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        global _RECOMPUTING
+        (x,) = ctx.saved_tensors
+        x = x.detach().requires_grad_(True)
+        enabled, dtype = ctx.autocast
+        was = _RECOMPUTING
+        _RECOMPUTING = True
+        try:
+            with torch.enable_grad(), torch.autocast(x.device.type, dtype=dtype, enabled=enabled):
+                y = ctx.run(x)
+        finally:
+            _RECOMPUTING = was
+        torch.autograd.backward((y,), (dy.to(y.dtype),))
+        return None, x.grad
+
+
+def checkpoint_block(run, x: Tensor) -> Tensor:
+    """`run(x)` with activation checkpointing when a gradient will flow (otherwise plain)."""
+    if torch.is_grad_enabled() and x.requires_grad and not _RECOMPUTING:
+        return _CheckpointedBlock.apply(run, x)
+    return run(x)
+
+
 class _BN2dAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool):
@@ -29,8 +73,8 @@ class _BN2dAct(torch.autograd.Function):
         # the ReLU mask can be recomputed from x unless a residual was added before it; then the
         # forward writes a 1-bit mask (or, for C % 32 != 0, the backward re-reads y)
         need_mask = relu and residual is not None
-        y, save, ss, mask = _capi.bn2d_fwd(x, residual, weight, bias, bn.running_mean, bn.running_var,
-                                           bn.num_batches_tracked, training, bn.eps,
+        rm, rv, nbt = bn._stat_buffers(training)
+        y, save, ss, mask = _capi.bn2d_fwd(x, residual, weight, bias, rm, rv, nbt, training, bn.eps,
                                            bn.momentum if bn.momentum is not None else 0.1, relu, want_mask=need_mask,
                                            sync_group=bn.sync_group if training else None)
         keep = mask if mask is not None else (y if need_mask else None)
@@ -60,8 +104,8 @@ class _BN2dReluPool(torch.autograd.Function):
     def forward(ctx, x, weight, bias, bn: "FusedBatchNormAct2d"):
         training = bn.training or not bn.track_running_stats
         sync = bn.sync_group if training else None
-        y, x_at_max, code, save, ss = _capi.bn2d_pool_fwd(x, weight, bias, bn.running_mean, bn.running_var,
-                                                bn.num_batches_tracked, training, bn.eps,
+        rm, rv, nbt = bn._stat_buffers(training)
+        y, x_at_max, code, save, ss = _capi.bn2d_pool_fwd(x, weight, bias, rm, rv, nbt, training, bn.eps,
                                                 bn.momentum if bn.momentum is not None else 0.1, sync_group=sync)
         ctx.save_for_backward(x, x_at_max, code, save, ss)
         ctx.cfg = (training, sync)
@@ -74,6 +118,31 @@ class _BN2dReluPool(torch.autograd.Function):
         dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         dx, dgamma, dbeta = _capi.bn2d_pool_bwd(dy, x, x_at_max, code, save, ss, training, sync_group=sync)
         return dx, dgamma, dbeta, None
+
+
+class _BN2dAddReluAvgPool(torch.autograd.Function):
+    """Encoder tail (the last residual block's bn + identity + ReLU, then AdaptiveAvgPool2d((1, 1)) and
+    flatten): returns the pooled fp32 [N, C] features; the [N, C, H, W] activation is never materialised,
+    and the backward forms the pool's broadcast gradient on the fly."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d"):
+        training = bn.training or not bn.track_running_stats
+        sync = bn.sync_group if training else None
+        rm, rv, nbt = bn._stat_buffers(training)
+        pooled, mask, save, ss = _capi.bn2d_avgpool_fwd(x, residual, weight, bias, rm, rv, nbt, training, bn.eps,
+                                                        bn.momentum if bn.momentum is not None else 0.1, sync_group=sync)
+        ctx.save_for_backward(x, mask, save, ss)
+        ctx.cfg = (training, sync)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, d_pooled):
+        x, mask, save, ss = ctx.saved_tensors
+        training, sync = ctx.cfg
+        dx, dgamma, dbeta, dres = _capi.bn2d_avgpool_bwd(d_pooled.float().contiguous(), x, mask, save, ss, training,
+                                                         sync_group=sync)
+        return dx, dgamma, dbeta, dres, None
 
 
 class _ForkConv1x1(torch.autograd.Function):
@@ -117,9 +186,9 @@ def fork_conv1x1(conv: nn.Conv2d, x: Tensor):
     """`(conv(x), x)` with the fused input gradient when `conv.hip_fork` is set (enable_hip_batchnorm does
     it for the bottlenecks' first 1x1 convolution) and the activations are channels_last on a HIP device,
     fp32 (no autocast) or bf16 (under bf16 autocast); the stock ops otherwise."""
-    autocast = torch.is_autocast_enabled()
+    autocast = torch.is_autocast_enabled("cuda")
     dtype_ok = ((x.dtype == torch.float32 and not autocast)
-                or (x.dtype == torch.bfloat16 and autocast and torch.get_autocast_gpu_dtype() == torch.bfloat16))
+                or (x.dtype == torch.bfloat16 and autocast and torch.get_autocast_dtype("cuda") == torch.bfloat16))
     ok = (getattr(conv, "hip_fork", False) and x.is_cuda and dtype_ok
           and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
           and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and x.requires_grad
@@ -137,9 +206,20 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
         self.hip = False
         self.default_relu = False  # stem BN inside an nn.Sequential: fuse the ReLU that follows it
         self.default_pool = False  # ... and the MaxPool2d(3, 2, 1) after that (the encoder's stem)
+        # last BatchNorm of layer4 inside the encoder wrapper: in HIP mode its fused pass also performs the
+        # AdaptiveAvgPool2d((1, 1)) + flatten that follow the block and returns fp32 [N, C]
+        self.tail_avgpool = False
         # data parallel: a process group -> training statistics over the rows of ALL its ranks (what one
         # device holding the concatenated batch computes); None -> per-rank statistics (DDP's default)
         self.sync_group = None
+
+    def _stat_buffers(self, training: bool):
+        """Running statistics the kernels should update -- none while a checkpointed block is being re-run in
+        the backward pass (the first run already moved them), unless they are needed as the common shift of
+        synchronised statistics."""
+        if training and _RECOMPUTING and self.sync_group is None:
+            return None, None, None
+        return self.running_mean, self.running_var, self.num_batches_tracked
 
     def forward(self, x: Tensor, residual: Optional[Tensor] = None, relu: Optional[bool] = None) -> Tensor:
         relu = self.default_relu if relu is None else relu
@@ -149,10 +229,15 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
                 raise _capi.PeclrHipError("fused BatchNorm2d needs affine=True and a fixed momentum")
             if pool:
                 return _BN2dReluPool.apply(x, self.weight, self.bias, self)
+            if self.tail_avgpool and relu and residual is not None and self.num_features % 32 == 0:
+                return _BN2dAddReluAvgPool.apply(x, self.weight, self.bias, residual, self)
             return _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu)
         if self.sync_group is not None and self.training:
             raise _capi.PeclrHipError("synchronised statistics are implemented by the HIP kernels only (hip=True)")
-        y = super().forward(x)
+        if self.training and _RECOMPUTING:   # re-run of a checkpointed block: batch statistics, buffers untouched
+            y = F.batch_norm(x, None, None, self.weight, self.bias, True, 0.0, self.eps)
+        else:
+            y = super().forward(x)
         if residual is not None:
             y = y + residual
         y = F.relu(y) if relu else y

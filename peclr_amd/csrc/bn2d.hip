@@ -359,6 +359,56 @@ __global__ __launch_bounds__(T) void bn2d_apply_kernel(const IO* __restrict__ x,
     }
 }
 
+// Last block of layer4: BatchNorm2d + identity + ReLU + AdaptiveAvgPool2d((1, 1)) + flatten in one pass
+// (resnet_model.py:24-26 features[7][-1] .. features[8], then `.flatten(1)`): the [N, HW, C] activation is
+// never written -- no later kernel reads it (the pool's backward is a broadcast, this BatchNorm's backward
+// reads x and the 1-bit mask) -- only its per-image channel means, as the fp32 [N, C] encoder output the
+// projection head's first GEMM consumes.  grid = (column blocks, images); the block's row lanes walk the
+// image's HW rows.
+template <typename IO>
+__global__ __launch_bounds__(T) void bn2d_apply_avgpool_kernel(const IO* __restrict__ x, const IO* __restrict__ res, Geo g,
+                                                               const float* __restrict__ scale_shift, float inv_hw,
+                                                               float* __restrict__ pooled, unsigned* __restrict__ relu_mask) {
+    constexpr int W = Word<IO>::W, U = Word<IO>::U;
+    __shared__ float red[W * T];
+    int col, r0, r1, rl;
+    thread_geo<W>(g, col, r0, r1, rl);   // rows_per_block = HW: [r0, r1) = this image's rows
+    const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
+    Fv<W> sum = zero<W>();
+    auto emit = [&](int row, const Fv<W>& v, const Fv<W>& w) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const float a = fmaf(v.v[k], sc.v[k], sh.v[k]) + w.v[k];
+            bits |= (a > 0.f ? 1u : 0u) << k;
+            sum.v[k] += fmaxf(a, 0.f);
+        }
+        mask_store<W>(relu_mask, row, col, g.C, bits);
+    };
+    int r = r0 + rl;
+    for (; r + (U - 1) * g.RPP < r1; r += U * g.RPP) {
+        Fv<W> v[U], w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t o = (size_t)(r + u * g.RPP) * g.C + col;
+            v[u] = Word<IO>::load(x + o);
+            w[u] = Word<IO>::load(res + o);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) emit(r + u * g.RPP, v[u], w[u]);
+    }
+    for (; r < r1; r += g.RPP) {
+        const size_t o = (size_t)r * g.C + col;
+        emit(r, Word<IO>::load(x + o), Word<IO>::load(res + o));
+    }
+    sum = lane_reduce<W>(sum, red, g, rl);
+    if (rl == 0) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) sum.v[k] *= inv_hw;
+        storep<W>(pooled + (size_t)blockIdx.y * g.C + col, sum);
+    }
+}
+
 // ------------------------------------------------------------------ backward
 // MASK: 0 = no ReLU, 1 = ReLU mask recomputed from x (no residual), 2 = ReLU mask read from y,
 //       3 = ReLU mask read from the 1-bit-per-element mask the forward wrote.
@@ -377,15 +427,30 @@ __device__ __forceinline__ Fv<W> masked(const Fv<W>& d, const Fv<W>& xv, const F
     return r;
 }
 
-template <typename IO, int MASK>
+// POOL: the incoming gradient is that of the fused average pool: dy[row] = d_pooled[row / hw] / hw, an
+// fp32 [N, C] matrix broadcast over the image's rows (no [R, C] gradient tensor exists).
+template <int W>
+__device__ __forceinline__ Fv<W> pooled_dy(const float* __restrict__ d_pooled, int row, int hw, float inv_hw, int C, int col) {
+    Fv<W> d = loadp<W>(d_pooled + (size_t)(row / hw) * C + col);
+#pragma unroll
+    for (int k = 0; k < W; ++k) d.v[k] *= inv_hw;
+    return d;
+}
+
+template <typename IO, int MASK, bool POOL = false>
 __global__ __launch_bounds__(T) void bn2d_bwd_reduce_kernel(const IO* __restrict__ dy, const IO* __restrict__ x,
                                                             const IO* __restrict__ y, const unsigned* __restrict__ relu_mask, Geo g,
                                                             const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
-                                                            const float* __restrict__ scale_shift, float* __restrict__ partial) {
+                                                            const float* __restrict__ scale_shift, float* __restrict__ partial,
+                                                            const float* __restrict__ d_pooled = nullptr, int hw = 1, float inv_hw = 1.f) {
     constexpr int W = Word<IO>::W, U = Word<IO>::U;
     __shared__ float red[W * T];
     int col, r0, r1, rl;
     thread_geo<W>(g, col, r0, r1, rl);
+    auto load_dy = [&](int row) -> Fv<W> {
+        if constexpr (POOL) return pooled_dy<W>(d_pooled, row, hw, inv_hw, g.C, col);
+        else return Word<IO>::load(dy + (size_t)row * g.C + col);
+    };
     const Fv<W> mean = loadp<W>(save_mean + col), invstd = loadp<W>(save_invstd + col);
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
     Fv<W> sb = zero<W>(), sg = zero<W>();
@@ -404,7 +469,7 @@ __global__ __launch_bounds__(T) void bn2d_bwd_reduce_kernel(const IO* __restrict
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t o = (size_t)(r + u * g.RPP) * g.C + col;
-            d[u] = Word<IO>::load(dy + o);
+            d[u] = load_dy(r + u * g.RPP);
             xv[u] = Word<IO>::load(x + o);
             if (MASK == 2) yv[u] = Word<IO>::load(y + o);
             mb[u] = MASK == 3 ? mask_load<W>(relu_mask, r + u * g.RPP, col, g.C) : 0u;
@@ -415,7 +480,7 @@ __global__ __launch_bounds__(T) void bn2d_bwd_reduce_kernel(const IO* __restrict
     for (; r < r1; r += g.RPP) {
         const size_t o = (size_t)r * g.C + col;
         const Fv<W> xv = Word<IO>::load(x + o);
-        acc(Word<IO>::load(dy + o), xv, MASK == 2 ? Word<IO>::load(y + o) : xv,
+        acc(load_dy(r), xv, MASK == 2 ? Word<IO>::load(y + o) : xv,
             MASK == 3 ? mask_load<W>(relu_mask, r, col, g.C) : 0u);
     }
     sb = lane_reduce<W>(sb, red, g, rl);
@@ -446,15 +511,20 @@ __global__ __launch_bounds__(FT) void bn2d_bwd_finalize_kernel(const float* __re
     coef[C + c] = training ? (float)(-k1 * sg / R) : 0.f;
 }
 
-template <typename IO, int MASK, bool DRES>
+template <typename IO, int MASK, bool DRES, bool POOL = false>
 __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict__ dy, const IO* __restrict__ x,
                                                            const IO* __restrict__ y, const unsigned* __restrict__ relu_mask, Geo g,
                                                            const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                            const float* __restrict__ scale_shift, const float* __restrict__ coef,
-                                                           IO* __restrict__ dx, IO* __restrict__ dres) {
+                                                           IO* __restrict__ dx, IO* __restrict__ dres,
+                                                           const float* __restrict__ d_pooled = nullptr, int hw = 1, float inv_hw = 1.f) {
     constexpr int W = Word<IO>::W, U = Word<IO>::U;
     int col, r0, r1, rl;
     thread_geo<W>(g, col, r0, r1, rl);
+    auto load_dy = [&](int row) -> Fv<W> {
+        if constexpr (POOL) return pooled_dy<W>(d_pooled, row, hw, inv_hw, g.C, col);
+        else return Word<IO>::load(dy + (size_t)row * g.C + col);
+    };
     const Fv<W> mean = loadp<W>(save_mean + col), invstd = loadp<W>(save_invstd + col);
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
     const Fv<W> k2 = loadp<W>(coef + col), k3 = loadp<W>(coef + g.C + col);
@@ -476,7 +546,7 @@ __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict_
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t o = (size_t)(r + u * g.RPP) * g.C + col;
-            d[u] = Word<IO>::load(dy + o);
+            d[u] = load_dy(r + u * g.RPP);
             xv[u] = Word<IO>::load(x + o);
             if (MASK == 2) yv[u] = Word<IO>::load(y + o);
             mb[u] = MASK == 3 ? mask_load<W>(relu_mask, r + u * g.RPP, col, g.C) : 0u;
@@ -488,7 +558,7 @@ __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict_
     for (; r < r1; r += g.RPP) {
         const size_t o = (size_t)r * g.C + col;
         const Fv<W> xv = Word<IO>::load(x + o);
-        emit(o, Word<IO>::load(dy + o), xv, MASK == 2 ? Word<IO>::load(y + o) : xv,
+        emit(o, load_dy(r), xv, MASK == 2 ? Word<IO>::load(y + o) : xv,
              MASK == 3 ? mask_load<W>(relu_mask, r, col, g.C) : 0u);
     }
 }
@@ -965,5 +1035,70 @@ extern "C" int peclr_bn2d_pool_bwd_apply(const void* dy_pool, const void* x, con
         hipLaunchKernelGGL((bn2d_pool_bwd_apply_kernel<bf16_t>), dim3(blocks), dim3(T), 0, s, static_cast<const bf16_t*>(dy_pool),
                            static_cast<const bf16_t*>(x), code, g, save_mean, save_invstd, scale_shift, coef,
                            static_cast<bf16_t*>(dx));
+    return launch_status();
+}
+
+// ---- layer4's last block: BN + identity + ReLU + global average pool (+ flatten)
+extern "C" int peclr_bn2d_apply_avgpool(const void* x, const void* residual, int io_dtype, int N, int HW, int C,
+                                        const float* scale_shift, float* pooled, uint32_t* relu_mask, peclr_stream_t stream) {
+    if (!x || !residual || !scale_shift || !pooled || !relu_mask) return PECLR_ERR_NULL;
+    if (N <= 0 || HW <= 0 || C % 32 || (long long)N * HW > 0x7fffffffLL) return PECLR_ERR_SHAPE;
+    Plan p;
+    if (!plan_for(io_dtype, N * HW, C, 1, p)) return PECLR_ERR_SHAPE;
+    if (!all_aligned({x, residual, scale_shift, pooled})) return PECLR_ERR_ALIGN;
+    p.g.rows_per_block = HW;                       // one image per block row
+    const dim3 grid(p.grid.x, N);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float inv = 1.0f / (float)HW;
+    if (io_dtype == PECLR_DTYPE_F32)
+        hipLaunchKernelGGL((bn2d_apply_avgpool_kernel<float>), grid, dim3(T), 0, s, static_cast<const float*>(x),
+                           static_cast<const float*>(residual), p.g, scale_shift, inv, pooled, relu_mask);
+    else
+        hipLaunchKernelGGL((bn2d_apply_avgpool_kernel<bf16_t>), grid, dim3(T), 0, s, static_cast<const bf16_t*>(x),
+                           static_cast<const bf16_t*>(residual), p.g, scale_shift, inv, pooled, relu_mask);
+    return launch_status();
+}
+
+extern "C" int peclr_bn2d_bwd_reduce_avgpool(const float* d_pooled, const void* x, const uint32_t* relu_mask, int io_dtype,
+                                             int N, int HW, int C, const float* save_mean, const float* save_invstd,
+                                             const float* scale_shift, float* partial, int n_split, peclr_stream_t stream) {
+    if (!d_pooled || !x || !relu_mask || !save_mean || !save_invstd || !scale_shift || !partial) return PECLR_ERR_NULL;
+    if (N <= 0 || HW <= 0 || C % 32 || (long long)N * HW > 0x7fffffffLL) return PECLR_ERR_SHAPE;
+    Plan p;
+    if (n_split < 1 || !plan_for(io_dtype, N * HW, C, n_split, p)) return PECLR_ERR_SHAPE;
+    if (!all_aligned({d_pooled, x, partial})) return PECLR_ERR_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float inv = 1.0f / (float)HW;
+    if (io_dtype == PECLR_DTYPE_F32)
+        hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<float, 3, true>), p.grid, dim3(T), 0, s, (const float*)nullptr,
+                           static_cast<const float*>(x), (const float*)nullptr, relu_mask, p.g, save_mean, save_invstd, scale_shift,
+                           partial, d_pooled, HW, inv);
+    else
+        hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<bf16_t, 3, true>), p.grid, dim3(T), 0, s, (const bf16_t*)nullptr,
+                           static_cast<const bf16_t*>(x), (const bf16_t*)nullptr, relu_mask, p.g, save_mean, save_invstd,
+                           scale_shift, partial, d_pooled, HW, inv);
+    return launch_status();
+}
+
+extern "C" int peclr_bn2d_bwd_apply_avgpool(const float* d_pooled, const void* x, const uint32_t* relu_mask, int io_dtype,
+                                            int N, int HW, int C, const float* save_mean, const float* save_invstd,
+                                            const float* scale_shift, const float* coef, void* dx, void* d_residual,
+                                            peclr_stream_t stream) {
+    if (!d_pooled || !x || !relu_mask || !save_mean || !save_invstd || !scale_shift || !coef || !dx || !d_residual)
+        return PECLR_ERR_NULL;
+    if (N <= 0 || HW <= 0 || C % 32 || (long long)N * HW > 0x7fffffffLL) return PECLR_ERR_SHAPE;
+    Plan p;
+    if (!plan_for(io_dtype, N * HW, C, 0, p)) return PECLR_ERR_SHAPE;
+    if (!all_aligned({d_pooled, x, dx, d_residual})) return PECLR_ERR_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float inv = 1.0f / (float)HW;
+    if (io_dtype == PECLR_DTYPE_F32)
+        hipLaunchKernelGGL((bn2d_bwd_apply_kernel<float, 3, true, true>), p.grid, dim3(T), 0, s, (const float*)nullptr,
+                           static_cast<const float*>(x), (const float*)nullptr, relu_mask, p.g, save_mean, save_invstd, scale_shift,
+                           coef, static_cast<float*>(dx), static_cast<float*>(d_residual), d_pooled, HW, inv);
+    else
+        hipLaunchKernelGGL((bn2d_bwd_apply_kernel<bf16_t, 3, true, true>), p.grid, dim3(T), 0, s, (const bf16_t*)nullptr,
+                           static_cast<const bf16_t*>(x), (const bf16_t*)nullptr, relu_mask, p.g, save_mean, save_invstd,
+                           scale_shift, coef, static_cast<bf16_t*>(dx), static_cast<bf16_t*>(d_residual), d_pooled, HW, inv);
     return launch_status();
 }

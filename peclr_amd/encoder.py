@@ -18,6 +18,16 @@ from .bn2d import FusedBatchNormAct2d
 from .config import Config
 
 
+class TailAvgPool(nn.AdaptiveAvgPool2d):
+    """AdaptiveAvgPool2d((1, 1)) that lets an already pooled [N, C] tensor through unchanged."""
+
+    def __init__(self):
+        super().__init__(output_size=(1, 1))
+
+    def forward(self, x):
+        return x if x.dim() == 2 else super().forward(x)
+
+
 class ResNetModel(nn.Module):
     def __init__(self, config, mode: str = ""):
         super().__init__()
@@ -33,9 +43,13 @@ class ResNetModel(nn.Module):
         # writes the 112x112 activation.
         model.bn1.default_relu = True
         model.bn1.default_pool = True
+        # features.8: the global average pool.  In HIP mode the last block's final BatchNorm performs it inside
+        # its fused pass (bn + identity + ReLU + mean over H x W, fp32 [N, C] out: SURVEY.md section 8 f4) and
+        # this module receives an already pooled 2-D tensor, which it passes through.
+        last = model.layer4[-1]
+        (last.bn3 if hasattr(last, "bn3") else last.bn2).tail_avgpool = True
         self.features = nn.Sequential(model.conv1, model.bn1, nn.Identity(), nn.Identity(), model.layer1,
-                                      model.layer2, model.layer3, model.layer4,
-                                      nn.AdaptiveAvgPool2d(output_size=(1, 1)))
+                                      model.layer2, model.layer3, model.layer4, TailAvgPool())
         self.final_layer = nn.Sequential(nn.Linear(model.fc.in_features, 21 * 3 + 1))
 
     def get_resnet(self, resnet_name):

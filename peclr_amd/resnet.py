@@ -16,7 +16,7 @@ from typing import List, Type, Union
 import torch
 from torch import Tensor, nn
 
-from .bn2d import FusedBatchNormAct2d, fork_conv1x1
+from .bn2d import FusedBatchNormAct2d, checkpoint_block, fork_conv1x1
 
 
 def conv3x3(cin, cout, stride=1):
@@ -51,7 +51,12 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
+    checkpoint = False  # keep only the block input for backward and re-run the block there (set per instance)
+
     def forward(self, x: Tensor) -> Tensor:
+        return checkpoint_block(self._run, x) if self.checkpoint else self._run(x)
+
+    def _run(self, x: Tensor) -> Tensor:
         identity = x if self.downsample is None else self.downsample(x)
         out = _bn(self.bn1, self.conv1(x), relu=True)
         return _bn(self.bn2, self.conv2(out), identity, relu=True)
@@ -73,7 +78,12 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
+    checkpoint = False
+
     def forward(self, x: Tensor) -> Tensor:
+        return checkpoint_block(self._run, x) if self.checkpoint else self._run(x)
+
+    def _run(self, x: Tensor) -> Tensor:
         # x has two consumers; in backward "conv1's input gradient + the residual branch's gradient" is one GEMM
         out, identity = fork_conv1x1(self.conv1, x)
         if self.downsample is not None:
@@ -134,6 +144,18 @@ def _make(name: str, pretrained: Union[bool, str] = False, norm_layer=None, **kw
     if isinstance(pretrained, str):  # explicit weight file (no network on the target)
         model.load_state_dict(torch.load(pretrained, map_location="cpu"))
     return model
+
+
+def set_activation_checkpointing(module: nn.Module, enabled: bool = True) -> int:
+    """Every residual block under `module` keeps only its input for the backward pass and recomputes its
+    convolutions / BatchNorms there (one extra forward, ~1/3 more compute) -- activation memory drops from
+    "every tensor between two convolutions" to "one tensor per block".  Returns the number of blocks switched."""
+    n = 0
+    for m in module.modules():
+        if isinstance(m, (BasicBlock, Bottleneck)):
+            m.checkpoint = enabled
+            n += 1
+    return n
 
 
 def resnet18(pretrained=False, **kw): return _make("resnet18", pretrained, **kw)

@@ -35,8 +35,11 @@ class Trainer:
     def __init__(self, max_epochs: int = 1, accumulate_grad_batches: int = 1, precision: str = "fp32",
                  checkpoint_dir: Optional[str] = None, save_top_k: int = 1, process_group=None,
                  bucket_bytes: int = 32 << 20, channels_last: bool = False, grad_buckets=None,
-                 sync_batchnorm: bool = False, hip_graph: bool = False):
+                 sync_batchnorm: bool = False, hip_graph: bool = False, activation_checkpointing: bool = False):
         self.max_epochs = max_epochs
+        # True: residual blocks of the encoder keep only their input for backward and recompute the rest there
+        # (peclr_amd.resnet.set_activation_checkpointing): for batches / resolutions whose activations do not fit
+        self.activation_checkpointing = activation_checkpointing
         self.accumulate_grad_batches = accumulate_grad_batches
         # "fp32" | "bf16" | 16 / "16" / "fp16".  16 is the reference's default (training_config.json:9,
         # peclr_training.py:78-79: Lightning native AMP = fp16 autocast + a dynamic GradScaler); it is
@@ -75,6 +78,11 @@ class Trainer:
         model.setup("fit")
         pdist.broadcast_module_state(model, 0, self.process_group)
         self.model = model
+        if self.activation_checkpointing:
+            from .resnet import set_activation_checkpointing
+
+            if set_activation_checkpointing(model.encoder, True) == 0:
+                raise RuntimeError("activation_checkpointing: the encoder has no peclr_amd.resnet blocks")
         if self.sync_batchnorm and self.world_size > 1:
             self._enable_sync_batchnorm(model)
         if self.world_size > 1 or self.grad_buckets:

@@ -1256,3 +1256,110 @@ def copy_state(sd):
     import copy
 
     return copy.deepcopy(sd)
+
+
+@pytest.mark.parametrize("shape", [(8, 2048, 7, 7), (4, 512, 7, 7), (3, 512, 2, 2), (16, 2048, 14, 14), (5, 64, 3, 3),
+                                   (2, 256, 1, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_add_relu_avgpool_fused_matches_torch(shape, dtype, training):
+    """Encoder tail: bn + identity + ReLU + AdaptiveAvgPool2d((1,1)) + flatten in one
+    pass (fp32 [N, C] out, the activation never written), forward and backward, against float64 torch on the
+    same (bf16-rounded) inputs."""
+    from peclr_amd.bn2d import FusedBatchNormAct2d
+
+    n, c, h, w = shape
+    g = torch.Generator(device=DEV).manual_seed(n * c + h)
+    x = (torch.randn(shape, device=DEV, generator=g) * 1.3 + 0.2).to(dtype).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(shape, device=DEV, generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    bn = FusedBatchNormAct2d(c).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, device=DEV, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, device=DEV, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(c, device=DEV, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(c, device=DEV, generator=g) + 0.5)
+    bn.train(training)
+    ref = torch.nn.BatchNorm2d(c).to(DEV).double()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    ref.train(training)
+    bn.hip, bn.tail_avgpool = True, True
+    xf, rf = x.clone().requires_grad_(), res.clone().requires_grad_()
+    pooled = bn(xf, rf, True)
+    assert pooled.shape == (n, c) and pooled.dtype == torch.float32
+    xd, rd = x.double().requires_grad_(), res.double().requires_grad_()
+    want = torch.relu(ref(xd) + rd).mean(dim=(2, 3))
+    tol = 2e-5 if dtype == torch.float32 else 2e-5   # fp32 arithmetic on identical inputs either way
+    np.testing.assert_allclose(host(pooled), host(want), atol=tol * max(1.0, float(want.abs().max())), rtol=0)
+    gp = torch.randn(n, c, device=DEV, generator=g)
+    pooled.backward(gp)
+    want.backward(gp.double())
+    scale = max(1e-6, float(xd.grad.abs().max()))
+    gtol = 3e-5 if dtype == torch.float32 else 1.2e-2        # bf16: dx / d_residual are stored as bf16
+    np.testing.assert_allclose(host(xf.grad.double()), host(xd.grad), atol=gtol * scale, rtol=0)
+    np.testing.assert_allclose(host(rf.grad.double()), host(rd.grad), atol=gtol * max(1e-6, float(rd.grad.abs().max())), rtol=0)
+    np.testing.assert_allclose(host(bn.weight.grad.double()), host(ref.weight.grad),
+                               atol=1e-4 * max(1.0, float(ref.weight.grad.abs().max())), rtol=0)
+    np.testing.assert_allclose(host(bn.bias.grad.double()), host(ref.bias.grad),
+                               atol=1e-4 * max(1.0, float(ref.bias.grad.abs().max())), rtol=0)
+    if training:
+        np.testing.assert_allclose(host(bn.running_var), host(ref.running_var), rtol=1e-5, atol=1e-6)
+    # a width the mask layout cannot hold falls back to the un-pooled fused pass (4-D out), never silently to torch
+    odd = FusedBatchNormAct2d(16).to(DEV)
+    odd.hip, odd.tail_avgpool = True, True
+    xo = torch.randn(2, 16, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+    assert odd(xo, xo, True).dim() == 4
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_activation_checkpointing_on_the_fused_glue(precision):
+    """Checkpointed residual blocks on the HIP glue (fused BN kernels, fork GEMM, stem and tail fusions): same
+    loss, same gradients up to MIOpen's atomic weight-gradient noise, running statistics moved once, and a
+    smaller activation footprint."""
+    import copy
+    import warnings
+
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config, resnet
+    from peclr_amd.bn2d import enable_hip_batchnorm
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(31)
+    n = 16
+    cfg = hybrid2_config(resnet_size="50", projection_head_input_dim=2048, augmentation=["crop", "rotate"],
+                         batch_size=n, num_samples=64, pretrained=False)
+    base = Hybrid2Model(cfg).to(DEV).train()
+    base.encoder = base.encoder.to(memory_format=torch.channels_last)
+    enable_hip_batchnorm(base.encoder)
+    g = torch.Generator().manual_seed(32)
+    batch = {"transformed_image1": torch.randn(n, 3, 128, 128, generator=g), "transformed_image2": torch.randn(n, 3, 128, 128, generator=g),
+             "jitter_x_1": torch.randint(-14, 1, (n,), generator=g), "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+             "jitter_y_1": torch.randint(-14, 1, (n,), generator=g), "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+             "angle_1": torch.randint(-45, 46, (n,), generator=g).double(), "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    for k in ("transformed_image1", "transformed_image2"):
+        batch[k] = batch[k].contiguous(memory_format=torch.channels_last)
+    res = {}
+    for ckpt in (False, True):
+        model = copy.deepcopy(base)
+        tr = Trainer(max_epochs=1, precision=precision, activation_checkpointing=ckpt).attach(model)
+        tr.zero_grad()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        before = torch.cuda.memory_allocated()
+        with tr._autocast():
+            out = model.training_step(batch, 0)
+        held = torch.cuda.memory_allocated() - before           # activations kept for the backward pass
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        res[ckpt] = (float(out["loss"]), [p.grad.detach().clone() for p in model.parameters() if p.grad is not None], held,
+                     {k: v.clone() for k, v in model.named_buffers()})
+    (l0, g0, m0, b0), (l1, g1, m1, b1) = res[False], res[True]
+    assert l1 == pytest.approx(l0, rel=1e-6 if precision == "fp32" else 1e-3)
+    num = sum(float((a - b).double().pow(2).sum()) for a, b in zip(g0, g1))
+    den = sum(float(a.double().pow(2).sum()) for a in g0)
+    assert len(g0) == len(g1) and (num / den) ** 0.5 <= (2e-2 if precision == "fp32" else 6e-2)
+    for k in b0:
+        # moved once (a second update would shift them by ~10 % of the batch statistic); the two runs' forward
+        # convolutions agree to ~1e-6, not bit for bit
+        assert torch.allclose(b0[k].float(), b1[k].float(), rtol=1e-4, atol=1e-6), k
+    assert m1 < 0.55 * m0, (m0, m1)
+    assert resnet.set_activation_checkpointing(base.encoder, False) == 16

@@ -470,3 +470,43 @@ def test_peclr_to_torchvision_reports_and_stops_on_a_mismatch(tmp_path, capsys):
     torch.save({"state_dict": bad}, path)
     peclr_to_torchvision(resnet.resnet18(), path)
     assert "PeCLR layers don't match" in capsys.readouterr().out
+
+
+def test_activation_checkpointing_is_exact_and_moves_running_stats_once():
+    """residual blocks keep only their input and re-run in the backward pass.  Same
+    outputs, same gradients, and the BatchNorm running statistics / num_batches_tracked move ONCE per step."""
+    import copy
+    import warnings
+
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config, resnet
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(0)
+    plain = resnet.resnet50().train()
+    ckpt = copy.deepcopy(plain)
+    assert resnet.set_activation_checkpointing(ckpt) == 16
+    x = torch.randn(2, 3, 64, 64)
+    ya, yb = plain(x), ckpt(x)
+    assert torch.equal(ya, yb)
+    ya.square().mean().backward()
+    yb.square().mean().backward()
+    for (n, p), (_, q) in zip(plain.named_parameters(), ckpt.named_parameters()):
+        assert torch.equal(p.grad, q.grad), n
+    for (n, p), (_, q) in zip(plain.named_buffers(), ckpt.named_buffers()):
+        assert torch.equal(p, q), n
+    assert int(ckpt.layer3[2].bn2.num_batches_tracked) == 1
+    with torch.no_grad():                      # no gradient -> no checkpoint machinery, same numbers
+        assert torch.equal(ckpt(x), plain(x))
+    # through the trainer flag
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, augmentation=["crop"], batch_size=2,
+                         num_samples=8, pretrained=False)
+    torch.manual_seed(1)
+    a = Hybrid2Model(cfg)
+    b = copy.deepcopy(a)
+    batches = _tiny_batches(2, 2, seed=9)
+    Trainer(max_epochs=1).fit(a, batches)
+    tr = Trainer(max_epochs=1, activation_checkpointing=True)
+    tr.fit(b, batches)
+    assert all(m.checkpoint for m in b.encoder.modules() if isinstance(m, resnet.BasicBlock))
+    for (k, u), (_, v) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(u, v), k
