@@ -514,8 +514,11 @@ def main():
                                    f"LARS(Adam) step, {args.dtype}",
                        "global_batch": world * 2 * args.pairs * args.accum, "parallelism": f"dp{world}",
                        "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn, "fork_gemm": bool(fused_bn and args.fork_gemm), "activation_checkpointing": bool(args.checkpoint),
-                       "launch": ("two hipGraph replays per step (forward to z | backward from dz), collectives, "
-                                  "NT-Xent and optimiser eager between/after them" if split else
+                       "launch": ((("three hipGraph replays per step (forward to z | backward of head + layer4 | backward of "
+                                    "layer3..stem, the first stage's gradient all-reduce in flight under the second), "
+                                    if getattr(trainer, "_graph_b2", None) is not None else
+                                    "two hipGraph replays per step (forward to z | backward from dz), ") +
+                                   "collectives, NT-Xent and optimiser eager between/after them") if split else
                                   f"{args.accum} hipGraph replays (micro-batch forward + backward) + eager accumulate / optimiser per step"
                                   if use_graph and args.accum > 1 else
                                   "one hipGraph replay per step (whole step captured)" if use_graph else

@@ -121,22 +121,28 @@ class GradReducer:
     the optimiser step, and `zero_grad()` instead of `optimizer.zero_grad()`.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 32 << 20):
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 32 << 20, stage_of=None):
+        """stage_of (optional): parameter -> int.  A bucket never mixes stages, so that a backward pass cut
+        into stages (Trainer.capture_split_graphs: head + layer4 | the rest) can all-reduce a finished
+        stage's buckets while the next stage is still computing."""
         self.group = group
         self.world = world_size(group)
         params = [p for p in params if p.requires_grad]
+        stage_of = stage_of or (lambda p: 0)
         # buckets in REVERSE registration order: the last layers' grads are ready first
         self.buckets: List[_Bucket] = []
         cur, cur_bytes = [], 0
         for p in reversed(params):
             nbytes = p.numel() * p.element_size()
-            if cur and (cur_bytes + nbytes > bucket_bytes or p.dtype != cur[0].dtype):
+            if cur and (cur_bytes + nbytes > bucket_bytes or p.dtype != cur[0].dtype or stage_of(p) != stage_of(cur[0])):
                 self.buckets.append(_Bucket(cur))
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
         if cur:
             self.buckets.append(_Bucket(cur))
+        for b in self.buckets:
+            b.stage = stage_of(b.params[0])
         self._armed = False
         self._owner = {}
         for b in self.buckets:
@@ -180,6 +186,13 @@ class GradReducer:
             handles = [dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
             for h in handles:
                 h.wait()
+
+    def launch(self, buckets: Iterable[_Bucket]) -> list:
+        """Start the SUM all-reduce of some buckets asynchronously (RCCL's own stream picks up after the work
+        already queued on the current stream); returns handles to `wait()` on before the optimiser step."""
+        if self.world == 1:
+            return []
+        return [dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in buckets]
 
     def zero_grad(self):
         for b in self.buckets:

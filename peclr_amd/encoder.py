@@ -59,8 +59,17 @@ class ResNetModel(nn.Module):
             raise NotImplementedError  # resnet_model.py:42-43
         return table[resnet_name]
 
-    def forward(self, x):
-        z = self.features(x).flatten(start_dim=1)
+    CUT = 7  # features[:7] = stem + layer1..3, features[7:] = layer4 + global average pool
+
+    def forward(self, x, cut=None):
+        """cut (optional): callable applied to layer3's output before layer4 sees it -- the trainer uses it to
+        split the autograd graph there (backward in two stages, so that the gradient all-reduce of head +
+        layer4 overlaps the backward of layer1..3)."""
+        if cut is None:
+            z = self.features(x)
+        else:
+            z = self.features[self.CUT:](cut(self.features[:self.CUT](x)))
+        z = z.flatten(start_dim=1)
         if self.mode == "pretraining":
             return z
         z = self.final_layer(z)

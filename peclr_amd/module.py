@@ -161,11 +161,12 @@ class SimCLR(BaseModel):
             return stacked
         return torch.cat((batch["transformed_image1"], batch["transformed_image2"]), dim=0)
 
-    def _project(self, batch: Dict[str, Tensor]):
+    def _project(self, batch: Dict[str, Tensor], cut=None):
         """Per-rank part of the step (no collective): images -> unit embeddings z [2N,128] (+ per-row
         projection statistics, empty here).  simclr_model.py:37-47: one F.normalize, no alignment."""
         n_pairs = batch["transformed_image1"].size(0)
-        z, row_stats = self._head_align(self.get_encodings(self._two_views(batch)),
+        views = self._two_views(batch)
+        z, row_stats = self._head_align(self.get_encodings(views) if cut is None else self.encoder(views, cut=cut),
                                         ops.AlignSpec(n_pairs=n_pairs, single_norm=True, want_stats=False))
         return z, row_stats, n_pairs
 
@@ -244,8 +245,10 @@ class Hybrid2Model(SimCLR):
             spec.angles = (batch["angle_1"].contiguous(), batch["angle_2"].contiguous())
         return spec
 
-    def _project(self, batch: Dict[str, Tensor]):
-        encodings = self.encoder(self._two_views(batch))
+    def _project(self, batch: Dict[str, Tensor], cut=None):
+        """cut: see `peclr_amd.encoder.ResNetModel.forward` (only the in-tree encoder takes it)."""
+        views = self._two_views(batch)
+        encodings = self.encoder(views) if cut is None else self.encoder(views, cut=cut)
         spec = self._spec(batch)
         z, row_stats = self._head_align(encodings, spec)
         return z, row_stats, spec.n_pairs

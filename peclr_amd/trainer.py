@@ -86,11 +86,24 @@ class Trainer:
         if self.sync_batchnorm and self.world_size > 1:
             self._enable_sync_batchnorm(model)
         if self.world_size > 1 or self.grad_buckets:
-            self.reducer = pdist.GradReducer(model.parameters(), self.process_group, self.bucket_bytes)
+            self.reducer = pdist.GradReducer(model.parameters(), self.process_group, self.bucket_bytes,
+                                             stage_of=self._backward_stage_of(model))
         (self.optimizer,), (sched,) = model.configure_optimizers()
         self.scheduler = sched["scheduler"]
         self._unused = [p for n, p in model.named_parameters() if "final_layer" in n]
         return self
+
+    @staticmethod
+    def _backward_stage_of(model):
+        """Backward stage of every parameter for the two-stage split backward: 0 = projection head + layer4
+        (+ the unused final_layer), 1 = stem + layer1..3.  None when the encoder is not the in-tree wrapper."""
+        from .encoder import ResNetModel
+
+        enc = getattr(model, "encoder", None)
+        if not isinstance(enc, ResNetModel):
+            return None
+        early = {id(p) for p in enc.features[:ResNetModel.CUT].parameters()}
+        return lambda p: 1 if id(p) in early else 0
 
     def _enable_sync_batchnorm(self, model):
         import torch.distributed as td
@@ -265,7 +278,11 @@ class Trainer:
     # ~800 launches per step replayed instead of issued.  Collectives stay outside the graphs, so this
     # does not depend on RCCL's capture support; the price is that the all-reduce no longer overlaps
     # with backward (RN-50: 98 MB over xGMI, well under a millisecond against a ~7 ms gain).
-    def capture_split_graphs(self, example_batch: Dict[str, torch.Tensor], warmup: int = 3):
+    def capture_split_graphs(self, example_batch: Dict[str, torch.Tensor], warmup: int = 3, two_stage: Optional[bool] = None):
+        """two_stage (default: when the encoder is the in-tree ResNet wrapper): the backward is captured as TWO
+        graphs cut at layer4's input -- B1 = head + layer4, B2 = layer3..stem.  After B1 its gradients are copied
+        into their buckets and all-reduced ASYNCHRONOUSLY while B2 replays (RN-50: ~64 MB of the ~98 MB travel
+        under ~35 ms of remaining backward), so only the early layers' buckets stay exposed."""
         self._no_fp16_graphs()
         if self.accumulate_grad_batches != 1:
             raise RuntimeError("capture_split_graphs needs accumulate_grad_batches=1")
@@ -275,6 +292,11 @@ class Trainer:
         if self.sync_batchnorm and self.world_size > 1:
             raise RuntimeError("capture_split_graphs: synchronised BatchNorm puts collectives inside the graphs")
         model = self.model
+        can_cut = self._backward_stage_of(model) is not None
+        if two_stage is None:
+            two_stage = can_cut
+        if two_stage and not can_cut:
+            raise RuntimeError("two_stage backward needs the in-tree encoder (peclr_amd.encoder.ResNetModel)")
         self._static_batch = self._clone_batch(example_batch)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -288,21 +310,41 @@ class Trainer:
         torch.cuda.synchronize()
         params = [p for p in model.parameters() if p.requires_grad]
         for p in params:
-            p.grad = None                     # graph B allocates the gradients in the graphs' pool
+            p.grad = None                     # the backward graphs allocate the gradients in the graphs' pool
         self.reducer._armed = False           # hooks stay inert: no collective inside a capture
         pool = torch.cuda.graph_pool_handle()
         self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self._graph_b2 = torch.cuda.CUDAGraph() if two_stage else None
+        seam = {}
+
+        def cut(x3):                          # layer3's output: graph B1 ends here, graph B2 starts here
+            seam["out"], seam["leaf"] = x3, x3.detach().requires_grad_()
+            return seam["leaf"]
+
         with torch.cuda.graph(self._graph_a, pool=pool, capture_error_mode="thread_local"):
             with self._autocast():
-                z, row_stats, n_pairs = model._project(self._static_batch)
+                z, row_stats, n_pairs = model._project(self._static_batch, cut=cut) if two_stage else \
+                    model._project(self._static_batch)
         self._split_z, self._split_rows, self._split_n = z, row_stats, n_pairs
         self._split_dz = torch.zeros_like(z)
         with torch.cuda.graph(self._graph_b, pool=pool, capture_error_mode="thread_local"):
             torch.autograd.backward((z,), (self._split_dz,))
-        captured = [(p, p.grad) for p in params if p.grad is not None]
+        late = [(p, p.grad) for p in params if p.grad is not None]
+        early = []
+        if two_stage:
+            with torch.cuda.graph(self._graph_b2, pool=pool, capture_error_mode="thread_local"):
+                torch.autograd.backward((seam["out"],), (seam["leaf"].grad,))
+            seen = {id(p) for p, _ in late}
+            early = [(p, p.grad) for p in params if p.grad is not None and id(p) not in seen]
+            self._split_seam = seam           # keeps the seam tensors (graph-pool memory) referenced
         self.reducer.zero_grad()              # .grad = bucket views again (optimiser + all-reduce read those)
-        self._split_src = [g for _, g in captured]
-        self._split_dst = [p.grad for p, _ in captured]
+        self._split_stages = []               # per stage: (captured gradients, their bucket views, the stage's buckets)
+        for stage, pairs in enumerate((late, early) if two_stage else (late,)):
+            buckets = [b for b in self.reducer.buckets if b.stage == stage] if two_stage else list(self.reducer.buckets)
+            owned = {id(p) for b in buckets for p in b.params}
+            if any(id(p) not in owned for p, _ in pairs):
+                raise RuntimeError("two_stage backward: a gradient of one stage lives in another stage's bucket")
+            self._split_stages.append(([g for _, g in pairs], [p.grad for p, _ in pairs], buckets))
         return self
 
     def replay_split(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
@@ -314,9 +356,13 @@ class Trainer:
         loss = model._contrast(z, self._split_n, self._split_rows)     # collectives live here
         (dz,) = torch.autograd.grad(loss, z)
         self._split_dz.copy_(dz)
-        self._graph_b.replay()
-        torch._foreach_copy_(self._split_dst, self._split_src)
-        self.reducer.all_reduce_now()
+        handles = []
+        for graph, (src, dst, buckets) in zip((self._graph_b, self._graph_b2), self._split_stages):
+            graph.replay()
+            torch._foreach_copy_(dst, src)
+            handles += self.reducer.launch(buckets)    # travels while the next stage's graph replays
+        for h in handles:
+            h.wait()
         self.optimizer.step()
         self.scheduler.step()
         self.global_step += 1

@@ -1338,9 +1338,9 @@ def test_activation_checkpointing_on_the_fused_glue(precision):
     for k in ("transformed_image1", "transformed_image2"):
         batch[k] = batch[k].contiguous(memory_format=torch.channels_last)
     res = {}
-    for ckpt in (False, True):
+    for ckpt in (False, True, None):           # None: a second plain run = the run-to-run noise of the stack itself
         model = copy.deepcopy(base)
-        tr = Trainer(max_epochs=1, precision=precision, activation_checkpointing=ckpt).attach(model)
+        tr = Trainer(max_epochs=1, precision=precision, activation_checkpointing=bool(ckpt)).attach(model)
         tr.zero_grad()
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
@@ -1352,14 +1352,83 @@ def test_activation_checkpointing_on_the_fused_glue(precision):
         torch.cuda.synchronize()
         res[ckpt] = (float(out["loss"]), [p.grad.detach().clone() for p in model.parameters() if p.grad is not None], held,
                      {k: v.clone() for k, v in model.named_buffers()})
-    (l0, g0, m0, b0), (l1, g1, m1, b1) = res[False], res[True]
-    assert l1 == pytest.approx(l0, rel=1e-6 if precision == "fp32" else 1e-3)
-    num = sum(float((a - b).double().pow(2).sum()) for a, b in zip(g0, g1))
-    den = sum(float(a.double().pow(2).sum()) for a in g0)
-    assert len(g0) == len(g1) and (num / den) ** 0.5 <= (2e-2 if precision == "fp32" else 6e-2)
+    (l0, g0, m0, b0), (l1, g1, m1, b1), (l2, g2, _, _) = res[False], res[True], res[None]
+
+    def dev(ga, gb):
+        num = sum(float((a - b).double().pow(2).sum()) for a, b in zip(ga, gb))
+        return (num / sum(float(a.double().pow(2).sum()) for a in ga)) ** 0.5
+
+    # MIOpen's split-K kernels (weight gradients; some bf16 forward kernels too) add with float atomics, so two
+    # IDENTICAL runs already differ; the checkpointed run must sit within a small multiple of that noise
+    loss_noise, grad_noise = abs(l2 - l0) / abs(l0), dev(g0, g2)
+    assert abs(l1 - l0) / abs(l0) <= max(4 * loss_noise, 1e-6 if precision == "fp32" else 2e-3), (l0, l1, l2)
+    assert len(g0) == len(g1) and dev(g0, g1) <= max(4 * grad_noise, 1e-3), (dev(g0, g1), grad_noise)
     for k in b0:
         # moved once (a second update would shift them by ~10 % of the batch statistic); the two runs' forward
         # convolutions agree to ~1e-6, not bit for bit
-        assert torch.allclose(b0[k].float(), b1[k].float(), rtol=1e-4, atol=1e-6), k
+        rt, at = (1e-4, 1e-6) if precision == "fp32" else (2e-2, 1e-3)     # (a second update would be ~90 % off)
+        assert torch.allclose(b0[k].float(), b1[k].float(), rtol=rt, atol=at), k
     assert m1 < 0.55 * m0, (m0, m1)
     assert resnet.set_activation_checkpointing(base.encoder, False) == 16
+
+
+def test_two_stage_split_backward_equals_single_backward_graph():
+    """capture_split_graphs(two_stage=True): backward captured as two graphs cut at layer4's input (so that the
+    first stage's buckets can be all-reduced under the second) against the single backward graph: same loss,
+    same bucket contents after a replay, buckets never mix stages."""
+    import copy
+    import warnings
+
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config
+    from peclr_amd.bn2d import enable_hip_batchnorm
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(41)
+    n = 8
+    cfg = hybrid2_config(resnet_size="50", projection_head_input_dim=2048, augmentation=["crop", "rotate"],
+                         batch_size=n, num_samples=64, warmup_epochs=1, pretrained=False)
+    base = Hybrid2Model(cfg).to(DEV).train()
+    base.encoder = base.encoder.to(memory_format=torch.channels_last)
+    enable_hip_batchnorm(base.encoder)
+    g = torch.Generator().manual_seed(42)
+    batch = {"transformed_image1": torch.randn(n, 3, 96, 96, generator=g), "transformed_image2": torch.randn(n, 3, 96, 96, generator=g),
+             "jitter_x_1": torch.randint(-14, 1, (n,), generator=g), "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+             "jitter_y_1": torch.randint(-14, 1, (n,), generator=g), "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+             "angle_1": torch.randint(-45, 46, (n,), generator=g).double(), "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    for k in ("transformed_image1", "transformed_image2"):
+        batch[k] = batch[k].contiguous(memory_format=torch.channels_last)
+    runs = {}
+    for key, two_stage in (("one", False), ("two", True), ("one_again", False)):
+        model = copy.deepcopy(base)
+        tr = Trainer(max_epochs=10, grad_buckets=True, bucket_bytes=8 << 20).attach(model)
+        tr.zero_grad()
+        stages = [b.stage for b in tr.reducer.buckets]
+        assert stages == sorted(stages) and set(stages) == {0, 1}        # head + layer4 buckets first, never mixed
+        early = {id(p) for p in model.encoder.features[:7].parameters()}
+        assert all((id(p) in early) == (b.stage == 1) for b in tr.reducer.buckets for p in b.params)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        grabbed = []
+        with torch.cuda.stream(side):
+            tr.capture_split_graphs(batch, warmup=1, two_stage=two_stage)
+            assert (tr._graph_b2 is not None) == two_stage and len(tr._split_stages) == (2 if two_stage else 1)
+            real = tr.optimizer.step
+            tr.optimizer.step = lambda *a, **kw: (grabbed.append([b.flat.clone() for b in tr.reducer.buckets]), real(*a, **kw))[1]
+            losses = [float(tr.replay_split()["loss"]) for _ in range(3)]
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        runs[key] = (losses, grabbed)
+    (l1, g1), (l2, g2), (l3, g3) = runs["one"], runs["two"], runs["one_again"]
+    assert l2[0] == pytest.approx(l1[0], rel=1e-5) and l2 == pytest.approx(l1, rel=5e-2)
+
+    def dev(ga, gb):
+        num = sum(float((a - b).double().pow(2).sum()) for a, b in zip(ga, gb))
+        return (num / sum(float(a.double().pow(2).sum()) for a in ga)) ** 0.5
+
+    # bar = the single-graph path against ITSELF (MIOpen's atomically accumulated weight gradients through
+    # small-batch BatchNorm: ~2e-2 norm-wise here); a stage that lost or doubled gradients would be O(1)
+    noise = dev(g1[0], g3[0])
+    assert dev(g1[0], g2[0]) <= max(4 * noise, 1e-3), (dev(g1[0], g2[0]), noise)
+    for a, b, c in zip(g1[0], g2[0], g3[0]):         # every bucket individually, not just the total
+        assert float((a - b).norm()) <= max(6 * float((a - c).norm()), 1e-3 * float(a.norm())) + 1e-6
