@@ -17,6 +17,8 @@
 // the K-contiguous image be read 16 bytes at a time; both read patterns are bank-conflict
 // free (row stride 36 dwords under the 64-bank b128 rule, 68 dwords under the 32-bank b32
 // rule).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace peclr {
@@ -167,6 +169,112 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
+// ---- 128 x 128 workgroup tile, NN layout (A [M][K] K-contiguous, B [K][N] N-contiguous): the fused
+// "conv1x1 input gradient + residual gradient" GEMM of the bottleneck entries (M = N*H*W rows, K = Cmid,
+// N = Cin).  Each wave owns a 64 x 64 quadrant = 2 x 2 MFMA tiles in FOUR independent accumulators:
+//   * consecutive MFMAs never write the same accumulator (a dependent v_mfma_f32_32x32x2_f32 chain pays for
+//     every instruction the compiler slips between two of its links; the 64 x 64 kernel above is such a chain);
+//   * every A / B fragment read from the LDS feeds two MFMAs, and a K-tile (BK = 32) is 64 MFMAs = 4096 cycles
+//     per wave, so the one-tile-ahead register prefetch covers the global-load latency;
+//   * 32 FLOP per byte fetched into the CU instead of 16.
+// One LDS image (35 KiB -> 4 workgroups per CU), two barriers per K-tile, <= 128 VGPRs.
+constexpr int TM = 128, TN = 128;
+constexpr int LDN128 = TN + 4;
+
+__global__ __launch_bounds__(256, 4) void gemm_f32_nn128_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float la[TM * LDK];        // [128][36]
+    __shared__ __attribute__((aligned(16))) float lb[BK * LDN128];     // [32][132]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, kh = lane >> 5;
+    const int nct = (g.N + TN - 1) / TN;
+    const int j = blockIdx.x / 8;
+    const int row_block = 8 * (j / nct) + (int)(blockIdx.x % 8);      // all column tiles of a row block on one XCD
+    if (row_block * TM >= g.M) return;
+    const int m0 = row_block * TM, n0 = (j % nct) * TN;
+    const int nk = (g.K + BK - 1) / BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // global -> registers: A 128 x 32 (4 float4 per thread: row = tid/8 + 32*rep, k = (tid%8)*4),
+    //                      B 32 x 128 (4 float4 per thread: k = tid/32 + 8*rep, n = (tid%32)*4)
+    float4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) {
+            const int row = m0 + (tid >> 3) + 32 * rep, k = k0 + (tid & 7) * 4;
+            ra[rep] = (row < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.A + (size_t)row * g.lda + k)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int kb = k0 + (tid >> 5) + 8 * rep, n = n0 + (tid & 31) * 4;
+            rb[rep] = (kb < g.K && n < g.N) ? *reinterpret_cast<const float4*>(g.B + (size_t)kb * g.ldb + n)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) {
+            *reinterpret_cast<float4*>(la + ((tid >> 3) + 32 * rep) * LDK + (tid & 7) * 4) = ra[rep];
+            *reinterpret_cast<float4*>(lb + ((tid >> 5) + 8 * rep) * LDN128 + (tid & 31) * 4) = rb[rep];
+        }
+    };
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload((kt + 1) * BK);
+#pragma unroll
+        for (int t = 0; t < BK / 8; ++t) {
+            const float4 a0 = *reinterpret_cast<const float4*>(la + (wm * 64 + i) * LDK + 8 * t + 4 * kh);
+            const float4 a1 = *reinterpret_cast<const float4*>(la + (wm * 64 + 32 + i) * LDK + 8 * t + 4 * kh);
+            const float* pb = lb + (8 * t + 4 * kh) * LDN128 + wn * 64 + i;
+            const float4 b0 = make_float4(pb[0], pb[LDN128], pb[2 * LDN128], pb[3 * LDN128]);
+            const float4 b1 = make_float4(pb[32], pb[LDN128 + 32], pb[2 * LDN128 + 32], pb[3 * LDN128 + 32]);
+#define PECLR_MMA4(E)                                                                   \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.E, b0.E, acc[0][0], 0, 0, 0);   \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.E, b1.E, acc[0][1], 0, 0, 0);   \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.E, b0.E, acc[1][0], 0, 0, 0);   \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.E, b1.E, acc[1][1], 0, 0, 0);
+            PECLR_MMA4(x) PECLR_MMA4(y) PECLR_MMA4(z) PECLR_MMA4(w)
+#undef PECLR_MMA4
+        }
+        __syncthreads();                 // every wave is done with this K-tile's image
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
+    }
+    // epilogue: C = acc (+ addend), 32 consecutive floats per row segment and store instruction
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wn * 64 + b * 32 + i;
+            if (n >= g.N) continue;
+            float dv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + a * 32 + mfma32_row(r, kh);
+                dv[r] = (g.addend && m < g.M) ? __builtin_nontemporal_load(g.addend + (size_t)m * g.ldd + n) : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + a * 32 + mfma32_row(r, kh);
+                if (m < g.M) {
+                    if (g.stream_out) __builtin_nontemporal_store(acc[a][b][r] + dv[r], g.out + (size_t)m * g.ldo + n);
+                    else g.out[(size_t)m * g.ldo + n] = acc[a][b][r] + dv[r];
+                }
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
                                                           size_t count4, int cols, const float* __restrict__ bias,
                                                           float* __restrict__ out) {
@@ -253,6 +361,14 @@ int gemm_launch(int layout, int M, int N, int K, const float* A, int lda, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nrb = (M + BM - 1) / BM, nct = (N + BN - 1) / BN;
     dim3 grid(8 * ((nrb + 7) / 8) * nct, 1, split_k), block(256);
+    // PECLR_GEMM_TILE=64 pins the 64 x 64 kernel (A/B experiments); default: NN problems with at least one
+    // full 128-row block and no split-K / bias take the 128 x 128 kernel
+    static const int pin = [] { const char* e = getenv("PECLR_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    if (pin != 64 && a_kc && !b_kc && split_k == 1 && !bias && M >= TM && N >= 64) {
+        const int nrb128 = (M + TM - 1) / TM, nct128 = (N + TN - 1) / TN;
+        hipLaunchKernelGGL(gemm_f32_nn128_kernel, dim3(8 * ((nrb128 + 7) / 8) * nct128), block, 0, s, g);
+        return launch_status();
+    }
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g);
     else if (a_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, g);
