@@ -69,17 +69,28 @@ def bn1d_running_update(running_mean, running_var, mean, var_biased, m_rows: int
     return new_mean, new_var
 
 
-def projection_head_fwd(h, w1, b1, gamma, beta, w2, eps: float = BN_EPS):
+RELU_TIE = 1e-5  # |pre-activation| below which another fp32 evaluation may rectify the other way
+
+
+def projection_head_fwd(h, w1, b1, gamma, beta, w2, eps: float = BN_EPS, relu_ties=None):
     """Linear(Din,H,bias) -> BatchNorm1d(H) -> ReLU -> Linear(H,D,no bias).
 
     simclr_model.py:20-35.  Returns p [M,D] and a cache for the backward.
+    relu_ties (checker use only): bool [M,H], the rectifier decisions of the implementation under test.
+    They are adopted ONLY where this evaluation's pre-activation is within RELU_TIE of zero -- there the
+    sign is decided by fp32 round-off, both choices are "the reference's", and the two backward passes
+    are only comparable if they agree on it; everywhere else the oracle's own decision stands, so a wrong
+    mask in the implementation still shows up.
     """
     a_pre = linear_fwd(h, w1, b1)
     y, (mean, var, invstd, xhat) = bn1d_train_fwd(a_pre, gamma, beta, eps)
-    a = np.maximum(y, 0)
+    on = y > 0
+    if relu_ties is not None:
+        on = np.where(np.abs(y) < RELU_TIE, np.asarray(relu_ties, bool), on)
+    a = np.where(on, y, 0)
     p = linear_fwd(a, w2)
     cache = dict(h=h, w1=w1, w2=w2, gamma=gamma, a_pre=a_pre, mean=mean, var=var,
-                 invstd=invstd, xhat=xhat, y=y, a=a)
+                 invstd=invstd, xhat=xhat, y=y, a=a, on=on)
     return p, cache
 
 
@@ -89,11 +100,11 @@ def projection_head_bwd(dp, cache):
     Returns dict(dh, dw1, db1, dgamma, dbeta, dw2).
     """
     h, w1, w2 = cache["h"], cache["w1"], cache["w2"]
-    gamma, invstd, xhat, y, a = (cache[k] for k in ("gamma", "invstd", "xhat", "y", "a"))
+    gamma, invstd, xhat, a, on = (cache[k] for k in ("gamma", "invstd", "xhat", "a", "on"))
     m = h.shape[0]
     dw2 = dp.T @ a
     da = dp @ w2
-    dy = da * (y > 0)
+    dy = da * on
     dbeta = dy.sum(axis=0)
     dgamma = (dy * xhat).sum(axis=0)
     da_pre = (gamma * invstd / m) * (m * dy - dbeta - xhat * dgamma)
@@ -322,8 +333,8 @@ def ntxent_bwd(z: np.ndarray, lse: np.ndarray, n_half: int, temperature: float =
 # --------------------------------------------------------------------------- #
 def head_loss_fwd_bwd(h, w1, b1, gamma, beta, w2, n_pairs: int, *, crop=False, rotate=False,
                       jitter_x=None, jitter_y=None, angle=None, image_hw=(224, 224),
-                      temperature: float = 0.5, double_norm: bool = True):
-    p, hc = projection_head_fwd(h, w1, b1, gamma, beta, w2)
+                      temperature: float = 0.5, double_norm: bool = True, relu_ties=None):
+    p, hc = projection_head_fwd(h, w1, b1, gamma, beta, w2, relu_ties=relu_ties)
     z, stats, ac = align_fwd(p, n_pairs, crop=crop, rotate=rotate, jitter_x=jitter_x,
                              jitter_y=jitter_y, angle=angle, image_hw=image_hw,
                              double_norm=double_norm)
@@ -332,7 +343,8 @@ def head_loss_fwd_bwd(h, w1, b1, gamma, beta, w2, n_pairs: int, *, crop=False, r
     dp = align_bwd(dz, ac)
     grads = projection_head_bwd(dp, hc)
     return dict(loss=loss, sim=s, lse=lse, z=z, p=p, stats=stats, dz=dz, dp=dp, **grads,
-                bn_mean=hc["mean"], bn_var=hc["var"], a_pre=hc["a_pre"])
+                bn_mean=hc["mean"], bn_var=hc["var"], a_pre=hc["a_pre"],
+                relu_tie_count=int((np.abs(hc["y"]) < RELU_TIE).sum()))
 
 
 # --------------------------------------------------------------------------- #

@@ -28,7 +28,8 @@ def head_params(model) -> Dict[str, np.ndarray]:
                                               w2=ph[3].weight).items()}
 
 
-def oracle_on(h: np.ndarray, w: Dict[str, np.ndarray], batch: Dict[str, torch.Tensor], augmentation) -> dict:
+def oracle_on(h: np.ndarray, w: Dict[str, np.ndarray], batch: Dict[str, torch.Tensor], augmentation,
+              relu_ties=None) -> dict:
     """The reference's head + alignment + loss (+ closed-form backward) on encoder output `h` [2N, Din]."""
     n = h.shape[0] // 2
     crop, rotate = "crop" in augmentation, "rotate" in augmentation
@@ -43,7 +44,7 @@ def oracle_on(h: np.ndarray, w: Dict[str, np.ndarray], batch: Dict[str, torch.Te
     # fp32 evaluations with different summation orders (BatchNorm1d's backward amplifies both)
     f64 = {k: v.astype(np.float64) for k, v in w.items()}
     return O.head_loss_fwd_bwd(h.astype(np.float64), f64["w1"], f64["b1"], f64["gamma"], f64["beta"], f64["w2"], n,
-                               crop=crop, rotate=rotate, image_hw=hw, **kw)
+                               crop=crop, rotate=rotate, image_hw=hw, relu_ties=relu_ties, **kw)
 
 
 def step_deltas(model, batch: Dict[str, torch.Tensor], autocast=None, backward: bool = False) -> dict:
@@ -59,6 +60,15 @@ def step_deltas(model, batch: Dict[str, torch.Tensor], autocast=None, backward: 
     hook = model.encoder.register_forward_hook(lambda m, i, o: feats.__setitem__("h", o))
     w = head_params(model)
     ctx = autocast if autocast is not None else torch.autocast("cuda", enabled=False)
+    # the hidden activation of the HIP head (post-ReLU), to settle rectifier ties (see oracle.projection_head_fwd)
+    real_bn_relu = _capi.bn_relu_fwd
+
+    def spy_bn_relu(*a, **k):
+        out = real_bn_relu(*a, **k)
+        feats["a"] = out[1]
+        return out
+
+    _capi.bn_relu_fwd = spy_bn_relu
     try:
         with torch.set_grad_enabled(backward), ctx:
             z, row_stats, n = model._project(batch)
@@ -67,16 +77,18 @@ def step_deltas(model, batch: Dict[str, torch.Tensor], autocast=None, backward: 
             h_t.retain_grad()
     finally:
         hook.remove()
+        _capi.bn_relu_fwd = real_bn_relu
+    ties = (_np(feats["a"]) > 0) if "a" in feats else None
     zc = z.detach().contiguous()
     m = zc.shape[0]
     out17, _lse, sim = _capi.ntxent_fwd(zc, 0, zc, n, 1.0 / 0.5, 1.0 / m,
                                         row_stats if row_stats.numel() else None, n, want_sim=True)
-    ref = oracle_on(_np(h_t), w, batch, model.config.augmentation)
+    ref = oracle_on(_np(h_t), w, batch, model.config.augmentation, relu_ties=ties)
     res = {"loss_hip": float(out17[16]), "loss_oracle": float(ref["loss"]),
            "loss_delta_vs_oracle": abs(float(out17[16]) - float(ref["loss"])),
            "sim_max_abs_delta": float(np.abs(_np(sim) - ref["sim"]).max()),
            "z_max_abs_delta": float(np.abs(_np(z) - ref["z"]).max()),
-           "rows": int(m), "encoder_dim": int(h_t.shape[1])}
+           "rows": int(m), "encoder_dim": int(h_t.shape[1]), "relu_tie_count": ref["relu_tie_count"]}
     if row_stats.numel():
         res["stats_max_abs_delta"] = float(np.abs(_np(out17[:16]) - np.asarray(ref["stats"], np.float64)).max())
     if backward:

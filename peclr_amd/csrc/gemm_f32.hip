@@ -361,11 +361,12 @@ int gemm_launch(int layout, int M, int N, int K, const float* A, int lda, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nrb = (M + BM - 1) / BM, nct = (N + BN - 1) / BN;
     dim3 grid(8 * ((nrb + 7) / 8) * nct, 1, split_k), block(256);
-    // PECLR_GEMM_TILE=64 pins the 64 x 64 kernel (A/B experiments); default: NN problems with at least one
-    // full 128-row block and no split-K / bias take the 128 x 128 kernel
+    // PECLR_GEMM_TILE=64 pins the 64 x 64 kernel (A/B experiments); default: NN problems without split-K / bias
+    // that fill the chip with 128 x 128 tiles (>= 2 per CU) take the 128 x 128 kernel -- the projection head's
+    // own NN GEMMs (M = 256 rows: 32 such tiles) stay on the 64 x 64 kernel, which gives them 4x the workgroups
     static const int pin = [] { const char* e = getenv("PECLR_GEMM_TILE"); return e ? atoi(e) : 0; }();
-    if (pin != 64 && a_kc && !b_kc && split_k == 1 && !bias && M >= TM && N >= 64) {
-        const int nrb128 = (M + TM - 1) / TM, nct128 = (N + TN - 1) / TN;
+    const int nrb128 = (M + TM - 1) / TM, nct128 = (N + TN - 1) / TN;
+    if (pin != 64 && a_kc && !b_kc && split_k == 1 && !bias && (long)nrb128 * nct128 >= 512) {
         hipLaunchKernelGGL(gemm_f32_nn128_kernel, dim3(8 * ((nrb128 + 7) / 8) * nct128), block, 0, s, g);
         return launch_status();
     }

@@ -77,8 +77,12 @@ def test_gemm_large_shapes(capi, m, n, k):
     got = host(capi.gemm(capi.GEMM_NT, dev(a), dev(b), dev(bias)))
     np.testing.assert_allclose(got, a.astype(np.float64) @ b.astype(np.float64).T + bias, rtol=0, atol=tol)
     bn, d = rnd((k, n), 24), rnd((m, n), 25)
-    got = host(capi.gemm_add(capi.GEMM_NN, dev(a), dev(bn), dev(d)))
+    got = host(capi.gemm_add(capi.GEMM_NN, dev(a), dev(bn), dev(d)))      # >= 512 tiles of 128 x 128: the nn128 kernel
     np.testing.assert_allclose(got, a.astype(np.float64) @ bn.astype(np.float64) + d, rtol=0, atol=tol)
+    got = host(capi.gemm(capi.GEMM_NN, dev(a), dev(bn)))                  # the same kernel without an addend
+    np.testing.assert_allclose(got, a.astype(np.float64) @ bn.astype(np.float64), rtol=0, atol=tol)
+    got = host(capi.gemm(capi.GEMM_NN, dev(a[:300]), dev(bn)))            # few tiles: the 64 x 64 kernel
+    np.testing.assert_allclose(got, a[:300].astype(np.float64) @ bn.astype(np.float64), rtol=0, atol=tol)
     at = rnd((k, m), 26)
     got = host(capi.gemm(capi.GEMM_TN, dev(at), dev(bn)))
     np.testing.assert_allclose(got, at.astype(np.float64).T @ bn.astype(np.float64), rtol=0, atol=tol)
@@ -1366,8 +1370,11 @@ def test_activation_checkpointing_on_the_fused_glue(precision):
     for k in b0:
         # moved once (a second update would shift them by ~10 % of the batch statistic); the two runs' forward
         # convolutions agree to ~1e-6, not bit for bit
-        rt, at = (1e-4, 1e-6) if precision == "fp32" else (2e-2, 1e-3)     # (a second update would be ~90 % off)
-        assert torch.allclose(b0[k].float(), b1[k].float(), rtol=rt, atol=at), k
+        if precision == "fp32":
+            assert torch.allclose(b0[k].float(), b1[k].float(), rtol=1e-4, atol=1e-6), k
+        else:    # bf16 forward passes differ run to run (deep layers: ~1e-2); a second update would be ~90 % off
+            a, b = b0[k].float(), b1[k].float()
+            assert float((a - b).norm()) <= 0.05 * float(a.norm()) + 1e-6, k
     assert m1 < 0.55 * m0, (m0, m1)
     assert resnet.set_activation_checkpointing(base.encoder, False) == 16
 

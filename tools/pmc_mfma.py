@@ -30,8 +30,8 @@ import sys
 
 # bench name (or its stem after '::') -> substring the kernel symbol must contain
 EXPECT = {
-    "gemm_k1_fwd": "gemm_f32_kernel", "gemm_k2_fwd": "gemm_f32_kernel", "gemm_dw1": "gemm_f32_kernel",
-    "gemm_dw2": "gemm_f32_kernel", "gemm_da": "gemm_f32_kernel", "gemm_dh": "gemm_f32_kernel",
+    "gemm_k1_fwd": "gemm_f32_", "gemm_k2_fwd": "gemm_f32_", "gemm_dw1": "gemm_f32_",
+    "gemm_dw2": "gemm_f32_", "gemm_da": "gemm_f32_", "gemm_dh": "gemm_f32_",
     "conv1x1_dgrad_add": "gemm_", "bn_relu_fwd": "bn_relu_fwd_kernel", "bn_relu_bwd": "bn_relu_bwd_kernel",
     "align_fwd": "align_fwd_kernel", "align_bwd": "align_bwd_kernel", "ntxent_fwd": "ntxent_kernel<false>",
     "ntxent_bwd": "ntxent_kernel<true>", "ntxent_finalize": "ntxent_finalize_kernel", "slab_reduce": "slab_reduce_kernel",
@@ -39,6 +39,8 @@ EXPECT = {
     "bn2d_finalize": "finalize", "bn2d_apply": "bn2d_apply_kernel", "bn2d_bwd_reduce": "bn2d_bwd_reduce_kernel",
     "bn2d_bwd_finalize": "finalize", "bn2d_bwd_apply": "bn2d_bwd_apply_kernel", "bn2d_pool_apply": "bn2d_pool_apply_kernel",
     "bn2d_pool_bwd_reduce": "bn2d_pool_bwd_reduce_kernel", "bn2d_pool_bwd_apply": "bn2d_pool_bwd_apply_kernel",
+    "bn2d_apply_avgpool": "bn2d_apply_avgpool_kernel", "bn2d_bwd_reduce_avgpool": "bn2d_bwd_reduce_kernel",
+    "bn2d_bwd_apply_avgpool": "bn2d_bwd_apply_kernel",
 }
 CUS, SIMD_NUM, XCCS, SES = 256, 1024, 8, 32
 
