@@ -523,6 +523,7 @@ def main():
                                   if use_graph and args.accum > 1 else
                                   "one hipGraph replay per step (whole step captured)" if use_graph else
                                   "eager launches" + (f" ({graph_note})" if graph_note else "")),
+                       "graph_fallback": graph_note,   # None unless --graph auto had to fall back to eager launches
                        "bn": "global-batch statistics (synchronised)" if (args.sync_bn and world > 1)
                        else "per-rank batch statistics"},
             "loss": round(loss, 6),

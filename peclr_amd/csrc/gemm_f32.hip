@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 // One LDS image (35 KiB -> 4 workgroups per CU), two barriers per K-tile, <= 128 VGPRs.
 constexpr int TM = 128, TN = 128;
 constexpr int LDN128 = TN + 4;
+constexpr int EPL = 36;   // row stride (floats) of a wave's 32 x 32 transpose buffer in the epilogue
 
 __global__ __launch_bounds__(256, 4) void gemm_f32_nn128_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float la[TM * LDK];        // [128][36]
@@ -251,28 +252,70 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_nn128_kernel(GemmArgs g) {
             __syncthreads();
         }
     }
-    // epilogue: C = acc (+ addend), 32 consecutive floats per row segment and store instruction
+    // Epilogue.  The MFMA accumulator layout gives a lane ONE column of a 32 x 32 tile (16 rows of it), so a
+    // direct epilogue moves 4 bytes per lane and instruction -- too few bytes in flight to stream the residual
+    // gradient in and the result out at HBM rate.  Each wave therefore transposes its tiles through its share of
+    // the (now idle) LDS: a lane then owns 4 consecutive columns of 4 rows, and every addend load and every store
+    // is 16 bytes per lane, 1 KiB per wave-instruction (8 rows x 128 bytes).
+    float* wlds = la + wave * (32 * EPL);                  // 4 x 4608 bytes of `la` (18432 bytes), wave-private
+    const int er = lane >> 3, ec = (lane & 7) * 4;         // this lane's row (+ 8 j) and first column in a tile
+    const bool vec_ok = (g.N % 4 == 0) && (g.ldo % 4 == 0) && (!g.addend || g.ldd % 4 == 0);
+    auto addend_tile = [&](int a, int b, float4 (&dv)[4]) {
+        const int mt = m0 + wm * 64 + a * 32, nt = n0 + wn * 64 + b * 32;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int n = n0 + wn * 64 + b * 32 + i;
-            if (n >= g.N) continue;
-            float dv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + a * 32 + mfma32_row(r, kh);
-                dv[r] = (g.addend && m < g.M) ? __builtin_nontemporal_load(g.addend + (size_t)m * g.ldd + n) : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + a * 32 + mfma32_row(r, kh);
-                if (m < g.M) {
-                    if (g.stream_out) __builtin_nontemporal_store(acc[a][b][r] + dv[r], g.out + (size_t)m * g.ldo + n);
-                    else g.out[(size_t)m * g.ldo + n] = acc[a][b][r] + dv[r];
+        for (int jj = 0; jj < 4; ++jj) {
+            const int m = mt + er + 8 * jj, n = nt + ec;
+            dv[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.addend && m < g.M && n < g.N) {
+                const float* src = g.addend + (size_t)m * g.ldd + n;
+                if (vec_ok) {
+                    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+                    dv[jj] = make_float4(t[0], t[1], t[2], t[3]);
+                } else {
+                    dv[jj].x = src[0];
+                    if (n + 1 < g.N) dv[jj].y = src[1];
+                    if (n + 2 < g.N) dv[jj].z = src[2];
+                    if (n + 3 < g.N) dv[jj].w = src[3];
                 }
             }
         }
+    };
+    auto store_tile = [&](int a, int b, const f32x16& c16, const float4 (&dv)[4]) {
+        const int mt = m0 + wm * 64 + a * 32, nt = n0 + wn * 64 + b * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * EPL + i] = c16[r];
+        // same wave wrote and reads: LDS operations of one wave complete in order
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int m = mt + er + 8 * jj, n = nt + ec;
+            float4 c = *reinterpret_cast<const float4*>(wlds + (er + 8 * jj) * EPL + ec);
+            c.x += dv[jj].x; c.y += dv[jj].y; c.z += dv[jj].z; c.w += dv[jj].w;
+            if (m < g.M && n < g.N) {
+                float* dst = g.out + (size_t)m * g.ldo + n;
+                if (vec_ok) {
+                    const f32x4 t = {c.x, c.y, c.z, c.w};
+                    if (g.stream_out) __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(dst));
+                    else *reinterpret_cast<f32x4*>(dst) = t;
+                } else {
+                    dst[0] = c.x;
+                    if (n + 1 < g.N) dst[1] = c.y;
+                    if (n + 2 < g.N) dst[2] = c.z;
+                    if (n + 3 < g.N) dst[3] = c.w;
+                }
+            }
+        }
+    };
+    // two tiles' residual gradients in flight at any time (the next tile's loads are issued before this tile's
+    // transpose and stores)
+    float4 d0[4], d1[4];
+    addend_tile(0, 0, d0);
+    addend_tile(0, 1, d1);
+    store_tile(0, 0, acc[0][0], d0);
+    addend_tile(1, 0, d0);
+    store_tile(0, 1, acc[0][1], d1);
+    addend_tile(1, 1, d1);
+    store_tile(1, 0, acc[1][0], d0);
+    store_tile(1, 1, acc[1][1], d1);
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
