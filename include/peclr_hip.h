@@ -81,6 +81,9 @@ int peclr_gemm_add_f32(int layout, int M, int N, int K, const float* A, int lda,
  * 1x1 weight transposed, [Cin][Cmid]); K, lda, ldb multiples of 8. */
 int peclr_gemm_add_bf16(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                         int ldc, const void* addend, int ldd, peclr_stream_t stream);
+/* the same kernel for IEEE fp16 activations (precision=16 / native AMP): v_mfma_f32_32x32x16_f16 */
+int peclr_gemm_add_f16(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                        int ldc, const void* addend, int ldd, peclr_stream_t stream);
 int peclr_gemm_pick_split_k(int M, int N, int K);
 
 /* out[i] = sum_s slabs[s][i] (+ bias[i % cols] if non-null), i < rows*cols. */
@@ -201,7 +204,7 @@ int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* sizes, int n_t
  * Replaces nn.BatchNorm2d + `out += identity` + nn.ReLU between the convolutions of the
  * torchvision ResNet blocks the reference builds (resnet_model.py:15, norm_layer=nn.BatchNorm2d).
  * Activations are NHWC (torch.channels_last): x, residual, y, dy, dx, d_residual are row-major
- * [R = N*H*W][C] of io_dtype (PECLR_DTYPE_F32, or PECLR_DTYPE_BF16 for autocast backbones);
+ * [R = N*H*W][C] of io_dtype (PECLR_DTYPE_F32, or PECLR_DTYPE_BF16 / PECLR_DTYPE_F16 for autocast backbones);
  * statistics, parameters and arithmetic are fp32.  With W = 4 (fp32) / 8 (bf16) channels per
  * 16-byte word, C/W must divide 256 or be a multiple of it (every ResNet width).
  * One entry point = one launch:
@@ -224,6 +227,7 @@ int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* sizes, int n_t
  * from the forward output y.  d_residual (nullable) receives the masked dy.                  */
 #define PECLR_DTYPE_F32 0
 #define PECLR_DTYPE_BF16 1
+#define PECLR_DTYPE_F16 2   /* IEEE half: precision=16 (native AMP), the reference's default */
 int peclr_bn2d_n_split(int R, int C, int io_dtype);
 int peclr_bn2d_stats(const void* x, int io_dtype, int R, int C, const float* shift,
                      float* partial, int n_split, peclr_stream_t stream);

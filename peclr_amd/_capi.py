@@ -29,6 +29,7 @@ SIGNATURES = {
     "peclr_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P]),
     "peclr_gemm_add_f32": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
     "peclr_gemm_add_bf16": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
+    "peclr_gemm_add_f16": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
     "peclr_gemm_pick_split_k": (c_int, [c_int, c_int, c_int]),
     "peclr_slab_reduce_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "peclr_bn_relu_fwd_f32": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, c_float, c_float, c_int, _P, _P,
@@ -339,32 +340,40 @@ def gemm_add(layout: int, a: torch.Tensor, b: torch.Tensor, addend: torch.Tensor
     return out
 
 
-def gemm_add_bf16(a: torch.Tensor, b_t: torch.Tensor, addend: Optional[torch.Tensor], tag: str = "gemm_add") -> torch.Tensor:
-    """C (bf16) = A[M,K] . B_t[N,K]^T + addend, bf16 row-major contiguous 2-D HIP tensors, fp32 accumulate."""
+def gemm_add_half(a: torch.Tensor, b_t: torch.Tensor, addend: Optional[torch.Tensor], tag: str = "gemm_add") -> torch.Tensor:
+    """C (16-bit) = A[M,K] . B_t[N,K]^T + addend, row-major contiguous 2-D HIP tensors that are ALL bf16 or ALL
+    fp16, fp32 accumulate (peclr_gemm_add_bf16 / peclr_gemm_add_f16)."""
     (m, k), (n, k2) = a.shape, b_t.shape
+    half = a.dtype
+    if half not in (torch.bfloat16, torch.float16):
+        raise PeclrHipError(f"gemm_add_half: bf16 or fp16 tensors expected, got {half}")
     for t in (a, b_t) + ((addend,) if addend is not None else ()):
-        if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
-            raise PeclrHipError("gemm_add_bf16: contiguous bf16 HIP tensors expected (peclr_amd has no CPU path)")
+        if not t.is_cuda or t.dtype != half or not t.is_contiguous():
+            raise PeclrHipError(f"gemm_add_half: contiguous {half} HIP tensors expected (peclr_amd has no CPU path)")
     if k != k2 or (addend is not None and tuple(addend.shape) != (m, n)):
-        raise PeclrHipError(f"gemm_add_bf16: shapes {tuple(a.shape)} x {tuple(b_t.shape)}^T")
-    out = torch.empty((m, n), device=a.device, dtype=torch.bfloat16)
+        raise PeclrHipError(f"gemm_add_half: shapes {tuple(a.shape)} x {tuple(b_t.shape)}^T")
+    out = torch.empty((m, n), device=a.device, dtype=half)
+    fn = lib().peclr_gemm_add_bf16 if half == torch.bfloat16 else lib().peclr_gemm_add_f16
     with _timed(tag, 2 * (m * k + k * n + 2 * m * n), 2 * m * n * k):
-        rc = lib().peclr_gemm_add_bf16(m, n, k, a.data_ptr(), k, b_t.data_ptr(), k, out.data_ptr(), n,
-                                       addend.data_ptr() if addend is not None else None, n, _stream())
-    _check(rc, "peclr_gemm_add_bf16")
+        rc = fn(m, n, k, a.data_ptr(), k, b_t.data_ptr(), k, out.data_ptr(), n,
+                addend.data_ptr() if addend is not None else None, n, _stream())
+    _check(rc, "peclr_gemm_add_bf16" if half == torch.bfloat16 else "peclr_gemm_add_f16")
     return out
 
 
+gemm_add_bf16 = gemm_add_half   # round-1 name
+
+
 # ------------------------------------------------------------------ backbone glue: BN2d (+add) (+ReLU), NHWC
-DTYPE_F32, DTYPE_BF16 = 0, 1
-_IO = {torch.float32: (DTYPE_F32, 4), torch.bfloat16: (DTYPE_BF16, 2)}
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+_IO = {torch.float32: (DTYPE_F32, 4), torch.bfloat16: (DTYPE_BF16, 2), torch.float16: (DTYPE_F16, 2)}
 
 
 def _nhwc_ptr(t: torch.Tensor, what: str, dtype=None):
     if not t.is_cuda:
         raise PeclrHipError(f"{what}: expected a HIP device tensor (peclr_amd has no CPU path)")
     if t.dtype not in _IO or t.dim() != 4 or (dtype is not None and t.dtype != dtype):
-        raise PeclrHipError(f"{what}: expected a 4-D {dtype or 'fp32/bf16'} tensor, got {t.dtype} {tuple(t.shape)}")
+        raise PeclrHipError(f"{what}: expected a 4-D {dtype or 'fp32/bf16/fp16'} tensor, got {t.dtype} {tuple(t.shape)}")
     if not t.is_contiguous(memory_format=torch.channels_last):
         raise PeclrHipError(f"{what}: tensor must be channels_last (NHWC) contiguous")
     return t.data_ptr()

@@ -8,7 +8,7 @@ takes the block's residual and a ReLU flag, so a ResNet block can hand the whole
 Two execution modes, chosen EXPLICITLY (no silent dispatch):
   hip = False (default)  stock PyTorch ops: F.batch_norm, add, relu -- any device / layout / dtype;
                          this is the PyTorch-ROCm backbone BASELINE.json:north_star describes.
-  hip = True             the hand-written HIP kernels; requires fp32 or bf16 (autocast) channels_last
+  hip = True             the hand-written HIP kernels; requires fp32, bf16 or fp16 (autocast) channels_last
                          HIP tensors and raises otherwise.  Turn it on with `enable_hip_batchnorm`.
 """
 from __future__ import annotations
@@ -173,9 +173,9 @@ class _ForkConv1x1(torch.autograd.Function):
             r = n * h * w
             a = gy.permute(0, 2, 3, 1).reshape(r, cmid)           # NHWC storage seen as [R, Cmid]: a view
             d = gid.permute(0, 2, 3, 1).reshape(r, cin)
-            if x.dtype == torch.bfloat16:                         # autocast backbone: bf16 MFMA, fp32 accumulate
-                wt = weight.detach().reshape(cmid, cin).t().contiguous().to(torch.bfloat16)
-                out = _capi.gemm_add_bf16(a, wt, d, tag="conv1x1_dgrad_add")
+            if x.dtype in (torch.bfloat16, torch.float16):       # autocast backbone: 16-bit MFMA, fp32 accumulate
+                wt = weight.detach().reshape(cmid, cin).t().contiguous().to(x.dtype)
+                out = _capi.gemm_add_half(a, wt, d, tag="conv1x1_dgrad_add")
             else:
                 out = _capi.gemm_add(_capi.GEMM_NN, a, weight.reshape(cmid, cin), d, tag="conv1x1_dgrad_add")
             dx = out.view(n, h, w, cin).permute(0, 3, 1, 2)       # back to a channels_last NCHW tensor
@@ -188,7 +188,7 @@ def fork_conv1x1(conv: nn.Conv2d, x: Tensor):
     fp32 (no autocast) or bf16 (under bf16 autocast); the stock ops otherwise."""
     autocast = torch.is_autocast_enabled("cuda")
     dtype_ok = ((x.dtype == torch.float32 and not autocast)
-                or (x.dtype == torch.bfloat16 and autocast and torch.get_autocast_dtype("cuda") == torch.bfloat16))
+                or (x.dtype in (torch.bfloat16, torch.float16) and autocast and torch.get_autocast_dtype("cuda") == x.dtype))
     ok = (getattr(conv, "hip_fork", False) and x.is_cuda and dtype_ok
           and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
           and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and x.requires_grad

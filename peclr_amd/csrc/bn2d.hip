@@ -76,6 +76,25 @@ template <> struct Word<bf16_t> {
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
+// fp16 activations (the reference's default precision=16 = native AMP): same 8-per-word geometry as bf16
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <> struct Word<f16_t> {
+    static constexpr int W = 8, U = 4;
+    static __device__ __forceinline__ Fv<8> load(const f16_t* p) {
+        const f16x8 t = *reinterpret_cast<const f16x8*>(p);
+        Fv<8> r;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r.v[k] = (float)t[k];
+        return r;
+    }
+    static __device__ __forceinline__ void store(f16_t* p, const Fv<8>& a) {
+        f16x8 t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (_Float16)a.v[k];   // round to nearest even; overflow -> inf (GradScaler's job)
+        *reinterpret_cast<f16x8*>(p) = t;
+    }
+};
 // per-channel fp32 parameters: W consecutive floats
 template <int W> __device__ __forceinline__ Fv<W> loadp(const float* p) {
     Fv<W> r;
@@ -781,8 +800,16 @@ inline bool make_plan(int R, int C, int W, int U, int want_split, Plan& p) {
 inline bool plan_for(int io_dtype, int R, int C, int want_split, Plan& p) {
     if (io_dtype == PECLR_DTYPE_F32) return make_plan(R, C, Word<float>::W, Word<float>::U, want_split, p);
     if (io_dtype == PECLR_DTYPE_BF16) return make_plan(R, C, Word<bf16_t>::W, Word<bf16_t>::U, want_split, p);
+    if (io_dtype == PECLR_DTYPE_F16) return make_plan(R, C, Word<f16_t>::W, Word<f16_t>::U, want_split, p);
     return false;
 }
+// Runs the statement(s) with `IO` = the activation type of `io` (callers have validated `io` through plan_for / pool_geo).
+#define PECLR_IO_SWITCH(io, ...)                                                  \
+    do {                                                                          \
+        if ((io) == PECLR_DTYPE_F32) { using IO = float; __VA_ARGS__; }           \
+        else if ((io) == PECLR_DTYPE_BF16) { using IO = bf16_t; __VA_ARGS__; }    \
+        else { using IO = f16_t; __VA_ARGS__; }                                   \
+    } while (0)
 inline bool all_aligned(std::initializer_list<const void*> ps) {
     for (const void* q : ps)
         if (q && !aligned16(q)) return false;
@@ -843,10 +870,7 @@ extern "C" int peclr_bn2d_stats(const void* x, int io_dtype, int R, int C, const
     if (n_split < 1 || !plan_for(io_dtype, R, C, n_split, p)) return PECLR_ERR_SHAPE;
     if (!all_aligned({x, partial, shift})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (io_dtype == PECLR_DTYPE_F32)
-        hipLaunchKernelGGL((bn2d_stats_kernel<float>), p.grid, dim3(T), 0, s, static_cast<const float*>(x), shift, p.g, n_split, partial);
-    else
-        hipLaunchKernelGGL((bn2d_stats_kernel<bf16_t>), p.grid, dim3(T), 0, s, static_cast<const bf16_t*>(x), shift, p.g, n_split, partial);
+    PECLR_IO_SWITCH(io_dtype, hipLaunchKernelGGL((bn2d_stats_kernel<IO>), p.grid, dim3(T), 0, s, static_cast<const IO*>(x), shift, p.g, n_split, partial));
     return launch_status();
 }
 
@@ -909,8 +933,7 @@ extern "C" int peclr_bn2d_apply(const void* x, const void* residual, int io_dtyp
     if (relu_mask && (C % 32 || !relu)) return PECLR_ERR_SHAPE;
     if (!all_aligned({x, y, scale_shift, residual})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (io_dtype == PECLR_DTYPE_F32) launch_apply<float>(p, s, x, residual, scale_shift, relu, y, relu_mask);
-    else launch_apply<bf16_t>(p, s, x, residual, scale_shift, relu, y, relu_mask);
+    PECLR_IO_SWITCH(io_dtype, launch_apply<IO>(p, s, x, residual, scale_shift, relu, y, relu_mask));
     return launch_status();
 }
 
@@ -924,8 +947,7 @@ extern "C" int peclr_bn2d_bwd_reduce(const void* dy, const void* x, const void* 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (relu_mask && C % 32) return PECLR_ERR_SHAPE;
     const int mm = mask_mode(relu, y, relu_mask);
-    if (io_dtype == PECLR_DTYPE_F32) launch_reduce<float>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, partial);
-    else launch_reduce<bf16_t>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, partial);
+    PECLR_IO_SWITCH(io_dtype, launch_reduce<IO>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, partial));
     return launch_status();
 }
 
@@ -950,17 +972,14 @@ extern "C" int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (relu_mask && C % 32) return PECLR_ERR_SHAPE;
     const int mm = mask_mode(relu, y, relu_mask);
-    if (io_dtype == PECLR_DTYPE_F32)
-        launch_bwd_apply<float>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, coef, dx, d_residual);
-    else
-        launch_bwd_apply<bf16_t>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, coef, dx, d_residual);
+    PECLR_IO_SWITCH(io_dtype, launch_bwd_apply<IO>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, coef, dx, d_residual));
     return launch_status();
 }
 
 // ---- stem: BN + ReLU + max-pool(3, 2, 1)
 namespace {
 bool pool_geo(int io_dtype, int N, int H, int W_, int C, peclr::PoolGeo& g) {
-    const int w = io_dtype == PECLR_DTYPE_F32 ? 4 : io_dtype == PECLR_DTYPE_BF16 ? 8 : 0;
+    const int w = io_dtype == PECLR_DTYPE_F32 ? 4 : (io_dtype == PECLR_DTYPE_BF16 || io_dtype == PECLR_DTYPE_F16) ? 8 : 0;
     if (!w || N <= 0 || H <= 0 || W_ <= 0 || C <= 0 || C % w) return false;
     const int cw = C / w;
     if (cw > T || T % cw) return false;
@@ -992,12 +1011,8 @@ extern "C" int peclr_bn2d_pool_apply(const void* x, int io_dtype, int N, int H, 
     if (!all_aligned({x, y, x_at_max, code, scale_shift})) return PECLR_ERR_ALIGN;
     const int blocks = pool_blocks(g, g.PH * g.PW, kPoolIter);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (io_dtype == PECLR_DTYPE_F32)
-        hipLaunchKernelGGL((bn2d_pool_apply_kernel<float>), dim3(blocks), dim3(T), 0, s, static_cast<const float*>(x), g,
-                           scale_shift, static_cast<float*>(y), static_cast<float*>(x_at_max), code);
-    else
-        hipLaunchKernelGGL((bn2d_pool_apply_kernel<bf16_t>), dim3(blocks), dim3(T), 0, s, static_cast<const bf16_t*>(x), g,
-                           scale_shift, static_cast<bf16_t*>(y), static_cast<bf16_t*>(x_at_max), code);
+    PECLR_IO_SWITCH(io_dtype, hipLaunchKernelGGL((bn2d_pool_apply_kernel<IO>), dim3(blocks), dim3(T), 0, s, static_cast<const IO*>(x), g,
+                           scale_shift, static_cast<IO*>(y), static_cast<IO*>(x_at_max), code));
     return launch_status();
 }
 
@@ -1009,12 +1024,8 @@ extern "C" int peclr_bn2d_pool_bwd_reduce(const void* dy_pool, const void* x_at_
     if (!pool_geo(io_dtype, N, H, W, C, g) || n_split < 1) return PECLR_ERR_SHAPE;
     if (!all_aligned({dy_pool, x_at_max, partial})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (io_dtype == PECLR_DTYPE_F32)
-        hipLaunchKernelGGL((bn2d_pool_bwd_reduce_kernel<float>), dim3(n_split), dim3(T), 0, s, static_cast<const float*>(dy_pool),
-                           static_cast<const float*>(x_at_max), g, save_mean, save_invstd, scale_shift, partial);
-    else
-        hipLaunchKernelGGL((bn2d_pool_bwd_reduce_kernel<bf16_t>), dim3(n_split), dim3(T), 0, s, static_cast<const bf16_t*>(dy_pool),
-                           static_cast<const bf16_t*>(x_at_max), g, save_mean, save_invstd, scale_shift, partial);
+    PECLR_IO_SWITCH(io_dtype, hipLaunchKernelGGL((bn2d_pool_bwd_reduce_kernel<IO>), dim3(n_split), dim3(T), 0, s, static_cast<const IO*>(dy_pool),
+                           static_cast<const IO*>(x_at_max), g, save_mean, save_invstd, scale_shift, partial));
     return launch_status();
 }
 
@@ -1027,14 +1038,9 @@ extern "C" int peclr_bn2d_pool_bwd_apply(const void* dy_pool, const void* x, con
     if (!all_aligned({dy_pool, x, code, dx})) return PECLR_ERR_ALIGN;
     const int blocks = pool_blocks(g, H * W, 2 * kPoolIter);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (io_dtype == PECLR_DTYPE_F32)
-        hipLaunchKernelGGL((bn2d_pool_bwd_apply_kernel<float>), dim3(blocks), dim3(T), 0, s, static_cast<const float*>(dy_pool),
-                           static_cast<const float*>(x), code, g, save_mean, save_invstd, scale_shift, coef,
-                           static_cast<float*>(dx));
-    else
-        hipLaunchKernelGGL((bn2d_pool_bwd_apply_kernel<bf16_t>), dim3(blocks), dim3(T), 0, s, static_cast<const bf16_t*>(dy_pool),
-                           static_cast<const bf16_t*>(x), code, g, save_mean, save_invstd, scale_shift, coef,
-                           static_cast<bf16_t*>(dx));
+    PECLR_IO_SWITCH(io_dtype, hipLaunchKernelGGL((bn2d_pool_bwd_apply_kernel<IO>), dim3(blocks), dim3(T), 0, s, static_cast<const IO*>(dy_pool),
+                           static_cast<const IO*>(x), code, g, save_mean, save_invstd, scale_shift, coef,
+                           static_cast<IO*>(dx)));
     return launch_status();
 }
 
@@ -1050,12 +1056,8 @@ extern "C" int peclr_bn2d_apply_avgpool(const void* x, const void* residual, int
     const dim3 grid(p.grid.x, N);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float inv = 1.0f / (float)HW;
-    if (io_dtype == PECLR_DTYPE_F32)
-        hipLaunchKernelGGL((bn2d_apply_avgpool_kernel<float>), grid, dim3(T), 0, s, static_cast<const float*>(x),
-                           static_cast<const float*>(residual), p.g, scale_shift, inv, pooled, relu_mask);
-    else
-        hipLaunchKernelGGL((bn2d_apply_avgpool_kernel<bf16_t>), grid, dim3(T), 0, s, static_cast<const bf16_t*>(x),
-                           static_cast<const bf16_t*>(residual), p.g, scale_shift, inv, pooled, relu_mask);
+    PECLR_IO_SWITCH(io_dtype, hipLaunchKernelGGL((bn2d_apply_avgpool_kernel<IO>), grid, dim3(T), 0, s, static_cast<const IO*>(x),
+                           static_cast<const IO*>(residual), p.g, scale_shift, inv, pooled, relu_mask));
     return launch_status();
 }
 
@@ -1069,14 +1071,9 @@ extern "C" int peclr_bn2d_bwd_reduce_avgpool(const float* d_pooled, const void* 
     if (!all_aligned({d_pooled, x, partial})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float inv = 1.0f / (float)HW;
-    if (io_dtype == PECLR_DTYPE_F32)
-        hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<float, 3, true>), p.grid, dim3(T), 0, s, (const float*)nullptr,
-                           static_cast<const float*>(x), (const float*)nullptr, relu_mask, p.g, save_mean, save_invstd, scale_shift,
-                           partial, d_pooled, HW, inv);
-    else
-        hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<bf16_t, 3, true>), p.grid, dim3(T), 0, s, (const bf16_t*)nullptr,
-                           static_cast<const bf16_t*>(x), (const bf16_t*)nullptr, relu_mask, p.g, save_mean, save_invstd,
-                           scale_shift, partial, d_pooled, HW, inv);
+    PECLR_IO_SWITCH(io_dtype, hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<IO, 3, true>), p.grid, dim3(T), 0, s, (const IO*)nullptr,
+                           static_cast<const IO*>(x), (const IO*)nullptr, relu_mask, p.g, save_mean, save_invstd, scale_shift,
+                           partial, d_pooled, HW, inv));
     return launch_status();
 }
 
@@ -1092,13 +1089,8 @@ extern "C" int peclr_bn2d_bwd_apply_avgpool(const float* d_pooled, const void* x
     if (!all_aligned({d_pooled, x, dx, d_residual})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float inv = 1.0f / (float)HW;
-    if (io_dtype == PECLR_DTYPE_F32)
-        hipLaunchKernelGGL((bn2d_bwd_apply_kernel<float, 3, true, true>), p.grid, dim3(T), 0, s, (const float*)nullptr,
-                           static_cast<const float*>(x), (const float*)nullptr, relu_mask, p.g, save_mean, save_invstd, scale_shift,
-                           coef, static_cast<float*>(dx), static_cast<float*>(d_residual), d_pooled, HW, inv);
-    else
-        hipLaunchKernelGGL((bn2d_bwd_apply_kernel<bf16_t, 3, true, true>), p.grid, dim3(T), 0, s, (const bf16_t*)nullptr,
-                           static_cast<const bf16_t*>(x), (const bf16_t*)nullptr, relu_mask, p.g, save_mean, save_invstd,
-                           scale_shift, coef, static_cast<bf16_t*>(dx), static_cast<bf16_t*>(d_residual), d_pooled, HW, inv);
+    PECLR_IO_SWITCH(io_dtype, hipLaunchKernelGGL((bn2d_bwd_apply_kernel<IO, 3, true, true>), p.grid, dim3(T), 0, s, (const IO*)nullptr,
+                           static_cast<const IO*>(x), (const IO*)nullptr, relu_mask, p.g, save_mean, save_invstd, scale_shift,
+                           coef, static_cast<IO*>(dx), static_cast<IO*>(d_residual), d_pooled, HW, inv));
     return launch_status();
 }

@@ -1,5 +1,6 @@
-// bf16-in / fp32-accumulate GEMM with an addend epilogue, for bf16 (autocast) backbones:
-//   C[M,N] (bf16) = A[M,K] (bf16) . B[N,K]^T (bf16) + D[M,N] (bf16)
+// 16-bit-in / fp32-accumulate GEMM with an addend epilogue, for bf16 or fp16 (autocast) backbones:
+//   C[M,N] (half) = A[M,K] (half) . B[N,K]^T (half) + D[M,N] (half),   half = bf16 (peclr_gemm_add_bf16) or IEEE
+//   fp16 (peclr_gemm_add_f16: v_mfma_f32_32x32x16_f16, same tile, same LDS image, same epilogue)
 // i.e. the bottleneck entry's "conv1 input gradient + residual branch gradient" (see peclr_gemm_add_f32)
 // when activations and gradients are bf16: dX[R,Cin] = dY[R,Cmid] . Wt[Cin,Cmid]^T + dRes[R,Cin].
 //
@@ -16,8 +17,9 @@
 namespace peclr {
 namespace {
 
-typedef uint16_t bf16_t;
+typedef uint16_t bf16_t;   // storage type of BOTH 16-bit formats in this file
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 64, BN = 64, BKH = 64;     // BKH: bf16 elements per K-tile
 constexpr int LDH = BKH + 8;                  // 72 bf16 = 36 dwords per LDS row
@@ -55,6 +57,28 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round to nearest ev
     return (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
+// per-format pieces: MFMA, 16-bit -> fp32, fp32 -> 16-bit (round to nearest even)
+struct BF16 {
+    static __device__ __forceinline__ f32x16 mma(const bf16_t* pa, const bf16_t* pb, f32x16 acc) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(pa), *reinterpret_cast<const bf16x8*>(pb),
+                                                      acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float up(unsigned lo16) { return __uint_as_float(lo16 << 16); }
+    static __device__ __forceinline__ unsigned down(float f) { return f32_to_bf16(f); }
+};
+struct F16 {
+    static __device__ __forceinline__ f32x16 mma(const bf16_t* pa, const bf16_t* pb, f32x16 acc) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(pa), *reinterpret_cast<const f16x8*>(pb),
+                                                     acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float up(unsigned lo16) {
+        const unsigned short h = (unsigned short)lo16;
+        return (float)__builtin_bit_cast(_Float16, h);
+    }
+    static __device__ __forceinline__ unsigned down(float f) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)f); }
+};
+
+template <typename H>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_add_kernel(GemmHArgs g) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][TILE_H];
     const int tid = threadIdx.x;
@@ -103,9 +127,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_add_kernel(GemmHArgs g) {
         const bf16_t* tb = lds[cur][1];
 #pragma unroll
         for (int t = 0; t < BKH / 16; ++t) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ta + (wm * 32 + i) * LDH + 16 * t + 8 * kh);
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(tb + (wn * 32 + i) * LDH + 16 * t + 8 * kh);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            acc = H::mma(ta + (wm * 32 + i) * LDH + 16 * t + 8 * kh, tb + (wn * 32 + i) * LDH + 16 * t + 8 * kh, acc);
         }
         if (more) {
             tile_store_h(lds[cur ^ 1][0], tid, ra);
@@ -129,8 +151,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_add_kernel(GemmHArgs g) {
         u4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float lo = c[2 * k] + __uint_as_float(d[k] << 16), hi = c[2 * k + 1] + __uint_as_float(d[k] & 0xFFFF0000u);
-            o[k] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+            const float lo = c[2 * k] + H::up(d[k] & 0xFFFFu), hi = c[2 * k + 1] + H::up(d[k] >> 16);
+            o[k] = H::down(lo) | (H::down(hi) << 16);
         }
         __builtin_nontemporal_store(o, reinterpret_cast<u4*>(g.out + (size_t)m * g.ldo + n));
     }
@@ -141,8 +163,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_add_kernel(GemmHArgs g) {
 
 using namespace peclr;
 
-extern "C" int peclr_gemm_add_bf16(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                                   const void* addend, int ldd, peclr_stream_t stream) {
+namespace {
+template <typename H>
+int gemm_add_half(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* addend,
+                  int ldd, peclr_stream_t stream) {
     if (!A || !B || !C) return PECLR_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0) return PECLR_ERR_SHAPE;
     if (K % 8 || N % 8 || lda % 8 || ldb % 8 || ldc % 8 || (addend && ldd % 8) || lda < K || ldb < K || ldc < N ||
@@ -156,7 +180,18 @@ extern "C" int peclr_gemm_add_bf16(int M, int N, int K, const void* A, int lda, 
     g.out = static_cast<bf16_t*>(C);
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldo = ldc; g.ldd = ldd;
     const int nrb = (M + BM - 1) / BM, nct = (N + BN - 1) / BN;
-    hipLaunchKernelGGL(gemm_bf16_nt_add_kernel, dim3(8 * ((nrb + 7) / 8) * nct), dim3(256), 0,
+    hipLaunchKernelGGL((gemm_bf16_nt_add_kernel<H>), dim3(8 * ((nrb + 7) / 8) * nct), dim3(256), 0,
                        static_cast<hipStream_t>(stream), g);
     return launch_status();
+}
+}  // namespace
+
+extern "C" int peclr_gemm_add_bf16(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                                   const void* addend, int ldd, peclr_stream_t stream) {
+    return gemm_add_half<BF16>(M, N, K, A, lda, B, ldb, C, ldc, addend, ldd, stream);
+}
+
+extern "C" int peclr_gemm_add_f16(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                                  const void* addend, int ldd, peclr_stream_t stream) {
+    return gemm_add_half<F16>(M, N, K, A, lda, B, ldb, C, ldc, addend, ldd, stream);
 }

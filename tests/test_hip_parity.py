@@ -491,7 +491,7 @@ def test_bn2d_fused_matches_torch(shape, relu, res, training):
 
 @pytest.mark.parametrize("shape", [(4, 64, 16, 16), (3, 64, 15, 17), (2, 64, 112, 112), (2, 128, 9, 9), (1, 64, 1, 5)])
 @pytest.mark.parametrize("training", [True, False])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["fp32", "bf16", "fp16"])
 def test_stem_bn_relu_maxpool_fused_matches_torch(shape, training, dtype):
     """features[1..3] of the encoder in one pass (the un-pooled activation is never written) against
     torch's BatchNorm2d -> ReLU -> MaxPool2d(3, 2, 1) in float64, forward and backward."""
@@ -526,7 +526,7 @@ def test_stem_bn_relu_maxpool_fused_matches_torch(shape, training, dtype):
     yd = hip(xd)
     assert yd.shape == yr.shape and yd.is_contiguous(memory_format=torch.channels_last)
     yd.backward(dy.to(DEV).contiguous(memory_format=torch.channels_last))
-    lo = dtype == torch.bfloat16
+    lo = dtype != torch.float32
     np.testing.assert_allclose(host(yd.float()), yr.detach().numpy(), atol=4e-2 if lo else 2e-5, rtol=1e-2 if lo else 0)
     scale = max(1.0, float(xr.grad.abs().max()))
     bad = np.abs(host(xd.grad.float()) - xr.grad.numpy()) > (3e-2 if lo else 3e-5) * scale
@@ -589,7 +589,7 @@ def test_bn2d_synchronised_route_matches_torch(solo_group, shape, relu, res, dty
     rd = r.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_() if res else None
     yd = bn(xd, rd, relu)
     yd.backward(dy.to(DEV).contiguous(memory_format=torch.channels_last))
-    lo = dtype == torch.bfloat16
+    lo = dtype != torch.float32
     np.testing.assert_allclose(host(yd.float()), yr.detach().numpy(), atol=4e-2 if lo else 2e-5, rtol=1e-2 if lo else 0)
     scale = max(1.0, float(xr.grad.abs().max()))
     np.testing.assert_allclose(host(xd.grad.float()), xr.grad.numpy(), atol=(3e-2 if lo else 3e-5) * scale)
@@ -670,25 +670,27 @@ def test_fork_conv1x1_fused_input_gradient(shape):
     np.testing.assert_allclose(host(outs[True][1]), ref.numpy(), atol=2e-5 * scale * max(1.0, cmid / 64) ** 0.5)
     np.testing.assert_allclose(host(outs[True][1]), host(outs[False][1]), atol=4e-5 * scale * max(1.0, cmid / 64) ** 0.5)
     np.testing.assert_allclose(host(outs[True][2]), host(outs[False][2]), rtol=1e-3, atol=1e-3 * float(outs[False][2].abs().max()))
-    # bf16 autocast backbone: bf16 activations / gradients, bf16 MFMA with fp32 accumulation
-    xb, gyb, gidb = (t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for t in (x, gy, gid))
-    refb = (torch.einsum("nmhw,mc->nchw", gyb.double().cpu(), conv.weight.detach().to(torch.bfloat16).double().cpu().view(cmid, cin))
-            + gidb.double().cpu())
-    res = {}
-    for fused in (False, True):
-        conv.hip_fork = fused
-        conv.weight.grad = None
-        xx = xb.clone().requires_grad_()
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            y, ident = fork_conv1x1(conv, xx)
-        assert y.dtype == torch.bfloat16
-        torch.autograd.backward((y, ident), (gyb, gidb))
-        assert xx.grad.dtype == torch.bfloat16 and conv.weight.grad.dtype == torch.float32
-        res[fused] = (xx.grad.float(), conv.weight.grad.clone())
-    sb = float(refb.abs().max())
-    np.testing.assert_allclose(host(res[True][0]), refb.numpy(), atol=1.2e-2 * sb)        # one bf16 rounding of the sum
-    np.testing.assert_allclose(host(res[False][0]), refb.numpy(), atol=2.5e-2 * sb)       # stock: rounds dgrad, then the sum
-    np.testing.assert_allclose(host(res[True][1]), host(res[False][1]), rtol=2e-2, atol=2e-2 * float(res[False][1].abs().max()))
+    # 16-bit autocast backbones (bf16, or fp16 = the reference's precision 16): 16-bit activations / gradients,
+    # 16-bit MFMA with fp32 accumulation
+    for half, ulp in ((torch.bfloat16, 2.0 ** -8), (torch.float16, 2.0 ** -11)):
+        xb, gyb, gidb = (t.to(half).contiguous(memory_format=torch.channels_last) for t in (x, gy, gid))
+        refb = (torch.einsum("nmhw,mc->nchw", gyb.double().cpu(), conv.weight.detach().to(half).double().cpu().view(cmid, cin))
+                + gidb.double().cpu())
+        res = {}
+        for fused in (False, True):
+            conv.hip_fork = fused
+            conv.weight.grad = None
+            xx = xb.clone().requires_grad_()
+            with torch.autocast("cuda", dtype=half):
+                y, ident = fork_conv1x1(conv, xx)
+            assert y.dtype == half
+            torch.autograd.backward((y, ident), (gyb, gidb))
+            assert xx.grad.dtype == half and conv.weight.grad.dtype == torch.float32
+            res[fused] = (xx.grad.float(), conv.weight.grad.clone())
+        sb = float(refb.abs().max())
+        np.testing.assert_allclose(host(res[True][0]), refb.numpy(), atol=3 * ulp * sb)       # one rounding of the sum
+        np.testing.assert_allclose(host(res[False][0]), refb.numpy(), atol=6.5 * ulp * sb)    # stock: rounds dgrad, then the sum
+        np.testing.assert_allclose(host(res[True][1]), host(res[False][1]), rtol=2e-2, atol=2e-2 * float(res[False][1].abs().max()))
 
 
 def test_encoder_wrapper_fused_stem_equals_stock_on_gpu():
@@ -787,16 +789,17 @@ def test_training_step_with_flat_grad_buckets_matches_plain():
 @pytest.mark.parametrize("shape", [(4, 64, 8, 8), (2, 256, 5, 7), (3, 2048, 2, 2), (16, 64, 56, 56), (5, 1024, 1, 1),
                                    (6, 128, 9, 9)])
 @pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
-def test_bn2d_fused_bf16_io(shape, relu, res):
-    """bf16 activations (autocast backbones), fp32 statistics/parameters.  Reference: float64 torch on
-    the SAME bf16-rounded inputs; outputs are bf16, so they agree to one bf16 ulp (2^-8 relative)."""
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_bn2d_fused_bf16_io(shape, relu, res, half):
+    """16-bit activations (bf16 or fp16 autocast backbones), fp32 statistics/parameters.  Reference: float64
+    torch on the SAME rounded inputs; outputs are 16-bit, so they agree to one ulp (2^-8 bf16, 2^-11 fp16)."""
     from peclr_amd.bn2d import FusedBatchNormAct2d
 
     n, c, h, w = shape
     g = torch.Generator().manual_seed(c + h + 1)
-    x = (torch.randn(shape, generator=g) * 1.5 + 0.7).bfloat16()
-    r = torch.randn(shape, generator=g).bfloat16() if res else None
-    dy = torch.randn(shape, generator=g).bfloat16()
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.7).to(half)
+    r = torch.randn(shape, generator=g).to(half) if res else None
+    dy = torch.randn(shape, generator=g).to(half)
     bn = FusedBatchNormAct2d(c)
     with torch.no_grad():
         bn.weight.uniform_(0.5, 1.5, generator=g)
@@ -817,9 +820,9 @@ def test_bn2d_fused_bf16_io(shape, relu, res):
     xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
     rd = r.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_() if res else None
     yd = bn(xd, rd, relu)
-    assert yd.dtype == torch.bfloat16 and yd.is_contiguous(memory_format=torch.channels_last)
+    assert yd.dtype == half and yd.is_contiguous(memory_format=torch.channels_last)
     yd.backward(dy.to(DEV).contiguous(memory_format=torch.channels_last))
-    ulp = 2.0 ** -8
+    ulp = 2.0 ** -8 if half == torch.bfloat16 else 2.0 ** -11
     yref = yr.detach().numpy()
     np.testing.assert_allclose(host(yd.float()), yref, atol=ulp * np.abs(yref).max() + 1e-6, rtol=ulp)
     dxr = xr.grad.numpy()
@@ -1264,7 +1267,7 @@ def copy_state(sd):
 
 @pytest.mark.parametrize("shape", [(8, 2048, 7, 7), (4, 512, 7, 7), (3, 512, 2, 2), (16, 2048, 14, 14), (5, 64, 3, 3),
                                    (2, 256, 1, 1)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_add_relu_avgpool_fused_matches_torch(shape, dtype, training):
     """Encoder tail: bn + identity + ReLU + AdaptiveAvgPool2d((1,1)) + flatten in one
@@ -1445,3 +1448,48 @@ def test_two_stage_split_backward_equals_single_backward_graph():
     worst_noise = max(rel(a, c) for a, c in zip(g1[0], g3[0]))
     for a, b in zip(g1[0], g2[0]):
         assert rel(a, b) <= max(5 * worst_noise, 1e-3), (rel(a, b), worst_noise)
+
+
+def test_precision_16_trains_on_the_fused_glue_with_a_grad_scaler():
+    """precision=16 (the reference's default: fp16 native AMP) end to end on the HIP glue: fp16 activations through
+    the fused BatchNorm / stem / tail / fork kernels, fp32 head and loss, dynamic loss scaling around the fused
+    optimiser.  Tracks the fp32 run on the same batch."""
+    import copy
+    import warnings
+
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config
+    from peclr_amd.bn2d import enable_hip_batchnorm
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(51)
+    n = 16
+    cfg = hybrid2_config(resnet_size="50", projection_head_input_dim=2048, augmentation=["crop", "rotate"],
+                         batch_size=n, num_samples=64, warmup_epochs=1, lr=1e-3, pretrained=False)
+    base = Hybrid2Model(cfg).to(DEV).train()
+    base.encoder = base.encoder.to(memory_format=torch.channels_last)
+    enable_hip_batchnorm(base.encoder)
+    g = torch.Generator().manual_seed(52)
+    batch = {"transformed_image1": torch.randn(n, 3, 96, 96, generator=g), "transformed_image2": torch.randn(n, 3, 96, 96, generator=g),
+             "jitter_x_1": torch.randint(-14, 1, (n,), generator=g), "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+             "jitter_y_1": torch.randint(-14, 1, (n,), generator=g), "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+             "angle_1": torch.randint(-45, 46, (n,), generator=g).double(), "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    for k in ("transformed_image1", "transformed_image2"):
+        batch[k] = batch[k].contiguous(memory_format=torch.channels_last)
+    curves = {}
+    for precision in ("fp32", 16):
+        model = copy.deepcopy(base)
+        tr = Trainer(max_epochs=10, precision=precision).attach(model)
+        tr.zero_grad()
+        curves[precision] = [float(tr.training_micro_step(batch, i)["loss"]) for i in range(12)]
+        if precision == 16:
+            assert tr.precision == "fp16" and tr._scaler is not None and 0 < tr._scaler.get_scale() <= 65536.0
+            assert tr.global_step == 12
+            assert all(torch.isfinite(p).all() for p in model.parameters())
+            assert any(getattr(m, "hip", False) for m in model.encoder.modules())     # the fused glue ran, in fp16
+    assert all(np.isfinite(curves[16]))
+    assert curves[16][0] == pytest.approx(curves["fp32"][0], rel=5e-3)                # same forward at step 0
+    # the scaler starts at 2^16 and skips steps (halving itself) until the scaled gradients fit fp16, so the fp16 run
+    # lags the fp32 one by its skipped steps; it must then learn at a comparable rate
+    assert curves[16][-1] < curves[16][0] - 0.25 * (curves["fp32"][0] - curves["fp32"][-1])
+    assert min(curves[16]) >= min(curves["fp32"]) - 0.05 * abs(curves["fp32"][0])
