@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--checkpoint", type=int, default=0,
                     help="1: activation checkpointing in the encoder (residual blocks keep only their input for backward "
                          "and re-run there): for batch sizes / resolutions beyond the activation budget; ~1/3 more compute")
+    ap.add_argument("--overlap-wgrad", type=int, default=0,
+                    help="1: the backbone's weight gradients run on a second HIP stream, next to the BatchNorm / residual "
+                         "glue of the layers below them (a parallel branch of the captured graph)")
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--sync-bn", type=int, default=0,
                     help="1: BatchNorm statistics over the global batch (exact N-rank == 1-device semantics, two small "
@@ -362,7 +365,8 @@ def main():
                 if getattr(m, "hip_fork", False):
                     m.hip_fork = False
     trainer = Trainer(max_epochs=100, accumulate_grad_batches=args.accum, precision=args.dtype,
-                      sync_batchnorm=bool(args.sync_bn), activation_checkpointing=bool(args.checkpoint)).attach(model)
+                      sync_batchnorm=bool(args.sync_bn), activation_checkpointing=bool(args.checkpoint),
+                      overlap_wgrad=bool(args.overlap_wgrad)).attach(model)
     trainer.zero_grad()
     batch = synthetic_batch(args.pairs, args.size, 5 + rank, device, channels_last=bool(args.channels_last))
 
@@ -513,7 +517,7 @@ def main():
                                    f"views per GPU, crop+rotate equivariance alignment, NT-Xent tau=0.5, "
                                    f"LARS(Adam) step, {args.dtype}",
                        "global_batch": world * 2 * args.pairs * args.accum, "parallelism": f"dp{world}",
-                       "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn, "fork_gemm": bool(fused_bn and args.fork_gemm), "activation_checkpointing": bool(args.checkpoint),
+                       "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn, "fork_gemm": bool(fused_bn and args.fork_gemm), "activation_checkpointing": bool(args.checkpoint), "overlap_wgrad": bool(args.overlap_wgrad),
                        "launch": ((("three hipGraph replays per step (forward to z | backward of head + layer4 | backward of "
                                     "layer3..stem, the first stage's gradient all-reduce in flight under the second), "
                                     if getattr(trainer, "_graph_b2", None) is not None else

@@ -145,6 +145,103 @@ class _BN2dAddReluAvgPool(torch.autograd.Function):
         return dx, dgamma, dbeta, dres, None
 
 
+# ---- weight gradients on a side stream.  In the backward pass a convolution's weight gradient (MFMA-bound) is
+# needed only by the optimiser, while its input gradient feeds the next BatchNorm backward (HBM-bound) at once.
+# With `enable_wgrad_overlap`, every convolution of the in-tree ResNet computes its weight gradient on a second
+# HIP stream: it runs next to the glue kernels of the layers below it instead of in front of them, so the chip's
+# MFMA pipes and its memory system are busy at the same time.  Such a gradient does NOT travel through autograd's
+# AccumulateGrad (which would read it on the main stream): it is parked and handed to its parameter by
+# `wgrad_join()`, which the caller runs after backward, once the main stream has waited for the side stream.
+# Under hipGraph capture the side stream becomes a parallel branch of the graph.
+class _WgradOverlap:
+    stream = None        # torch.cuda.Stream or None (= off: everything on the current stream, through autograd)
+    parked: list = []    # (parameter, gradient computed on the side stream, tensors it read)
+
+
+def enable_wgrad_overlap(enabled: bool = True):
+    """Switch the side-stream weight gradients on (a dedicated stream is created on first use) or off."""
+    if enabled and _WgradOverlap.stream is None:
+        _WgradOverlap.stream = torch.cuda.Stream()
+    elif not enabled:
+        wgrad_join()
+        _WgradOverlap.stream = None
+
+
+def wgrad_join():
+    """After backward: wait for the side stream, then give every parked gradient to its parameter
+    (`.grad = g`, or `.grad += g` when one is already there: accumulation windows, all-reduce bucket views)."""
+    if not _WgradOverlap.parked:
+        return
+    torch.cuda.current_stream().wait_stream(_WgradOverlap.stream)
+    with torch.no_grad():
+        for param, g, _inputs in _WgradOverlap.parked:
+            if param.grad is None:
+                param.grad = g
+            else:
+                param.grad.add_(g)
+    _WgradOverlap.parked.clear()
+
+
+def _conv_wgrad(gy: Tensor, x: Tensor, weight: Tensor, stride, padding, param=None):
+    """d(weight) of conv2d(x, weight) for output gradient gy.  Overlap off (or no parameter to park it for):
+    computed here and returned.  Overlap on: issued on the side stream, parked for `param`, returns None."""
+    def run():
+        g = torch.ops.aten.convolution_backward(gy, x, weight.to(x.dtype), None, list(stride), list(padding), [1, 1], False,
+                                                [0, 0], 1, [False, True, False])[1]
+        return g.to((param if param is not None else weight).dtype)
+    st = _WgradOverlap.stream
+    if st is None or param is None or not gy.is_cuda:
+        return run()
+    st.wait_stream(torch.cuda.current_stream())          # gy (and x) are ready where the side stream picks up
+    with torch.cuda.stream(st):
+        g = run()
+        if g.stride() != param.stride():                 # the parameter's layout (channels_last weights)
+            g = torch.empty_like(param).copy_(g)
+    _WgradOverlap.parked.append((param, g, (gy, x)))     # inputs stay referenced until the join
+    return None
+
+
+class _Conv2dSplitBackward(torch.autograd.Function):
+    """conv2d (no bias, groups 1, dilation 1) whose backward computes the input gradient on the current stream and
+    the weight gradient through `_conv_wgrad` (parked on the side stream when overlap is on)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding, param):
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (tuple(stride), tuple(padding), param)
+        return F.conv2d(x, weight, None, stride, padding)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, padding, param = ctx.cfg
+        gy = gy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        dw = _conv_wgrad(gy, x, weight, stride, padding, param) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(gy, x, weight.to(x.dtype), None, list(stride), list(padding), [1, 1], False,
+                                                     [0, 0], 1, [True, False, False])[0]
+        if dw is not None and dw.dtype != weight.dtype:
+            dw = dw.to(weight.dtype)
+        return dx, dw, None, None, None
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters / state_dict) that routes through `_Conv2dSplitBackward` while the side-stream
+    weight gradients are enabled and the input is a channels_last HIP tensor; the stock op otherwise."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        if (_WgradOverlap.stream is not None and x.is_cuda and torch.is_grad_enabled() and self.bias is None
+                and self.groups == 1 and self.dilation == (1, 1) and isinstance(self.padding, tuple)
+                and x.is_contiguous(memory_format=torch.channels_last) and self.weight.requires_grad):
+            w = self.weight
+            if torch.is_autocast_enabled("cuda"):
+                half = torch.get_autocast_dtype("cuda")
+                x, w = x.to(half), w.to(half)            # what autocast does for conv2d
+            return _Conv2dSplitBackward.apply(x, w, self.stride, self.padding, self.weight)
+        return super().forward(x)
+
+
 class _ForkConv1x1(torch.autograd.Function):
     """Bottleneck entry: (x, W) -> (conv1x1(x, W), x).  The block input feeds both the first convolution and
     the identity branch, so its gradient is dY W + d_identity: autograd runs MIOpen's dgrad and then an
@@ -154,6 +251,7 @@ class _ForkConv1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
+        ctx.param = weight if isinstance(weight, nn.Parameter) else None
         return F.conv2d(x, weight), x.view_as(x)
 
     @staticmethod
@@ -164,8 +262,7 @@ class _ForkConv1x1(torch.autograd.Function):
         dw = None
         gy = gy.to(x.dtype)
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(gy, x, weight.to(x.dtype), None, [1, 1], [0, 0], [1, 1], False,
-                                                     [0, 0], 1, [False, True, False])[1].to(weight.dtype)
+            dw = _conv_wgrad(gy.contiguous(memory_format=torch.channels_last), x, weight, (1, 1), (0, 0), ctx.param)
         dx = None
         if ctx.needs_input_grad[0]:
             gy = gy.contiguous(memory_format=torch.channels_last)

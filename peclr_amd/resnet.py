@@ -16,15 +16,15 @@ from typing import List, Type, Union
 import torch
 from torch import Tensor, nn
 
-from .bn2d import FusedBatchNormAct2d, checkpoint_block, fork_conv1x1
+from .bn2d import Conv2d, FusedBatchNormAct2d, checkpoint_block, fork_conv1x1
 
 
 def conv3x3(cin, cout, stride=1):
-    return nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False)
+    return Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False)
 
 
 def conv1x1(cin, cout, stride=1):
-    return nn.Conv2d(cin, cout, 1, stride=stride, bias=False)
+    return Conv2d(cin, cout, 1, stride=stride, bias=False)
 
 
 def _bn(bn, x, residual=None, relu=False):
@@ -100,7 +100,7 @@ class ResNet(nn.Module):
         norm_layer = norm_layer or FusedBatchNormAct2d  # an nn.BatchNorm2d (same state_dict) that can fuse
         self._norm_layer = norm_layer
         self.inplanes = 64
-        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.conv1 = Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = norm_layer(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)

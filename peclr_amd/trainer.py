@@ -35,8 +35,12 @@ class Trainer:
     def __init__(self, max_epochs: int = 1, accumulate_grad_batches: int = 1, precision: str = "fp32",
                  checkpoint_dir: Optional[str] = None, save_top_k: int = 1, process_group=None,
                  bucket_bytes: int = 32 << 20, channels_last: bool = False, grad_buckets=None,
-                 sync_batchnorm: bool = False, hip_graph: bool = False, activation_checkpointing: bool = False):
+                 sync_batchnorm: bool = False, hip_graph: bool = False, activation_checkpointing: bool = False,
+                 overlap_wgrad: bool = False):
         self.max_epochs = max_epochs
+        # True: the backbone's weight gradients are computed on a second HIP stream (peclr_amd.bn2d), next to the
+        # BatchNorm / residual glue of the layers below instead of in front of it; joined after every backward.
+        self.overlap_wgrad = overlap_wgrad
         # True: residual blocks of the encoder keep only their input for backward and recompute the rest there
         # (peclr_amd.resnet.set_activation_checkpointing): for batches / resolutions whose activations do not fit
         self.activation_checkpointing = activation_checkpointing
@@ -83,6 +87,10 @@ class Trainer:
 
             if set_activation_checkpointing(model.encoder, True) == 0:
                 raise RuntimeError("activation_checkpointing: the encoder has no peclr_amd.resnet blocks")
+        if self.overlap_wgrad:
+            from . import bn2d as _bn2d
+
+            _bn2d.enable_wgrad_overlap(True)
         if self.sync_batchnorm and self.world_size > 1:
             self._enable_sync_batchnorm(model)
         if self.world_size > 1 or self.grad_buckets:
@@ -173,6 +181,7 @@ class Trainer:
             out = self.model.training_step(batch, batch_idx)
         loss = out["loss"] / k
         (scaler.scale(loss) if scaler is not None else loss).backward()
+        self._join_wgrad()
         if last:
             if self.reducer is not None:
                 self.reducer.finish()
@@ -185,6 +194,13 @@ class Trainer:
             self.scheduler.step()
             self.global_step += 1
         return {key: v.detach() for key, v in out.items()}
+
+    def _join_wgrad(self):
+        """After a backward pass: the current stream waits for the side stream's weight gradients."""
+        if self.overlap_wgrad:
+            from . import bn2d as _bn2d
+
+            _bn2d.wgrad_join()
 
     def _no_fp16_graphs(self):
         if self.precision == "fp16":
@@ -237,6 +253,7 @@ class Trainer:
             with self._autocast():
                 eager_out = self.model.training_step(self._static_batch, 0)
             eager_out["loss"].backward()
+            self._join_wgrad()
             self._capture_eager_out = {k: v.detach().clone() for k, v in eager_out.items()}
             self.optimizer.prepare_step()
             self.optimizer.launch_only()          # performs that step eagerly (and builds the work list)
@@ -250,6 +267,7 @@ class Trainer:
             with self._autocast():
                 out = self.model.training_step(self._static_batch, 0)
             out["loss"].backward()
+            self._join_wgrad()
             self.optimizer.launch_only(reuse_worklist=True)
         self.optimizer.repoint_worklist()         # gradients now live in the graph's private pool
         # the captured optimiser launch reads this work list's device tables: keep it alive even if a
@@ -329,11 +347,13 @@ class Trainer:
         self._split_dz = torch.zeros_like(z)
         with torch.cuda.graph(self._graph_b, pool=pool, capture_error_mode="thread_local"):
             torch.autograd.backward((z,), (self._split_dz,))
+            self._join_wgrad()
         late = [(p, p.grad) for p in params if p.grad is not None]
         early = []
         if two_stage:
             with torch.cuda.graph(self._graph_b2, pool=pool, capture_error_mode="thread_local"):
                 torch.autograd.backward((seam["out"],), (seam["leaf"].grad,))
+                self._join_wgrad()
             seen = {id(p) for p, _ in late}
             early = [(p, p.grad) for p in params if p.grad is not None and id(p) not in seen]
             self._split_seam = seam           # keeps the seam tensors (graph-pool memory) referenced
@@ -394,6 +414,7 @@ class Trainer:
             with self._autocast():
                 out = self.model.training_step(self._static_batch, 0)
             out["loss"].backward()
+            self._join_wgrad()
         pairs = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
         self._micro_src = [g for _, g in pairs]
         self._micro_acc = [torch.zeros_like(g) for g in self._micro_src]
