@@ -31,7 +31,8 @@ BENCH_KERNELS = {
     "bn2d_bwd_reduce": "bn2d_bwd_reduce_kernel", "bn2d_bwd_finalize": "bn2d_bwd_finalize_kernel",
     "bn2d_bwd_apply": "bn2d_bwd_apply_kernel",
     "bn2d_pool_apply": "bn2d_pool_apply_kernel", "bn2d_pool_bwd_reduce": "bn2d_pool_bwd_reduce_kernel",
-    "bn2d_pool_bwd_apply": "bn2d_pool_bwd_apply_kernel",
+    "bn2d_pool_bwd_apply": "bn2d_pool_bwd_apply_kernel", "bn2d_apply_avgpool": "bn2d_apply_avgpool_kernel",
+    "conv1x1_dgrad_add": "gemm_f32_nn128_kernel",
 }
 
 

@@ -1,5 +1,6 @@
 #!/bin/bash
-# rocprofv3 passes behind profiles/r02_*: kernel trace + two SQ counter passes (8 SQ slots per pass; counters
+# rocprofv3 passes behind profiles/r02_* and profiles/pmc_traffic.json: kernel trace + two SQ counter passes + the two
+# HBM-traffic passes (FETCH_SIZE and WRITE_SIZE need separate passes: TCC slots) (8 SQ slots per pass; counters
 # only with --kernel-trace, never with the sys/hip/hsa trace domains), for (a) the labelled MFMA probe and
 # (b) the eager default bench.  Run from the repo root on the MI355X box:  bash tools/profile_passes.sh <outdir>
 set -u
@@ -28,7 +29,10 @@ run probe_pmc_b "$PMC_B" python "$ROOT/tools/mfma_probe.py"
 run bench_trace "" $BENCH
 run bench_pmc_a "$PMC_A" $BENCH
 run bench_pmc_b "$PMC_B" $BENCH
+run bench_pmc_fetch "FETCH_SIZE" $BENCH
+run bench_pmc_write "WRITE_SIZE" $BENCH
 cd "$ROOT"
+python tools/pmc_traffic.py --table "$OUT/bench_pmc_fetch/p_results.db" "$OUT/bench_pmc_write/p_results.db" "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.txt" 2>&1
 python tools/pmc_mfma.py "$OUT/probe_trace/p_results.db" "$OUT/probe_trace/manifest.json" "$OUT/probe_mfma.json" \
   "$OUT/probe_pmc_a/p_results.db" "$OUT/probe_pmc_b/p_results.db" > "$OUT/probe_mfma.txt" 2>&1
 python tools/pmc_mfma.py "$OUT/bench_trace/p_results.db" "$OUT/bench_trace/manifest.json" "$OUT/bench_mfma.json" \
