@@ -159,3 +159,28 @@ def test_single_process_helpers_are_noops():
         lin.weight.grad.data_ptr() == red.buckets[0].views[0].data_ptr()
     red.zero_grad()
     assert float(lin.weight.grad.abs().sum()) == 0.0
+
+
+def test_grad_buckets_never_mix_backward_stages():
+    """GradReducer(stage_of=...): a bucket closes where the backward stage changes (head + layer4 | the rest), so the
+    first stage's buckets can be all-reduced while the second stage's backward is still running."""
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config
+    from peclr_amd import dist as pdist
+
+    import warnings
+
+    warnings.simplefilter("ignore")
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, batch_size=2, num_samples=8, pretrained=False)
+    model = Hybrid2Model(cfg)
+    stage_of = Trainer._backward_stage_of(model)
+    red = pdist.GradReducer(model.parameters(), None, bucket_bytes=4 << 20, stage_of=stage_of)
+    stages = [b.stage for b in red.buckets]
+    assert stages == sorted(stages) and set(stages) == {0, 1} and len(red.buckets) > 3
+    early = {id(p) for p in model.encoder.features[:7].parameters()}
+    for b in red.buckets:
+        assert all((id(p) in early) == (b.stage == 1) for p in b.params)
+    assert sum(len(b.params) for b in red.buckets) == sum(1 for p in model.parameters() if p.requires_grad)
+    assert red.launch(red.buckets) == []          # single process: nothing to reduce
+    # an encoder that is not the in-tree wrapper has no seam: one stage
+    model.encoder = torch.nn.Flatten()
+    assert Trainer._backward_stage_of(model) is None
