@@ -510,3 +510,38 @@ def test_activation_checkpointing_is_exact_and_moves_running_stats_once():
     assert all(m.checkpoint for m in b.encoder.modules() if isinstance(m, resnet.BasicBlock))
     for (k, u), (_, v) in zip(a.state_dict().items(), b.state_dict().items()):
         assert torch.equal(u, v), k
+
+
+def test_static_batch_keeps_the_stacked_views_relation():
+    """Graph replay copies every new batch into static buffers.  When both views arrive as halves of ONE
+    [2N,...] tensor (`transformed_images`: no per-step concatenation), the static copy must keep that relation, and
+    a later batch may arrive stacked or as two separate tensors."""
+    from peclr_amd import Trainer
+    from peclr_amd.module import SimCLR
+
+    n = 3
+    stacked = torch.arange(2 * n * 4, dtype=torch.float32).view(2 * n, 1, 2, 2)
+    batch = {"transformed_images": stacked, "transformed_image1": stacked[:n], "transformed_image2": stacked[n:],
+             "angle_1": torch.zeros(n, dtype=torch.float64)}
+    static = Trainer._clone_batch(batch)
+    assert static["transformed_images"].data_ptr() != stacked.data_ptr()
+    assert static["transformed_image1"].data_ptr() == static["transformed_images"].data_ptr()
+    assert static["transformed_image2"].data_ptr() == static["transformed_images"][n:].data_ptr()
+    assert SimCLR._two_views(static) is static["transformed_images"]              # no torch.cat
+    # stacked -> stacked
+    new = {k: v + 100 if v.is_floating_point() else v for k, v in batch.items()}
+    new["transformed_image1"], new["transformed_image2"] = new["transformed_images"][:n], new["transformed_images"][n:]
+    Trainer._load_static(static, new)
+    assert torch.equal(static["transformed_image2"], stacked[n:] + 100)
+    # two separate tensors -> the stacked static buffer, through its halves
+    sep = {"transformed_image1": torch.full((n, 1, 2, 2), 7.0), "transformed_image2": torch.full((n, 1, 2, 2), 9.0),
+           "angle_1": torch.ones(n, dtype=torch.float64)}
+    Trainer._load_static(static, sep)
+    assert float(static["transformed_images"][:n].mean()) == 7.0 and float(static["transformed_images"][n:].mean()) == 9.0
+    assert float(static["angle_1"].sum()) == n
+    # a static batch WITHOUT the stacked tensor accepts a stacked batch through its halves
+    plain = Trainer._clone_batch(sep)
+    assert "transformed_images" not in plain
+    Trainer._load_static(plain, new)
+    assert torch.equal(plain["transformed_image1"], new["transformed_image1"])
+    assert torch.equal(SimCLR._two_views(plain), torch.cat([new["transformed_image1"], new["transformed_image2"]]))
