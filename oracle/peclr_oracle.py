@@ -12,9 +12,14 @@ Pinning: the reference has no tests or known-answer vectors of its own
 in the build container from the reference's own functions imported under
 third-party stubs (`tests/golden/make_golden.py`, fixtures `tests/golden/*.npz`).
 `tests/test_oracle_golden.py` holds that check.  Two pieces have no importable
-reference and are therefore "parity unpinned" (see DESIGN.md): the torchvision
-ResNet arithmetic and pl_bolts' LARSWrapper / LinearWarmupCosineAnnealingLR
-(restated from their published behaviour in `lars_adam_step` / `warmup_cosine_lr`).
+reference: torchvision 0.8's ResNet -- the in-tree restatement
+(`peclr_amd/resnet.py`) is instead pinned against an INDEPENDENT implementation of the
+same published architecture, `transformers.ResNetModel` (equal to 1e-10 in float64 with
+copied weights, eval and train mode: tests/test_host_logic.py) -- and pl_bolts'
+LARSWrapper / LinearWarmupCosineAnnealingLR, restated from their published behaviour in
+`lars_adam_step` / `warmup_cosine_lr` and "parity unpinned" (nothing implementing them is
+installed); the numbers the reference feeds them are pinned by golden G7.
+`bench.py` also uses `oracle/step_check.py` for its parity line (checker, untimed).
 
 All citations are `path:line` relative to /root/reference.
 

@@ -545,3 +545,67 @@ def test_static_batch_keeps_the_stacked_views_relation():
     Trainer._load_static(plain, new)
     assert torch.equal(plain["transformed_image1"], new["transformed_image1"])
     assert torch.equal(SimCLR._two_views(plain), torch.cat([new["transformed_image1"], new["transformed_image2"]]))
+
+
+@pytest.mark.parametrize("name,depths,widths,kind", [("resnet18", [2, 2, 2, 2], [64, 128, 256, 512], "basic"),
+                                                      ("resnet50", [3, 4, 6, 3], [256, 512, 1024, 2048], "bottleneck")])
+def test_resnet_arithmetic_matches_an_independent_implementation(name, depths, widths, kind):
+    """torchvision (the reference's encoder, resnet_model.py:15,31-43) is not installed here, but `transformers`
+    ships an independent implementation of the same published architecture (its ResNetModel hosts the converted
+    torchvision checkpoints: v1.5 bottlenecks with the stride on the 3x3, conv7x7/2 + max-pool stem, 1x1-conv + BN
+    shortcuts).  With the in-tree network's weights copied into it block by block, both must compute the same
+    features -- in eval mode (running statistics) and in train mode (batch statistics, running-stat updates)."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import ResNetConfig
+    from transformers import ResNetModel as HFResNet
+
+    from peclr_amd import resnet
+
+    torch.manual_seed(3)
+    mine = getattr(resnet, name)().double()
+    with torch.no_grad():          # non-trivial normalisation state everywhere
+        for m in mine.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+                m.running_mean.uniform_(-0.3, 0.3)
+                m.running_var.uniform_(0.5, 2.0)
+    hf = HFResNet(ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=widths, depths=depths, layer_type=kind,
+                               hidden_act="relu", downsample_in_first_stage=False, downsample_in_bottleneck=False)).double()
+
+    def put(conv_layer, conv, bn):
+        conv_layer.convolution.load_state_dict(conv.state_dict())
+        conv_layer.normalization.load_state_dict(bn.state_dict())
+
+    put(hf.embedder.embedder, mine.conv1, mine.bn1)
+    for s, stage in enumerate((mine.layer1, mine.layer2, mine.layer3, mine.layer4)):
+        for b, block in enumerate(stage):
+            tgt = hf.encoder.stages[s].layers[b]
+            convs = [(block.conv1, block.bn1), (block.conv2, block.bn2)] + ([(block.conv3, block.bn3)] if kind == "bottleneck" else [])
+            assert len(tgt.layer) == len(convs)
+            for layer, (c, n) in zip(tgt.layer, convs):
+                assert layer.convolution.stride == c.stride and layer.convolution.kernel_size == c.kernel_size
+                put(layer, c, n)
+            if block.downsample is not None:
+                put(tgt.shortcut, block.downsample[0], block.downsample[1])
+            else:
+                assert isinstance(tgt.shortcut, torch.nn.Identity)
+    assert sum(p.numel() for p in hf.parameters()) == sum(p.numel() for n_, p in mine.named_parameters() if not n_.startswith("fc."))
+
+    x = torch.randn(3, 3, 64, 64, dtype=torch.float64)
+
+    def features(net):
+        return torch.flatten(net.avgpool(net.layer4(net.layer3(net.layer2(net.layer1(net.maxpool(net.relu(net.bn1(net.conv1(x))))))))), 1)
+
+    for training in (False, True):
+        mine.train(training)
+        hf.train(training)
+        want = hf(x).pooler_output.flatten(1)
+        got = features(mine)
+        assert got.shape == want.shape == (3, widths[-1])
+        assert float((got - want).abs().max()) <= 1e-10 * max(1.0, float(want.abs().max())), training
+    # train mode moved both sets of running statistics identically (momentum 0.1, unbiased variance)
+    last_mine = mine.layer4[-1].bn3 if kind == "bottleneck" else mine.layer4[-1].bn2
+    last_hf = hf.encoder.stages[3].layers[-1].layer[-1].normalization
+    assert torch.allclose(last_mine.running_var, last_hf.running_var, rtol=1e-12, atol=0)
+    assert int(last_mine.num_batches_tracked) == int(last_hf.num_batches_tracked) == 1
