@@ -538,6 +538,12 @@ def main():
                          "unit": "TFLOP/s", "frac": round(ach_tf / peak_tf, 4)},
             "hand_written_us_per_step": round(sum(k["avg_us"] * k["launches"] / table_steps
                                                   for k in kernels.values()), 1),
+            # launch-count reduction of the head / alignment / loss (reference: ~100 stock-op
+            # launches forward incl. a CPU round trip, ~60 backward through autograd)
+            "head_launches_per_step": {name: kernels[name]["launches"] // (table_steps * args.accum) for name in
+                                       ("gemm_k1_fwd", "bn_relu_fwd", "gemm_k2_fwd", "align_fwd", "ntxent_fwd", "ntxent_finalize",
+                                        "ntxent_bwd", "slab_reduce", "align_bwd", "gemm_dw2", "gemm_da", "bn_relu_bwd",
+                                        "gemm_dw1", "gemm_dh") if name in kernels},
         }
         if parity is not None:
             result["parity"] = parity
