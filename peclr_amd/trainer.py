@@ -424,25 +424,70 @@ class Trainer:
         self._static_out = out
         return self
 
-    def replay_micro(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    def replay_micro(self, batch: Optional[Dict[str, torch.Tensor]] = None, batch_idx: Optional[int] = None,
+                     is_final_batch: bool = False) -> Dict[str, torch.Tensor]:
+        """One micro-batch: replay, add its gradients / k into the accumulators, and step the optimiser when the
+        window is full -- counted by `batch_idx` when given (fit: Lightning's rule, incl. the epoch's final batch),
+        by the number of replays otherwise (bench)."""
         k = self.accumulate_grad_batches
         if batch is not None and batch is not self._static_batch:
             self._load_static(self._static_batch, batch)
         self._graph.replay()
         torch._foreach_add_(self._micro_acc, self._micro_src, alpha=1.0 / k)
         self._micro_count += 1
-        if self._micro_count % k == 0:
+        last = (self._micro_count % k == 0) if batch_idx is None else ((batch_idx + 1) % k == 0 or is_final_batch)
+        if last:
             self.optimizer.step()
             torch._foreach_zero_(self._micro_acc)
             self.scheduler.step()
             self.global_step += 1
+            self._micro_count = 0
         return self._static_out
+
+    def _capture_micro_in_fit(self, batch, batch_idx, is_final_batch):
+        """fit() with accumulation: the first batch is trained on ONCE, eagerly; its gradients become the initial
+        content of the accumulators; the micro-batch graph is then captured (a capture records, it does not run)."""
+        out = self.training_micro_step(batch, batch_idx, is_final_batch)
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        carried = {p: p.grad for p in params if p.grad is not None}      # empty if that batch closed a window
+        for p in params:
+            p.grad = None
+        self._static_batch = self._clone_batch(batch)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            with self._autocast():
+                g_out = self.model.training_step(self._static_batch, 0)
+            g_out["loss"].backward()
+            self._join_wgrad()
+        pairs = [(p, p.grad) for p in params if p.grad is not None]
+        self._micro_src = [g for _, g in pairs]
+        self._micro_acc = [carried[p] if p in carried else torch.zeros_like(g) for p, g in pairs]
+        for (p, _), a in zip(pairs, self._micro_acc):
+            p.grad = a
+        self._micro_pairs = [(p, a) for (p, _), a in zip(pairs, self._micro_acc)]
+        self._micro_count = 0
+        self._static_out = g_out
+        return out
 
     def _graph_step(self, batch: Dict[str, torch.Tensor], batch_idx: int,
                     is_final_batch: bool = False) -> Dict[str, torch.Tensor]:
         """fit()'s step when hip_graph is on: capture on the first batch (which is trained on exactly
         once, by the eager step the capture routine runs), replay for equal shapes, eager otherwise."""
         sig = tuple((k, tuple(v.shape), v.dtype) for k, v in batch.items())
+        if self.accumulate_grad_batches > 1:       # single process: one graph per micro-batch + accumulators
+            if self._graph_sig is None:
+                self._graph_sig = sig
+                return self._capture_micro_in_fit(batch, batch_idx, is_final_batch)
+            if sig != self._graph_sig:             # ragged batch: eager, accumulating into the same buffers
+                out = self.training_micro_step(batch, batch_idx, is_final_batch)
+                for p, a in self._micro_pairs:     # an optimiser step inside dropped .grad: hand the buffers back
+                    if p.grad is None:
+                        a.zero_()
+                        p.grad = a
+                return out
+            out = self.replay_micro(batch, batch_idx, is_final_batch)
+            return {k: v.detach().clone() for k, v in out.items()}
         if self._graph_sig is None:
             self._graph_sig = sig
             if self.reducer is None:
@@ -473,8 +518,8 @@ class Trainer:
         if self.model is not model:
             self.attach(model)
         self.zero_grad()
-        use_graph = (self.hip_graph and self.accumulate_grad_batches == 1
-                     and not (self.sync_batchnorm and self.world_size > 1))
+        use_graph = (self.hip_graph and not (self.sync_batchnorm and self.world_size > 1) and self.precision != "fp16"
+                     and (self.accumulate_grad_batches == 1 or (self.world_size == 1 and self.reducer is None)))
         step = self._graph_step if use_graph else self.training_micro_step
         # with graphs the whole loop lives on one side stream: a backward on the default stream before the
         # capture would pull the legacy stream into it (see capture_step_graph)

@@ -1561,3 +1561,51 @@ def test_side_stream_weight_gradients_match_the_single_stream_backward(mode):
     assert l1[0] == pytest.approx(l0[0], rel=1e-5 if mode != "graph" else 5e-3) and l1 == pytest.approx(l0, rel=5e-2)
     noise = dev(g0, g2)
     assert dev(g0, g1) <= max(4 * noise, 1e-3), (dev(g0, g1), noise)
+
+
+def test_fit_with_hip_graph_and_accumulation_matches_eager_fit():
+    """Trainer(hip_graph=True, accumulate_grad_batches=2).fit: the first batch is trained on once (eagerly) and seeds
+    the accumulators, equal shapes replay the micro-batch graph, the ragged batch runs eagerly into the same
+    accumulators, the epoch's final batch closes a partial window -- same step count, schedule and epoch metrics
+    as the eager loop."""
+    import copy
+    import warnings
+
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config
+    from peclr_amd.bn2d import enable_hip_batchnorm
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(71)
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, augmentation=["crop", "rotate"],
+                         batch_size=8, num_samples=38, warmup_epochs=1, num_of_mini_batch=2, pretrained=False)
+    base = Hybrid2Model(cfg).to(DEV).train()
+    base.encoder = base.encoder.to(memory_format=torch.channels_last)
+    enable_hip_batchnorm(base.encoder)
+
+    def batches(epoch):
+        g = torch.Generator().manual_seed(300 + epoch)
+        for n in (8, 8, 8, 6, 8):                                      # a ragged batch mid-epoch, 5 batches: final closes a window of one
+            b = {"transformed_image1": torch.randn(n, 3, 64, 64, generator=g), "transformed_image2": torch.randn(n, 3, 64, 64, generator=g),
+                 "jitter_x_1": torch.randint(-14, 1, (n,), generator=g), "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+                 "jitter_y_1": torch.randint(-14, 1, (n,), generator=g), "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+                 "angle_1": torch.randint(-45, 46, (n,), generator=g).double(), "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+            b = {k: v.to(DEV) for k, v in b.items()}
+            for k in ("transformed_image1", "transformed_image2"):
+                b[k] = b[k].contiguous(memory_format=torch.channels_last)
+            yield b
+
+    runs = {}
+    for graph in (False, True):
+        m = copy.deepcopy(base)
+        tr = Trainer(max_epochs=2, accumulate_grad_batches=2, hip_graph=graph)
+        tr.fit(m, batches)
+        torch.cuda.synchronize()
+        runs[graph] = (tr, m)
+    (te, me), (tg, mg) = runs[False], runs[True]
+    assert tg.global_step == te.global_step == 6                       # 2 epochs x (2 full windows + the final batch)
+    assert tg.scheduler.last_epoch == te.scheduler.last_epoch
+    assert hasattr(tg, "_micro_src") and not hasattr(te, "_micro_src")
+    assert float(mg.train_metrics_epoch["loss"]) == pytest.approx(float(me.train_metrics_epoch["loss"]), rel=6e-2)
+    assert int(mg.projection_head[1].num_batches_tracked) == int(me.projection_head[1].num_batches_tracked) == 10
+    wd = float((mg.projection_head[3].weight - me.projection_head[3].weight).norm() / me.projection_head[3].weight.norm())
+    assert wd <= 5e-3, wd
