@@ -178,6 +178,8 @@ class TwoViewAugmenter:
         rw, rh = self.params["resize_shape"]
         out, _ = _capi.augment_views(images, params.to(images.device, non_blocking=True), (rh, rw), IMAGENET_MEAN,
                                      IMAGENET_STD, self.channels_last)
-        batch = {"transformed_image1": out[:b], "transformed_image2": out[b:]}
+        # both views are the halves of ONE buffer; `transformed_images` lets the model skip its cat(view1, view2)
+        # (hybrid2_model.py:30-32) -- an extra "image" entry, which the reference's consumers of the dict ignore
+        batch = {"transformed_images": out, "transformed_image1": out[:b], "transformed_image2": out[b:]}
         batch.update({k: t.to(images.device, non_blocking=True) for k, t in self.collate(views).items()})
         return batch

@@ -154,8 +154,8 @@ class SimCLR(BaseModel):
     @staticmethod
     def _two_views(batch: Dict[str, Tensor]) -> Tensor:
         """Both views as one [2N, 3, H, W] tensor, view 1 first (hybrid2_model.py:30-32).  A batch that
-        already carries them stacked (`transformed_images`, e.g. from TwoViewAugmenter(stacked=True))
-        is used as is: no copy."""
+        already carries them stacked (`transformed_images`: TwoViewAugmenter and bench.py emit the two
+        views as halves of one buffer) is used as is: no copy."""
         stacked = batch.get("transformed_images")
         if stacked is not None:
             return stacked
