@@ -37,6 +37,7 @@ struct GemmArgs {
     const float* addend;  // optional [M][N] matrix added in the epilogue (row stride ldd)
     int M, N, K, lda, ldb, ldo, ldd, kchunk;
     int stream_out;       // output (and addend) larger than the caches: non-temporal epilogue
+    int flat_tiles;       // < 8 row blocks: plain tile order instead of the XCD-aware one (64 x 64 kernel)
     size_t slab_stride;  // 0 when writing C directly
 };
 
@@ -90,11 +91,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     // the 8 XCDs round-robin, so hardware block b runs row block 8 * (j / nct) + b % 8, column tile j % nct
     // with j = b / 8: every column tile of a row block lands on the SAME XCD, one after the other, and the
     // 64 x K operand tile they share is read from HBM once and from that XCD's L2 afterwards.
+    // With fewer than 8 row blocks (the projection head: M = 256 rows = 4 row blocks) that order would leave XCDs
+    // idle -- there the tiles are simply dealt out one by one (g.flat_tiles), which spreads them over all XCDs.
     const int nct = (g.N + BN - 1) / BN;
-    const int j = blockIdx.x / 8;
-    const int row_block = 8 * (j / nct) + (int)(blockIdx.x % 8);
+    int row_block, col_tile;
+    if (g.flat_tiles) {
+        row_block = blockIdx.x / nct;
+        col_tile = blockIdx.x % nct;
+    } else {
+        const int j = blockIdx.x / 8;
+        row_block = 8 * (j / nct) + (int)(blockIdx.x % 8);
+        col_tile = j % nct;
+    }
     if (row_block * BM >= g.M) return;
-    const int m0 = row_block * BM, n0 = (j % nct) * BN;
+    const int m0 = row_block * BM, n0 = col_tile * BN;
     const int kbeg = blockIdx.z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
@@ -403,7 +413,8 @@ int gemm_launch(int layout, int M, int N, int K, const float* A, int lda, const 
     else { g.out = slabs; g.ldo = N; g.bias = nullptr; g.slab_stride = (size_t)M * N; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nrb = (M + BM - 1) / BM, nct = (N + BN - 1) / BN;
-    dim3 grid(8 * ((nrb + 7) / 8) * nct, 1, split_k), block(256);
+    g.flat_tiles = nrb < 8;
+    dim3 grid(g.flat_tiles ? nrb * nct : 8 * ((nrb + 7) / 8) * nct, 1, split_k), block(256);
     // PECLR_GEMM_TILE=64 pins the 64 x 64 kernel (A/B experiments); default: NN problems without split-K / bias
     // that fill the chip with 128 x 128 tiles (>= 2 per CU) take the 128 x 128 kernel -- the projection head's
     // own NN GEMMs (M = 256 rows: 32 such tiles) stay on the 64 x 64 kernel, which gives them 4x the workgroups
