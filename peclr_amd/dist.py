@@ -130,17 +130,28 @@ class GradReducer:
         params = [p for p in params if p.requires_grad]
         stage_of = stage_of or (lambda p: 0)
         # buckets in REVERSE registration order: the last layers' grads are ready first
-        self.buckets: List[_Bucket] = []
+        groups: List[List[torch.nn.Parameter]] = []
         cur, cur_bytes = [], 0
         for p in reversed(params):
             nbytes = p.numel() * p.element_size()
             if cur and (cur_bytes + nbytes > bucket_bytes or p.dtype != cur[0].dtype or stage_of(p) != stage_of(cur[0])):
-                self.buckets.append(_Bucket(cur))
+                groups.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
         if cur:
-            self.buckets.append(_Bucket(cur))
+            groups.append(cur)
+        # a small tail (the last few parameters of a stage) rides with its predecessor instead of paying for an
+        # all-reduce of its own: every collective costs a fixed latency over xGMI
+        size = lambda g: sum(p.numel() * p.element_size() for p in g)  # noqa: E731
+        merged: List[List[torch.nn.Parameter]] = []
+        for g in groups:
+            if (merged and size(g) < bucket_bytes // 8 and g[0].dtype == merged[-1][0].dtype
+                    and stage_of(g[0]) == stage_of(merged[-1][0])):
+                merged[-1] = merged[-1] + g
+            else:
+                merged.append(g)
+        self.buckets: List[_Bucket] = [_Bucket(g) for g in merged]
         for b in self.buckets:
             b.stage = stage_of(b.params[0])
         self._armed = False
