@@ -55,8 +55,9 @@ def parse():
     ap.add_argument("--resnet", default="50")
     ap.add_argument("--pairs", type=int, default=128, help="view pairs per device (N); 2N images/step/device")
     ap.add_argument("--size", type=int, default=224)
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="backbone compute dtype (configs[1] is fp32; head/logits/loss are always fp32)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
+                    help="backbone compute dtype (configs[1] is fp32; head/logits/loss are always fp32); fp16 = the "
+                         "reference's precision 16 (native AMP with a GradScaler): eager launches only")
     ap.add_argument("--channels-last", type=int, default=1,
                     help="NHWC activations/weights for the MIOpen backbone (default): its gfx950 igemm kernels "
                          "are NHWC-native, NCHW costs ~11%% of the step in layout transposes "
@@ -328,6 +329,10 @@ def main():
     args = parse()
     warnings.simplefilter("ignore")
     graph_note = None
+    if args.dtype == "fp16":
+        if args.graph == "1":
+            raise SystemExit("--dtype fp16 runs eagerly (the GradScaler's skip-on-overflow is a host branch)")
+        args.graph = "0"
     if args.graph == "auto":
         single = int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1
         if single and not os.environ.get("PECLR_BENCH_CHILD"):
@@ -505,7 +510,7 @@ def main():
                     algorithmic_bytes=kernels[dominant]["bytes"], algorithmic_flops=kernels[dominant]["flops"])
         flops_img = conv_flops_per_image(model.encoder.features, (args.size, args.size))
         step_flops = 3 * flops_img * 2 * args.pairs * args.accum
-        peak_tf = MFMA_F32_PEAK_TF if args.dtype == "fp32" else MFMA_BF16_PEAK_TF
+        peak_tf = MFMA_F32_PEAK_TF if args.dtype == "fp32" else MFMA_BF16_PEAK_TF   # fp16 dense peak = the bf16 one
         ach_tf = step_flops * args.steps / dt / 1e12
         result = {
             "metric": "images/sec (2-view) ResNet-50 bs128 @1/2/4/8 MI355X; NT-Xent loss Δ vs ref",
