@@ -523,9 +523,10 @@ def main():
                                    f"LARS(Adam) step, {args.dtype}",
                        "global_batch": world * 2 * args.pairs * args.accum, "parallelism": f"dp{world}",
                        "accumulate_grad_batches": args.accum, "channels_last": bool(args.channels_last), "fused_bn": fused_bn, "fork_gemm": bool(fused_bn and args.fork_gemm), "activation_checkpointing": bool(args.checkpoint), "overlap_wgrad": bool(args.overlap_wgrad),
-                       "launch": ((("three hipGraph replays per step (forward to z | backward of head + layer4 | backward of "
-                                    "layer3..stem, the first stage's gradient all-reduce in flight under the second), "
-                                    if getattr(trainer, "_graph_b2", None) is not None else
+                       "launch": (((f"{['zero', 'one', 'two', 'three', 'four', 'five'][1 + len(trainer._graph_bs)]} hipGraph replays per step "
+                                    "(forward to z | backward of head + layer4 | of layer3 | of layer2..stem, each stage's "
+                                    "gradient all-reduce in flight under the next stage), "
+                                    if len(getattr(trainer, "_graph_bs", [])) > 1 else
                                     "two hipGraph replays per step (forward to z | backward from dz), ") +
                                    "collectives, NT-Xent and optimiser eager between/after them") if split else
                                   f"{args.accum} hipGraph replays (micro-batch forward + backward) + eager accumulate / optimiser per step"

@@ -59,16 +59,22 @@ class ResNetModel(nn.Module):
             raise NotImplementedError  # resnet_model.py:42-43
         return table[resnet_name]
 
-    CUT = 7  # features[:7] = stem + layer1..3, features[7:] = layer4 + global average pool
+    # where the trainer may cut the autograd graph for a staged backward: before layer4 (features[7]) and before
+    # layer3 (features[6]) -- stage 0 = head + layer4, stage 1 = layer3, stage 2 = layer2 + layer1 + stem
+    SEAMS = (7, 6)
 
     def forward(self, x, cut=None):
-        """cut (optional): callable applied to layer3's output before layer4 sees it -- the trainer uses it to
-        split the autograd graph there (backward in two stages, so that the gradient all-reduce of head +
-        layer4 overlaps the backward of layer1..3)."""
+        """cut (optional): callable `cut(index, tensor) -> tensor` applied to the input of features[index] for every
+        index in SEAMS -- the trainer uses it to split the autograd graph there (backward in stages, so that the
+        gradient all-reduce of the later layers overlaps the backward of the earlier ones)."""
         if cut is None:
             z = self.features(x)
         else:
-            z = self.features[self.CUT:](cut(self.features[:self.CUT](x)))
+            z, lo = x, 0
+            for at in sorted(self.SEAMS):
+                z = cut(at, self.features[lo:at](z))
+                lo = at
+            z = self.features[lo:](z)
         z = z.flatten(start_dim=1)
         if self.mode == "pretraining":
             return z

@@ -103,15 +103,21 @@ class Trainer:
 
     @staticmethod
     def _backward_stage_of(model):
-        """Backward stage of every parameter for the two-stage split backward: 0 = projection head + layer4
-        (+ the unused final_layer), 1 = stem + layer1..3.  None when the encoder is not the in-tree wrapper."""
+        """Backward stage of every parameter for the staged split backward: 0 = projection head + layer4 (+ the
+        unused final_layer), 1 = layer3, 2 = layer2 + layer1 + stem (cuts at ResNetModel.SEAMS).  None when the
+        encoder is not the in-tree wrapper."""
         from .encoder import ResNetModel
 
         enc = getattr(model, "encoder", None)
         if not isinstance(enc, ResNetModel):
             return None
-        early = {id(p) for p in enc.features[:ResNetModel.CUT].parameters()}
-        return lambda p: 1 if id(p) in early else 0
+        stage = {}
+        bounds = sorted(ResNetModel.SEAMS, reverse=True)            # (7, 6)
+        for k, hi in enumerate(bounds):                             # features[bounds[k+1] : bounds[k]] is stage k + 1
+            lo = bounds[k + 1] if k + 1 < len(bounds) else 0
+            for p in enc.features[lo:hi].parameters():
+                stage[id(p)] = k + 1
+        return lambda p: stage.get(id(p), 0)
 
     def _enable_sync_batchnorm(self, model):
         import torch.distributed as td
@@ -297,10 +303,11 @@ class Trainer:
     # does not depend on RCCL's capture support; the price is that the all-reduce no longer overlaps
     # with backward (RN-50: 98 MB over xGMI, well under a millisecond against a ~7 ms gain).
     def capture_split_graphs(self, example_batch: Dict[str, torch.Tensor], warmup: int = 3, two_stage: Optional[bool] = None):
-        """two_stage (default: when the encoder is the in-tree ResNet wrapper): the backward is captured as TWO
-        graphs cut at layer4's input -- B1 = head + layer4, B2 = layer3..stem.  After B1 its gradients are copied
-        into their buckets and all-reduced ASYNCHRONOUSLY while B2 replays (RN-50: ~64 MB of the ~98 MB travel
-        under ~35 ms of remaining backward), so only the early layers' buckets stay exposed."""
+        """two_stage (default: when the encoder is the in-tree ResNet wrapper; the name is round 2's first version --
+        there are three stages now): the backward is captured as one graph per stage, cut at layer4's and layer3's
+        inputs -- B1 = head + layer4, B2 = layer3, B3 = layer2..stem.  After each stage its gradients are copied into
+        their buckets and all-reduced ASYNCHRONOUSLY while the next stage replays (RN-50: 65 MB, then 28 MB, travel
+        under the remaining backward), so only the last stage's ~6 MB stay exposed."""
         self._no_fp16_graphs()
         if self.accumulate_grad_batches != 1:
             raise RuntimeError("capture_split_graphs needs accumulate_grad_batches=1")
@@ -314,7 +321,7 @@ class Trainer:
         if two_stage is None:
             two_stage = can_cut
         if two_stage and not can_cut:
-            raise RuntimeError("two_stage backward needs the in-tree encoder (peclr_amd.encoder.ResNetModel)")
+            raise RuntimeError("a staged backward needs the in-tree encoder (peclr_amd.encoder.ResNetModel)")
         self._static_batch = self._clone_batch(example_batch)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -331,13 +338,12 @@ class Trainer:
             p.grad = None                     # the backward graphs allocate the gradients in the graphs' pool
         self.reducer._armed = False           # hooks stay inert: no collective inside a capture
         pool = torch.cuda.graph_pool_handle()
-        self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        self._graph_b2 = torch.cuda.CUDAGraph() if two_stage else None
-        seam = {}
+        self._graph_a = torch.cuda.CUDAGraph()
+        seams = {}                            # features index -> (tensor that ends the later graph, leaf that starts it)
 
-        def cut(x3):                          # layer3's output: graph B1 ends here, graph B2 starts here
-            seam["out"], seam["leaf"] = x3, x3.detach().requires_grad_()
-            return seam["leaf"]
+        def cut(at, t):
+            seams[at] = (t, t.detach().requires_grad_())
+            return seams[at][1]
 
         with torch.cuda.graph(self._graph_a, pool=pool, capture_error_mode="thread_local"):
             with self._autocast():
@@ -345,25 +351,32 @@ class Trainer:
                     model._project(self._static_batch)
         self._split_z, self._split_rows, self._split_n = z, row_stats, n_pairs
         self._split_dz = torch.zeros_like(z)
-        with torch.cuda.graph(self._graph_b, pool=pool, capture_error_mode="thread_local"):
-            torch.autograd.backward((z,), (self._split_dz,))
-            self._join_wgrad()
-        late = [(p, p.grad) for p in params if p.grad is not None]
-        early = []
-        if two_stage:
-            with torch.cuda.graph(self._graph_b2, pool=pool, capture_error_mode="thread_local"):
-                torch.autograd.backward((seam["out"],), (seam["leaf"].grad,))
+        # one backward graph per stage, from the loss side down: (z, dz), then (seam output, the gradient its leaf
+        # received from the graph before) for every seam in descending order
+        roots = [(z, self._split_dz)] + [None] * len(seams)
+        self._graph_bs, per_stage, seen = [], [], set()
+        for k in range(len(roots)):
+            if k > 0:
+                out, leaf = seams[sorted(seams, reverse=True)[k - 1]]
+                roots[k] = (out, leaf.grad)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                torch.autograd.backward((roots[k][0],), (roots[k][1],))
                 self._join_wgrad()
-            seen = {id(p) for p, _ in late}
-            early = [(p, p.grad) for p in params if p.grad is not None and id(p) not in seen]
-            self._split_seam = seam           # keeps the seam tensors (graph-pool memory) referenced
+            self._graph_bs.append(g)
+            fresh = [(p, p.grad) for p in params if p.grad is not None and id(p) not in seen]
+            seen.update(id(p) for p, _ in fresh)
+            per_stage.append(fresh)
+        self._split_seams = seams             # keeps the seam tensors (graph-pool memory) referenced
+        self._graph_b = self._graph_bs[0]
+        self._graph_b2 = self._graph_bs[1] if len(self._graph_bs) > 1 else None
         self.reducer.zero_grad()              # .grad = bucket views again (optimiser + all-reduce read those)
         self._split_stages = []               # per stage: (captured gradients, their bucket views, the stage's buckets)
-        for stage, pairs in enumerate((late, early) if two_stage else (late,)):
+        for stage, pairs in enumerate(per_stage):
             buckets = [b for b in self.reducer.buckets if b.stage == stage] if two_stage else list(self.reducer.buckets)
             owned = {id(p) for b in buckets for p in b.params}
             if any(id(p) not in owned for p, _ in pairs):
-                raise RuntimeError("two_stage backward: a gradient of one stage lives in another stage's bucket")
+                raise RuntimeError("staged backward: a gradient of one stage lives in another stage's bucket")
             self._split_stages.append(([g for _, g in pairs], [p.grad for p, _ in pairs], buckets))
         return self
 
@@ -377,7 +390,7 @@ class Trainer:
         (dz,) = torch.autograd.grad(loss, z)
         self._split_dz.copy_(dz)
         handles = []
-        for graph, (src, dst, buckets) in zip((self._graph_b, self._graph_b2), self._split_stages):
+        for graph, (src, dst, buckets) in zip(self._graph_bs, self._split_stages):
             graph.replay()
             torch._foreach_copy_(dst, src)
             handles += self.reducer.launch(buckets)    # travels while the next stage's graph replays

@@ -175,10 +175,12 @@ def test_grad_buckets_never_mix_backward_stages():
     stage_of = Trainer._backward_stage_of(model)
     red = pdist.GradReducer(model.parameters(), None, bucket_bytes=4 << 20, stage_of=stage_of)
     stages = [b.stage for b in red.buckets]
-    assert stages == sorted(stages) and set(stages) == {0, 1} and len(red.buckets) > 3
-    early = {id(p) for p in model.encoder.features[:7].parameters()}
+    assert stages == sorted(stages) and set(stages) == {0, 1, 2} and len(red.buckets) > 3
+    layer3 = {id(p) for p in model.encoder.features[6].parameters()}
+    early = {id(p) for p in model.encoder.features[:6].parameters()}
     for b in red.buckets:
-        assert all((id(p) in early) == (b.stage == 1) for p in b.params)
+        for p in b.params:
+            assert b.stage == (1 if id(p) in layer3 else 2 if id(p) in early else 0)
     assert sum(len(b.params) for b in red.buckets) == sum(1 for p in model.parameters() if p.requires_grad)
     assert red.launch(red.buckets) == []          # single process: nothing to reduce
     # an encoder that is not the in-tree wrapper has no seam: one stage

@@ -196,7 +196,7 @@ def test_bench_two_ranks_on_one_gpu_emits_a_valid_line(graph):
     assert r["config"]["global_batch"] == 2 * 2 * 8 and r["config"]["parallelism"] == "dp2"
     assert r["value"] == pytest.approx(2 * 2 * 8 * 3 / (r["ms_per_step"] * 3e-3), rel=1e-3)   # whole-job aggregate
     assert np.isfinite(r["loss"]) and 0 < r["loss"] < 10
-    assert ("three hipGraph replays" in r["config"]["launch"]) == (graph == "auto")
+    assert ("four hipGraph replays" in r["config"]["launch"]) == (graph == "auto")
     assert r["loss_delta_vs_oracle"] <= 1e-4 and r["sim_max_abs_delta"] <= 1e-4
     d = r["dist"]
     assert d["ranks_seen"] == 2 and d["backend"] == "gloo" and len(d["grad_buckets"]) >= 1

@@ -1417,15 +1417,16 @@ def test_two_stage_split_backward_equals_single_backward_graph():
         tr = Trainer(max_epochs=10, grad_buckets=True, bucket_bytes=8 << 20).attach(model)
         tr.zero_grad()
         stages = [b.stage for b in tr.reducer.buckets]
-        assert stages == sorted(stages) and set(stages) == {0, 1}        # head + layer4 buckets first, never mixed
-        early = {id(p) for p in model.encoder.features[:7].parameters()}
-        assert all((id(p) in early) == (b.stage == 1) for b in tr.reducer.buckets for p in b.params)
+        assert stages == sorted(stages) and set(stages) == {0, 1, 2}     # head + layer4 | layer3 | the rest, never mixed
+        layer3 = {id(p) for p in model.encoder.features[6].parameters()}
+        early = {id(p) for p in model.encoder.features[:6].parameters()}
+        assert all(b.stage == (1 if id(p) in layer3 else 2 if id(p) in early else 0) for b in tr.reducer.buckets for p in b.params)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         grabbed = []
         with torch.cuda.stream(side):
             tr.capture_split_graphs(batch, warmup=1, two_stage=two_stage)
-            assert (tr._graph_b2 is not None) == two_stage and len(tr._split_stages) == (2 if two_stage else 1)
+            assert (tr._graph_b2 is not None) == two_stage and len(tr._split_stages) == len(tr._graph_bs) == (3 if two_stage else 1)
             real = tr.optimizer.step
             tr.optimizer.step = lambda *a, **kw: (grabbed.append([b.flat.clone() for b in tr.reducer.buckets]), real(*a, **kw))[1]
             losses = [float(tr.replay_split()["loss"]) for _ in range(3)]
