@@ -1,4 +1,4 @@
-# Experiment: cost of cutting the step into two graphs (N>1 form) vs one graph, on ONE GPU (no collectives):
+# Experiment: cost of cutting the step into its N>1 form (forward graph + one backward graph per stage) vs one graph, on ONE GPU (no collectives):
 # the extra eager launches between / after the graphs and the gradient copy into the flat buckets.
 import os, sys, time, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,9 +18,7 @@ model = bench.build_model(A, dev, 128)
 model.encoder = model.encoder.to(memory_format=torch.channels_last)
 enable_hip_batchnorm(model.encoder)
 tr = Trainer(max_epochs=100, grad_buckets=(mode == "split") or None).attach(model)
-batch = bench.synthetic_batch(128, 224, 5, dev)
-for k in ("transformed_image1", "transformed_image2"):
-    batch[k] = batch[k].contiguous(memory_format=torch.channels_last)
+batch = bench.synthetic_batch(128, 224, 5, dev, channels_last=True)
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
     if mode == "split":
