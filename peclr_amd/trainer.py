@@ -64,8 +64,9 @@ class Trainer:
         # samples compute exactly what one device with N*B samples computes (costs two small
         # all-reduces per BN layer per step).  False: per-rank statistics, like DDP without SyncBatchNorm.
         self.sync_batchnorm = sync_batchnorm
-        # True: fit() captures the training step on the first batch (one hipGraph; two around the
-        # collectives when gradients live in all-reduce buckets) and replays it for every later batch of
+        # True: fit() captures the training step on the first batch (one hipGraph; a forward graph + one
+        # backward graph per stage around the collectives when gradients live in all-reduce buckets; one
+        # micro-batch graph with accumulate_grad_batches > 1) and replays it for every later batch of
         # the same shapes; other shapes (a ragged last batch) run eagerly.
         self.hip_graph = hip_graph
         self._graph_sig = None
@@ -293,15 +294,15 @@ class Trainer:
         return self._static_out
 
     # ---- split hipGraphs (any world size): the step is cut where its collectives are.
-    #   graph A  images -> encoder -> head -> alignment -> z_local            (per-rank, ~350 launches)
-    #   eager    all-gather z, NT-Xent forward, gather lse/loss, NT-Xent backward -> dz_local  (~8 launches)
-    #   graph B  backward of graph A from dz_local -> parameter gradients     (per-rank, ~450 launches)
-    #   eager    gradients -> flat buckets, SUM all-reduce, fused optimiser, scheduler
-    # Gradients are allocated inside graph B's capture (parameters have no .grad then, see above) and
+    #   graph A      images -> encoder -> head -> alignment -> z_local            (per-rank, ~350 launches)
+    #   eager        all-gather z, NT-Xent forward, gather lse/stats/loss, NT-Xent backward -> dz_local  (~8 launches)
+    #   graphs B1..  backward of graph A from dz_local, one graph per stage (head + layer4 | layer3 | the rest)
+    #   eager        after each stage: its gradients -> flat buckets, SUM all-reduce launched asynchronously;
+    #                after the last one: wait, fused optimiser, scheduler
+    # Gradients are allocated inside the backward captures (parameters have no .grad then, see above) and
     # copied into the all-reduce buckets after each replay: one extra pass over 98 MB (~40 us) buys
     # ~800 launches per step replayed instead of issued.  Collectives stay outside the graphs, so this
-    # does not depend on RCCL's capture support; the price is that the all-reduce no longer overlaps
-    # with backward (RN-50: 98 MB over xGMI, well under a millisecond against a ~7 ms gain).
+    # does not depend on RCCL's capture support.
     def capture_split_graphs(self, example_batch: Dict[str, torch.Tensor], warmup: int = 3, two_stage: Optional[bool] = None):
         """two_stage (default: when the encoder is the in-tree ResNet wrapper; the name is round 2's first version --
         there are three stages now): the backward is captured as one graph per stage, cut at layer4's and layer3's
