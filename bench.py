@@ -377,7 +377,7 @@ def main():
                 return
             args.graph = "0"
         else:
-            args.graph = "1" if (not single and args.accum == 1 and not args.sync_bn) else "0"
+            args.graph = "1" if (not single and not args.sync_bn) else "0"
     use_graph = args.graph == "1"
     from peclr_amd import Trainer, _capi
     from peclr_amd import dist as pdist
@@ -432,8 +432,8 @@ def main():
             out = trainer.training_micro_step(next_batch(), i * args.accum + micro)
         return out
 
-    if use_graph and world > 1 and (args.accum != 1 or args.sync_bn):
-        raise SystemExit("--graph 1 at N>1 needs --accum 1 and per-rank BatchNorm statistics")
+    if use_graph and world > 1 and args.sync_bn:
+        raise SystemExit("--graph 1 at N>1 needs per-rank BatchNorm statistics")
     split = use_graph and world > 1
     # Everything runs on ONE non-default stream: hipStreamEndCapture crashes on this ROCm build when the
     # process has already run the step eagerly on the default stream (tools/exp/graph_capture_sizes.py).
@@ -459,7 +459,10 @@ def main():
         if use_graph:
             # W untimed eager steps (on a side stream) + the capture, then K timed replays
             if split:
-                replay = lambda: trainer.replay_split(next_batch() if args.augment else None)  # noqa: E731
+                def replay():                      # one optimiser step = `accum` micro-batches through the split graphs
+                    for _ in range(args.accum):
+                        out = trainer.replay_split(next_batch() if args.augment else None)
+                    return out
             elif args.accum > 1:      # one graph per micro-batch, accumulators + optimiser step every accum-th replay
                 trainer.capture_micro_graph(batch, warmup_windows=max(args.warmup, 1))
 
@@ -563,7 +566,9 @@ def main():
                                     "gradient all-reduce in flight under the next stage), "
                                     if len(getattr(trainer, "_graph_bs", [])) > 1 else
                                     "two hipGraph replays per step (forward to z | backward from dz), ") +
-                                   "collectives, NT-Xent and optimiser eager between/after them") if split else
+                                   "collectives, NT-Xent and optimiser eager between/after them" +
+                                   (f"; {args.accum} micro-batches per optimiser step, gradients added into the buckets, "
+                                    "all-reduce and optimiser on the window's last one" if args.accum > 1 else "")) if split else
                                   f"{args.accum} hipGraph replays (micro-batch forward + backward) + eager accumulate / optimiser per step"
                                   if use_graph and args.accum > 1 else
                                   "one hipGraph replay per step (whole step captured)" if use_graph else

@@ -310,8 +310,6 @@ class Trainer:
         their buckets and all-reduced ASYNCHRONOUSLY while the next stage replays (RN-50: 65 MB, then 28 MB, travel
         under the remaining backward), so only the last stage's ~6 MB stay exposed."""
         self._no_fp16_graphs()
-        if self.accumulate_grad_batches != 1:
-            raise RuntimeError("capture_split_graphs needs accumulate_grad_batches=1")
         if self.reducer is None:
             raise RuntimeError("capture_split_graphs works on the flat gradient buckets: Trainer(grad_buckets=True) "
                                "or world_size > 1")
@@ -328,12 +326,14 @@ class Trainer:
         side.wait_stream(torch.cuda.current_stream())
         if warmup < 1:
             raise ValueError("capture_split_graphs needs at least one eager step first (kernel JIT, optimiser state)")
+        kacc = self.accumulate_grad_batches
         with torch.cuda.stream(side):
-            for i in range(warmup):
+            for i in range(-(-warmup // kacc) * kacc):        # whole accumulation windows: ends on an optimiser step
                 eager_out = self.training_micro_step(self._static_batch, i)
             self._capture_eager_out = {k: v.clone() for k, v in eager_out.items()}
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self._split_count = 0
         params = [p for p in model.parameters() if p.requires_grad]
         for p in params:
             p.grad = None                     # the backward graphs allocate the gradients in the graphs' pool
@@ -381,10 +381,19 @@ class Trainer:
             self._split_stages.append(([g for _, g in pairs], [p.grad for p, _ in pairs], buckets))
         return self
 
-    def replay_split(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    def replay_split(self, batch: Optional[Dict[str, torch.Tensor]] = None, batch_idx: Optional[int] = None,
+                     is_final_batch: bool = False) -> Dict[str, torch.Tensor]:
+        """One (micro-)batch through the split graphs.  accumulate_grad_batches = k > 1: every micro-batch has its
+        own NT-Xent over the gathered embeddings (negatives are not pooled across micro-batches, as in the
+        reference's Lightning loop); its gradients are ADDED, scaled by 1/k, into the buckets, and only the
+        window's last micro-batch launches the all-reduces and steps the optimiser (window end by `batch_idx` when
+        given -- fit: Lightning's rule incl. the epoch's final batch -- else by the number of replays)."""
         model = self.model
+        k = self.accumulate_grad_batches
         if batch is not None and batch is not self._static_batch:
             self._load_static(self._static_batch, batch)
+        self._split_count += 1
+        last = (self._split_count % k == 0) if batch_idx is None else ((batch_idx + 1) % k == 0 or is_final_batch)
         self._graph_a.replay()
         z = self._split_z.detach().requires_grad_()
         loss = model._contrast(z, self._split_n, self._split_rows)     # collectives live here
@@ -393,13 +402,21 @@ class Trainer:
         handles = []
         for graph, (src, dst, buckets) in zip(self._graph_bs, self._split_stages):
             graph.replay()
-            torch._foreach_copy_(dst, src)
-            handles += self.reducer.launch(buckets)    # travels while the next stage's graph replays
-        for h in handles:
-            h.wait()
-        self.optimizer.step()
-        self.scheduler.step()
-        self.global_step += 1
+            if k == 1:
+                torch._foreach_copy_(dst, src)
+            else:
+                torch._foreach_add_(dst, src, alpha=1.0 / k)   # the buckets were zeroed after the last optimiser step
+            if last:
+                handles += self.reducer.launch(buckets)        # travels while the next stage's graph replays
+        if last:
+            for h in handles:
+                h.wait()
+            self.optimizer.step()
+            self.scheduler.step()
+            self.global_step += 1
+            self._split_count = 0
+            if k > 1:
+                self.reducer.zero_grad()
         out = model._step_outputs(self._static_batch, loss)
         return {key: v.detach() for key, v in out.items()}
 

@@ -1610,3 +1610,64 @@ def test_fit_with_hip_graph_and_accumulation_matches_eager_fit():
     assert int(mg.projection_head[1].num_batches_tracked) == int(me.projection_head[1].num_batches_tracked) == 10
     wd = float((mg.projection_head[3].weight - me.projection_head[3].weight).norm() / me.projection_head[3].weight.norm())
     assert wd <= 5e-3, wd
+
+
+def test_split_graphs_with_accumulation_match_the_eager_window():
+    """accumulate_grad_batches = 2 through the split graphs (the N > 1 form of C4): every micro-batch replays the
+    forward graph, its own NT-Xent and the backward graphs; gradients are added / k into the buckets; all-reduce
+    and optimiser only on the window's last micro-batch.  Same window gradient and step count as the eager loop."""
+    import copy
+    import warnings
+
+    from peclr_amd import Hybrid2Model, Trainer, hybrid2_config
+    from peclr_amd.bn2d import enable_hip_batchnorm
+
+    warnings.simplefilter("ignore")
+    torch.manual_seed(81)
+    n, k = 8, 2
+    cfg = hybrid2_config(resnet_size="18", projection_head_input_dim=512, augmentation=["crop", "rotate"],
+                         batch_size=n, num_samples=64, warmup_epochs=1, num_of_mini_batch=k, pretrained=False)
+    base = Hybrid2Model(cfg).to(DEV).train()
+    base.encoder = base.encoder.to(memory_format=torch.channels_last)
+    enable_hip_batchnorm(base.encoder)
+
+    def make(seed):
+        g = torch.Generator().manual_seed(seed)
+        b = {"transformed_image1": torch.randn(n, 3, 64, 64, generator=g), "transformed_image2": torch.randn(n, 3, 64, 64, generator=g),
+             "jitter_x_1": torch.randint(-14, 1, (n,), generator=g), "jitter_x_2": torch.randint(-14, 1, (n,), generator=g),
+             "jitter_y_1": torch.randint(-14, 1, (n,), generator=g), "jitter_y_2": torch.randint(-14, 1, (n,), generator=g),
+             "angle_1": torch.randint(-45, 46, (n,), generator=g).double(), "angle_2": torch.randint(-45, 46, (n,), generator=g).double()}
+        b = {kk: v.to(DEV) for kk, v in b.items()}
+        for kk in ("transformed_image1", "transformed_image2"):
+            b[kk] = b[kk].contiguous(memory_format=torch.channels_last)
+        return b
+
+    micro = [make(90 + i) for i in range(4)]
+    seen = {}
+    for graph in (False, True):
+        model = copy.deepcopy(base)
+        tr = Trainer(max_epochs=10, accumulate_grad_batches=k, grad_buckets=True).attach(model)
+        tr.zero_grad()
+        grabbed = []
+        real = tr.optimizer.step
+        tr.optimizer.step = lambda *a, _real=real, _tr=tr, _g=grabbed, **kw: (_g.append([b.flat.clone() for b in _tr.reducer.buckets]),
+                                                                               _real(*a, **kw))[1]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            if graph:
+                tr.capture_split_graphs(micro[0], warmup=k)            # one eager window on micro[0]
+                losses = [float(tr.replay_split(micro[i])["loss"]) for i in range(4)]
+            else:
+                for i in range(k):
+                    tr.training_micro_step(micro[0], i)
+                losses = [float(tr.training_micro_step(micro[i], k + i)["loss"]) for i in range(4)]
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert tr.global_step == 3 and len(grabbed) == 3                # warm-up window + two windows
+        seen[graph] = (losses, grabbed)
+    (le, ge), (lg, gg) = seen[False], seen[True]
+    assert lg[0] == pytest.approx(le[0], rel=2e-3) and lg == pytest.approx(le, rel=5e-2)
+    num = sum(float((a - b).double().pow(2).sum()) for a, b in zip(ge[1], gg[1]))
+    den = sum(float(a.double().pow(2).sum()) for a in ge[1])
+    assert (num / den) ** 0.5 <= 3e-2, (num / den) ** 0.5               # window gradient (a lost micro-batch would be ~0.5+)
