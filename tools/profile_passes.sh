@@ -38,6 +38,7 @@ python tools/pmc_mfma.py "$OUT/probe_trace/p_results.db" "$OUT/probe_trace/manif
 python tools/pmc_mfma.py "$OUT/bench_trace/p_results.db" "$OUT/bench_trace/manifest.json" "$OUT/bench_mfma.json" \
   "$OUT/bench_pmc_a/p_results.db" "$OUT/bench_pmc_b/p_results.db" > "$OUT/bench_mfma.txt" 2>&1
 python tools/rocpd_stats.py "$OUT/bench_trace/p_results.db" 80 > "$OUT/bench_kernel_trace_stats.txt" 2>&1
+python tools/step_breakdown.py "$OUT/bench_trace/p_results.db" "$OUT/bench_trace/manifest.json" > "$OUT/step_breakdown.txt" 2>&1
 # the databases are large: keep the summaries, drop the raw files beyond the 64 MiB merge limit
 du -sh "$OUT"/*/ | tail -8
 find "$OUT" -name "*.db" -size +20M -delete
