@@ -18,6 +18,10 @@ Pinning status
     (imgproc/src/imgwarp.cpp `warpAffine` fixed-point bilinear, imgproc/src/resize.cpp INTER_AREA
     incl. its integer fast path and the area-mode linear path used for up-scaling,
     imgproc/src/color_hsv.cpp 8-bit BGR<->HSV).  The reference has no test or fixture for them.
+    Cross-checked (not pinned) against INDEPENDENT implementations of the same operations in
+    tests/test_augment_host.py: scipy.ndimage.affine_transform (bilinear) for the warp, exact
+    fractional-cell integration for INTER_AREA, colorsys for HSV -- agreement to <= 1-2 grey levels,
+    which rules out geometric / sector / weight errors but not a different 8-bit rounding than OpenCV's.
 """
 from __future__ import annotations
 

@@ -164,3 +164,97 @@ def test_prepare_hybrid2_sample_dict():
     for k, ref in c["emitted"].items():
         assert float(out[k]) == ref["value"], k
     assert not np.array_equal(out["transformed_image1"], out["transformed_image2"])
+
+
+# ---- pixel half: cross-checks against INDEPENDENT implementations of the same published operations.
+# OpenCV itself is not installed (the restatement of its 8-bit fixed-point arithmetic stays unpinned), but the
+# operations are standard: an affine warp with bilinear interpolation (SciPy), area-averaging resize (exact
+# integration of the source over each destination cell) and RGB<->HSV (the standard library).  OpenCV's 8-bit
+# paths differ from the exact operations only by their fixed-point rounding, so the restatement must agree with
+# these references to within 1-2 grey levels on smooth content; a wrong centre, axis order, interpolation weight or
+# hue sector would be off by tens.
+def _smooth_image(h, w, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([127 + 90 * np.sin(xx / rng.uniform(9, 25) + rng.uniform(0, 6)) * np.cos(yy / rng.uniform(9, 25)),
+                    127 + 100 * np.cos((xx + yy) / rng.uniform(12, 30) + rng.uniform(0, 6)),
+                    127 + 80 * np.sin(yy / rng.uniform(8, 20) + rng.uniform(0, 6))], axis=2)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("angle", [0.0, 17.0, -33.5, 45.0, 90.0])
+def test_warp_affine_agrees_with_scipy_bilinear(angle):
+    from scipy import ndimage
+
+    from oracle import augment_oracle as A
+
+    img = _smooth_image(96, 112, 3)
+    m = A.rotation_matrix_2d((56, 48), angle)                     # forward matrix, as cv2.getRotationMatrix2D
+    got = A.warp_affine_u8(img, m).astype(np.float64)
+    mi = A.invert_affine(m)                                       # dst (x, y) -> src (x, y)
+    # scipy works in (row, col) = (y, x): src_rc = M_rc @ dst_rc + off_rc
+    m_rc = np.array([[mi[1, 1], mi[1, 0]], [mi[0, 1], mi[0, 0]]])
+    off = np.array([mi[1, 2], mi[0, 2]])
+    want = np.stack([ndimage.affine_transform(img[..., c].astype(np.float64), m_rc, offset=off, order=1, mode="constant", cval=0.0)
+                     for c in range(3)], axis=2)
+    inner = np.zeros(img.shape[:2], bool)
+    inner[2:-2, 2:-2] = True
+    # where the source footprint lies fully inside the image both are plain bilinear interpolation
+    src_x = mi[0, 0] * np.arange(112)[None, :] + mi[0, 1] * np.arange(96)[:, None] + mi[0, 2]
+    src_y = mi[1, 0] * np.arange(112)[None, :] + mi[1, 1] * np.arange(96)[:, None] + mi[1, 2]
+    inside = inner & (src_x > 1) & (src_x < 110) & (src_y > 1) & (src_y < 94)
+    diff = np.abs(got - want)[inside]
+    assert inside.sum() > 3000 and diff.max() <= 2.0 and (diff > 1.0).mean() < 0.02, (diff.max(), (diff > 1.0).mean())
+
+
+@pytest.mark.parametrize("src_hw,dst_wh", [((120, 90), (40, 30)), ((97, 131), (64, 64)), ((100, 100), (37, 53)), ((64, 64), (128, 128))])
+def test_resize_area_agrees_with_exact_area_integration(src_hw, dst_wh):
+    """INTER_AREA when shrinking = the mean of the source over each destination cell (cells have fractional edges);
+    when enlarging OpenCV switches to bilinear with area-mode coefficients: checked against the exact cell mean only
+    for shrinking, and for monotonicity / range when enlarging."""
+    from oracle import augment_oracle as A
+
+    sh, sw = src_hw
+    dw, dh = dst_wh
+    img = _smooth_image(sh, sw, 11)
+    got = A.resize_area_u8(img, (dw, dh)).astype(np.float64)
+    assert got.shape == (dh, dw, 3)
+    if dw > sw or dh > sh:
+        assert got.min() >= img.min() - 1 and got.max() <= img.max() + 1
+        return
+
+    def weights(s, d):                      # [d, s] overlap of source pixel [j, j+1) with destination cell [i*s/d, (i+1)*s/d)
+        scale = s / d
+        wm = np.zeros((d, s))
+        for i in range(d):
+            lo, hi = i * scale, (i + 1) * scale
+            for j in range(int(np.floor(lo)), min(s, int(np.ceil(hi)))):
+                wm[i, j] = max(0.0, min(hi, j + 1) - max(lo, j))
+        return wm / scale
+
+    wy, wx = weights(sh, dh), weights(sw, dw)
+    want = np.einsum("ij,jkc,lk->ilc", wy, img.astype(np.float64), wx)
+    diff = np.abs(got - want)
+    assert diff.max() <= 1.0 and (diff > 0.51).mean() < 0.01, (diff.max(), (diff > 0.51).mean())
+
+
+def test_hsv_round_trip_agrees_with_colorsys():
+    import colorsys
+
+    from oracle import augment_oracle as A
+
+    rng = np.random.default_rng(5)
+    px = rng.integers(0, 256, (4000, 3), dtype=np.uint8)
+    px[:6] = [[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [128, 128, 128]]
+    img = px.reshape(40, 100, 3)
+    hsv = A.bgr2hsv_u8(img).reshape(-1, 3).astype(np.float64)
+    # OpenCV 8-bit HSV: channel order (b, g, r) in, H in [0, 180) = degrees / 2, S and V scaled to 255
+    ref = np.array([colorsys.rgb_to_hsv(r / 255.0, g / 255.0, b / 255.0) for b, g, r in px.astype(np.float64)])
+    ref_h, ref_s, ref_v = ref[:, 0] * 180.0, ref[:, 1] * 255.0, ref[:, 2] * 255.0
+    dh = np.abs(hsv[:, 0] - ref_h)
+    dh = np.minimum(dh, 180.0 - dh)                                # hue is circular
+    grey = ref_s < 1.0                                              # hue of a grey pixel is arbitrary
+    assert dh[~grey].max() <= 1.0 and np.abs(hsv[:, 1] - ref_s).max() <= 1.0 and np.abs(hsv[:, 2] - ref_v).max() == 0.0
+    back = A.hsv2bgr_u8(A.bgr2hsv_u8(img)).astype(np.int64)
+    # quantising H to 180 steps and S to 8 bits loses information; the round trip stays within a few levels
+    assert np.abs(back - img.astype(np.int64)).max() <= 6 and np.abs(back - img.astype(np.int64)).mean() < 1.2
