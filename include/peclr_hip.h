@@ -200,6 +200,42 @@ int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* sizes, int n_t
                                int use_lars, float lars_eta, float lars_eps, int lars_clip,
                                peclr_stream_t stream);
 
+/* ---- precision=16: the dynamic loss scaler folded into the optimiser step -------------------
+ * Replaces torch.cuda.amp.GradScaler.unscale_/step/update around the optimiser, which Lightning 1.0.8's
+ * native-AMP plugin runs when the reference trains at its default `precision: 16`
+ * (training_config.json:9, peclr_training.py:78-79).  GradScaler.step reads found_inf back to the host to
+ * decide whether to step; here the decision is taken on the device, so the step can live in a hipGraph:
+ *   peclr_lars_sumsq_amp_f32        the gradients hold scale*g: norms of g = grad/scale, and
+ *                                   amp->found_inf = 1 if any gradient element is inf / nan;
+ *   peclr_lars_adam_update_amp_f32  returns without touching param / moments when found_inf is set (with
+ *                                   use_lars == 2 it leaves grad/scale in grad, as unscale_ does); else the
+ *                                   update on grad/scale with bias corrections 1 - beta^(good_steps + 1), evaluated in
+ *                                   double from the double betas (bit-equal to the host's `1 - beta ** step`);
+ *   peclr_amp_update                GradScaler.update: found_inf ? scale *= backoff, tracker = 0
+ *                                   : (good_steps += 1; ++tracker == interval ? scale *= growth, tracker = 0),
+ *                                   then found_inf = 0.  One thread.
+ * Launch the three in this order on one stream.  `amp` is DEVICE memory, 16 bytes, owned by the caller
+ * (initialise scale = 65536, the rest 0 for torch's defaults).                                         */
+typedef struct peclr_amp_state {
+    float scale;          /* current loss scale                                   */
+    float found_inf;      /* 0 / 1, raised by the sumsq pass, cleared by update   */
+    int32_t growth_tracker; /* consecutive steps without inf / nan                */
+    int32_t good_steps;   /* optimiser steps actually taken (Adam's `step`)       */
+} peclr_amp_state;
+int peclr_lars_sumsq_amp_f32(float* const* ptrs, const int64_t* sizes, int n_tensors,
+                             const int32_t* chunk_tensor, const int64_t* chunk_offset, int n_chunks,
+                             float* norms_ws, peclr_amp_state* amp, peclr_stream_t stream);
+int peclr_lars_adam_update_amp_f32(float* const* ptrs, const int64_t* sizes, int n_tensors,
+                                   const int32_t* chunk_tensor, const int64_t* chunk_offset,
+                                   const int32_t* tensor_chunk_begin, const int32_t* tensor_group,
+                                   int n_chunks, const float* norms_ws, const float* device_hyper,
+                                   const float* group_lr, const float* group_weight_decay, int n_groups,
+                                   double beta1, double beta2, float adam_eps, int use_lars, float lars_eta,
+                                   float lars_eps, int lars_clip, const peclr_amp_state* amp,
+                                   peclr_stream_t stream);
+int peclr_amp_update(peclr_amp_state* amp, float growth_factor, float backoff_factor, int growth_interval,
+                     peclr_stream_t stream);
+
 /* ---- backbone glue: fused BatchNorm2d (+ residual add) (+ ReLU), NHWC --------------------
  * Replaces nn.BatchNorm2d + `out += identity` + nn.ReLU between the convolutions of the
  * torchvision ResNet blocks the reference builds (resnet_model.py:15, norm_layer=nn.BatchNorm2d).

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_void_p
 from typing import Optional
 
 import torch  # must be imported BEFORE the CDLL: the .so binds to torch's libamdhip64.so.7
@@ -69,6 +69,10 @@ SIGNATURES = {
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
                                            _P]),
+    "peclr_lars_sumsq_amp_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P, _P]),
+    "peclr_lars_adam_update_amp_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_double,
+                                               c_double, c_float, c_int, c_float, c_float, c_int, _P, _P]),
+    "peclr_amp_update": (c_int, [_P, c_float, c_float, c_int, _P]),
 }
 
 
@@ -299,9 +303,11 @@ def ntxent_bwd(z_rows, row_offset, z_all, n_half, inv_tau, lse_all, dloss, grad_
 # ------------------------------------------------------------------ optimiser
 def lars_adam_step(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_chunk_begin, tensor_group, n_chunks,
                    norms_ws, group_lr, group_wd, beta1, beta2, adam_eps, bias_corr1, bias_corr2, use_lars,
-                   lars_eta, lars_eps, lars_clip, device_hyper=None):
+                   lars_eta, lars_eps, lars_clip, device_hyper=None, amp=None):
     """group_lr / group_wd: Python float lists, one entry per parameter group (host arrays).
-    device_hyper: optional device float[18] that overrides lr / wd / bias corrections (graph replay)."""
+    device_hyper: optional device float[18] that overrides lr / wd / bias corrections (graph replay).
+    amp: optional (state int32[4] device tensor = peclr_amp_state, growth_factor, backoff_factor, growth_interval):
+    the gradients hold scale*g; inf/nan check + unscale + skip + scale update on the device (three launches)."""
     p = _ptr(ptrs, torch.int64, "ptrs")
     sz = _ptr(sizes, torch.int64, "sizes")
     ct = _ptr(chunk_tensor, torch.int32, "chunk_tensor")
@@ -309,6 +315,25 @@ def lars_adam_step(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_ch
     ng = len(group_lr)
     lr_arr = (c_float * ng)(*group_lr)
     wd_arr = (c_float * ng)(*group_wd)
+    if amp is not None:
+        state, growth, backoff, interval = amp
+        st = _ptr(state, torch.int32, "amp state")
+        if state.numel() != 4:
+            raise PeclrHipError("amp state: expected 4 x 32-bit words (peclr_amp_state)")
+        with _timed("lars_sumsq"):
+            rc = lib().peclr_lars_sumsq_amp_f32(p, sz, n_tensors, ct, co, n_chunks, _ptr(norms_ws), st, _stream())
+        _check(rc, "peclr_lars_sumsq_amp_f32")
+        with _timed("lars_adam_update"):
+            rc = lib().peclr_lars_adam_update_amp_f32(
+                p, sz, n_tensors, ct, co, _ptr(tensor_chunk_begin, torch.int32, "tensor_chunk_begin"),
+                _ptr(tensor_group, torch.int32, "tensor_group"), n_chunks, _ptr(norms_ws), _ptr(device_hyper),
+                ctypes.cast(lr_arr, c_void_p), ctypes.cast(wd_arr, c_void_p), ng, beta1, beta2, adam_eps,
+                int(use_lars), lars_eta, lars_eps, int(lars_clip), st, _stream())
+        _check(rc, "peclr_lars_adam_update_amp_f32")
+        with _timed("amp_update", nbytes=16):
+            rc = lib().peclr_amp_update(st, growth, backoff, int(interval), _stream())
+        _check(rc, "peclr_amp_update")
+        return
     if use_lars:
         with _timed("lars_sumsq"):
             rc = lib().peclr_lars_sumsq_f32(p, sz, n_tensors, ct, co, n_chunks, _ptr(norms_ws), _stream())

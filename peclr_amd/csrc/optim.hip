@@ -7,6 +7,12 @@
 //   2. per-chunk update: combine the tensor's chunk sums in a fixed order (bit-reproducible),
 //      LARS trust ratio, weight decay, Adam moments and the parameter update in registers.
 // Roofline: HBM.  Algorithmic bytes per parameter: 8 (norm pass) + 16 read + 12 written = 36 B.
+//
+// precision=16 (the reference's default: Lightning native AMP = torch GradScaler around the optimiser,
+// peclr_training.py:78-79): the `_amp` entry points fold the scaler into the same two launches -- pass 1 also
+// looks for a non-finite gradient, pass 2 multiplies by 1/scale on load, returns early when pass 1 found one
+// (GradScaler.step's skip) and takes the bias corrections from a DEVICE count of the steps actually taken; a
+// one-thread third launch is GradScaler.update.  No host branch: the step stays capturable in a hipGraph.
 #include "common.hpp"
 
 namespace peclr {
@@ -26,12 +32,20 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
+__device__ __forceinline__ int non_finite(float x) { return (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u; }
+
+// AMP: the gradients hold scale * g.  The norms are those of the unscaled g (what LARS sees after
+// GradScaler.unscale_), and amp->found_inf is raised if any element is inf / nan (torch's
+// _amp_foreach_non_finite_check_and_unscale_: element test, not a test of the sum).
+template <bool AMP>
 __global__ __launch_bounds__(256) void sumsq_kernel(float* const* __restrict__ ptrs,
                                                     const int64_t* __restrict__ sizes, int n_tensors,
                                                     const int32_t* __restrict__ chunk_tensor,
                                                     const int64_t* __restrict__ chunk_offset, int n_chunks,
-                                                    float* __restrict__ norms_ws) {
+                                                    float* __restrict__ norms_ws, peclr_amp_state* amp) {
     __shared__ float red[4];
+    const float inv = AMP ? 1.f / amp->scale : 1.f;
+    int bad = 0;
     const int c = blockIdx.x;
     const int t = chunk_tensor[c];
     const int64_t off = chunk_offset[c];
@@ -50,20 +64,31 @@ __global__ __launch_bounds__(256) void sumsq_kernel(float* const* __restrict__ p
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             sp += a[j].x * a[j].x + a[j].y * a[j].y + a[j].z * a[j].z + a[j].w * a[j].w;
+            if (AMP) {
+                bad |= non_finite(b[j].x) | non_finite(b[j].y) | non_finite(b[j].z) | non_finite(b[j].w);
+                b[j].x *= inv; b[j].y *= inv; b[j].z *= inv; b[j].w *= inv;
+            }
             sg += b[j].x * b[j].x + b[j].y * b[j].y + b[j].z * b[j].z + b[j].w * b[j].w;
         }
     } else {
         for (int64_t k = threadIdx.x; k < n; k += 256) {
-            const float a = p[k], b = g[k];
+            const float a = p[k];
+            float b = g[k];
+            if (AMP) {
+                bad |= non_finite(b);
+                b *= inv;
+            }
             sp += a * a;
             sg += b * b;
         }
     }
     sp = block_sum(sp, red);
     sg = block_sum(sg, red);
+    if (AMP) bad = __syncthreads_or(bad);
     if (threadIdx.x == 0) {
         norms_ws[c] = sp;
         norms_ws[n_chunks + c] = sg;
+        if (AMP && bad) amp->found_inf = 1.f;   // every writer stores the same value
     }
 }
 
@@ -72,6 +97,7 @@ struct OptArgs {
     float lr[MAX_GROUPS], weight_decay[MAX_GROUPS];  // per parameter group
     float beta1, beta2, adam_eps, bias_corr1, bias_corr2, lars_eta, lars_eps;
     int use_lars, lars_clip;
+    double beta1_d, beta2_d;  // AMP: bias corrections are computed on the device, in the host's precision
 };
 
 // Streaming stores: the moments and the parameter are written once per step and not re-read by this
@@ -83,6 +109,7 @@ __device__ __forceinline__ void store_nt(float4* a, float4 x) {
     __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(a));
 }
 
+template <bool AMP>
 __global__ __launch_bounds__(256) void lars_adam_kernel(float* const* __restrict__ ptrs,
                                                         const int64_t* __restrict__ sizes, int n_tensors,
                                                         const int32_t* __restrict__ chunk_tensor,
@@ -90,7 +117,8 @@ __global__ __launch_bounds__(256) void lars_adam_kernel(float* const* __restrict
                                                         const int32_t* __restrict__ tensor_chunk_begin,
                                                         const int32_t* __restrict__ tensor_group,
                                                         int n_chunks, const float* __restrict__ norms_ws,
-                                                        const float* __restrict__ device_hyper, OptArgs a) {
+                                                        const float* __restrict__ device_hyper, OptArgs a,
+                                                        const peclr_amp_state* amp) {
     const int c = blockIdx.x;
     const int t = chunk_tensor[c];
     const int grp = tensor_group ? tensor_group[t] : 0;
@@ -99,14 +127,30 @@ __global__ __launch_bounds__(256) void lars_adam_kernel(float* const* __restrict
     // (read into locals: writing the by-value argument struct would demote it to scratch memory)
     const float lr = device_hyper ? device_hyper[grp] : a.lr[grp];
     const float wd_group = device_hyper ? device_hyper[MAX_GROUPS + grp] : a.weight_decay[grp];
-    const float bias_corr1 = device_hyper ? device_hyper[2 * MAX_GROUPS] : a.bias_corr1;
-    const float bias_corr2 = device_hyper ? device_hyper[2 * MAX_GROUPS + 1] : a.bias_corr2;
+    float bias_corr1 = device_hyper ? device_hyper[2 * MAX_GROUPS] : a.bias_corr1;
+    float bias_corr2 = device_hyper ? device_hyper[2 * MAX_GROUPS + 1] : a.bias_corr2;
     const int64_t off = chunk_offset[c];
     const int64_t n = min((int64_t)CHUNK, sizes[t] - off);
     float* p = ptrs[t] + off;
     const float* g = ptrs[n_tensors + t] + off;
     float* m = ptrs[2 * n_tensors + t] + off;
     float* v = ptrs[3 * n_tensors + t] + off;
+    const float inv = AMP ? 1.f / amp->scale : 1.f;
+    if (AMP) {
+        if (amp->found_inf != 0.f) {
+            // GradScaler.step: no optimiser step.  The reference's wrapper has unscaled p.grad in place by
+            // then; only the write-back mode exposes that, so only it pays for the pass.
+            if (a.use_lars == 2) {
+                float* gw = const_cast<float*>(g);
+                for (int64_t k = threadIdx.x; k < n; k += 256) gw[k] *= inv;
+            }
+            return;
+        }
+        // the host cannot know how many steps were skipped: the count of steps TAKEN lives next to the scale
+        const double step = (double)(amp->good_steps + 1);
+        bias_corr1 = (float)(1.0 - pow(a.beta1_d, step));
+        bias_corr2 = (float)(1.0 - pow(a.beta2_d, step));
+    }
 
     float trust = 1.f, wd = wd_group;
     if (a.use_lars) {
@@ -135,6 +179,7 @@ __global__ __launch_bounds__(256) void lars_adam_kernel(float* const* __restrict
     const bool write_back = a.use_lars == 2;   // LARSWrapper.update_p mutates p.grad in place
     float* gw = const_cast<float*>(g);
     auto upd = [&](float& pk, float& gk, float& mk, float& vk) {
+        if (AMP) gk *= inv;
         gk = (gk + wd * pk) * trust;
         mk = b1 * mk + (1.f - b1) * gk;
         vk = b2 * vk + (1.f - b2) * gk * gk;
@@ -176,18 +221,95 @@ __global__ __launch_bounds__(256) void lars_adam_kernel(float* const* __restrict
     }
 }
 
+// torch.amp.GradScaler.update (= _amp_update_scale_) + the count of optimiser steps actually taken
+__global__ void amp_update_kernel(peclr_amp_state* amp, float growth_factor, float backoff_factor,
+                                  int growth_interval) {
+    if (amp->found_inf != 0.f) {
+        amp->scale *= backoff_factor;
+        amp->growth_tracker = 0;
+    } else {
+        amp->good_steps += 1;
+        const int ok = amp->growth_tracker + 1;
+        if (ok == growth_interval) {
+            const float grown = amp->scale * growth_factor;
+            if (!non_finite(grown)) amp->scale = grown;
+            amp->growth_tracker = 0;
+        } else {
+            amp->growth_tracker = ok;
+        }
+    }
+    amp->found_inf = 0.f;
+}
+
 }  // namespace
 }  // namespace peclr
 
 using namespace peclr;
 
+static int sumsq_launch(float* const* ptrs, const int64_t* sizes, int n_tensors, const int32_t* chunk_tensor,
+                        const int64_t* chunk_offset, int n_chunks, float* norms_ws, peclr_amp_state* amp,
+                        peclr_stream_t stream) {
+    if (!ptrs || !sizes || !chunk_tensor || !chunk_offset || !norms_ws) return PECLR_ERR_NULL;
+    if (n_tensors <= 0 || n_chunks <= 0) return PECLR_ERR_SHAPE;
+    if (amp)
+        hipLaunchKernelGGL(sumsq_kernel<true>, dim3(n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream), ptrs,
+                           sizes, n_tensors, chunk_tensor, chunk_offset, n_chunks, norms_ws, amp);
+    else
+        hipLaunchKernelGGL(sumsq_kernel<false>, dim3(n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream), ptrs,
+                           sizes, n_tensors, chunk_tensor, chunk_offset, n_chunks, norms_ws, amp);
+    return launch_status();
+}
+
 extern "C" int peclr_lars_sumsq_f32(float* const* ptrs, const int64_t* sizes, int n_tensors,
                                     const int32_t* chunk_tensor, const int64_t* chunk_offset, int n_chunks,
                                     float* norms_ws, peclr_stream_t stream) {
-    if (!ptrs || !sizes || !chunk_tensor || !chunk_offset || !norms_ws) return PECLR_ERR_NULL;
-    if (n_tensors <= 0 || n_chunks <= 0) return PECLR_ERR_SHAPE;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream), ptrs, sizes,
-                       n_tensors, chunk_tensor, chunk_offset, n_chunks, norms_ws);
+    return sumsq_launch(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, n_chunks, norms_ws, nullptr, stream);
+}
+
+extern "C" int peclr_lars_sumsq_amp_f32(float* const* ptrs, const int64_t* sizes, int n_tensors,
+                                        const int32_t* chunk_tensor, const int64_t* chunk_offset, int n_chunks,
+                                        float* norms_ws, peclr_amp_state* amp, peclr_stream_t stream) {
+    if (!amp) return PECLR_ERR_NULL;
+    return sumsq_launch(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, n_chunks, norms_ws, amp, stream);
+}
+
+extern "C" int peclr_amp_update(peclr_amp_state* amp, float growth_factor, float backoff_factor,
+                                int growth_interval, peclr_stream_t stream) {
+    if (!amp) return PECLR_ERR_NULL;
+    if (!(growth_factor > 1.f) || !(backoff_factor > 0.f && backoff_factor < 1.f) || growth_interval < 1)
+        return PECLR_ERR_SHAPE;
+    hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), amp, growth_factor,
+                       backoff_factor, growth_interval);
+    return launch_status();
+}
+
+static int update_launch(float* const* ptrs, const int64_t* sizes, int n_tensors, const int32_t* chunk_tensor,
+                         const int64_t* chunk_offset, const int32_t* tensor_chunk_begin, const int32_t* tensor_group,
+                         int n_chunks, const float* norms_ws, const float* device_hyper, const float* group_lr,
+                         const float* group_weight_decay, int n_groups, double beta1, double beta2, float adam_eps,
+                         float bias_corr1, float bias_corr2, int use_lars, float lars_eta, float lars_eps,
+                         int lars_clip, const peclr_amp_state* amp, peclr_stream_t stream) {
+    if (!ptrs || !sizes || !chunk_tensor || !chunk_offset || !tensor_chunk_begin) return PECLR_ERR_NULL;
+    if (!device_hyper && (!group_lr || !group_weight_decay)) return PECLR_ERR_NULL;
+    if (use_lars && !norms_ws) return PECLR_ERR_NULL;
+    if (n_tensors <= 0 || n_chunks <= 0 || n_groups < 1 || n_groups > MAX_GROUPS) return PECLR_ERR_SHAPE;
+    if (n_groups > 1 && !tensor_group) return PECLR_ERR_NULL;
+    if (!device_hyper && !amp && (!(bias_corr1 > 0.f) || !(bias_corr2 > 0.f))) return PECLR_ERR_SHAPE;
+    OptArgs a = {};
+    for (int g = 0; g < n_groups && !device_hyper; ++g) {
+        a.lr[g] = group_lr[g];
+        a.weight_decay[g] = group_weight_decay[g];
+    }
+    a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.beta1_d = beta1; a.beta2_d = beta2; a.adam_eps = adam_eps; a.bias_corr1 = bias_corr1; a.bias_corr2 = bias_corr2;
+    a.lars_eta = lars_eta; a.lars_eps = lars_eps; a.use_lars = use_lars; a.lars_clip = lars_clip;
+    if (amp)
+        hipLaunchKernelGGL(lars_adam_kernel<true>, dim3(n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_chunk_begin, tensor_group,
+                           n_chunks, norms_ws, device_hyper, a, amp);
+    else
+        hipLaunchKernelGGL(lars_adam_kernel<false>, dim3(n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_chunk_begin, tensor_group,
+                           n_chunks, norms_ws, device_hyper, a, amp);
     return launch_status();
 }
 
@@ -200,21 +322,22 @@ extern "C" int peclr_lars_adam_update_f32(float* const* ptrs, const int64_t* siz
                                           float beta2, float adam_eps, float bias_corr1, float bias_corr2,
                                           int use_lars, float lars_eta, float lars_eps, int lars_clip,
                                           peclr_stream_t stream) {
-    if (!ptrs || !sizes || !chunk_tensor || !chunk_offset || !tensor_chunk_begin) return PECLR_ERR_NULL;
-    if (!device_hyper && (!group_lr || !group_weight_decay)) return PECLR_ERR_NULL;
-    if (use_lars && !norms_ws) return PECLR_ERR_NULL;
-    if (n_tensors <= 0 || n_chunks <= 0 || n_groups < 1 || n_groups > MAX_GROUPS) return PECLR_ERR_SHAPE;
-    if (n_groups > 1 && !tensor_group) return PECLR_ERR_NULL;
-    if (!device_hyper && (!(bias_corr1 > 0.f) || !(bias_corr2 > 0.f))) return PECLR_ERR_SHAPE;
-    OptArgs a = {};
-    for (int g = 0; g < n_groups && !device_hyper; ++g) {
-        a.lr[g] = group_lr[g];
-        a.weight_decay[g] = group_weight_decay[g];
-    }
-    a.beta1 = beta1; a.beta2 = beta2; a.adam_eps = adam_eps; a.bias_corr1 = bias_corr1; a.bias_corr2 = bias_corr2;
-    a.lars_eta = lars_eta; a.lars_eps = lars_eps; a.use_lars = use_lars; a.lars_clip = lars_clip;
-    hipLaunchKernelGGL(lars_adam_kernel, dim3(n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream), ptrs, sizes,
-                       n_tensors, chunk_tensor, chunk_offset, tensor_chunk_begin, tensor_group, n_chunks, norms_ws,
-                       device_hyper, a);
-    return launch_status();
+    return update_launch(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_chunk_begin, tensor_group, n_chunks,
+                         norms_ws, device_hyper, group_lr, group_weight_decay, n_groups, beta1, beta2, adam_eps,
+                         bias_corr1, bias_corr2, use_lars, lars_eta, lars_eps, lars_clip, nullptr, stream);
+}
+
+extern "C" int peclr_lars_adam_update_amp_f32(float* const* ptrs, const int64_t* sizes, int n_tensors,
+                                              const int32_t* chunk_tensor, const int64_t* chunk_offset,
+                                              const int32_t* tensor_chunk_begin, const int32_t* tensor_group,
+                                              int n_chunks, const float* norms_ws, const float* device_hyper,
+                                              const float* group_lr, const float* group_weight_decay, int n_groups,
+                                              double beta1, double beta2, float adam_eps, int use_lars,
+                                              float lars_eta, float lars_eps, int lars_clip,
+                                              const peclr_amp_state* amp,
+                                              peclr_stream_t stream) {
+    if (!amp) return PECLR_ERR_NULL;
+    return update_launch(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_chunk_begin, tensor_group, n_chunks,
+                         norms_ws, device_hyper, group_lr, group_weight_decay, n_groups, beta1, beta2, adam_eps, 1.f,
+                         1.f, use_lars, lars_eta, lars_eps, lars_clip, amp, stream);
 }

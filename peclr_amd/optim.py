@@ -11,6 +11,9 @@ restated from its published behaviour, see oracle/peclr_oracle.py:lars_adam_step
       fused=False                the same update written with torch foreach ops (any device); used for
                                  CPU runs and as the comparison arm in tests.
   LARSWrapper(optimizer)         the reference's spelling: wraps an Adam built by the caller.
+  DeviceLossScaler               precision=16: torch.amp.GradScaler's algorithm with the skip-on-inf decision taken
+                                 on the device inside the fused step (`LARSAdam.attach_scaler`), so fp16 runs
+                                 need no host sync per step and can be captured in hipGraphs.
   LinearWarmupCosineAnnealingLR  closed-form warm-up + cosine schedule, stepped per optimiser step.
 """
 from __future__ import annotations
@@ -65,6 +68,58 @@ class _FusedWorkList:
         self.norms_ws = torch.empty(2 * self.n_chunks, dtype=torch.float32, device=dev)
 
 
+class DeviceLossScaler:
+    """Dynamic loss scaling for precision=16 with torch.amp.GradScaler's algorithm and defaults (what
+    Lightning 1.0.8's native-AMP plugin wraps around the reference's optimiser, peclr_training.py:78-79):
+
+        backward on loss * scale;  at the optimiser step: g <- g / scale, and if any g is inf / nan the step
+        is skipped and scale *= backoff_factor, else after `growth_interval` clean steps scale *= growth_factor.
+
+    GradScaler.step() reads the inf flag back to the host.  Here the 16-byte state (`peclr_amp_state`: scale,
+    found_inf, growth_tracker, good_steps) stays in device memory and the fused optimiser kernels act on it
+    (peclr_lars_sumsq_amp_f32 / peclr_lars_adam_update_amp_f32 / peclr_amp_update): no sync, capturable.
+    Use: `opt.attach_scaler(s)`; `s.scale(loss).backward()`; `opt.step()` -- there is no separate
+    unscale_/step/update.  `state_dict()` has GradScaler's keys (Lightning's `native_amp_scaling_state`), so
+    either class loads the other's checkpoint."""
+
+    def __init__(self, device, init_scale: float = 2.0 ** 16, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000):
+        if not (growth_factor > 1.0 and 0.0 < backoff_factor < 1.0 and growth_interval >= 1):
+            raise ValueError("DeviceLossScaler: growth_factor > 1, 0 < backoff_factor < 1, growth_interval >= 1")
+        if torch.device(device).type != "cuda":
+            raise _capi.PeclrHipError("DeviceLossScaler lives in HIP device memory (CPU runs: torch.amp.GradScaler)")
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.state = torch.zeros(4, dtype=torch.int32, device=device)      # peclr_amp_state
+        self._f = self.state.view(torch.float32)                            # words 0, 1: scale, found_inf
+        self._f[0] = float(init_scale)
+
+    def scale(self, loss: torch.Tensor) -> torch.Tensor:
+        return loss * self._f[0]
+
+    def get_scale(self) -> float:
+        return float(self._f[0].item())
+
+    def good_steps(self) -> int:
+        return int(self.state[3].item())
+
+    def set_good_steps(self, n: int):
+        self.state[3] = int(n)
+
+    def kernel_args(self):
+        return (self.state, float(self.growth_factor), float(self.backoff_factor), int(self.growth_interval))
+
+    def state_dict(self):
+        return {"scale": self.get_scale(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(self.state[2].item())}
+
+    def load_state_dict(self, sd):
+        self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self.growth_interval = int(sd["growth_interval"])
+        self._f[0] = float(sd["scale"])
+        self._f[1] = 0.0
+        self.state[2] = int(sd["_growth_tracker"])
+
+
 class LARSAdam(Optimizer):
     """Adam (torch defaults: betas (0.9, 0.999), eps 1e-8) with the LARSWrapper pre-step:
 
@@ -95,6 +150,30 @@ class LARSAdam(Optimizer):
         # `prepare_step()` OUTSIDE the graph; the captured launch (`launch_only()`) only reads them
         self._hyper = self._hyper_host = None
         self._prepared = None
+        self._amp = None
+
+    def attach_scaler(self, scaler: "DeviceLossScaler"):
+        """precision=16: from now on the gradients this optimiser sees are scale * g.  Every fused step
+        unscales them in registers, is skipped ON THE DEVICE when one is inf / nan, and updates the scale.
+        Adam's step count (bias corrections) becomes the device's count of steps actually taken; the host-side
+        `state[p]["step"]` is refreshed from it in `state_dict()`."""
+        if not self.fused:
+            raise _capi.PeclrHipError("attach_scaler needs the fused HIP optimiser (CPU runs: torch.amp.GradScaler)")
+        self._amp = scaler
+        steps = [int(st["step"]) for st in self.state.values() if "step" in st]
+        scaler.set_good_steps(max(steps) if steps else 0)
+        return self
+
+    def _amp_args(self):
+        return None if self._amp is None else self._amp.kernel_args()
+
+    def state_dict(self):
+        if self._amp is not None:                      # skipped steps were counted on the host, not on the device
+            n = self._amp.good_steps()
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"] = n
+        return super().state_dict()
 
     def _lars_mode(self) -> int:
         return (2 if self.write_back else 1) if self.lars else 0
@@ -106,6 +185,9 @@ class LARSAdam(Optimizer):
         super().load_state_dict(state_dict)
         self._fused_cache.clear()
         self._prepared = None
+        if self._amp is not None:
+            steps = [int(st["step"]) for st in self.state.values() if "step" in st]
+            self._amp.set_good_steps(max(steps) if steps else 0)
 
     def _prepare(self, group):
         """Lazy state init + step count for one group; returns (params, grads, m, v, step)."""
@@ -185,6 +267,9 @@ class LARSAdam(Optimizer):
         if self.fused and uniform and len(prepared) <= 8:
             self._step_fused(prepared)  # ONE launch pair for every parameter group
             return loss
+        if self._amp is not None:
+            raise _capi.PeclrHipError("a DeviceLossScaler needs ONE fused launch for all parameter groups (<= 8 "
+                                      "groups with common betas / eps): the scale is updated once per step")
         for g, params, grads, m, v, step in prepared:
             b1, b2 = g["betas"]
             bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
@@ -204,7 +289,7 @@ class LARSAdam(Optimizer):
             _capi.lars_adam_step(wl.ptrs, wl.sizes, wl.n_tensors, wl.chunk_tensor, wl.chunk_offset, wl.begin,
                                  wl.group, wl.n_chunks, wl.norms_ws, [0.0] * len(prepared), [0.0] * len(prepared), b1,
                                  b2, g0["eps"], 1.0, 1.0, self._lars_mode(), self.eta, self.lars_eps, self.clip,
-                                 device_hyper=device_hyper)
+                                 device_hyper=device_hyper, amp=self._amp_args())
             return
         params = [p for t in prepared for p in t[1]]
         grads = [x for t in prepared for x in t[2]]
@@ -233,7 +318,7 @@ class LARSAdam(Optimizer):
                              wl.n_chunks, wl.norms_ws, [float(t[0]["lr"]) for t in prepared],
                              [float(t[0]["weight_decay"]) for t in prepared], b1, b2, g0["eps"], 1.0 - b1 ** step,
                              1.0 - b2 ** step, self._lars_mode(), self.eta, self.lars_eps, self.clip,
-                             device_hyper=device_hyper)
+                             device_hyper=device_hyper, amp=self._amp_args())
 
     # ---- torch foreach restatement (any device)
     def _step_foreach(self, params, grads, m, v, lr, b1, b2, eps, wd, bc1, bc2):

@@ -144,13 +144,32 @@ class Trainer:
         return torch.autocast(dev, dtype=torch.bfloat16 if self.precision == "bf16" else torch.float16)
 
     def _grad_scaler(self):
-        """fp16 only: the dynamic loss scaler of native AMP (created on first use, saved in checkpoints)."""
+        """fp16 only: the dynamic loss scaler of native AMP (created on first use, saved in checkpoints).
+        With the fused HIP optimiser it is a `DeviceLossScaler` attached to it -- same algorithm and checkpoint
+        keys as torch's GradScaler, decision taken on the device (no host sync; hipGraph-capturable); on other
+        devices torch's own GradScaler around the foreach optimiser."""
         if self.precision != "fp16":
             return None
         if self._scaler is None:
-            dev = "cuda" if next(self.model.parameters()).is_cuda else "cpu"
-            self._scaler = torch.amp.GradScaler(dev)
+            p = next(self.model.parameters())
+            if getattr(self.optimizer, "fused", False) and hasattr(self.optimizer, "attach_scaler"):
+                from .optim import DeviceLossScaler
+
+                self._scaler = DeviceLossScaler(p.device)
+                self.optimizer.attach_scaler(self._scaler)
+            else:
+                self._scaler = torch.amp.GradScaler("cuda" if p.is_cuda else "cpu")
         return self._scaler
+
+    def _device_scaler(self):
+        from .optim import DeviceLossScaler
+
+        return isinstance(self._grad_scaler(), DeviceLossScaler)
+
+    def _scaled(self, loss):
+        """precision=16: loss * scale (a device scalar: nothing is read back), else the loss itself."""
+        scaler = self._grad_scaler()
+        return loss if scaler is None else scaler.scale(loss)
 
     def _check_uniform_batch(self, batch):
         """N > 1: the all-gather of the embeddings has a fixed shape and the positive-pair index map uses
@@ -192,11 +211,11 @@ class Trainer:
         if last:
             if self.reducer is not None:
                 self.reducer.finish()
-            if scaler is not None:
+            if scaler is not None and not self._device_scaler():
                 scaler.step(self.optimizer)   # unscale, inf/nan check, step unless one was found
                 scaler.update()
             else:
-                self.optimizer.step()
+                self.optimizer.step()         # fp16 + fused: unscale / check / skip / scale update inside
             self.zero_grad()
             self.scheduler.step()
             self.global_step += 1
@@ -210,9 +229,9 @@ class Trainer:
             _bn2d.wgrad_join()
 
     def _no_fp16_graphs(self):
-        if self.precision == "fp16":
-            raise RuntimeError("hipGraph capture with precision=16: the GradScaler's skip-on-inf decision is a host "
-                               "branch; use bf16 (no scaler) or hip_graph=False")
+        if self.precision == "fp16" and not self._device_scaler():
+            raise RuntimeError("hipGraph capture with precision=16 needs the fused HIP optimiser (LARSAdam(fused=True)): "
+                               "torch's GradScaler.step decides on the host whether to step")
 
     @staticmethod
     def _clone_batch(batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -259,7 +278,7 @@ class Trainer:
             # optimiser's work list and stage the scalars of the step the graph will perform first
             with self._autocast():
                 eager_out = self.model.training_step(self._static_batch, 0)
-            eager_out["loss"].backward()
+            self._scaled(eager_out["loss"]).backward()
             self._join_wgrad()
             self._capture_eager_out = {k: v.detach().clone() for k, v in eager_out.items()}
             self.optimizer.prepare_step()
@@ -273,7 +292,7 @@ class Trainer:
         with torch.cuda.graph(self._graph):
             with self._autocast():
                 out = self.model.training_step(self._static_batch, 0)
-            out["loss"].backward()
+            self._scaled(out["loss"]).backward()
             self._join_wgrad()
             self.optimizer.launch_only(reuse_worklist=True)
         self.optimizer.repoint_worklist()         # gradients now live in the graph's private pool
@@ -397,7 +416,7 @@ class Trainer:
         self._graph_a.replay()
         z = self._split_z.detach().requires_grad_()
         loss = model._contrast(z, self._split_n, self._split_rows)     # collectives live here
-        (dz,) = torch.autograd.grad(loss, z)
+        (dz,) = torch.autograd.grad(self._scaled(loss), z)
         self._split_dz.copy_(dz)
         handles = []
         for graph, (src, dst, buckets) in zip(self._graph_bs, self._split_stages):
@@ -444,7 +463,7 @@ class Trainer:
         with torch.cuda.graph(self._graph):
             with self._autocast():
                 out = self.model.training_step(self._static_batch, 0)
-            out["loss"].backward()
+            self._scaled(out["loss"]).backward()
             self._join_wgrad()
         pairs = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
         self._micro_src = [g for _, g in pairs]
@@ -489,7 +508,7 @@ class Trainer:
         with torch.cuda.graph(self._graph):
             with self._autocast():
                 g_out = self.model.training_step(self._static_batch, 0)
-            g_out["loss"].backward()
+            self._scaled(g_out["loss"]).backward()
             self._join_wgrad()
         pairs = [(p, p.grad) for p in params if p.grad is not None]
         self._micro_src = [g for _, g in pairs]
@@ -549,7 +568,8 @@ class Trainer:
         if self.model is not model:
             self.attach(model)
         self.zero_grad()
-        use_graph = (self.hip_graph and not (self.sync_batchnorm and self.world_size > 1) and self.precision != "fp16"
+        use_graph = (self.hip_graph and not (self.sync_batchnorm and self.world_size > 1)
+                     and (self.precision != "fp16" or self._device_scaler())
                      and (self.accumulate_grad_batches == 1 or (self.world_size == 1 and self.reducer is None)))
         step = self._graph_step if use_graph else self.training_micro_step
         # with graphs the whole loop lives on one side stream: a backward on the default stream before the

@@ -176,15 +176,16 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, sync_bn):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("graph", ["auto", "0"], ids=["split_graphs", "eager"])
-def test_bench_two_ranks_on_one_gpu_emits_a_valid_line(graph):
+@pytest.mark.parametrize("graph,dtype", [("auto", "fp32"), ("0", "fp32"), ("auto", "fp16")],
+                         ids=["split_graphs", "eager", "split_graphs_fp16"])
+def test_bench_two_ranks_on_one_gpu_emits_a_valid_line(graph, dtype):
     """The N > 1 leg of bench.py itself (the command the driver launches for SCALE), as two ranks sharing
     cuda:0 over gloo: launch mode, aggregate accounting, the parity deltas and the dist record."""
     import json
 
     port = free_port()
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--resnet", "18",
-           "--pairs", "8", "--size", "64", "--graph", graph]
+           "--pairs", "8", "--size", "64", "--graph", graph, "--dtype", dtype]
     env = dict(os.environ, PECLR_DIST_BACKEND="gloo", PECLR_SHARE_DEVICE="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(port))
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
@@ -195,6 +196,7 @@ def test_bench_two_ranks_on_one_gpu_emits_a_valid_line(graph):
     assert len(lines) == 1 and not [ln for ln in outs[1][0].decode().splitlines() if ln.startswith("{")]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak" and r["unit"] == "images/sec"
+    assert r["dtype"] == dtype               # fp16: the scaled gradients are all-reduced, every rank takes the same skip decision
     assert r["config"]["global_batch"] == 2 * 2 * 8 and r["config"]["parallelism"] == "dp2"
     assert r["value"] == pytest.approx(2 * 2 * 8 * 3 / (r["ms_per_step"] * 3e-3), rel=1e-3)   # whole-job aggregate
     assert np.isfinite(r["loss"]) and 0 < r["loss"] < 10

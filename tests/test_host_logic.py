@@ -609,3 +609,18 @@ def test_resnet_arithmetic_matches_an_independent_implementation(name, depths, w
     last_hf = hf.encoder.stages[3].layers[-1].layer[-1].normalization
     assert torch.allclose(last_mine.running_var, last_hf.running_var, rtol=1e-12, atol=0)
     assert int(last_mine.num_batches_tracked) == int(last_hf.num_batches_tracked) == 1
+
+
+def test_device_loss_scaler_is_hip_only_and_cpu_runs_keep_torch_grad_scaler():
+    """The device-side scaler lives in HIP memory and inside the fused optimiser; without them precision=16 keeps
+    torch's own GradScaler around the foreach optimiser (test above) -- nothing silently degrades."""
+    from peclr_amd import _capi
+    from peclr_amd.optim import DeviceLossScaler, LARSAdam
+
+    with pytest.raises(_capi.PeclrHipError, match="HIP device memory"):
+        DeviceLossScaler("cpu")
+    with pytest.raises(ValueError):
+        DeviceLossScaler("cpu", growth_factor=1.0)
+    opt = LARSAdam([torch.nn.Parameter(torch.ones(3))], lr=1e-3, fused=False)
+    with pytest.raises(_capi.PeclrHipError, match="fused HIP optimiser"):
+        opt.attach_scaler(object())
