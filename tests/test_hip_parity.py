@@ -1672,3 +1672,34 @@ def test_split_graphs_with_accumulation_match_the_eager_window():
     num = sum(float((a - b).double().pow(2).sum()) for a, b in zip(ge[1], gg[1]))
     den = sum(float(a.double().pow(2).sum()) for a in ge[1])
     assert (num / den) ** 0.5 <= 1e-1, (num / den) ** 0.5               # window gradient (a lost micro-batch would be ~0.5+)
+
+
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("m,n,k,with_addend", [(128 * 70 + 37, 1000, 72, True), (65536 + 8, 256, 64, True), (20000, 512, 136, True),
+                                               (128 * 64, 1024, 256, False), (12544, 2048, 512, True), (300, 128, 64, True)])
+def test_gemm_add_half_128_tile_kernel_matches_float64(capi, half, m, n, k, with_addend):
+    """peclr_gemm_add_bf16 / _f16 at shapes that take the 128 x 128-tile kernel (>= 512 tiles; the last shape stays on
+    the 64 x 64 one): ragged M (not a multiple of 128), N and K that are multiples of 8 only, one or many K-tiles,
+    with and without the addend.  Reference: float64 on the same 16-bit inputs; the result is rounded once."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = (torch.randn(m, k, generator=g) * 0.5).to(half).to(DEV)
+    bt = (torch.randn(n, k, generator=g) * 0.5).to(half).to(DEV)
+    d = torch.randn(m, n, generator=g).to(half).to(DEV) if with_addend else None
+    out = capi.gemm_add_half(a, bt, d)
+    assert out.dtype == half and out.shape == (m, n)
+    rows = torch.cat([torch.arange(0, min(m, 300)), torch.arange(max(0, m - 300), m), torch.randint(0, m, (400,), generator=g)]).unique()
+    ref = a[rows].double().cpu() @ bt.double().cpu().T
+    if with_addend:
+        ref = ref + d[rows].double().cpu()
+    got = out[rows].double().cpu()
+    ulp = 2.0 ** -8 if half == torch.bfloat16 else 2.0 ** -11
+    err = (got - ref).abs()
+    # one rounding to the 16-bit format (half an ulp of the value) + fp32 accumulation error
+    bound = 0.51 * ulp * ref.abs().clamp_min(1e-3) * 2 + 1e-4
+    assert bool((err <= bound).all()), (float(err.max()), float((err / bound).max()))
+    # every row was written exactly once: a checksum over the WHOLE output against the float64 matmul
+    full = (a.double() @ bt.double().T)
+    if with_addend:
+        full = full + d.double()
+    assert float((out.double() - full).abs().max()) <= float((4 * ulp * full.abs().clamp_min(1.0)).max())
+    assert float(out.double().sum()) == pytest.approx(float(full.sum()), abs=ulp * float(full.abs().sum()) * 0.05 + 1.0)
