@@ -361,6 +361,13 @@ def try_graph_child():
     return None, f"graph child exited with {p.returncode}"
 
 
+def amp_steps_taken(trainer):
+    """fp16 only: optimiser steps actually TAKEN so far (the device-side loss scaler skips a step whose gradients
+    overflowed); read outside the timed region."""
+    scaler = getattr(trainer, "_scaler", None)
+    return scaler.good_steps() if hasattr(scaler, "good_steps") else None
+
+
 def main():
     args = parse()
     warnings.simplefilter("ignore")
@@ -473,6 +480,7 @@ def main():
             if world > 1:
                 torch.distributed.barrier()
             torch.cuda.synchronize()
+            amp_before = amp_steps_taken(trainer)
             t0 = time.perf_counter()
             for i in range(args.steps):
                 out = replay()
@@ -480,6 +488,7 @@ def main():
             if world > 1:
                 torch.distributed.barrier()
             dt = time.perf_counter() - t0
+            amp_after = amp_steps_taken(trainer)
             loss = float(out["loss"])
             # per-kernel HIP events cannot sit inside a graph: the SAME K steps once more, eagerly, with an
             # event pair around every hand-written launch (same kernels, same shapes, same stream)
@@ -494,6 +503,7 @@ def main():
             if world > 1:
                 torch.distributed.barrier()
             torch.cuda.synchronize()
+            amp_before = amp_steps_taken(trainer)
             t0 = time.perf_counter()
             for i in range(args.steps):
                 out = one_step(args.warmup + i)
@@ -501,6 +511,7 @@ def main():
             if world > 1:
                 torch.distributed.barrier()
             dt = time.perf_counter() - t0
+            amp_after = amp_steps_taken(trainer)
             loss = float(out["loss"])
     table_steps = args.steps
     event_log, _capi.EVENT_LOG = _capi.EVENT_LOG, None
@@ -571,6 +582,11 @@ def main():
                                   "one hipGraph replay per step (whole step captured)" if use_graph else
                                   "eager launches" + (f" ({graph_note})" if graph_note else "")),
                        "graph_fallback": graph_note,   # None unless --graph auto had to fall back to eager launches
+                       # fp16: dynamic loss scaling skips a step whose scaled gradients overflow (the launches still
+                       # run, the update kernel returns early): how many of the K timed steps were real updates
+                       "amp": None if amp_after is None else {
+                           "loss_scale": trainer._scaler.get_scale(), "optimizer_steps_taken_in_timed_region": amp_after - amp_before,
+                           "timed_steps": args.steps, "scaler": "device-side (peclr_amp_state), inside the fused optimiser launches"},
                        "bn": "global-batch statistics (synchronised)" if (args.sync_bn and world > 1)
                        else "per-rank batch statistics"},
             "loss": round(loss, 6),

@@ -15,14 +15,15 @@ from pmc_mfma import EXPECT  # noqa: E402
 CATS = OrderedDict([
     ("MIOpen / CK convolution forward", lambda n: ("igemm_fwd" in n or "conv_fwd" in n or "ConvFwd" in n or "grouped_conv_fwd" in n)),
     ("MIOpen / CK convolution input gradient", lambda n: ("igemm_bwd" in n or "conv_bwd_data" in n or "ConvBwdData" in n)),
-    ("MIOpen / CK convolution weight gradient", lambda n: ("igemm_wrw" in n or "conv_bwd_weight" in n or "ConvBwdWeight" in n)),
-    ("MIOpen zero-fill / cast for split-K weight gradients", lambda n: "SubTensorOp" in n),
-    ("hand-written: BatchNorm2d glue (bn2d_*)", lambda n: "peclr::" in n and "bn2d_" in n),
-    ("hand-written: fused dgrad + residual GEMM (128x128)", lambda n: "peclr::" in n and "gemm_f32_nn128" in n),
-    ("hand-written: head GEMMs / bf16 GEMM", lambda n: "peclr::" in n and "gemm_" in n),
-    ("hand-written: BN1d+ReLU, align, NT-Xent", lambda n: "peclr::" in n and any(k in n for k in ("bn_relu", "align_", "ntxent", "slab_reduce"))),
-    ("hand-written: LARS / Adam", lambda n: "peclr::" in n and ("sumsq" in n or "lars_adam" in n)),
-    ("hand-written: other", lambda n: "peclr::" in n),
+    ("MIOpen / CK convolution weight gradient", lambda n: ("igemm_wrw" in n or "conv_bwd_weight" in n or "ConvBwdWeight" in n
+                                                          or "kernel_batched_gemm_xdl" in n)),   # CK's wrw-as-batched-GEMM solver
+    ("MIOpen zero-fill / cast for split-K weight gradients", lambda n: "SubTensorOp" in n or "fillBufferAligned" in n),
+    ("hand-written: BatchNorm2d glue (bn2d_*)", lambda n: "peclr" in n and "bn2d_" in n),
+    ("hand-written: fused dgrad + residual GEMM (128x128)", lambda n: "peclr" in n and "gemm_f32_nn128" in n),
+    ("hand-written: head GEMMs / bf16 GEMM", lambda n: "peclr" in n and "gemm_" in n),
+    ("hand-written: BN1d+ReLU, align, NT-Xent", lambda n: "peclr" in n and any(k in n for k in ("bn_relu", "align_", "ntxent", "slab_reduce"))),
+    ("hand-written: LARS / Adam", lambda n: "peclr" in n and ("sumsq" in n or "lars_adam" in n)),
+    ("hand-written: other", lambda n: "peclr" in n),
     ("ATen / other", lambda n: True),
 ])
 
@@ -34,7 +35,7 @@ def main():
     order = order["order"]
     c = sqlite3.connect(db)
     rows = c.execute("select dispatch_id, name, end - start from kernels order by dispatch_id").fetchall()
-    ours = [r for r in rows if "peclr::" in r[1]]
+    ours = [r for r in rows if "peclr" in r[1]]
     wants = [EXPECT.get(name.split("::")[-1]) for name in order]
     for off in range(len(ours) - len(order) + 1):
         lo = len(ours) - len(order) - off
@@ -42,7 +43,10 @@ def main():
             first, last = ours[lo][0], ours[lo + len(order) - 1][0]
             break
     else:
-        raise SystemExit("measured pass not found")
+        lo = len(ours) - len(order)
+        bad = [(k, order[k], ours[lo + k][1][:90]) for k, w in enumerate(wants) if w is not None and w not in ours[lo + k][1]][:5]
+        raise SystemExit(f"measured pass not found: {len(ours)} peclr:: dispatches, manifest {len(order)}; first mismatches "
+                         f"when aligned at the end: {bad}")
     tot = OrderedDict((k, [0.0, 0]) for k in CATS)
     for did, name, dur in rows:
         if first <= did <= last:
