@@ -271,7 +271,8 @@ class _ForkConv1x1(torch.autograd.Function):
             a = gy.permute(0, 2, 3, 1).reshape(r, cmid)           # NHWC storage seen as [R, Cmid]: a view
             d = gid.permute(0, 2, 3, 1).reshape(r, cin)
             if x.dtype in (torch.bfloat16, torch.float16):       # autocast backbone: 16-bit MFMA, fp32 accumulate
-                wt = weight.detach().reshape(cmid, cin).t().contiguous().to(x.dtype)
+                wt = torch.empty((cin, cmid), device=x.device, dtype=x.dtype)
+                wt.copy_(weight.detach().reshape(cmid, cin).t())      # transpose + cast in ONE launch
                 out = _capi.gemm_add_half(a, wt, d, tag="conv1x1_dgrad_add")
             else:
                 out = _capi.gemm_add(_capi.GEMM_NN, a, weight.reshape(cmid, cin), d, tag="conv1x1_dgrad_add")
