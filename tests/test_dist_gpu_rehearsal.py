@@ -197,6 +197,10 @@ def test_bench_two_ranks_on_one_gpu_emits_a_valid_line(graph, dtype):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak" and r["unit"] == "images/sec"
     assert r["dtype"] == dtype               # fp16: the scaled gradients are all-reduced, every rank takes the same skip decision
+    amp = r["config"]["amp"]
+    assert (amp is None) == (dtype != "fp16")
+    if amp is not None:
+        assert 0 <= amp["optimizer_steps_taken_in_timed_region"] <= 3 and 0 < amp["loss_scale"] <= 65536.0
     assert r["config"]["global_batch"] == 2 * 2 * 8 and r["config"]["parallelism"] == "dp2"
     assert r["value"] == pytest.approx(2 * 2 * 8 * 3 / (r["ms_per_step"] * 3e-3), rel=1e-3)   # whole-job aggregate
     assert np.isfinite(r["loss"]) and 0 < r["loss"] < 10
