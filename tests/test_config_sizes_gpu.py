@@ -314,3 +314,35 @@ def test_bf16_fused_glue_tracks_stock_autocast_step_by_step(resnet, pairs, size)
     assert t["bf16_fused"][0] == pytest.approx(t["fp32"][0], rel=1e-2)          # same forward at step 0
     assert all(v[-1] < v[0] for v in t.values())                                 # every arm learns
     assert abs(s["gap_bf16_fused_to_fp32_final"] - s["gap_bf16_stock_to_fp32_final"]) <= 0.05 * t["fp32"][0]
+
+
+# ------------------------------------------------------------------ C2 at the reference's own precision (16)
+def test_c2_precision_16_head_matches_oracle_and_the_step_trains_eager_and_replayed():
+    """training_config.json:9 sets `precision: 16`: fp16 autocast backbone (on the fused glue), fp32 head, dynamic loss
+    scaling.  At the headline size: (i) the head / alignment / NT-Xent are exact on whatever h the fp16 backbone
+    produced and the fp16 loss stays close to the fp32 one; (ii) the loop with the device-side scaler skips the
+    overflowing first steps, then takes real ones, eagerly and as ONE hipGraph per step, with finite weights and a
+    falling loss."""
+    from peclr_amd import Trainer
+    from peclr_amd.optim import DeviceLossScaler
+
+    model = build("50", 128)
+    batch = synthetic_batch(128, 224, 7)
+    d32 = step_check.step_deltas(copy.deepcopy(model), batch)
+    d16 = step_check.step_deltas(copy.deepcopy(model), batch, autocast=torch.autocast("cuda", dtype=torch.float16))
+    assert d16["rows"] == 256 and d16["loss_delta_vs_oracle"] <= 1e-4 and d16["sim_max_abs_delta"] <= 1e-4
+    assert abs(d16["loss_hip"] - d32["loss_hip"]) <= 5e-3 * abs(d32["loss_hip"])
+    tr = Trainer(max_epochs=100, precision=16).attach(model)
+    tr.zero_grad()
+    tr.capture_step_graph(batch, warmup=5)                       # 5 eager steps + the eager step the capture needs
+    sc = tr._scaler
+    assert isinstance(sc, DeviceLossScaler)
+    eager_taken, scale = sc.good_steps(), sc.get_scale()
+    assert 1 <= eager_taken <= 6 and 2.0 ** 8 <= scale <= 2.0 ** 16     # 2^16 x fp16 gradients overflows at first
+    first = float(tr._capture_eager_out["loss"])
+    losses = [float(tr.replay_step()["loss"]) for _ in range(12)]
+    # the replayed steps are real updates (one more halving can still happen while the scale settles)
+    assert sc.good_steps() >= eager_taken + 11 and scale / 2 <= sc.get_scale() <= scale
+    assert all(np.isfinite(losses)) and losses[-1] < first - 0.3
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    assert tr.global_step == 18
