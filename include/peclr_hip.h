@@ -84,6 +84,14 @@ int peclr_gemm_add_bf16(int M, int N, int K, const void* A, int lda, const void*
 /* the same kernel for IEEE fp16 activations (precision=16 / native AMP): v_mfma_f32_32x32x16_f16 */
 int peclr_gemm_add_f16(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                         int ldc, const void* addend, int ldd, peclr_stream_t stream);
+/* fp32 GEMM on the bf16 matrix cores, fp32 accuracy: C[M,N] = A[M,K] . B[N,K]^T (+ addend[M,N], nullable), all fp32,
+ * both operands K-contiguous.  Every fp32 operand is split EXACTLY into three bf16 numbers (x = h + m + l by
+ * truncation); six of the nine partial products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, the three
+ * dropped ones are <= 2^-24 of the product (one fp32 rounding).  2.67x the fp32 MFMA rate.  Serves the GEMM-shaped fp32
+ * work of the backbone (same call sites as peclr_gemm_add_f32: the 1x1-convolution input gradient + residual gradient;
+ * and the 1x1 convolutions of the torchvision Bottleneck, resnet_model.py:15).  K, lda, ldb multiples of 4.       */
+int peclr_gemm_x6_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                      const float* addend, int ldd, peclr_stream_t stream);
 int peclr_gemm_pick_split_k(int M, int N, int K);
 
 /* out[i] = sum_s slabs[s][i] (+ bias[i % cols] if non-null), i < rows*cols. */

@@ -65,6 +65,7 @@ SIGNATURES = {
     "peclr_augment_warp_crop_u8": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "peclr_augment_resize_color_norm": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, _P,
                                                 _P]),
+    "peclr_gemm_x6_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
@@ -362,6 +363,21 @@ def gemm_add(layout: int, a: torch.Tensor, b: torch.Tensor, addend: torch.Tensor
         rc = lib().peclr_gemm_add_f32(layout, m, n, k, _ptr(a), a.shape[1], _ptr(b), b.shape[1], out.data_ptr(), n,
                                       _ptr(addend), n, _stream())
     _check(rc, "peclr_gemm_add_f32")
+    return out
+
+
+def gemm_x6(a: torch.Tensor, b_t: torch.Tensor, addend: Optional[torch.Tensor] = None, tag: str = "gemm_x6",
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C (fp32) = A[M,K] . B_t[N,K]^T (+ addend), fp32 row-major contiguous 2-D HIP tensors, computed on the bf16
+    matrix cores at fp32 accuracy (exact three-way bf16 split of both operands, six products: peclr_gemm_x6_f32)."""
+    (m, k), (n, k2) = a.shape, b_t.shape
+    if k != k2 or (addend is not None and tuple(addend.shape) != (m, n)):
+        raise PeclrHipError(f"gemm_x6: shapes {tuple(a.shape)} x {tuple(b_t.shape)}^T")
+    if out is None:
+        out = torch.empty((m, n), device=a.device, dtype=torch.float32)
+    with _timed(tag, 4 * (m * k + k * n + (2 if addend is not None else 1) * m * n), 2 * m * n * k):
+        rc = lib().peclr_gemm_x6_f32(m, n, k, _ptr(a), k, _ptr(b_t), k, _ptr(out), n, _ptr(addend), n, _stream())
+    _check(rc, "peclr_gemm_x6_f32")
     return out
 
 

@@ -13,6 +13,8 @@ Two execution modes, chosen EXPLICITLY (no silent dispatch):
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -64,6 +66,9 @@ def checkpoint_block(run, x: Tensor) -> Tensor:
     if torch.is_grad_enabled() and x.requires_grad and not _RECOMPUTING:
         return _CheckpointedBlock.apply(run, x)
     return run(x)
+
+
+_GEMM_X6 = os.environ.get("PECLR_GEMM_X6", "1") != "0"    # A/B switch: fp32 GEMMs as six bf16 MFMA products
 
 
 class _BN2dAct(torch.autograd.Function):
@@ -274,6 +279,10 @@ class _ForkConv1x1(torch.autograd.Function):
                 wt = torch.empty((cin, cmid), device=x.device, dtype=x.dtype)
                 wt.copy_(weight.detach().reshape(cmid, cin).t())      # transpose + cast in ONE launch
                 out = _capi.gemm_add_half(a, wt, d, tag="conv1x1_dgrad_add")
+            elif _GEMM_X6 and cmid >= 256 and (r // 128) * (cin // 128) >= 512:
+                # fp32 on the bf16 matrix cores (exact 3-way split, six products: fp32 accuracy at 2.67x the fp32 MFMA rate)
+                wt = weight.detach().reshape(cmid, cin).t().contiguous()
+                out = _capi.gemm_x6(a, wt, d, tag="conv1x1_dgrad_add")
             else:
                 out = _capi.gemm_add(_capi.GEMM_NN, a, weight.reshape(cmid, cin), d, tag="conv1x1_dgrad_add")
             dx = out.view(n, h, w, cin).permute(0, 3, 1, 2)       # back to a channels_last NCHW tensor

@@ -1,0 +1,234 @@
+// fp32 GEMM on the bf16 matrix cores: C[M,N] = A[M,K] . B[N,K]^T (+ addend[M,N]), fp32 in, fp32 out.
+//
+// gfx950 multiplies bf16 16x faster than fp32 (v_mfma_f32_32x32x16_bf16: 32 768 flop in 32 cycles; v_mfma_f32_32x32x2_f32:
+// 4 096 flop in 64).  An fp32 number splits EXACTLY into three bf16 numbers by truncation,
+//     h = x & 0xFFFF0000,  m = (x - h) & 0xFFFF0000,  l = (x - h) - m        (x == h + m + l; 8 + 8 + 8 significand bits)
+// so a.b = sum of nine bf16 products; the three smallest (m.l, l.m, l.l: <= 2^-24 |a.b|, the size of ONE fp32 rounding)
+// are dropped and the other six run on the bf16 MFMA with fp32 accumulation:
+//     a.b ~= h.h + (h.m + m.h) + (h.l + l.h + m.m)
+// Six MFMAs of 32 cycles replace eight of 64 per 32x32x16 block: 2.67x the fp32 MFMA rate at fp32 accuracy (measured
+// against float64 in tests/test_hip_parity.py next to the v_mfma_f32 kernel).  Used for the GEMM-shaped fp32 work of
+// the backbone: the bottleneck entry's fused input gradient (dX = dY W + dRes) and the 1x1 convolutions.
+//
+// Kernel: 128 x 128 tile, 4 waves x (2 x 2) MFMA tiles, K-tile = 32 fp32.  Both operands are K-contiguous ("NT"): a
+// thread loads 16-byte words of 4 consecutive k, splits them in registers (and / sub / perm: 5.5 VALU ops per element,
+// ~40 % of the MFMA time, on the other pipe) and writes three bf16 planes per operand to LDS (row pitch 80 bytes:
+// ds_read_b128 fragments of 8 k-values, bank-conflict free).  One 60 KiB LDS image, next K-tile staged in registers,
+// 2 workgroups per CU.  Epilogue as in gemm_f32_nn128_kernel: wave-private 32 x 32 transposes through LDS so that
+// every addend load / store is 16 bytes per lane.
+#include <stdlib.h>
+
+#include "common.hpp"
+
+namespace peclr {
+namespace {
+
+typedef uint16_t bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XM = 128, XN = 128, XK = 32;
+constexpr int XLD = XK + 8;              // bf16 per LDS row: 80 bytes
+constexpr int PLANE = 128 * XLD;         // bf16 per plane
+constexpr int XEPL = 36;                 // floats per row of a wave's 32 x 32 transpose buffer
+
+struct X6Args {
+    const float* A;
+    const float* B;
+    const float* addend;
+    float* out;
+    int M, N, K, lda, ldb, ldo, ldd;
+    int stream_out;
+};
+
+// x -> (h, m, l), exact.  The results keep their value in the HIGH 16 bits (a bf16 is the top half of an fp32).
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));   // <= 8 significant bits: its low half is zero
+}
+__device__ __forceinline__ unsigned pack_hi(unsigned lo_elem, unsigned hi_elem) {   // {hi_elem[31:16], lo_elem[31:16]}
+    return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302u);
+}
+// one float4 (4 consecutive k) -> 8 bytes in each of the three planes
+__device__ __forceinline__ void split_store(bf16_t* planes, int offset, const float4& v) {
+    unsigned h[4], m[4], l[4];
+    split3(v.x, h[0], m[0], l[0]);
+    split3(v.y, h[1], m[1], l[1]);
+    split3(v.z, h[2], m[2], l[2]);
+    split3(v.w, h[3], m[3], l[3]);
+    *reinterpret_cast<uint2*>(planes + offset) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
+    *reinterpret_cast<uint2*>(planes + PLANE + offset) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
+    *reinterpret_cast<uint2*>(planes + 2 * PLANE + offset) = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
+}
+__device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_x6_nt128_kernel(X6Args g) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 3 * PLANE];   // A planes h, m, l | B planes h, m, l: 61 440 bytes
+    bf16_t* la = lds;
+    bf16_t* lb = lds + 3 * PLANE;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, kh = lane >> 5;
+    const int nct = (g.N + XN - 1) / XN;
+    const int j = blockIdx.x / 8;
+    const int row_block = 8 * (j / nct) + (int)(blockIdx.x % 8);      // all column tiles of a row block on one XCD
+    if (row_block * XM >= g.M) return;
+    const int m0 = row_block * XM, n0 = (j % nct) * XN;
+    const int nk = (g.K + XK - 1) / XK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // global -> registers: 128 rows x 32 fp32 per operand = 1024 x 16 bytes, 4 per thread and operand.  TWO K-tiles
+    // are staged ahead (register sets 0 / 1 alternate): at 32 cycles per MFMA one K-tile's multiply phase (0.64 us)
+    // is shorter than a loaded HBM round trip, two of them plus the split phase in between are not.
+    float4 ra[2][4], rb[2][4];
+    const int lr = tid >> 3, lk = (tid & 7) * 4;
+    auto gload = [&](int k0, float4 (&qa)[4], float4 (&qb)[4]) {
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) {
+            const int row = lr + 32 * rep, k = k0 + lk;
+            qa[rep] = (m0 + row < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + row) * g.lda + k)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            qb[rep] = (n0 + row < g.N && k < g.K) ? *reinterpret_cast<const float4*>(g.B + (size_t)(n0 + row) * g.ldb + k)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](const float4 (&qa)[4], const float4 (&qb)[4]) {
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) {
+            split_store(la, (lr + 32 * rep) * XLD + lk, qa[rep]);
+            split_store(lb, (lr + 32 * rep) * XLD + lk, qb[rep]);
+        }
+    };
+    auto mma_tile = [&]() {
+#pragma unroll
+        for (int t = 0; t < XK / 16; ++t) {
+            const int ko = 16 * t + 8 * kh;
+            uint4 a[2][3], b[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[0][p] = *reinterpret_cast<const uint4*>(la + p * PLANE + (wm * 64 + i) * XLD + ko);
+                a[1][p] = *reinterpret_cast<const uint4*>(la + p * PLANE + (wm * 64 + 32 + i) * XLD + ko);
+                b[0][p] = *reinterpret_cast<const uint4*>(lb + p * PLANE + (wn * 64 + i) * XLD + ko);
+                b[1][p] = *reinterpret_cast<const uint4*>(lb + p * PLANE + (wn * 64 + 32 + i) * XLD + ko);
+            }
+            // smallest products first; the four accumulators are independent chains
+#define PECLR_X6(P, Q)                                    \
+    acc[0][0] = mma(a[0][P], b[0][Q], acc[0][0]);         \
+    acc[0][1] = mma(a[0][P], b[1][Q], acc[0][1]);         \
+    acc[1][0] = mma(a[1][P], b[0][Q], acc[1][0]);         \
+    acc[1][1] = mma(a[1][P], b[1][Q], acc[1][1]);
+            PECLR_X6(2, 0) PECLR_X6(0, 2) PECLR_X6(1, 1) PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)
+#undef PECLR_X6
+        }
+    };
+    // one K-tile: issue the loads of tile kt + 2 into the set that tile kt just vacated, multiply tile kt, then split
+    // tile kt + 1 (loaded one iteration ago) into the LDS image
+    auto step = [&](int kt, float4 (&na)[4], float4 (&nb)[4], float4 (&fa)[4], float4 (&fb)[4]) {
+        if (kt + 2 < nk) gload((kt + 2) * XK, fa, fb);
+        mma_tile();
+        __syncthreads();                 // every wave is done with this K-tile's image
+        if (kt + 1 < nk) {
+            lstore(na, nb);
+            __syncthreads();
+        }
+    };
+    gload(0, ra[0], rb[0]);
+    if (nk > 1) gload(XK, ra[1], rb[1]);
+    lstore(ra[0], rb[0]);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, ra[1], rb[1], ra[0], rb[0]);            // next = set 1, far loads into set 0
+        if (kt + 1 < nk) step(kt + 1, ra[0], rb[0], ra[1], rb[1]);
+    }
+    // epilogue (see gemm_f32_nn128_kernel): wave-private transposes, 16 bytes per lane, two tiles' addends in flight
+    float* wlds = reinterpret_cast<float*>(lds) + wave * (32 * XEPL);
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+    const bool vec_ok = (g.N % 4 == 0) && (g.ldo % 4 == 0) && (!g.addend || g.ldd % 4 == 0);
+    auto addend_tile = [&](int a, int b, float4 (&dv)[4]) {
+        const int mt = m0 + wm * 64 + a * 32, nt = n0 + wn * 64 + b * 32;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int m = mt + er + 8 * jj, n = nt + ec;
+            dv[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.addend && m < g.M && n < g.N) {
+                const float* src = g.addend + (size_t)m * g.ldd + n;
+                if (vec_ok) {
+                    const f32x4 t = g.stream_out ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src))
+                                                 : *reinterpret_cast<const f32x4*>(src);
+                    dv[jj] = make_float4(t[0], t[1], t[2], t[3]);
+                } else {
+                    dv[jj].x = src[0];
+                    if (n + 1 < g.N) dv[jj].y = src[1];
+                    if (n + 2 < g.N) dv[jj].z = src[2];
+                    if (n + 3 < g.N) dv[jj].w = src[3];
+                }
+            }
+        }
+    };
+    auto store_tile = [&](int a, int b, const f32x16& c16, const float4 (&dv)[4]) {
+        const int mt = m0 + wm * 64 + a * 32, nt = n0 + wn * 64 + b * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = c16[r];
+        // same wave wrote and reads: LDS operations of one wave complete in order
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int m = mt + er + 8 * jj, n = nt + ec;
+            float4 c = *reinterpret_cast<const float4*>(wlds + (er + 8 * jj) * XEPL + ec);
+            c.x += dv[jj].x; c.y += dv[jj].y; c.z += dv[jj].z; c.w += dv[jj].w;
+            if (m < g.M && n < g.N) {
+                float* dst = g.out + (size_t)m * g.ldo + n;
+                if (vec_ok) {
+                    const f32x4 t = {c.x, c.y, c.z, c.w};
+                    if (g.stream_out) __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(dst));
+                    else *reinterpret_cast<f32x4*>(dst) = t;
+                } else {
+                    dst[0] = c.x;
+                    if (n + 1 < g.N) dst[1] = c.y;
+                    if (n + 2 < g.N) dst[2] = c.z;
+                    if (n + 3 < g.N) dst[3] = c.w;
+                }
+            }
+        }
+    };
+    float4 d0[4], d1[4];
+    addend_tile(0, 0, d0);
+    addend_tile(0, 1, d1);
+    store_tile(0, 0, acc[0][0], d0);
+    addend_tile(1, 0, d0);
+    store_tile(0, 1, acc[0][1], d1);
+    addend_tile(1, 1, d1);
+    store_tile(1, 0, acc[1][0], d0);
+    store_tile(1, 1, acc[1][1], d1);
+}
+
+}  // namespace
+}  // namespace peclr
+
+using namespace peclr;
+
+extern "C" int peclr_gemm_x6_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                 const float* addend, int ldd, peclr_stream_t stream) {
+    if (!A || !B || !C) return PECLR_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0) return PECLR_ERR_SHAPE;
+    if (K % 4 || lda % 4 || ldb % 4 || lda < K || ldb < K || ldc < N || (addend && ldd < N)) return PECLR_ERR_SHAPE;
+    if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (addend && !aligned16(addend))) return PECLR_ERR_ALIGN;
+    X6Args g;
+    g.A = A; g.B = B; g.addend = addend; g.out = C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldo = ldc; g.ldd = ldd;
+    g.stream_out = (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
+    const int nrb = (M + XM - 1) / XM, nct = (N + XN - 1) / XN;
+    hipLaunchKernelGGL(gemm_x6_nt128_kernel, dim3(8 * ((nrb + 7) / 8) * nct), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    return launch_status();
+}

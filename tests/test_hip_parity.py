@@ -1703,3 +1703,37 @@ def test_gemm_add_half_128_tile_kernel_matches_float64(capi, half, m, n, k, with
         full = full + d.double()
     assert float((out.double() - full).abs().max()) <= float((4 * ulp * full.abs().clamp_min(1.0)).max())
     assert float(out.double().sum()) == pytest.approx(float(full.sum()), abs=ulp * float(full.abs().sum()) * 0.05 + 1.0)
+
+
+@pytest.mark.parametrize("m,n,k,with_addend", [(128 * 70 + 37, 1000, 72, True), (65536 + 8, 256, 64, True), (20000, 512, 136, False),
+                                               (12544, 2048, 512, True), (50176, 256, 1024, False), (300, 132, 64, True)])
+def test_gemm_x6_is_an_fp32_gemm(capi, m, n, k, with_addend):
+    """peclr_gemm_x6_f32: fp32 operands split exactly into three bf16 numbers, six of the nine partial products on the
+    bf16 MFMA, fp32 accumulation.  Held to the SAME bar as the v_mfma_f32 kernel against float64 on the same fp32
+    inputs, and its error may not exceed that kernel's by more than 2x: it is an fp32 GEMM, not a reduced-precision
+    one.  Ragged M and N, K tails, with and without the addend; adversarial operands (wide exponent range)."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    a *= torch.exp2(torch.randint(-6, 7, (m, 1), generator=g).float())            # rows of very different magnitude
+    bt = torch.randn(n, k, generator=g) * 0.05
+    a, bt = a.to(DEV), bt.to(DEV)
+    d = torch.randn(m, n, generator=g).to(DEV) if with_addend else None
+    got = capi.gemm_x6(a, bt, d)
+    b = bt.t().contiguous()
+    f32 = capi.gemm_add(capi.GEMM_NN, a, b, d) if with_addend else capi.gemm(capi.GEMM_NN, a, b)
+    ref = a.double() @ bt.double().t()
+    if with_addend:
+        ref = ref + d.double()
+    # per-row scale: |a_row| . |b| bounds the rounding error of every term of the row
+    bound = (a.double().abs() @ bt.double().abs().t()) + (d.double().abs() if with_addend else 0)
+    e6 = ((got.double() - ref).abs() / bound).max().item()
+    e32 = ((f32.double() - ref).abs() / bound).max().item()
+    assert e6 <= 2.0 ** -21, (e6, e32)                 # a few fp32 ulps of the term magnitudes
+    assert e6 <= 2.0 * e32 + 2.0 ** -24, (e6, e32)     # no worse than the fp32 MFMA kernel
+    # exactness of the split itself: integers up to 2^24 times a power of two multiply exactly
+    ai = torch.randint(-2 ** 11, 2 ** 11, (256, 64), generator=g).float().to(DEV)
+    bi = torch.randint(-2 ** 11, 2 ** 11, (256, 64), generator=g).float().to(DEV)
+    exact = ai.double() @ bi.double().t()
+    assert float(exact.abs().max()) < 2 ** 30          # the fp32 accumulation below stays within 2^-24 relative
+    gi = capi.gemm_x6(ai, bi)
+    assert float((gi.double() - exact).abs().max()) <= 2.0 ** -22 * float(exact.abs().max())
