@@ -231,11 +231,64 @@ class _Conv2dSplitBackward(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
+def _x6_pays(rows: int, n_out: int, k: int) -> bool:
+    """Does peclr_gemm_x6_f32 beat MIOpen's fp32 1x1 convolution for a [rows, k] x [k, n_out] product?  Measured on
+    ResNet-50's shapes (tools/exp/conv1x1_probe.py): yes from K = 256 on when the 128-wide column tile is full and the
+    128 x 128 tiles fill the chip; the K = 64 / 128 and N = 64 shapes of layer1 / layer2 are HBM-bound either way."""
+    return _GEMM_X6 and k >= 256 and k % 4 == 0 and n_out >= 128 and n_out % 4 == 0 and (rows // 128) * (n_out // 128) >= 196
+
+
+class _Conv1x1Gemm(torch.autograd.Function):
+    """1x1 / stride-1 convolution of an NHWC fp32 tensor as the GEMM it is, on the bf16 matrix cores at fp32 accuracy
+    (peclr_gemm_x6_f32): forward y[R, Cout] = x[R, Cin] . W^T and / or the input gradient dx[R, Cin] = dy[R, Cout] . W,
+    each where `_x6_pays`; the other direction and the weight gradient stay on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight, param, use_fwd: bool, use_bwd: bool):
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (param, use_bwd)
+        if not use_fwd:
+            return F.conv2d(x, weight)
+        n, cin, h, w = x.shape
+        cout = weight.shape[0]
+        y = _capi.gemm_x6(x.permute(0, 2, 3, 1).reshape(n * h * w, cin), weight.detach().reshape(cout, cin), tag="conv1x1_fwd")
+        return y.view(n, h, w, cout).permute(0, 3, 1, 2)          # channels_last NCHW view of the NHWC result
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        param, use_bwd = ctx.cfg
+        n, cin, h, w = x.shape
+        cout = weight.shape[0]
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        dw = _conv_wgrad(gy, x, weight, (1, 1), (0, 0), param) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if use_bwd:
+                wt = weight.detach().reshape(cout, cin).t().contiguous()              # [Cin][Cout]: K-contiguous B operand
+                dx = _capi.gemm_x6(gy.permute(0, 2, 3, 1).reshape(n * h * w, cout), wt, tag="conv1x1_dgrad")
+                dx = dx.view(n, h, w, cin).permute(0, 3, 1, 2)
+            else:
+                dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
+        return dx, dw, None, None, None
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d (same parameters / state_dict) that routes through `_Conv2dSplitBackward` while the side-stream
     weight gradients are enabled and the input is a channels_last HIP tensor; the stock op otherwise."""
 
+    hip_gemm = False   # enable_hip_batchnorm: fp32 1x1 / stride-1 convolutions as GEMMs on the bf16 matrix cores
+
     def forward(self, x: Tensor) -> Tensor:
+        if (self.hip_gemm and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")
+                and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1
+                and self.bias is None and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+            rows = x.shape[0] * x.shape[2] * x.shape[3]
+            use_fwd = _x6_pays(rows, self.out_channels, self.in_channels)
+            use_bwd = _x6_pays(rows, self.in_channels, self.out_channels) and torch.is_grad_enabled() and x.requires_grad
+            if use_fwd or use_bwd:
+                return _Conv1x1Gemm.apply(x, self.weight, self.weight, use_fwd, use_bwd)
         if (_WgradOverlap.stream is not None and x.is_cuda and torch.is_grad_enabled() and self.bias is None
                 and self.groups == 1 and self.dilation == (1, 1) and isinstance(self.padding, tuple)
                 and x.is_contiguous(memory_format=torch.channels_last) and self.weight.requires_grad):
@@ -257,6 +310,11 @@ class _ForkConv1x1(torch.autograd.Function):
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
         ctx.param = weight if isinstance(weight, nn.Parameter) else None
+        n, cin, h, w = x.shape
+        cmid = weight.shape[0]
+        if x.dtype == torch.float32 and _x6_pays(n * h * w, cmid, cin):
+            y = _capi.gemm_x6(x.permute(0, 2, 3, 1).reshape(n * h * w, cin), weight.detach().reshape(cmid, cin), tag="conv1x1_fwd")
+            return y.view(n, h, w, cmid).permute(0, 3, 1, 2), x.view_as(x)
         return F.conv2d(x, weight), x.view_as(x)
 
     @staticmethod
@@ -363,4 +421,6 @@ def enable_hip_batchnorm(module: nn.Module, enabled: bool = True, sync_group=Non
             n += 1
         elif getattr(m, "fork_entry", False):   # bottleneck conv1 (resnet.Bottleneck marks it)
             m.hip_fork = enabled
+        if isinstance(m, Conv2d) and m.kernel_size == (1, 1) and m.stride == (1, 1):
+            m.hip_gemm = enabled                # fp32 1x1 convolutions as GEMMs where that is faster (`_x6_pays`)
     return n

@@ -1737,3 +1737,45 @@ def test_gemm_x6_is_an_fp32_gemm(capi, m, n, k, with_addend):
     assert float(exact.abs().max()) < 2 ** 30          # the fp32 accumulation below stays within 2^-24 relative
     gi = capi.gemm_x6(ai, bi)
     assert float((gi.double() - exact).abs().max()) <= 2.0 ** -22 * float(exact.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,hw,n", [(1024, 256, 14, 256), (256, 1024, 14, 256), (512, 128, 28, 64), (64, 256, 8, 4)])
+def test_conv1x1_as_gemm_on_the_matrix_cores_matches_float64(cin, cout, hw, n):
+    """bn2d.Conv2d(hip_gemm=True): fp32 1x1 / stride-1 convolutions of NHWC tensors as peclr_gemm_x6_f32 where that
+    beats MIOpen (forward and / or input gradient, `_x6_pays`), MIOpen otherwise (last shape).  Output, input gradient
+    and weight gradient against float64, held to the bar MIOpen's own fp32 result meets on the same data."""
+    from peclr_amd import _capi
+    from peclr_amd import bn2d as B
+
+    g = torch.Generator().manual_seed(cin + cout + hw)
+    conv = B.Conv2d(cin, cout, 1, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    x = torch.randn(n, cin, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, cout, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    calls = []
+    real = _capi.gemm_x6
+    _capi.gemm_x6 = lambda *a, **k: (calls.append(k.get("tag")), real(*a, **k))[1]
+    res = {}
+    try:
+        for mode in (False, True):
+            conv.hip_gemm = mode
+            conv.weight.grad = None
+            xx = x.clone().requires_grad_()
+            y = conv(xx)
+            y.backward(gy)
+            res[mode] = (y.detach(), xx.grad.clone(), conv.weight.grad.clone())
+    finally:
+        _capi.gemm_x6 = real
+    rows = n * hw * hw
+    want_calls = [t for t, ok in (("conv1x1_fwd", B._x6_pays(rows, cout, cin)), ("conv1x1_dgrad", B._x6_pays(rows, cin, cout))) if ok]
+    assert calls == want_calls, (calls, want_calls)
+    assert res[True][0].is_contiguous(memory_format=torch.channels_last) and res[True][1].is_contiguous(memory_format=torch.channels_last)
+    w64 = conv.weight.detach().double().view(cout, cin)
+    sub = slice(0, min(n, 8))
+    y_ref = torch.einsum("nchw,oc->nohw", x[sub].double(), w64)
+    dx_ref = torch.einsum("nohw,oc->nchw", gy[sub].double(), w64)
+    for k, ref in ((0, y_ref), (1, dx_ref)):
+        scale = float(ref.abs().max())
+        e_new = float((res[True][k][sub].double() - ref).abs().max()) / scale
+        e_old = float((res[False][k][sub].double() - ref).abs().max()) / scale
+        assert e_new <= max(2 * e_old, 2e-6), (k, e_new, e_old)
+    np.testing.assert_allclose(host(res[True][2]), host(res[False][2]), rtol=1e-3, atol=1e-3 * float(res[False][2].abs().max()))
