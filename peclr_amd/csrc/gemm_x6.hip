@@ -93,7 +93,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt128_kernel(X6Args g) {
     // are staged ahead (register sets 0 / 1 alternate): at 32 cycles per MFMA one K-tile's multiply phase (0.64 us)
     // is shorter than a loaded HBM round trip, two of them plus the split phase in between are not.
     float4 ra[2][4], rb[2][4];
-    const int lr = tid >> 3, lk = (tid & 7) * 4;
+    // row of this thread's 16-byte words (+ 32 per rep).  ds_write_b64 is serviced in contiguous 16-lane groups on 32
+    // banks: a group writes two rows' 64-byte pieces, which must not share banks -- at an 80-byte pitch rows r and
+    // r + 4 do not (20 * 4 = 16 mod 32 dwords), rows r and r + 1 do (2-way: every plane store twice as long; this was
+    // a third of all LDS cycles).  So consecutive 8-thread groups take rows r, r + 4, r + 1, r + 5, ...
+    const int lg = tid >> 3;
+    const int lr = (lg & ~7) | ((lg & 1) << 2) | ((lg >> 1) & 3), lk = (tid & 7) * 4;
     auto gload = [&](int k0, float4 (&qa)[4], float4 (&qb)[4]) {
 #pragma unroll
         for (int rep = 0; rep < 4; ++rep) {
