@@ -582,6 +582,13 @@ def main():
                                   "one hipGraph replay per step (whole step captured)" if use_graph else
                                   "eager launches" + (f" ({graph_note})" if graph_note else "")),
                        "graph_fallback": graph_note,   # None unless --graph auto had to fall back to eager launches
+                       # fp32 runs: the GEMM-shaped backbone work (1x1 convolutions forward / input gradient with K >= 256,
+                       # the fused entry gradient) runs on the bf16 matrix cores at fp32 ACCURACY: every fp32 operand is split
+                       # exactly into three bf16 numbers and six of the nine partial products are accumulated in fp32
+                       # (peclr_gemm_x6_f32; error vs float64 <= the v_mfma_f32 kernel's, tests/test_hip_parity.py)
+                       "fp32_gemm": (("exact 3-way bf16 split, 6 MFMA products, fp32 accumulate (fp32 accuracy)"
+                                      if os.environ.get("PECLR_GEMM_X6", "1") != "0" else "v_mfma_f32 / MIOpen fp32")
+                                     if args.dtype == "fp32" else None),
                        # fp16: dynamic loss scaling skips a step whose scaled gradients overflow (the launches still
                        # run, the update kernel returns early): how many of the K timed steps were real updates
                        "amp": None if amp_after is None else {
