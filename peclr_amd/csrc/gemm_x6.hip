@@ -89,31 +89,30 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt128_kernel(X6Args g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // global -> registers: 128 rows x 32 fp32 per operand = 1024 x 16 bytes, 4 per thread and operand.  TWO K-tiles
-    // are staged ahead (register sets 0 / 1 alternate): at 32 cycles per MFMA one K-tile's multiply phase (0.64 us)
-    // is shorter than a loaded HBM round trip, two of them plus the split phase in between are not.
-    float4 ra[2][4], rb[2][4];
-    // row of this thread's 16-byte words (+ 32 per rep).  ds_write_b64 is serviced in contiguous 16-lane groups on 32
-    // banks: a group writes two rows' 64-byte pieces, which must not share banks -- at an 80-byte pitch rows r and
-    // r + 4 do not (20 * 4 = 16 mod 32 dwords), rows r and r + 1 do (2-way: every plane store twice as long; this was
+    // global -> registers: 128 rows x 32 fp32 per operand = 1024 x 16 bytes, 4 per thread and operand; the next K-tile
+    // is in flight in registers while this one is multiplied (a second tile ahead changed nothing: not latency-bound).
+    // Row of this thread's 16-byte words (+ 32 per rep): ds_write_b64 is serviced in contiguous 16-lane groups on 32
+    // banks; a group writes two rows' 64-byte pieces, which must not share banks -- at an 80-byte pitch rows r and
+    // r + 4 do not (20 * 4 = 16 mod 32 dwords), rows r and r + 1 do (2-way: every plane store twice as long; that was
     // a third of all LDS cycles).  So consecutive 8-thread groups take rows r, r + 4, r + 1, r + 5, ...
+    float4 ra[4], rb[4];
     const int lg = tid >> 3;
     const int lr = (lg & ~7) | ((lg & 1) << 2) | ((lg >> 1) & 3), lk = (tid & 7) * 4;
-    auto gload = [&](int k0, float4 (&qa)[4], float4 (&qb)[4]) {
+    auto gload = [&](int k0) {
 #pragma unroll
         for (int rep = 0; rep < 4; ++rep) {
             const int row = lr + 32 * rep, k = k0 + lk;
-            qa[rep] = (m0 + row < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + row) * g.lda + k)
+            ra[rep] = (m0 + row < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + row) * g.lda + k)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-            qb[rep] = (n0 + row < g.N && k < g.K) ? *reinterpret_cast<const float4*>(g.B + (size_t)(n0 + row) * g.ldb + k)
+            rb[rep] = (n0 + row < g.N && k < g.K) ? *reinterpret_cast<const float4*>(g.B + (size_t)(n0 + row) * g.ldb + k)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto lstore = [&](const float4 (&qa)[4], const float4 (&qb)[4]) {
+    auto lstore = [&]() {
 #pragma unroll
         for (int rep = 0; rep < 4; ++rep) {
-            split_store(la, (lr + 32 * rep) * XLD + lk, qa[rep]);
-            split_store(lb, (lr + 32 * rep) * XLD + lk, qb[rep]);
+            split_store(la, (lr + 32 * rep) * XLD + lk, ra[rep]);
+            split_store(lb, (lr + 32 * rep) * XLD + lk, rb[rep]);
         }
     };
     auto mma_tile = [&]() {
@@ -138,24 +137,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt128_kernel(X6Args g) {
 #undef PECLR_X6
         }
     };
-    // one K-tile: issue the loads of tile kt + 2 into the set that tile kt just vacated, multiply tile kt, then split
-    // tile kt + 1 (loaded one iteration ago) into the LDS image
-    auto step = [&](int kt, float4 (&na)[4], float4 (&nb)[4], float4 (&fa)[4], float4 (&fb)[4]) {
-        if (kt + 2 < nk) gload((kt + 2) * XK, fa, fb);
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload((kt + 1) * XK);  // in flight under this tile's MFMAs
         mma_tile();
         __syncthreads();                 // every wave is done with this K-tile's image
-        if (kt + 1 < nk) {
-            lstore(na, nb);
+        if (more) {
+            lstore();
             __syncthreads();
         }
-    };
-    gload(0, ra[0], rb[0]);
-    if (nk > 1) gload(XK, ra[1], rb[1]);
-    lstore(ra[0], rb[0]);
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, ra[1], rb[1], ra[0], rb[0]);            // next = set 1, far loads into set 0
-        if (kt + 1 < nk) step(kt + 1, ra[0], rb[0], ra[1], rb[1]);
     }
     // epilogue (see gemm_f32_nn128_kernel): wave-private transposes, 16 bytes per lane, two tiles' addends in flight
     float* wlds = reinterpret_cast<float*>(lds) + wave * (32 * XEPL);
