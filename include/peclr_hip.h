@@ -92,6 +92,14 @@ int peclr_gemm_add_f16(int M, int N, int K, const void* A, int lda, const void* 
  * and the 1x1 convolutions of the torchvision Bottleneck, resnet_model.py:15).  K, lda, ldb multiples of 4.       */
 int peclr_gemm_x6_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                       const float* addend, int ldd, peclr_stream_t stream);
+/* The 1x1 weight gradient on the same scheme: dW[M=Cout, N=Cin] = A[K=R, M]^T . B[K=R, N] with A = dY and B = X as they
+ * lie in NHWC memory (K is the slow dimension of both; lda >= M, ldb >= N; M, N, lda, ldb multiples of 4).  K is split
+ * over peclr_gemm_x6_tn_slabs(M, N, K) workgroup rows, each writing one fp32 slab [M][N]; add them with
+ * peclr_slab_reduce_f32 (fixed order: the result is deterministic, unlike the atomically accumulated split-K weight
+ * gradients of the library kernels).  Replaces MIOpen's fp32 weight gradient of the 1x1 convolutions.            */
+int peclr_gemm_x6_tn_slabs(int M, int N, int K);
+int peclr_gemm_x6_tn_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs,
+                         int n_slabs, peclr_stream_t stream);
 int peclr_gemm_pick_split_k(int M, int N, int K);
 
 /* out[i] = sum_s slabs[s][i] (+ bias[i % cols] if non-null), i < rows*cols. */

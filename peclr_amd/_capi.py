@@ -66,6 +66,8 @@ SIGNATURES = {
     "peclr_augment_resize_color_norm": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, _P,
                                                 _P]),
     "peclr_gemm_x6_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
+    "peclr_gemm_x6_tn_slabs": (c_int, [c_int, c_int, c_int]),
+    "peclr_gemm_x6_tn_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
@@ -379,6 +381,23 @@ def gemm_x6(a: torch.Tensor, b_t: torch.Tensor, addend: Optional[torch.Tensor] =
         rc = lib().peclr_gemm_x6_f32(m, n, k, _ptr(a), k, _ptr(b_t), k, _ptr(out), n, _ptr(addend), n, _stream())
     _check(rc, "peclr_gemm_x6_f32")
     return out
+
+
+def gemm_x6_tn(a: torch.Tensor, b: torch.Tensor, tag: str = "gemm_x6_tn") -> torch.Tensor:
+    """C[M,N] (fp32) = A[K,M]^T . B[K,N], fp32 row-major contiguous 2-D HIP tensors whose ROWS are the contraction
+    index (the 1x1 weight gradient dW = dY^T X on NHWC storage), on the bf16 matrix cores at fp32 accuracy; split-K
+    slabs summed in a fixed order (peclr_gemm_x6_tn_f32 + peclr_slab_reduce_f32): deterministic."""
+    (k, m), (k2, n) = a.shape, b.shape
+    if k != k2:
+        raise PeclrHipError(f"gemm_x6_tn: shapes {tuple(a.shape)}^T x {tuple(b.shape)}")
+    ns = lib().peclr_gemm_x6_tn_slabs(m, n, k)
+    if ns < 1:
+        raise PeclrHipError(f"gemm_x6_tn: unsupported shape M={m} N={n} K={k}")
+    slabs = torch.empty((ns, m, n), device=a.device, dtype=torch.float32)
+    with _timed(tag, 4 * (k * m + k * n + ns * m * n), 2 * m * n * k):
+        rc = lib().peclr_gemm_x6_tn_f32(m, n, k, _ptr(a), m, _ptr(b), n, slabs.data_ptr(), ns, _stream())
+    _check(rc, "peclr_gemm_x6_tn_f32")
+    return slabs[0] if ns == 1 else slab_reduce(slabs)
 
 
 def gemm_add_half(a: torch.Tensor, b_t: torch.Tensor, addend: Optional[torch.Tensor], tag: str = "gemm_add") -> torch.Tensor:

@@ -238,6 +238,34 @@ def _x6_pays(rows: int, n_out: int, k: int) -> bool:
     return _GEMM_X6 and k >= 256 and k % 4 == 0 and n_out >= 128 and n_out % 4 == 0 and (rows // 128) * (n_out // 128) >= 196
 
 
+def _x6_wgrad_pays(rows: int, cout: int, cin: int) -> bool:
+    """peclr_gemm_x6_tn_f32 against MIOpen's fp32 1x1 weight gradient (tools/exp/conv1x1_probe.py): 150-205 us against
+    208-267 from layer2 on; with 64 output or input channels (layer1) half of every 128-wide tile would be empty."""
+    return _GEMM_X6 and cout >= 128 and cin >= 128 and cout % 4 == 0 and cin % 4 == 0 and rows >= 8192
+
+
+def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
+    """d(weight) of a 1x1 / stride-1 convolution as dY^T X on the bf16 matrix cores (fp32 accuracy, deterministic
+    split-K), shaped and strided like the weight; parked for `param` on the side stream when that mode is on."""
+    n, cin, h, w = x.shape
+    cout = gy.shape[1]
+
+    def run():
+        dw = _capi.gemm_x6_tn(gy.permute(0, 2, 3, 1).reshape(n * h * w, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin),
+                              tag="conv1x1_wgrad")
+        ref = param if param is not None else weight
+        return dw.as_strided(ref.shape, ref.stride())       # same memory, the parameter's (channels_last) strides
+
+    st = _WgradOverlap.stream
+    if st is None or param is None:
+        return run()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = run()
+    _WgradOverlap.parked.append((param, g, (gy, x)))
+    return None
+
+
 class _Conv1x1Gemm(torch.autograd.Function):
     """1x1 / stride-1 convolution of an NHWC fp32 tensor as the GEMM it is, on the bf16 matrix cores at fp32 accuracy
     (peclr_gemm_x6_f32): forward y[R, Cout] = x[R, Cin] . W^T and / or the input gradient dx[R, Cin] = dy[R, Cout] . W,
@@ -261,7 +289,10 @@ class _Conv1x1Gemm(torch.autograd.Function):
         n, cin, h, w = x.shape
         cout = weight.shape[0]
         gy = gy.contiguous(memory_format=torch.channels_last)
-        dw = _conv_wgrad(gy, x, weight, (1, 1), (0, 0), param) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = (_wgrad_1x1_x6(gy, x, weight, param) if _x6_wgrad_pays(n * h * w, cout, cin)
+                  else _conv_wgrad(gy, x, weight, (1, 1), (0, 0), param))
         dx = None
         if ctx.needs_input_grad[0]:
             if use_bwd:
@@ -287,7 +318,9 @@ class Conv2d(nn.Conv2d):
             rows = x.shape[0] * x.shape[2] * x.shape[3]
             use_fwd = _x6_pays(rows, self.out_channels, self.in_channels)
             use_bwd = _x6_pays(rows, self.in_channels, self.out_channels) and torch.is_grad_enabled() and x.requires_grad
-            if use_fwd or use_bwd:
+            use_wgrad = (_x6_wgrad_pays(rows, self.out_channels, self.in_channels) and torch.is_grad_enabled()
+                         and self.weight.requires_grad)
+            if use_fwd or use_bwd or use_wgrad:
                 return _Conv1x1Gemm.apply(x, self.weight, self.weight, use_fwd, use_bwd)
         if (_WgradOverlap.stream is not None and x.is_cuda and torch.is_grad_enabled() and self.bias is None
                 and self.groups == 1 and self.dilation == (1, 1) and isinstance(self.padding, tuple)
@@ -325,7 +358,9 @@ class _ForkConv1x1(torch.autograd.Function):
         dw = None
         gy = gy.to(x.dtype)
         if ctx.needs_input_grad[1]:
-            dw = _conv_wgrad(gy.contiguous(memory_format=torch.channels_last), x, weight, (1, 1), (0, 0), ctx.param)
+            gyc = gy.contiguous(memory_format=torch.channels_last)
+            dw = (_wgrad_1x1_x6(gyc, x, weight, ctx.param) if (x.dtype == torch.float32 and _x6_wgrad_pays(n * h * w, cmid, cin))
+                  else _conv_wgrad(gyc, x, weight, (1, 1), (0, 0), ctx.param))
         dx = None
         if ctx.needs_input_grad[0]:
             gy = gy.contiguous(memory_format=torch.channels_last)

@@ -211,6 +211,111 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt128_kernel(X6Args g) {
     store_tile(1, 1, acc[1][1], d1);
 }
 
+
+// ---- "TN" variant for the 1x1 weight gradients: C[M,N] = sum_k A[k,M] . B[k,N]  (dW[Cout,Cin] = dY[R,Cout]^T X[R,Cin]),
+// K = R (rows of the activation) split over gridDim.y workgroups into fp32 slabs that peclr_slab_reduce_f32 adds up in
+// a fixed order (deterministic, unlike the atomically accumulated split-K of the library kernels).  Both operands have
+// K as their SLOW dimension, the MFMA fragments want 8 consecutive k per lane: a thread loads a 4 (k) x 4 (columns)
+// block as four 16-byte words, splits the 16 values and stores, per column and plane, the four k-values as one
+// ds_write_b64 into the same [column][k] planes the NT kernel uses -- the transpose happens in the choice of registers
+// to pack, and the store count is the NT kernel's.  Lanes run over 8 k-groups x 8 column chunks: a 16-lane store group
+// covers two column chunks x 8 k-groups = 32 distinct banks, and a load instruction reads 8 rows x 128 contiguous bytes.
+__global__ __launch_bounds__(256, 2) void gemm_x6_tn128_kernel(X6Args g, int kchunk) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 3 * PLANE];
+    bf16_t* la = lds;
+    bf16_t* lb = lds + 3 * PLANE;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, kh = lane >> 5;
+    const int nct = (g.N + XN - 1) / XN;
+    const int m0 = (int)(blockIdx.x / nct) * XM, n0 = (int)(blockIdx.x % nct) * XN;
+    const int kbeg = blockIdx.y * kchunk, kend = min(g.K, kbeg + kchunk);
+    const int nk = (kend - kbeg + XK - 1) / XK;
+    float* out = g.out + (size_t)blockIdx.y * g.M * g.N;     // this split's slab, ld = N
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra[4], rb[4];                                      // rows k .. k + 3 of this thread's 4 columns
+    const int kg = lane & 7, chunk = 8 * wave + (lane >> 3);   // k-group (4 rows), column chunk (4 columns)
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + 4 * kg + q;
+            ra[q] = (k < kend && m0 + 4 * chunk < g.M) ? *reinterpret_cast<const float4*>(g.A + (size_t)k * g.lda + m0 + 4 * chunk)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[q] = (k < kend && n0 + 4 * chunk < g.N) ? *reinterpret_cast<const float4*>(g.B + (size_t)k * g.ldb + n0 + 4 * chunk)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto tstore = [&](bf16_t* planes, const float4 (&v)[4]) {
+        const float c[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x}, {v[0].y, v[1].y, v[2].y, v[3].y},
+                               {v[0].z, v[1].z, v[2].z, v[3].z}, {v[0].w, v[1].w, v[2].w, v[3].w}};   // [column][k]
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc)
+            split_store(planes, (4 * chunk + jc) * XLD + 4 * kg, make_float4(c[jc][0], c[jc][1], c[jc][2], c[jc][3]));
+    };
+    auto mma_tile = [&]() {
+#pragma unroll
+        for (int t = 0; t < XK / 16; ++t) {
+            const int ko = 16 * t + 8 * kh;
+            uint4 a[2][3], b[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[0][p] = *reinterpret_cast<const uint4*>(la + p * PLANE + (wm * 64 + i) * XLD + ko);
+                a[1][p] = *reinterpret_cast<const uint4*>(la + p * PLANE + (wm * 64 + 32 + i) * XLD + ko);
+                b[0][p] = *reinterpret_cast<const uint4*>(lb + p * PLANE + (wn * 64 + i) * XLD + ko);
+                b[1][p] = *reinterpret_cast<const uint4*>(lb + p * PLANE + (wn * 64 + 32 + i) * XLD + ko);
+            }
+#define PECLR_X6(P, Q)                                    \
+    acc[0][0] = mma(a[0][P], b[0][Q], acc[0][0]);         \
+    acc[0][1] = mma(a[0][P], b[1][Q], acc[0][1]);         \
+    acc[1][0] = mma(a[1][P], b[0][Q], acc[1][0]);         \
+    acc[1][1] = mma(a[1][P], b[1][Q], acc[1][1]);
+            PECLR_X6(2, 0) PECLR_X6(0, 2) PECLR_X6(1, 1) PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)
+#undef PECLR_X6
+        }
+    };
+    gload(kbeg);
+    tstore(la, ra);
+    tstore(lb, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kbeg + (kt + 1) * XK);
+        mma_tile();
+        __syncthreads();
+        if (more) {
+            tstore(la, ra);
+            tstore(lb, rb);
+            __syncthreads();
+        }
+    }
+    // epilogue: wave-private 32 x 32 transposes, 16-byte stores into the slab
+    float* wlds = reinterpret_cast<float*>(lds) + wave * (32 * XEPL);
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int mt = m0 + wm * 64 + a * 32, nt = n0 + wn * 64 + b * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = acc[a][b][r];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = mt + er + 8 * jj, n = nt + ec;
+                const float4 c = *reinterpret_cast<const float4*>(wlds + (er + 8 * jj) * XEPL + ec);
+                if (m < g.M && n < g.N) *reinterpret_cast<float4*>(out + (size_t)m * g.N + n) = c;
+            }
+        }
+}
+
 }  // namespace
 }  // namespace peclr
 
@@ -228,5 +333,34 @@ extern "C" int peclr_gemm_x6_f32(int M, int N, int K, const float* A, int lda, c
     g.stream_out = (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
     const int nrb = (M + XM - 1) / XM, nct = (N + XN - 1) / XN;
     hipLaunchKernelGGL(gemm_x6_nt128_kernel, dim3(8 * ((nrb + 7) / 8) * nct), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    return launch_status();
+}
+
+// Split of the K (row) range for peclr_gemm_x6_tn_f32: enough slabs that tiles x slabs fill the chip (~2 workgroups
+// per CU), at least 8 K-tiles per workgroup.
+extern "C" int peclr_gemm_x6_tn_slabs(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const long tiles = (long)((M + XM - 1) / XM) * ((N + XN - 1) / XN);
+    long s = (512 + tiles - 1) / tiles;
+    const long max_s = (K + 8 * XK - 1) / (8 * XK);
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    const int kchunk = (int)(((K + s - 1) / s + XK - 1) / XK * XK);
+    return (K + kchunk - 1) / kchunk;
+}
+
+extern "C" int peclr_gemm_x6_tn_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs,
+                                    int n_slabs, peclr_stream_t stream) {
+    if (!A || !B || !slabs) return PECLR_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0 || n_slabs < 1) return PECLR_ERR_SHAPE;
+    if (M % 4 || N % 4 || lda % 4 || ldb % 4 || lda < M || ldb < N) return PECLR_ERR_SHAPE;
+    if (!aligned16(A) || !aligned16(B) || !aligned16(slabs)) return PECLR_ERR_ALIGN;
+    if (n_slabs != peclr_gemm_x6_tn_slabs(M, N, K)) return PECLR_ERR_WORKSPACE;
+    X6Args g;
+    g.A = A; g.B = B; g.addend = nullptr; g.out = slabs;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldo = N; g.ldd = 0; g.stream_out = 0;
+    const int kchunk = ((K + n_slabs - 1) / n_slabs + XK - 1) / XK * XK;
+    const int tiles = ((M + XM - 1) / XM) * ((N + XN - 1) / XN);
+    hipLaunchKernelGGL(gemm_x6_tn128_kernel, dim3(tiles, n_slabs), dim3(256), 0, static_cast<hipStream_t>(stream), g, kchunk);
     return launch_status();
 }

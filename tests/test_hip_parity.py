@@ -1752,8 +1752,9 @@ def test_conv1x1_as_gemm_on_the_matrix_cores_matches_float64(cin, cout, hw, n):
     x = torch.randn(n, cin, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
     gy = torch.randn(n, cout, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
     calls = []
-    real = _capi.gemm_x6
+    real, real_tn = _capi.gemm_x6, _capi.gemm_x6_tn
     _capi.gemm_x6 = lambda *a, **k: (calls.append(k.get("tag")), real(*a, **k))[1]
+    _capi.gemm_x6_tn = lambda *a, **k: (calls.append(k.get("tag")), real_tn(*a, **k))[1]
     res = {}
     try:
         for mode in (False, True):
@@ -1764,9 +1765,10 @@ def test_conv1x1_as_gemm_on_the_matrix_cores_matches_float64(cin, cout, hw, n):
             y.backward(gy)
             res[mode] = (y.detach(), xx.grad.clone(), conv.weight.grad.clone())
     finally:
-        _capi.gemm_x6 = real
+        _capi.gemm_x6, _capi.gemm_x6_tn = real, real_tn
     rows = n * hw * hw
-    want_calls = [t for t, ok in (("conv1x1_fwd", B._x6_pays(rows, cout, cin)), ("conv1x1_dgrad", B._x6_pays(rows, cin, cout))) if ok]
+    want_calls = [t for t, ok in (("conv1x1_fwd", B._x6_pays(rows, cout, cin)), ("conv1x1_wgrad", B._x6_wgrad_pays(rows, cout, cin)),
+                                  ("conv1x1_dgrad", B._x6_pays(rows, cin, cout))) if ok]
     assert calls == want_calls, (calls, want_calls)
     assert res[True][0].is_contiguous(memory_format=torch.channels_last) and res[True][1].is_contiguous(memory_format=torch.channels_last)
     w64 = conv.weight.detach().double().view(cout, cin)
@@ -1778,4 +1780,14 @@ def test_conv1x1_as_gemm_on_the_matrix_cores_matches_float64(cin, cout, hw, n):
         e_new = float((res[True][k][sub].double() - ref).abs().max()) / scale
         e_old = float((res[False][k][sub].double() - ref).abs().max()) / scale
         assert e_new <= max(2 * e_old, 2e-6), (k, e_new, e_old)
-    np.testing.assert_allclose(host(res[True][2]), host(res[False][2]), rtol=1e-3, atol=1e-3 * float(res[False][2].abs().max()))
+    assert res[True][2].stride() == conv.weight.stride()
+    dw_ref = torch.einsum("nohw,nchw->oc", gy.double(), x.double()).view(cout, cin, 1, 1)
+    sw = float(dw_ref.abs().max())
+    e_new = float((res[True][2].double() - dw_ref).abs().max()) / sw
+    e_old = float((res[False][2].double() - dw_ref).abs().max()) / sw
+    assert e_new <= max(2 * e_old, 1e-5), (e_new, e_old)         # MIOpen's own fp32 weight gradient is the bar
+    if B._x6_wgrad_pays(rows, cout, cin):                       # fixed-order slabs: bit-reproducible, unlike the atomics
+        conv.weight.grad = None
+        xx = x.clone().requires_grad_()
+        conv(xx).backward(gy)
+        assert torch.equal(conv.weight.grad, res[True][2])

@@ -41,5 +41,8 @@ for cin, cout, hw in SHAPES:
     t_wrw = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1, (False, True, False)))
     t6_fwd = timeit(lambda: _capi.gemm_x6(x2, w2))            # y[R,Cout] = x[R,Cin] . W[Cout,Cin]^T
     t6_bwd = timeit(lambda: _capi.gemm_x6(gy2, wt))           # dx[R,Cin] = gy[R,Cout] . Wt[Cin,Cout]^T
+    t6_wrw = timeit(lambda: _capi.gemm_x6_tn(gy2, x2))        # dW[Cout,Cin] = gy[R,Cout]^T . x[R,Cin]
+    dw_ref = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+    dw_err = float((_capi.gemm_x6_tn(gy2, x2) - dw_ref.reshape(cout, cin)).abs().max()) / float(dw_ref.abs().max())
     fl = 2 * r * cin * cout
-    print(f"{cin:5d}->{cout:5d} @{hw:2d}  MIOpen fwd {t_fwd:6.1f} ({fl / t_fwd / 1e6:5.0f} TF)  dgrad {t_bwd:6.1f}  wgrad {t_wrw:6.1f} | x6 fwd {t6_fwd:6.1f}  dgrad {t6_bwd:6.1f}")
+    print(f"{cin:5d}->{cout:5d} @{hw:2d}  MIOpen fwd {t_fwd:6.1f} ({fl / t_fwd / 1e6:5.0f} TF)  dgrad {t_bwd:6.1f}  wgrad {t_wrw:6.1f} | x6 fwd {t6_fwd:6.1f}  dgrad {t6_bwd:6.1f}  wgrad {t6_wrw:6.1f} (vs MIOpen {dw_err:.1e})")
