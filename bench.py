@@ -170,17 +170,29 @@ def kernel_table(event_log, m_rows, m_global, din, hid, n_params):
         else:  # shape-dependent launches (bn2d_*, conv1x1_dgrad_add): the wrapper recorded each launch's
             # algorithmic work; the roof that takes longer at its peak is the one that bounds the kernel
             nbytes, flops = sum(r[2] for r in recs) / len(recs), sum(r[3] for r in recs) / len(recs)
-            bound = "mfma" if flops / (MFMA_F32_PEAK_TF * 1e12) > nbytes / (HBM_PEAK_GBS * 1e9) else "hbm"
+            bound = "mfma" if flops / (mfma_peak(name) * 1e12) > nbytes / (HBM_PEAK_GBS * 1e9) else "hbm"
         entry = {"bound": bound, "launches": len(ms), "avg_us": round(avg_us, 3), "bytes": nbytes, "flops": flops}
         if bound == "hbm":
             ach = nbytes / (avg_us * 1e-6) / 1e9
             entry.update(achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5))
         else:
             ach = flops / (avg_us * 1e-6) / 1e12
-            entry.update(achieved=round(ach, 3), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                         frac=round(ach / MFMA_F32_PEAK_TF, 5))
+            entry.update(achieved=round(ach, 3), peak=round(mfma_peak(name), 1), unit="TFLOP/s",
+                         frac=round(ach / mfma_peak(name), 5))
+            if name in X6_TAGS:
+                entry["peak_note"] = "fp32 GEMM as six bf16 MFMA products: dense bf16 peak / 6"
+
         out[name] = entry
     return out
+
+
+# launches of peclr_gemm_x6_f32 / _tn_f32 (fp32 operands split into three bf16 numbers, six products on the bf16 MFMA):
+# their MFMA roof is the dense bf16 peak / 6 fp32-equivalent flop/s, not the v_mfma_f32 peak
+X6_TAGS = {"conv1x1_fwd", "conv1x1_dgrad", "conv1x1_wgrad", "gemm_x6", "gemm_x6_tn"}
+
+
+def mfma_peak(name):
+    return MFMA_BF16_PEAK_TF / 6.0 if name in X6_TAGS else MFMA_F32_PEAK_TF
 
 
 def pmc_traffic(kernel, args=None):
