@@ -52,40 +52,46 @@ __device__ __forceinline__ unsigned pack_hi(unsigned lo_elem, unsigned hi_elem) 
     return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302u);
 }
 // one float4 (4 consecutive k) -> 8 bytes in each of the three planes
-__device__ __forceinline__ void split_store(bf16_t* planes, int offset, const float4& v) {
+__device__ __forceinline__ void split_store(bf16_t* planes, int offset, const float4& v, int plane = PLANE) {
     unsigned h[4], m[4], l[4];
     split3(v.x, h[0], m[0], l[0]);
     split3(v.y, h[1], m[1], l[1]);
     split3(v.z, h[2], m[2], l[2]);
     split3(v.w, h[3], m[3], l[3]);
     *reinterpret_cast<uint2*>(planes + offset) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
-    *reinterpret_cast<uint2*>(planes + PLANE + offset) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
-    *reinterpret_cast<uint2*>(planes + 2 * PLANE + offset) = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
+    *reinterpret_cast<uint2*>(planes + plane + offset) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
+    *reinterpret_cast<uint2*>(planes + 2 * plane + offset) = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
 }
 __device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, f32x16 acc) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_x6_nt128_kernel(X6Args g) {
-    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 3 * PLANE];   // A planes h, m, l | B planes h, m, l: 61 440 bytes
+// NB = MFMA tiles per wave along N: 2 -> 128 x 128 workgroup tile; 1 -> 128 x 64 for outputs that are 64 wide (layer1's
+// 256 -> 64 convolutions: with the 128-wide tile half of every MFMA would multiply zeros and the HBM-bound shape
+// would become MFMA-bound).
+template <int NB>
+__global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void gemm_x6_nt128_kernel(X6Args g) {
+    constexpr int TNW = 64 * NB;
+    constexpr int PLANE_B = TNW * XLD;   // NB = 1: 46 KiB of LDS and 144 VGPRs -> 3 workgroups per CU
+    __shared__ __attribute__((aligned(16))) bf16_t lds[3 * PLANE + 3 * PLANE_B];   // A planes h, m, l | B planes h, m, l
     bf16_t* la = lds;
     bf16_t* lb = lds + 3 * PLANE;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, kh = lane >> 5;
-    const int nct = (g.N + XN - 1) / XN;
+    const int nct = (g.N + TNW - 1) / TNW;
     const int j = blockIdx.x / 8;
     const int row_block = 8 * (j / nct) + (int)(blockIdx.x % 8);      // all column tiles of a row block on one XCD
     if (row_block * XM >= g.M) return;
-    const int m0 = row_block * XM, n0 = (j % nct) * XN;
+    const int m0 = row_block * XM, n0 = (j % nct) * TNW;
     const int nk = (g.K + XK - 1) / XK;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt128_kernel(X6Args g) {
     // banks; a group writes two rows' 64-byte pieces, which must not share banks -- at an 80-byte pitch rows r and
     // r + 4 do not (20 * 4 = 16 mod 32 dwords), rows r and r + 1 do (2-way: every plane store twice as long; that was
     // a third of all LDS cycles).  So consecutive 8-thread groups take rows r, r + 4, r + 1, r + 5, ...
-    float4 ra[4], rb[4];
+    float4 ra[4], rb[2 * NB];
     const int lg = tid >> 3;
     const int lr = (lg & ~7) | ((lg & 1) << 2) | ((lg >> 1) & 3), lk = (tid & 7) * 4;
     auto gload = [&](int k0) {
@@ -104,35 +110,37 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt128_kernel(X6Args g) {
             const int row = lr + 32 * rep, k = k0 + lk;
             ra[rep] = (m0 + row < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + row) * g.lda + k)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[rep] = (n0 + row < g.N && k < g.K) ? *reinterpret_cast<const float4*>(g.B + (size_t)(n0 + row) * g.ldb + k)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rep < 2 * NB)
+                rb[rep] = (n0 + row < g.N && k < g.K) ? *reinterpret_cast<const float4*>(g.B + (size_t)(n0 + row) * g.ldb + k)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto lstore = [&]() {
 #pragma unroll
         for (int rep = 0; rep < 4; ++rep) {
             split_store(la, (lr + 32 * rep) * XLD + lk, ra[rep]);
-            split_store(lb, (lr + 32 * rep) * XLD + lk, rb[rep]);
+            if (rep < 2 * NB) split_store(lb, (lr + 32 * rep) * XLD + lk, rb[rep], PLANE_B);
         }
     };
     auto mma_tile = [&]() {
 #pragma unroll
         for (int t = 0; t < XK / 16; ++t) {
             const int ko = 16 * t + 8 * kh;
-            uint4 a[2][3], b[2][3];
+            uint4 a[2][3], b[NB][3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 a[0][p] = *reinterpret_cast<const uint4*>(la + p * PLANE + (wm * 64 + i) * XLD + ko);
                 a[1][p] = *reinterpret_cast<const uint4*>(la + p * PLANE + (wm * 64 + 32 + i) * XLD + ko);
-                b[0][p] = *reinterpret_cast<const uint4*>(lb + p * PLANE + (wn * 64 + i) * XLD + ko);
-                b[1][p] = *reinterpret_cast<const uint4*>(lb + p * PLANE + (wn * 64 + 32 + i) * XLD + ko);
+#pragma unroll
+                for (int y = 0; y < NB; ++y)
+                    b[y][p] = *reinterpret_cast<const uint4*>(lb + p * PLANE_B + (wn * 32 * NB + 32 * y + i) * XLD + ko);
             }
-            // smallest products first; the four accumulators are independent chains
-#define PECLR_X6(P, Q)                                    \
-    acc[0][0] = mma(a[0][P], b[0][Q], acc[0][0]);         \
-    acc[0][1] = mma(a[0][P], b[1][Q], acc[0][1]);         \
-    acc[1][0] = mma(a[1][P], b[0][Q], acc[1][0]);         \
-    acc[1][1] = mma(a[1][P], b[1][Q], acc[1][1]);
+            // smallest products first; the accumulators are independent chains
+#define PECLR_X6(P, Q)                                                        \
+    _Pragma("unroll") for (int y = 0; y < NB; ++y) {                          \
+        acc[0][y] = mma(a[0][P], b[y][Q], acc[0][y]);                         \
+        acc[1][y] = mma(a[1][P], b[y][Q], acc[1][y]);                         \
+    }
             PECLR_X6(2, 0) PECLR_X6(0, 2) PECLR_X6(1, 1) PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)
 #undef PECLR_X6
         }
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt128_kernel(X6Args g) {
     const int er = lane >> 3, ec = (lane & 7) * 4;
     const bool vec_ok = (g.N % 4 == 0) && (g.ldo % 4 == 0) && (!g.addend || g.ldd % 4 == 0);
     auto addend_tile = [&](int a, int b, float4 (&dv)[4]) {
-        const int mt = m0 + wm * 64 + a * 32, nt = n0 + wn * 64 + b * 32;
+        const int mt = m0 + wm * 64 + a * 32, nt = n0 + wn * 32 * NB + b * 32;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int m = mt + er + 8 * jj, n = nt + ec;
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt128_kernel(X6Args g) {
         }
     };
     auto store_tile = [&](int a, int b, const f32x16& c16, const float4 (&dv)[4]) {
-        const int mt = m0 + wm * 64 + a * 32, nt = n0 + wn * 64 + b * 32;
+        const int mt = m0 + wm * 64 + a * 32, nt = n0 + wn * 32 * NB + b * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = c16[r];
         // same wave wrote and reads: LDS operations of one wave complete in order
@@ -201,14 +209,21 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt128_kernel(X6Args g) {
         }
     };
     float4 d0[4], d1[4];
-    addend_tile(0, 0, d0);
-    addend_tile(0, 1, d1);
-    store_tile(0, 0, acc[0][0], d0);
-    addend_tile(1, 0, d0);
-    store_tile(0, 1, acc[0][1], d1);
-    addend_tile(1, 1, d1);
-    store_tile(1, 0, acc[1][0], d0);
-    store_tile(1, 1, acc[1][1], d1);
+    if constexpr (NB == 2) {
+        addend_tile(0, 0, d0);
+        addend_tile(0, 1, d1);
+        store_tile(0, 0, acc[0][0], d0);
+        addend_tile(1, 0, d0);
+        store_tile(0, 1, acc[0][1], d1);
+        addend_tile(1, 1, d1);
+        store_tile(1, 0, acc[1][0], d0);
+        store_tile(1, 1, acc[1][1], d1);
+    } else {
+        addend_tile(0, 0, d0);
+        addend_tile(1, 0, d1);
+        store_tile(0, 0, acc[0][0], d0);
+        store_tile(1, 0, acc[1][0], d1);
+    }
 }
 
 
@@ -220,25 +235,28 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt128_kernel(X6Args g) {
 // ds_write_b64 into the same [column][k] planes the NT kernel uses -- the transpose happens in the choice of registers
 // to pack, and the store count is the NT kernel's.  Lanes run over 8 k-groups x 8 column chunks: a 16-lane store group
 // covers two column chunks x 8 k-groups = 32 distinct banks, and a load instruction reads 8 rows x 128 contiguous bytes.
-__global__ __launch_bounds__(256, 2) void gemm_x6_tn128_kernel(X6Args g, int kchunk) {
-    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 3 * PLANE];
+template <int NB>   // 2: 128 x 128 tile; 1: 128 x 64 (64 input channels: layer1's conv3)
+__global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void gemm_x6_tn128_kernel(X6Args g, int kchunk) {
+    constexpr int TNW = 64 * NB;
+    constexpr int PLANE_B = TNW * XLD;
+    __shared__ __attribute__((aligned(16))) bf16_t lds[3 * PLANE + 3 * PLANE_B];
     bf16_t* la = lds;
     bf16_t* lb = lds + 3 * PLANE;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, kh = lane >> 5;
-    const int nct = (g.N + XN - 1) / XN;
-    const int m0 = (int)(blockIdx.x / nct) * XM, n0 = (int)(blockIdx.x % nct) * XN;
+    const int nct = (g.N + TNW - 1) / TNW;
+    const int m0 = (int)(blockIdx.x / nct) * XM, n0 = (int)(blockIdx.x % nct) * TNW;
     const int kbeg = blockIdx.y * kchunk, kend = min(g.K, kbeg + kchunk);
     const int nk = (kend - kbeg + XK - 1) / XK;
     float* out = g.out + (size_t)blockIdx.y * g.M * g.N;     // this split's slab, ld = N
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -250,41 +268,43 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_tn128_kernel(X6Args g, int kch
             const int k = k0 + 4 * kg + q;
             ra[q] = (k < kend && m0 + 4 * chunk < g.M) ? *reinterpret_cast<const float4*>(g.A + (size_t)k * g.lda + m0 + 4 * chunk)
                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[q] = (k < kend && n0 + 4 * chunk < g.N) ? *reinterpret_cast<const float4*>(g.B + (size_t)k * g.ldb + n0 + 4 * chunk)
-                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[q] = (k < kend && 4 * chunk < TNW && n0 + 4 * chunk < g.N)
+                        ? *reinterpret_cast<const float4*>(g.B + (size_t)k * g.ldb + n0 + 4 * chunk)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto tstore = [&](bf16_t* planes, const float4 (&v)[4]) {
+    auto tstore = [&](bf16_t* planes, const float4 (&v)[4], int plane) {
         const float c[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x}, {v[0].y, v[1].y, v[2].y, v[3].y},
                                {v[0].z, v[1].z, v[2].z, v[3].z}, {v[0].w, v[1].w, v[2].w, v[3].w}};   // [column][k]
 #pragma unroll
         for (int jc = 0; jc < 4; ++jc)
-            split_store(planes, (4 * chunk + jc) * XLD + 4 * kg, make_float4(c[jc][0], c[jc][1], c[jc][2], c[jc][3]));
+            split_store(planes, (4 * chunk + jc) * XLD + 4 * kg, make_float4(c[jc][0], c[jc][1], c[jc][2], c[jc][3]), plane);
     };
     auto mma_tile = [&]() {
 #pragma unroll
         for (int t = 0; t < XK / 16; ++t) {
             const int ko = 16 * t + 8 * kh;
-            uint4 a[2][3], b[2][3];
+            uint4 a[2][3], b[NB][3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 a[0][p] = *reinterpret_cast<const uint4*>(la + p * PLANE + (wm * 64 + i) * XLD + ko);
                 a[1][p] = *reinterpret_cast<const uint4*>(la + p * PLANE + (wm * 64 + 32 + i) * XLD + ko);
-                b[0][p] = *reinterpret_cast<const uint4*>(lb + p * PLANE + (wn * 64 + i) * XLD + ko);
-                b[1][p] = *reinterpret_cast<const uint4*>(lb + p * PLANE + (wn * 64 + 32 + i) * XLD + ko);
+#pragma unroll
+                for (int y = 0; y < NB; ++y)
+                    b[y][p] = *reinterpret_cast<const uint4*>(lb + p * PLANE_B + (wn * 32 * NB + 32 * y + i) * XLD + ko);
             }
-#define PECLR_X6(P, Q)                                    \
-    acc[0][0] = mma(a[0][P], b[0][Q], acc[0][0]);         \
-    acc[0][1] = mma(a[0][P], b[1][Q], acc[0][1]);         \
-    acc[1][0] = mma(a[1][P], b[0][Q], acc[1][0]);         \
-    acc[1][1] = mma(a[1][P], b[1][Q], acc[1][1]);
+#define PECLR_X6(P, Q)                                                        \
+    _Pragma("unroll") for (int y = 0; y < NB; ++y) {                          \
+        acc[0][y] = mma(a[0][P], b[y][Q], acc[0][y]);                         \
+        acc[1][y] = mma(a[1][P], b[y][Q], acc[1][y]);                         \
+    }
             PECLR_X6(2, 0) PECLR_X6(0, 2) PECLR_X6(1, 1) PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)
 #undef PECLR_X6
         }
     };
     gload(kbeg);
-    tstore(la, ra);
-    tstore(lb, rb);
+    tstore(la, ra, PLANE);
+    if (4 * chunk < TNW) tstore(lb, rb, PLANE_B);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
@@ -292,8 +312,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_tn128_kernel(X6Args g, int kch
         mma_tile();
         __syncthreads();
         if (more) {
-            tstore(la, ra);
-            tstore(lb, rb);
+            tstore(la, ra, PLANE);
+            if (4 * chunk < TNW) tstore(lb, rb, PLANE_B);
             __syncthreads();
         }
     }
@@ -303,8 +323,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_tn128_kernel(X6Args g, int kch
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int mt = m0 + wm * 64 + a * 32, nt = n0 + wn * 64 + b * 32;
+        for (int b = 0; b < NB; ++b) {
+            const int mt = m0 + wm * 64 + a * 32, nt = n0 + wn * 32 * NB + b * 32;
 #pragma unroll
             for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = acc[a][b][r];
 #pragma unroll
@@ -331,8 +351,12 @@ extern "C" int peclr_gemm_x6_f32(int M, int N, int K, const float* A, int lda, c
     g.A = A; g.B = B; g.addend = addend; g.out = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldo = ldc; g.ldd = ldd;
     g.stream_out = (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
-    const int nrb = (M + XM - 1) / XM, nct = (N + XN - 1) / XN;
-    hipLaunchKernelGGL(gemm_x6_nt128_kernel, dim3(8 * ((nrb + 7) / 8) * nct), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    const int nrb = (M + XM - 1) / XM;
+    if (N <= 64)       // a 64-wide output: the 128 x 64 tile (no half-empty MFMAs)
+        hipLaunchKernelGGL(gemm_x6_nt128_kernel<1>, dim3(8 * ((nrb + 7) / 8)), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    else
+        hipLaunchKernelGGL(gemm_x6_nt128_kernel<2>, dim3(8 * ((nrb + 7) / 8) * ((N + XN - 1) / XN)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), g);
     return launch_status();
 }
 
@@ -340,7 +364,8 @@ extern "C" int peclr_gemm_x6_f32(int M, int N, int K, const float* A, int lda, c
 // per CU), at least 8 K-tiles per workgroup.
 extern "C" int peclr_gemm_x6_tn_slabs(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const long tiles = (long)((M + XM - 1) / XM) * ((N + XN - 1) / XN);
+    const int tnw = N <= 64 ? 64 : XN;
+    const long tiles = (long)((M + XM - 1) / XM) * ((N + tnw - 1) / tnw);
     long s = (512 + tiles - 1) / tiles;
     const long max_s = (K + 8 * XK - 1) / (8 * XK);
     if (s > max_s) s = max_s;
@@ -360,7 +385,10 @@ extern "C" int peclr_gemm_x6_tn_f32(int M, int N, int K, const float* A, int lda
     g.A = A; g.B = B; g.addend = nullptr; g.out = slabs;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldo = N; g.ldd = 0; g.stream_out = 0;
     const int kchunk = ((K + n_slabs - 1) / n_slabs + XK - 1) / XK * XK;
-    const int tiles = ((M + XM - 1) / XM) * ((N + XN - 1) / XN);
-    hipLaunchKernelGGL(gemm_x6_tn128_kernel, dim3(tiles, n_slabs), dim3(256), 0, static_cast<hipStream_t>(stream), g, kchunk);
+    if (N <= 64)
+        hipLaunchKernelGGL(gemm_x6_tn128_kernel<1>, dim3((M + XM - 1) / XM, n_slabs), dim3(256), 0, static_cast<hipStream_t>(stream), g, kchunk);
+    else
+        hipLaunchKernelGGL(gemm_x6_tn128_kernel<2>, dim3(((M + XM - 1) / XM) * ((N + XN - 1) / XN), n_slabs), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), g, kchunk);
     return launch_status();
 }

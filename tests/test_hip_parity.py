@@ -1706,7 +1706,8 @@ def test_gemm_add_half_128_tile_kernel_matches_float64(capi, half, m, n, k, with
 
 
 @pytest.mark.parametrize("m,n,k,with_addend", [(128 * 70 + 37, 1000, 72, True), (65536 + 8, 256, 64, True), (20000, 512, 136, False),
-                                               (12544, 2048, 512, True), (50176, 256, 1024, False), (300, 132, 64, True)])
+                                               (12544, 2048, 512, True), (50176, 256, 1024, False), (300, 132, 64, True),
+                                               (128 * 40 + 5, 64, 264, True), (200704, 64, 256, False)])
 def test_gemm_x6_is_an_fp32_gemm(capi, m, n, k, with_addend):
     """peclr_gemm_x6_f32: fp32 operands split exactly into three bf16 numbers, six of the nine partial products on the
     bf16 MFMA, fp32 accumulation.  Held to the SAME bar as the v_mfma_f32 kernel against float64 on the same fp32
@@ -1739,7 +1740,8 @@ def test_gemm_x6_is_an_fp32_gemm(capi, m, n, k, with_addend):
     assert float((gi.double() - exact).abs().max()) <= 2.0 ** -22 * float(exact.abs().max())
 
 
-@pytest.mark.parametrize("cin,cout,hw,n", [(1024, 256, 14, 256), (256, 1024, 14, 256), (512, 128, 28, 64), (64, 256, 8, 4)])
+@pytest.mark.parametrize("cin,cout,hw,n", [(1024, 256, 14, 256), (256, 1024, 14, 256), (512, 128, 28, 64), (64, 256, 8, 4),
+                                           (256, 64, 56, 48), (64, 256, 56, 48)])
 def test_conv1x1_as_gemm_on_the_matrix_cores_matches_float64(cin, cout, hw, n):
     """bn2d.Conv2d(hip_gemm=True): fp32 1x1 / stride-1 convolutions of NHWC tensors as peclr_gemm_x6_f32 where that
     beats MIOpen (forward and / or input gradient, `_x6_pays`), MIOpen otherwise (last shape).  Output, input gradient

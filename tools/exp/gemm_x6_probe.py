@@ -12,7 +12,7 @@ from peclr_amd import _capi  # noqa: E402
 # conv1 forward / conv3 dgrad (K = 4 Cmid, N = Cmid)
 SHAPES = [(256 * 56 * 56, 256, 64, True), (256 * 28 * 28, 512, 128, True), (256 * 14 * 14, 1024, 256, True),
           (256 * 7 * 7, 2048, 512, True), (256 * 56 * 56, 256, 64, False), (256 * 14 * 14, 1024, 256, False),
-          (256 * 56 * 56, 128, 256, False), (256 * 14 * 14, 256, 1024, False), (256 * 7 * 7, 512, 2048, False)]
+          (256 * 56 * 56, 64, 256, False), (256 * 14 * 14, 256, 1024, False), (256 * 7 * 7, 512, 2048, False)]
 
 
 def timeit(fn):
