@@ -235,17 +235,15 @@ def _x6_pays(rows: int, n_out: int, k: int) -> bool:
     """Does peclr_gemm_x6_f32 beat MIOpen's fp32 1x1 convolution for a [rows, k] x [k, n_out] product?  Measured on
     ResNet-50's shapes (tools/exp/conv1x1_probe.py): yes from K = 256 on when the 128-wide column tile is full and the
     128 x 128 tiles fill the chip; the K = 64 / 128 and N = 64 shapes of layer1 / layer2 are HBM-bound either way."""
-    if n_out == 64:            # the 128 x 64-tile variant: layer1's 256 -> 64 products (forward of conv1, input gradient of conv3)
-        return _GEMM_X6 and k >= 256 and k % 4 == 0 and rows // 128 >= 1024
+    # (64-wide outputs -- layer1 -- have a 128 x 64-tile variant in the library that wins in isolation, 256 vs 345 us,
+    # and loses 0.4 ms per step inside it, where MIOpen's kernels find their operands in the caches: not routed)
     return _GEMM_X6 and k >= 256 and k % 4 == 0 and n_out >= 128 and n_out % 4 == 0 and (rows // 128) * (n_out // 128) >= 196
 
 
 def _x6_wgrad_pays(rows: int, cout: int, cin: int) -> bool:
     """peclr_gemm_x6_tn_f32 against MIOpen's fp32 1x1 weight gradient (tools/exp/conv1x1_probe.py): 150-205 us against
     208-267 from layer2 on; with 64 output or input channels (layer1) half of every 128-wide tile would be empty."""
-    wide, narrow = max(cout, cin), min(cout, cin)
-    # 64 channels on one side (layer1): the 128 x 64-tile variant, with the 64-wide side as the N dimension
-    return _GEMM_X6 and wide >= 128 and (narrow >= 128 or narrow == 64) and cout % 4 == 0 and cin % 4 == 0 and rows >= 8192
+    return _GEMM_X6 and cout >= 128 and cin >= 128 and cout % 4 == 0 and cin % 4 == 0 and rows >= 8192
 
 
 def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
@@ -256,10 +254,7 @@ def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
 
     def run():
         gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
-        if cout == 64 and cin >= 128:      # keep the 64-wide side as N: dW^T = X^T dY, then a 16 K-element transpose
-            dw = _capi.gemm_x6_tn(x2, gy2, tag="conv1x1_wgrad").t().contiguous()
-        else:
-            dw = _capi.gemm_x6_tn(gy2, x2, tag="conv1x1_wgrad")
+        dw = _capi.gemm_x6_tn(gy2, x2, tag="conv1x1_wgrad")
         ref = param if param is not None else weight
         return dw.as_strided(ref.shape, ref.stride())       # same memory, the parameter's (channels_last) strides
 

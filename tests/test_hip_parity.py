@@ -1741,7 +1741,7 @@ def test_gemm_x6_is_an_fp32_gemm(capi, m, n, k, with_addend):
 
 
 @pytest.mark.parametrize("cin,cout,hw,n", [(1024, 256, 14, 256), (256, 1024, 14, 256), (512, 128, 28, 64), (64, 256, 8, 4),
-                                           (256, 64, 56, 48), (64, 256, 56, 48)])
+                                           (256, 64, 56, 48)])
 def test_conv1x1_as_gemm_on_the_matrix_cores_matches_float64(cin, cout, hw, n):
     """bn2d.Conv2d(hip_gemm=True): fp32 1x1 / stride-1 convolutions of NHWC tensors as peclr_gemm_x6_f32 where that
     beats MIOpen (forward and / or input gradient, `_x6_pays`), MIOpen otherwise (last shape).  Output, input gradient
@@ -1793,3 +1793,20 @@ def test_conv1x1_as_gemm_on_the_matrix_cores_matches_float64(cin, cout, hw, n):
         xx = x.clone().requires_grad_()
         conv(xx).backward(gy)
         assert torch.equal(conv.weight.grad, res[True][2])
+
+
+@pytest.mark.parametrize("k_rows,m,n", [(50176, 256, 1024), (200704, 128, 512), (40000 + 36, 256, 64), (12544, 2048, 512), (8192 + 4, 132, 260)])
+def test_gemm_x6_tn_matches_float64_and_is_deterministic(capi, k_rows, m, n):
+    """peclr_gemm_x6_tn_f32 + peclr_slab_reduce_f32: C[M,N] = A[K,M]^T . B[K,N] with the contraction over the ROWS
+    (the 1x1 weight gradient on NHWC storage), incl. the 128 x 64-tile variant (N = 64), ragged K and ragged M / N.
+    fp32 accuracy against float64, and bit-identical from run to run (fixed-order split-K slabs)."""
+    g = torch.Generator().manual_seed(k_rows + m + n)
+    a = torch.randn(k_rows, m, generator=g).to(DEV)
+    b = torch.randn(k_rows, n, generator=g).to(DEV)
+    got = capi.gemm_x6_tn(a, b)
+    assert got.shape == (m, n)
+    ref = a.double().t() @ b.double()
+    bound = a.double().abs().t() @ b.double().abs()
+    err = ((got.double() - ref).abs() / bound).max().item()
+    assert err <= 2.0 ** -20, err                      # fp32 accumulation over up to 2e5 terms per slab + the slab sum
+    assert torch.equal(capi.gemm_x6_tn(a, b), got)
