@@ -9,6 +9,8 @@
 // Six MFMAs of 32 cycles replace eight of 64 per 32x32x16 block: 2.67x the fp32 MFMA rate at fp32 accuracy (measured
 // against float64 in tests/test_hip_parity.py next to the v_mfma_f32 kernel).  Used for the GEMM-shaped fp32 work of
 // the backbone: the bottleneck entry's fused input gradient (dX = dY W + dRes) and the 1x1 convolutions.
+// Corner cases: an infinite operand gives NaN (inf - inf in the split) where an fp32 FMA chain would give +-inf -- both
+// mean the run has diverged; parts below the bf16 denormal range (|x| < 2^-133) are flushed.
 //
 // Kernel: 128 x 128 tile, 4 waves x (2 x 2) MFMA tiles, K-tile = 32 fp32.  Both operands are K-contiguous ("NT"): a
 // thread loads 16-byte words of 4 consecutive k, splits them in registers (and / sub / perm: 5.5 VALU ops per element,
