@@ -624,3 +624,32 @@ def test_device_loss_scaler_is_hip_only_and_cpu_runs_keep_torch_grad_scaler():
     opt = LARSAdam([torch.nn.Parameter(torch.ones(3))], lr=1e-3, fused=False)
     with pytest.raises(_capi.PeclrHipError, match="fused HIP optimiser"):
         opt.attach_scaler(object())
+
+
+def test_x6_routing_rules_and_cpu_fallback():
+    """Which fp32 1x1 products go to peclr_gemm_x6_f32 / _tn_f32 (measured thresholds, bn2d._x6_pays /
+    _x6_wgrad_pays), and that a bn2d.Conv2d with hip_gemm set is the stock convolution on tensors the HIP path does
+    not take (CPU, NCHW, strided, 3x3)."""
+    from peclr_amd import bn2d as B
+
+    r56, r28, r14, r7 = 256 * 56 * 56, 256 * 28 * 28, 256 * 14 * 14, 256 * 7 * 7
+    # forward y[R, Cout] = x[R, Cin] W^T: (rows, n_out = Cout, k = Cin)
+    assert B._x6_pays(r28, 128, 512) and B._x6_pays(r14, 256, 1024) and B._x6_pays(r14, 1024, 256) and B._x6_pays(r7, 2048, 512)
+    assert not B._x6_pays(r56, 64, 256) and not B._x6_pays(r56, 256, 64) and not B._x6_pays(r28, 512, 128)   # layer1; K = 128
+    assert not B._x6_pays(16 * 14 * 14, 1024, 256)                                                        # too few tiles
+    assert B._x6_wgrad_pays(r28, 128, 512) and B._x6_wgrad_pays(r7, 512, 2048)
+    assert not B._x6_wgrad_pays(r56, 64, 256) and not B._x6_wgrad_pays(r56, 256, 64) and not B._x6_wgrad_pays(4096, 256, 1024)
+    torch.manual_seed(0)
+    conv = B.Conv2d(256, 512, 1, bias=False)
+    ref = torch.nn.Conv2d(256, 512, 1, bias=False)
+    ref.load_state_dict(conv.state_dict())
+    conv.hip_gemm = True
+    x = torch.randn(2, 256, 5, 5)
+    for inp in (x, x.contiguous(memory_format=torch.channels_last)):
+        a, b = inp.clone().requires_grad_(), inp.clone().requires_grad_()
+        ya, yb = conv(a), ref(b)
+        assert torch.equal(ya, yb)
+        ya.sum().backward()
+        yb.sum().backward()
+        assert torch.equal(a.grad, b.grad) and torch.equal(conv.weight.grad, ref.weight.grad)
+        conv.weight.grad = ref.weight.grad = None
