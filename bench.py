@@ -14,7 +14,7 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
                  / its average launch duration measured with HIP events on the launch stream
                  inside the timed region (one C-ABI entry point = one launch);
   "kernels"      the same figures for every hand-written kernel of the step;
-  "backbone"     the end-to-end MFMA figure of the PyTorch-ROCm/MIOpen encoder (not ours);
+  "backbone"     the end-to-end MFMA figure of the encoder (MIOpen's 3x3 / 7x7 convolutions + the hand-written 1x1 GEMMs);
   "cpu_baseline" the same step on the host cores: torch-CPU ResNet + the NumPy oracle head
                  (oracle/peclr_oracle.py) + the foreach LARS/Adam, on a bounded sample.
 """
@@ -611,7 +611,9 @@ def main():
             "loss": round(loss, 6),
             "roofline": roof,
             "kernels": kernels,
-            "backbone": {"note": "PyTorch-ROCm/MIOpen encoder (not hand-written); 3x forward conv FLOPs",
+            "backbone": {"note": "whole encoder, 3x forward conv FLOPs over the step time, against the v_mfma_f32 / bf16 MFMA peak: "
+                                 "3x3 / 7x7 / layer1 convolutions on PyTorch-ROCm/MIOpen, the other fp32 1x1 convolutions "
+                                 "hand-written (config.fp32_gemm)",
                          "flops_per_step_per_gpu": step_flops, "achieved": round(ach_tf, 2), "peak": peak_tf,
                          "unit": "TFLOP/s", "frac": round(ach_tf / peak_tf, 4)},
             "hand_written_us_per_step": round(sum(k["avg_us"] * k["launches"] / table_steps
