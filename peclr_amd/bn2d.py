@@ -69,6 +69,7 @@ def checkpoint_block(run, x: Tensor) -> Tensor:
 
 
 _GEMM_X6 = os.environ.get("PECLR_GEMM_X6", "1") != "0"    # A/B switch: fp32 GEMMs as six bf16 MFMA products
+_X6_MIN_K = int(os.environ.get("PECLR_GEMM_X6_MIN_K", "128"))   # in-step A/B: 128 beats 256 by 0.1-0.4 ms, 64 is HBM-bound
 
 
 class _BN2dAct(torch.autograd.Function):
@@ -233,11 +234,11 @@ class _Conv2dSplitBackward(torch.autograd.Function):
 
 def _x6_pays(rows: int, n_out: int, k: int) -> bool:
     """Does peclr_gemm_x6_f32 beat MIOpen's fp32 1x1 convolution for a [rows, k] x [k, n_out] product?  Measured on
-    ResNet-50's shapes (tools/exp/conv1x1_probe.py): yes from K = 256 on when the 128-wide column tile is full and the
-    128 x 128 tiles fill the chip; the K = 64 / 128 and N = 64 shapes of layer1 / layer2 are HBM-bound either way."""
+    ResNet-50's shapes (tools/exp/conv1x1_probe.py, and in the step): from K = 128 on when the 128-wide column tile is
+    full and the 128 x 128 tiles fill the chip; the K = 64 and N = 64 shapes of layer1 are HBM-bound either way."""
     # (64-wide outputs -- layer1 -- have a 128 x 64-tile variant in the library that wins in isolation, 256 vs 345 us,
     # and loses 0.4 ms per step inside it, where MIOpen's kernels find their operands in the caches: not routed)
-    return _GEMM_X6 and k >= 256 and k % 4 == 0 and n_out >= 128 and n_out % 4 == 0 and (rows // 128) * (n_out // 128) >= 196
+    return _GEMM_X6 and k >= _X6_MIN_K and k % 4 == 0 and n_out >= 128 and n_out % 4 == 0 and (rows // 128) * (n_out // 128) >= 196
 
 
 def _x6_wgrad_pays(rows: int, cout: int, cin: int) -> bool:
@@ -374,7 +375,7 @@ class _ForkConv1x1(torch.autograd.Function):
                 wt = torch.empty((cin, cmid), device=x.device, dtype=x.dtype)
                 wt.copy_(weight.detach().reshape(cmid, cin).t())      # transpose + cast in ONE launch
                 out = _capi.gemm_add_half(a, wt, d, tag="conv1x1_dgrad_add")
-            elif _GEMM_X6 and cmid >= 256 and (r // 128) * (cin // 128) >= 512:
+            elif _GEMM_X6 and cmid >= _X6_MIN_K and (r // 128) * (cin // 128) >= 512:
                 # fp32 on the bf16 matrix cores (exact 3-way split, six products: fp32 accuracy at 2.67x the fp32 MFMA rate)
                 wt = weight.detach().reshape(cmid, cin).t().contiguous()
                 out = _capi.gemm_x6(a, wt, d, tag="conv1x1_dgrad_add")
