@@ -594,7 +594,7 @@ def main():
                                   "one hipGraph replay per step (whole step captured)" if use_graph else
                                   "eager launches" + (f" ({graph_note})" if graph_note else "")),
                        "graph_fallback": graph_note,   # None unless --graph auto had to fall back to eager launches
-                       # fp32 runs: the GEMM-shaped backbone work (1x1 convolutions forward / input gradient with K >= 256,
+                       # fp32 runs: the GEMM-shaped backbone work (1x1 convolutions forward / input gradient / weight gradient from K = 128 on,
                        # the fused entry gradient) runs on the bf16 matrix cores at fp32 ACCURACY: every fp32 operand is split
                        # exactly into three bf16 numbers and six of the nine partial products are accumulated in fp32
                        # (peclr_gemm_x6_f32; error vs float64 <= the v_mfma_f32 kernel's, tests/test_hip_parity.py)
