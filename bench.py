@@ -373,6 +373,25 @@ def try_graph_child():
     return None, f"graph child exited with {p.returncode}"
 
 
+def fp32_gemm_check(device):
+    """Untimed, before the timed region: the error of peclr_gemm_x6_f32 / _tn_f32 (fp32 operands as three bf16 numbers,
+    six MFMA products) and of the v_mfma_f32 kernel against float64 on the same fp32 data, relative to the output
+    scale -- the bench line carries the evidence that its fp32 GEMMs are fp32-accurate."""
+    from peclr_amd import _capi
+
+    g = torch.Generator(device=device).manual_seed(1234)
+    m, n, k = 8192, 512, 1024
+    a = torch.randn(m, k, device=device, generator=g)
+    bt = torch.randn(n, k, device=device, generator=g) * 0.05
+    ref = a.double() @ bt.double().t()
+    scale = float(ref.abs().max())
+    err = lambda t: float((t.double() - ref).abs().max()) / scale  # noqa: E731
+    at = a.t().contiguous()                                         # [K, M]: the TN kernel contracts over rows
+    return {"shape": [m, n, k], "x6_max_err_over_scale": err(_capi.gemm_x6(a, bt)),
+            "x6_tn_max_err_over_scale": err(_capi.gemm_x6_tn(at, bt.t().contiguous())),
+            "v_mfma_f32_max_err_over_scale": err(_capi.gemm(_capi.GEMM_NT, a, bt)), "reference": "float64 on the same fp32 inputs"}
+
+
 def amp_steps_taken(trainer):
     """fp16 only: optimiser steps actually TAKEN so far (the device-side loss scaler skips a step whose gradients
     overflowed); read outside the timed region."""
@@ -459,6 +478,8 @@ def main():
     with torch.cuda.stream(stream):
         if rank == 0 or world > 1:   # forward-only, untimed; every rank runs it (BatchNorm state stays in step)
             parity = parity_line(model, batch, trainer._autocast() if args.dtype != "fp32" else None)
+        x6_check = (fp32_gemm_check(device) if (rank == 0 and args.dtype == "fp32" and os.environ.get("PECLR_GEMM_X6", "1") != "0")
+                    else None)
         if split:
             # every rank must take the same path: agree on whether all captures succeeded
             ok = 1
@@ -609,6 +630,7 @@ def main():
                        "bn": "global-batch statistics (synchronised)" if (args.sync_bn and world > 1)
                        else "per-rank batch statistics"},
             "loss": round(loss, 6),
+            "fp32_gemm_check": x6_check,
             "roofline": roof,
             "kernels": kernels,
             "backbone": {"note": "whole encoder, 3x forward conv FLOPs over the step time, against the v_mfma_f32 / bf16 MFMA peak: "
