@@ -100,6 +100,21 @@ int peclr_gemm_x6_f32(int M, int N, int K, const float* A, int lda, const float*
 int peclr_gemm_x6_tn_slabs(int M, int N, int K);
 int peclr_gemm_x6_tn_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs,
                          int n_slabs, peclr_stream_t stream);
+/* Second generation of the same scheme for a WEIGHT operand (a parameter: constant for a whole step, used by forward,
+ * input gradient and fused entry gradient of a 1x1 convolution, resnet_model.py:15): peclr_x6_pack_f32 splits the
+ * weight ONCE into three bf16 planes in MFMA fragment order (per 128 output columns x 16 k one 12 KiB chunk of twelve
+ * 1 KiB pieces [32-column block][plane]); peclr_gemm_x6p_f32 streams those chunks into LDS by LDS-DMA and only splits the
+ * activation operand in the kernel (once per 128 output columns, by the one wave that owns the row).
+ *   desc_table: DEVICE array of `count` entries of 8 int64 {src fp32 matrix, dst planes, n, k, ld (floats), transposed,
+ *   first chunk, 0}; B_t[n][k] = src[n * ld + k] (transposed = 0: forward, W[Cout][Cin]) or src[k * ld + n]
+ *   (transposed = 1: input gradients, B_t = W^T); n % 128 == 0, k % 16 == 0; chunks per matrix = (n / 128) * (k / 16);
+ *   dst holds peclr_x6_pack_bytes(n, k) = 6 n k bytes.  One launch packs every matrix of the table.
+ *   peclr_gemm_x6p_f32: C[M,N] = A[M,K] . B_t^T (+ addend); tile_rows 256, 128 or 0 (= peclr_gemm_x6p_tile_rows). */
+int64_t peclr_x6_pack_bytes(int N, int K);
+int peclr_x6_pack_f32(const void* desc_table, int count, int total_chunks, peclr_stream_t stream);
+int peclr_gemm_x6p_tile_rows(int M, int N, int K);
+int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
+                       const float* addend, int ldd, int tile_rows, peclr_stream_t stream);
 int peclr_gemm_pick_split_k(int M, int N, int K);
 
 /* out[i] = sum_s slabs[s][i] (+ bias[i % cols] if non-null), i < rows*cols. */

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 from typing import Optional
 
 import torch  # must be imported BEFORE the CDLL: the .so binds to torch's libamdhip64.so.7
@@ -68,6 +68,10 @@ SIGNATURES = {
     "peclr_gemm_x6_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
     "peclr_gemm_x6_tn_slabs": (c_int, [c_int, c_int, c_int]),
     "peclr_gemm_x6_tn_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
+    "peclr_x6_pack_bytes": (c_int64, [c_int, c_int]),
+    "peclr_x6_pack_f32": (c_int, [_P, c_int, c_int, _P]),
+    "peclr_gemm_x6p_tile_rows": (c_int, [c_int, c_int, c_int]),
+    "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
@@ -131,6 +135,7 @@ def _stream():
 # ---- optional per-kernel HIP-event timing (bench.py): one entry point = one launch, so an event
 # pair recorded on the launch stream around a call times exactly that kernel.
 EVENT_LOG = None  # None = off; dict name -> list[(start, end)] when bench.py turns it on
+WEIGHTS_EPOCH = 0    # bumped by every fused optimiser launch (it updates the parameters through raw pointers)
 LAUNCH_ORDER = None  # None = off; list of names in launch order (one entry per launch) while EVENT_LOG is on:
 #                      lets tools/pmc_mfma.py align a rocprofv3 dispatch table with the bench's kernel names
 
@@ -311,6 +316,8 @@ def lars_adam_step(ptrs, sizes, n_tensors, chunk_tensor, chunk_offset, tensor_ch
     device_hyper: optional device float[18] that overrides lr / wd / bias corrections (graph replay).
     amp: optional (state int32[4] device tensor = peclr_amp_state, growth_factor, backoff_factor, growth_interval):
     the gradients hold scale*g; inf/nan check + unscale + skip + scale update on the device (three launches)."""
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
     p = _ptr(ptrs, torch.int64, "ptrs")
     sz = _ptr(sizes, torch.int64, "sizes")
     ct = _ptr(chunk_tensor, torch.int32, "chunk_tensor")
@@ -380,6 +387,57 @@ def gemm_x6(a: torch.Tensor, b_t: torch.Tensor, addend: Optional[torch.Tensor] =
     with _timed(tag, 4 * (m * k + k * n + (2 if addend is not None else 1) * m * n), 2 * m * n * k):
         rc = lib().peclr_gemm_x6_f32(m, n, k, _ptr(a), k, _ptr(b_t), k, _ptr(out), n, _ptr(addend), n, _stream())
     _check(rc, "peclr_gemm_x6_f32")
+    return out
+
+
+class X6Planes:
+    """Weight matrices split once into fragment-ordered bf16 planes (peclr_x6_pack_f32) for peclr_gemm_x6p_f32.
+    `specs`: list of (fp32 2-D HIP tensor W, transposed) -- B_t = W ([N, K]) or W^T (W is [K, N]).  The device table is
+    built once (the tensors' storage must stay where it is: parameters do); `pack()` is ONE launch that re-splits every
+    matrix from its current values -- call it after the weights changed (once per optimiser step)."""
+
+    def __init__(self, specs):
+        if not specs:
+            raise PeclrHipError("X6Planes: nothing to pack")
+        dev = specs[0][0].device
+        rows, self.planes, self.shapes, chunk = [], [], [], 0
+        for w, transposed in specs:
+            _ptr(w, what="x6 weight")
+            if w.dim() != 2:
+                raise PeclrHipError("X6Planes: 2-D weight matrices expected")
+            n, k = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+            nbytes = lib().peclr_x6_pack_bytes(n, k)
+            if nbytes <= 0:
+                raise PeclrHipError(f"X6Planes: B_t[{n}, {k}] needs n % 128 == 0 and k % 16 == 0")
+            planes = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            rows.append([w.data_ptr(), planes.data_ptr(), n, k, w.stride(0), int(bool(transposed)), chunk, 0])
+            chunk += (n // 128) * (k // 16)
+            self.planes.append(planes)
+            self.shapes.append((n, k))
+        self._sources = [w for w, _ in specs]          # keep the storage alive
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.count, self.chunks = len(rows), chunk
+        self.nbytes = sum(p.numel() for p in self.planes) + 4 * sum(w.numel() for w in self._sources)
+
+    def pack(self):
+        with _timed("x6_pack", self.nbytes):
+            rc = lib().peclr_x6_pack_f32(self.table.data_ptr(), self.count, self.chunks, _stream())
+        _check(rc, "peclr_x6_pack_f32")
+        return self
+
+
+def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[torch.Tensor] = None, tag: str = "gemm_x6p",
+             tile_rows: int = 0) -> torch.Tensor:
+    """C (fp32) [M, n] = A[M, K] . B_t^T (+ addend) with B_t given as packed planes (X6Planes): fp32 accuracy on the
+    bf16 matrix cores, the weight operand split once per step (peclr_gemm_x6p_f32)."""
+    m, k = a.shape
+    if planes.dtype != torch.uint8 or planes.numel() != 6 * n * k or (addend is not None and tuple(addend.shape) != (m, n)):
+        raise PeclrHipError(f"gemm_x6p: A {tuple(a.shape)}, planes of {planes.numel()} bytes for B_t[{n}, {k}]")
+    out = torch.empty((m, n), device=a.device, dtype=torch.float32)
+    with _timed(tag, 4 * (m * k + (2 if addend is not None else 1) * m * n) + 6 * k * n, 2 * m * n * k):
+        rc = lib().peclr_gemm_x6p_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
+                                      tile_rows, _stream())
+    _check(rc, "peclr_gemm_x6p_f32")
     return out
 
 

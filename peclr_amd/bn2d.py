@@ -72,6 +72,68 @@ _GEMM_X6 = os.environ.get("PECLR_GEMM_X6", "1") != "0"    # A/B switch: fp32 GEM
 _X6_MIN_K = int(os.environ.get("PECLR_GEMM_X6_MIN_K", "128"))   # in-step A/B: 128 beats 256 by 0.1-0.4 ms, 64 is HBM-bound
 
 
+_GEMM_X6P = os.environ.get("PECLR_GEMM_X6P", "1") != "0"  # A/B switch: weight planes packed once per step (peclr_gemm_x6p_f32)
+
+
+class X6PackGroup:
+    """The 1x1-convolution weights of one encoder that run as peclr_gemm_x6p_f32 GEMMs, split into fragment-ordered
+    bf16 planes by ONE launch per optimiser step (peclr_x6_pack_f32): W[Cout][Cin] for the forward GEMM, W^T for the
+    input-gradient GEMMs.  A member convolution asks `planes(conv)` right before it launches; the group re-packs
+    everything when that convolution's weight changed since the last pack (in-place update: `_version`; fused optimiser
+    step, which writes through raw pointers: `_capi.WEIGHTS_EPOCH`; new storage: `data_ptr`).  While a hipGraph is
+    being captured the first member always packs, so that every replay re-splits the weights it is about to use."""
+
+    def __init__(self, convs):
+        self.convs = [c for c in convs if self.member(c)]
+        self._x6 = None
+        self._ptrs = None
+        self._stamp = {}
+        self._at = {id(c): 2 * i for i, c in enumerate(self.convs)}
+        for c in self.convs:
+            c.x6_group = self
+
+    @staticmethod
+    def member(conv) -> bool:
+        cout, cin = conv.out_channels, conv.in_channels
+        return (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+                and conv.bias is None and cout >= 128 and cin >= 128 and cout % 128 == 0 and cin % 128 == 0)
+
+    def _key(self, conv):
+        return (conv.weight.data_ptr(), conv.weight._version, _capi.WEIGHTS_EPOCH)
+
+    def pack(self):
+        ptrs = [c.weight.data_ptr() for c in self.convs]
+        if self._x6 is None or ptrs != self._ptrs:
+            specs = []
+            for c in self.convs:
+                w2 = c.weight.detach().reshape(c.out_channels, c.in_channels)
+                specs += [(w2, False), (w2, True)]
+            self._x6 = _capi.X6Planes(specs)
+            self._ptrs = ptrs
+        self._x6.pack()
+        for c in self.convs:
+            self._stamp[id(c)] = self._key(c)
+
+    def planes(self, conv):
+        """(forward planes of W [Cout, Cin], input-gradient planes of W^T), fresh."""
+        stale = self._stamp.get(id(conv)) != self._key(conv)
+        if not stale and conv is self.convs[0] and torch.cuda.is_current_stream_capturing():
+            stale = True
+        if stale:
+            self.pack()
+        at = self._at[id(conv)]
+        return self._x6.planes[at], self._x6.planes[at + 1]
+
+
+def _x6_planes(conv):
+    """Packed planes of `conv`'s weight, or None when the convolution is not in a pack group (then the GEMMs split the
+    weight per workgroup: peclr_gemm_x6_f32)."""
+    group = getattr(conv, "x6_group", None) if conv is not None else None
+    if group is None or not _GEMM_X6P or not conv.weight.is_cuda or conv.weight.dtype != torch.float32:
+        return None
+    return group.planes(conv)
+
+
 class _BN2dAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool):
@@ -270,25 +332,32 @@ def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
 
 
 class _Conv1x1Gemm(torch.autograd.Function):
-    """1x1 / stride-1 convolution of an NHWC fp32 tensor as the GEMM it is, on the bf16 matrix cores at fp32 accuracy
-    (peclr_gemm_x6_f32): forward y[R, Cout] = x[R, Cin] . W^T and / or the input gradient dx[R, Cin] = dy[R, Cout] . W,
-    each where `_x6_pays`; the other direction and the weight gradient stay on MIOpen."""
+    """1x1 / stride-1 convolution of an NHWC fp32 tensor as the GEMM it is, on the bf16 matrix cores at fp32 accuracy:
+    forward y[R, Cout] = x[R, Cin] . W^T and / or the input gradient dx[R, Cin] = dy[R, Cout] . W, each where `_x6_pays`
+    (weight planes packed once per step when the convolution belongs to an X6PackGroup: peclr_gemm_x6p_f32; otherwise
+    both operands split per workgroup: peclr_gemm_x6_f32); the other direction and small weight gradients stay on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, param, use_fwd: bool, use_bwd: bool):
+    def forward(ctx, x, weight, conv, use_fwd: bool, use_bwd: bool):
         ctx.save_for_backward(x, weight)
-        ctx.cfg = (param, use_bwd)
+        planes = _x6_planes(conv) if (use_fwd or use_bwd) else None
+        ctx.cfg = (conv, use_bwd, planes)
         if not use_fwd:
             return F.conv2d(x, weight)
         n, cin, h, w = x.shape
         cout = weight.shape[0]
-        y = _capi.gemm_x6(x.permute(0, 2, 3, 1).reshape(n * h * w, cin), weight.detach().reshape(cout, cin), tag="conv1x1_fwd")
+        x2 = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
+        if planes is not None:
+            y = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd")
+        else:
+            y = _capi.gemm_x6(x2, weight.detach().reshape(cout, cin), tag="conv1x1_fwd")
         return y.view(n, h, w, cout).permute(0, 3, 1, 2)          # channels_last NCHW view of the NHWC result
 
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        param, use_bwd = ctx.cfg
+        conv, use_bwd, planes = ctx.cfg
+        param = conv.weight if conv is not None else None
         n, cin, h, w = x.shape
         cout = weight.shape[0]
         gy = gy.contiguous(memory_format=torch.channels_last)
@@ -299,8 +368,12 @@ class _Conv1x1Gemm(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if use_bwd:
-                wt = weight.detach().reshape(cout, cin).t().contiguous()              # [Cin][Cout]: K-contiguous B operand
-                dx = _capi.gemm_x6(gy.permute(0, 2, 3, 1).reshape(n * h * w, cout), wt, tag="conv1x1_dgrad")
+                gy2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout)
+                if planes is not None:
+                    dx = _capi.gemm_x6p(gy2, planes[1], cin, tag="conv1x1_dgrad")
+                else:
+                    wt = weight.detach().reshape(cout, cin).t().contiguous()          # [Cin][Cout]: K-contiguous B operand
+                    dx = _capi.gemm_x6(gy2, wt, tag="conv1x1_dgrad")
                 dx = dx.view(n, h, w, cin).permute(0, 3, 1, 2)
             else:
                 dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
@@ -324,7 +397,7 @@ class Conv2d(nn.Conv2d):
             use_wgrad = (_x6_wgrad_pays(rows, self.out_channels, self.in_channels) and torch.is_grad_enabled()
                          and self.weight.requires_grad)
             if use_fwd or use_bwd or use_wgrad:
-                return _Conv1x1Gemm.apply(x, self.weight, self.weight, use_fwd, use_bwd)
+                return _Conv1x1Gemm.apply(x, self.weight, self, use_fwd, use_bwd)
         if (_WgradOverlap.stream is not None and x.is_cuda and torch.is_grad_enabled() and self.bias is None
                 and self.groups == 1 and self.dilation == (1, 1) and isinstance(self.padding, tuple)
                 and x.is_contiguous(memory_format=torch.channels_last) and self.weight.requires_grad):
@@ -340,16 +413,25 @@ class _ForkConv1x1(torch.autograd.Function):
     """Bottleneck entry: (x, W) -> (conv1x1(x, W), x).  The block input feeds both the first convolution and
     the identity branch, so its gradient is dY W + d_identity: autograd runs MIOpen's dgrad and then an
     elementwise add over the block input (3.6 % of the fp32 step); here both are ONE fp32 GEMM with the
-    identity gradient added in the epilogue.  Forward and the weight gradient stay on MIOpen."""
+    identity gradient added in the epilogue.  Small shapes' forward and weight gradient stay on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, conv):
         ctx.save_for_backward(x, weight)
         ctx.param = weight if isinstance(weight, nn.Parameter) else None
         n, cin, h, w = x.shape
         cmid = weight.shape[0]
-        if x.dtype == torch.float32 and _x6_pays(n * h * w, cmid, cin):
-            y = _capi.gemm_x6(x.permute(0, 2, 3, 1).reshape(n * h * w, cin), weight.detach().reshape(cmid, cin), tag="conv1x1_fwd")
+        r = n * h * w
+        use_fwd = x.dtype == torch.float32 and _x6_pays(r, cmid, cin)
+        use_bwd = x.dtype == torch.float32 and _GEMM_X6 and cmid >= _X6_MIN_K and (r // 128) * (cin // 128) >= 512
+        ctx.planes = _x6_planes(conv) if (use_fwd or use_bwd) else None
+        ctx.use_bwd = use_bwd
+        if use_fwd:
+            x2 = x.permute(0, 2, 3, 1).reshape(r, cin)
+            if ctx.planes is not None:
+                y = _capi.gemm_x6p(x2, ctx.planes[0], cmid, tag="conv1x1_fwd")
+            else:
+                y = _capi.gemm_x6(x2, weight.detach().reshape(cmid, cin), tag="conv1x1_fwd")
             return y.view(n, h, w, cmid).permute(0, 3, 1, 2), x.view_as(x)
         return F.conv2d(x, weight), x.view_as(x)
 
@@ -375,14 +457,16 @@ class _ForkConv1x1(torch.autograd.Function):
                 wt = torch.empty((cin, cmid), device=x.device, dtype=x.dtype)
                 wt.copy_(weight.detach().reshape(cmid, cin).t())      # transpose + cast in ONE launch
                 out = _capi.gemm_add_half(a, wt, d, tag="conv1x1_dgrad_add")
-            elif _GEMM_X6 and cmid >= _X6_MIN_K and (r // 128) * (cin // 128) >= 512:
-                # fp32 on the bf16 matrix cores (exact 3-way split, six products: fp32 accuracy at 2.67x the fp32 MFMA rate)
+            elif ctx.use_bwd and ctx.planes is not None:
+                # fp32 on the bf16 matrix cores (exact 3-way split, six products), weight planes packed once per step
+                out = _capi.gemm_x6p(a, ctx.planes[1], cin, d, tag="conv1x1_dgrad_add_x6")
+            elif ctx.use_bwd:
                 wt = weight.detach().reshape(cmid, cin).t().contiguous()
-                out = _capi.gemm_x6(a, wt, d, tag="conv1x1_dgrad_add")
+                out = _capi.gemm_x6(a, wt, d, tag="conv1x1_dgrad_add_x6")
             else:
                 out = _capi.gemm_add(_capi.GEMM_NN, a, weight.reshape(cmid, cin), d, tag="conv1x1_dgrad_add")
             dx = out.view(n, h, w, cin).permute(0, 3, 1, 2)       # back to a channels_last NCHW tensor
-        return dx, dw
+        return dx, dw, None
 
 
 def fork_conv1x1(conv: nn.Conv2d, x: Tensor):
@@ -398,7 +482,7 @@ def fork_conv1x1(conv: nn.Conv2d, x: Tensor):
           and x.is_contiguous(memory_format=torch.channels_last)
           and conv.weight.shape[0] % 8 == 0 and conv.weight.shape[1] % 8 == 0)
     if ok:
-        return _ForkConv1x1.apply(x, conv.weight)
+        return _ForkConv1x1.apply(x, conv.weight, conv)
     return conv(x), x
 
 
@@ -461,4 +545,7 @@ def enable_hip_batchnorm(module: nn.Module, enabled: bool = True, sync_group=Non
             m.hip_fork = enabled
         if isinstance(m, Conv2d) and m.kernel_size == (1, 1) and m.stride == (1, 1):
             m.hip_gemm = enabled                # fp32 1x1 convolutions as GEMMs where that is faster (`_x6_pays`)
+            m.x6_group = None
+    if enabled:                                 # their weights are split into bf16 planes once per step, all in one launch
+        X6PackGroup([m for m in module.modules() if isinstance(m, Conv2d) and (m.hip_gemm or getattr(m, "hip_fork", False))])
     return n

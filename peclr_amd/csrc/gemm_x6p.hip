@@ -1,0 +1,339 @@
+// fp32 GEMM on the bf16 matrix cores, second generation: C[M,N] = A[M,K] . W[N,K]^T (+ addend), fp32 in / fp32 out,
+// with the WEIGHT operand split once per optimiser step instead of once per workgroup.
+//
+// Same arithmetic as gemm_x6.hip (x == h + m + l exactly, three bf16 numbers by truncation; six of the nine partial
+// products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, smallest first), different data path:
+//
+//   * W is a parameter: it changes once per step and is used by thousands of workgroups (forward, input gradient,
+//     the fused entry gradient).  peclr_x6_pack_f32 splits it ONCE into three bf16 planes stored in MFMA fragment
+//     order -- per (128 output columns, 16 k) one contiguous 12 KiB chunk of twelve 1 KiB pieces [32-column block]
+//     [plane], a piece being lane l's 16 bytes at l * 16: columns n0 + (l & 31), k0 + 8 * (l >> 5) ... + 7.
+//     The GEMM brings a chunk into LDS with twelve `global_load_lds_dwordx4` (LDS-DMA: no VGPRs, no VALU, no
+//     ds_write, lane-linear = fragment order, bank-conflict free) and reads B fragments with ds_read_b128.
+//   * The ACTIVATION operand still has to be split in the kernel (its producer is an HBM-bound BatchNorm pass that
+//     cannot afford 6 more bytes per element).  Each wave owns 32 * WM rows x all 128 columns of the workgroup tile
+//     (WM x 4 MFMA tiles, six products each), so a row is split ONCE per 128 output columns by exactly one wave and
+//     its planes never leave that wave: fp32 rows arrive by LDS-DMA in a wave-private raw buffer, the wave reads them
+//     back (same lane that the DMA wrote), splits in registers and writes three [k-half][row][8 k] planes into a
+//     wave-private LDS region -- no workgroup barrier for A at all, in-order LDS execution of one wave orders the
+//     fragment reads of k-step t before the plane writes of k-step t + 1 (single buffer).
+//   * One raw s_barrier per k-step (16 k, 24 * WM MFMAs per wave) publishes the double-buffered B chunk; DMA waits are
+//     counted (`s_waitcnt vmcnt(n)`), never drained in the loop.
+//   LDS: 24 KiB (B, two chunks) + 4 waves x (3 planes + raw buffer) = 64.8 KiB at WM = 2 -> two workgroups per CU.
+//
+// The store path that bounded gemm_x6_nt128_kernel (six plane stores per operand element pair through the
+// VGPR -> LDS port: 49 KiB per 1536 MFMA cycles) carries 24 KiB per 3072 MFMA cycles here.
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace peclr {
+namespace {
+
+typedef uint16_t bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int PN = 128;                  // output columns per workgroup (and per packed chunk)
+constexpr int PK = 16;                   // k per step = one MFMA k-extent
+constexpr int CHUNK = 12 * 1024;         // bytes of packed B per (128 columns, 16 k)
+
+struct X6PArgs {
+    const float* A;
+    const void* Bp;                      // packed planes of W (peclr_x6_pack_f32)
+    const float* addend;
+    float* out;
+    int M, N, K, lda, ldo, ldd;
+    int stream_out;
+};
+
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));
+}
+__device__ __forceinline__ unsigned pack_hi(unsigned lo_elem, unsigned hi_elem) {
+    return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302u);
+}
+__device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+// 16 bytes per lane, global -> LDS at (wave-uniform) dst + lane * 16.  Issued through inline assembly on purpose: for
+// the builtin, hipcc's wait-count pass makes EVERY later ds_read wait for the DMA (vmcnt(0) right behind the issue --
+// LDS accesses carry no alias information that would tell the B buffer being filled from the one being read), which
+// serialises the pipeline.  Here the compiler does not know the instruction touches the vm counter; every wait on
+// it is written by hand below (and no other VMEM instruction is in flight while DMAs are).
+__device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_offset) {   // offset: wave-uniform, in an SGPR
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(src), "s"(lds_byte_offset) : "memory", "m0");
+}
+#define PECLR_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// WM: 32-row MFMA tiles per wave (2 -> 256 x 128 workgroup tile, 1 -> 128 x 128 for problems with few row blocks)
+// AREG: the fp32 rows travel global -> registers (inline-asm loads, hand-counted) instead of global -> LDS (DMA) -> registers
+// ABL: ablation switches for tools/exp/x6p_ablate.hip (0 in the library): 1 no split / plane stores in the loop, 2 no raw-row
+// loads either, 4 no B DMA in the loop, 8 no MFMAs (bits combine)
+template <int WM, int ABL = 0, bool AREG = true, bool ILV = true>
+__global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
+    constexpr int RM = 32 * WM;                          // rows per wave
+    constexpr int TM = 4 * RM;                           // rows per workgroup
+    constexpr int NRAW = RM / 16;                        // 1 KiB pieces of fp32 rows per wave and k-step
+    constexpr int NB = 3;                                // B chunks in LDS (two k-steps of DMA run-ahead)
+    constexpr int HALF = RM * 16 + 64;                   // bytes of one k-half of a plane (+64: the two halves of a row
+                                                         // land on different banks for the 8-byte plane stores)
+    constexpr int PLANE = 2 * HALF;
+    constexpr int XEPL = 36;                             // floats per row of the epilogue's 32 x 32 transpose buffer
+    constexpr int WAVE_PL = 3 * PLANE;
+    constexpr int RAW0 = NB * CHUNK, PL0 = RAW0 + (AREG ? 0 : 4 * RM * 64);   // DMA targets first (LDS-DMA addresses < 64 KiB)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[PL0 + 4 * WAVE_PL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    typedef __attribute__((address_space(3))) unsigned char* lptr_t;
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(lptr_t)lds;        // LDS byte address of the array
+    unsigned char* const planes = lds + PL0 + wave * WAVE_PL;
+    unsigned char* const raw = lds + RAW0 + wave * (RM * 64);
+    const unsigned raw_a = __builtin_amdgcn_readfirstlane(lds0 + RAW0 + wave * (RM * 64));
+    const unsigned b_a = __builtin_amdgcn_readfirstlane(lds0 + (3 * wave) * 1024);
+
+    const int nct = g.N / PN;
+    const int j = blockIdx.x / 8;
+    const int row_block = 8 * (j / nct) + (int)(blockIdx.x % 8);      // all column tiles of a row block on one XCD
+    if (row_block * TM >= g.M) return;
+    const int m0 = row_block * TM + wave * RM, ct = j % nct, n0 = ct * PN;
+    const int nk = g.K / PK;
+    const unsigned char* bsrc = static_cast<const unsigned char*>(g.Bp) + (size_t)ct * nk * CHUNK + (3 * wave) * 1024 + lane * 16;
+
+    f32x16 acc[WM][4];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][y][r] = 0.f;
+
+    // this lane's fp32 source: rows (lane >> 2) + 16 c of the wave's block, k-quad lane & 3 (rows past M re-read row M - 1)
+    const float* asrc[NRAW];
+#pragma unroll
+    for (int c = 0; c < NRAW; ++c) {
+        int row = m0 + 16 * c + (lane >> 2);
+        row = row < g.M ? row : g.M - 1;
+        asrc[c] = g.A + (size_t)row * g.lda + 4 * (lane & 3);
+    }
+    auto issue_b = [&](int t) {                           // wave's three pieces of chunk t -> buffer t % NB
+        const unsigned char* s = bsrc + (size_t)t * CHUNK;
+        const unsigned d = b_a + (t % NB) * CHUNK;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dma16(s + q * 1024, d + q * 1024);
+    };
+    f32x4 ar[NRAW];                                       // AREG: the next k-step's rows, in flight / landed
+    auto issue_a = [&](int t) {
+#pragma unroll
+        for (int c = 0; c < NRAW; ++c) {
+            if constexpr (AREG) ar[c] = *reinterpret_cast<const f32x4*>(asrc[c] + t * PK);
+            else dma16(asrc[c] + t * PK, raw_a + c * 1024);
+        }
+    };
+    // rows of the k-step just landed -> three planes [k-half][row][8 k] (this lane: row 16 c + (lane >> 2),
+    // k = 4 (lane & 3) ... + 3, i.e. k-half (lane >> 1) & 1, 8-byte slot lane & 1)
+    const int poff = ((lane >> 1) & 1) * HALF + (lane >> 2) * 16 + (lane & 1) * 8;
+    auto split_store = [&]() {
+#pragma unroll
+        for (int c = 0; c < NRAW; ++c) {
+            f32x4 v;
+            if constexpr (AREG) v = ar[c];
+            else v = *reinterpret_cast<const f32x4*>(raw + c * 1024 + lane * 16);
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) split3(v[q], h[q], m[q], l[q]);
+            unsigned char* d = planes + poff + c * 256;
+            *reinterpret_cast<uint2*>(d) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
+            *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
+            *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
+        }
+    };
+
+    // Every VMEM operation of the loop is issued in the MIDDLE of a k-step -- B chunk t + 2 (DMA), then the rows of step
+    // t + 2 -- and waited for in the middle of the next one.  The memory counter retires in order, so "the rows have
+    // arrived" (the wait hipcc puts in front of their first use when they are register loads; vmcnt(0) by hand when
+    // they are DMAs too) implies "my pieces of the older B chunk have landed"; the barrier at the top of step t + 2
+    // publishes them.  Three B buffers: t being read, t + 1 landed, t + 2 landing.
+    issue_b(0);
+    issue_a(0);
+    if constexpr (!AREG) PECLR_VMCNT(0);
+    split_store();
+    if constexpr (!AREG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (nk > 1) { issue_b(1); issue_a(1); }
+
+    const int foff = kh * HALF + i * 16;                  // this lane's fragment inside a plane (+ 512 per 32-row tile)
+    // one k-step; SPLIT: the rows of step t + 1 are split and stored (t + 1 < nk), interleaved with the first half's MFMAs
+    auto kstep = [&](int t, auto split_next) {
+        constexpr bool SPLIT = decltype(split_next)::value;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        uint4 af[WM][3];
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const uint4*>(planes + p * PLANE + foff + a * 512);
+        const unsigned char* bt = lds + (t % NB) * CHUNK + lane * 16;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint4 bf[2][3];
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[y][p] = *reinterpret_cast<const uint4*>(bt + ((2 * half + y) * 3 + p) * 1024);
+#define PECLR_X6(P, Q)                                                                        \
+    _Pragma("unroll") for (int y = 0; y < 2; ++y) _Pragma("unroll") for (int a = 0; a < WM; ++a) \
+        if constexpr (ABL & 8) { asm volatile("" :: "v"(af[a][P].x), "v"(af[a][P].w), "v"(bf[y][Q].x), "v"(bf[y][Q].w)); } \
+        else acc[a][2 * half + y] = mma(af[a][P], bf[y][Q], acc[a][2 * half + y]);
+            PECLR_X6(2, 0) PECLR_X6(0, 2) PECLR_X6(1, 1) PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)
+#undef PECLR_X6
+            if (half == 0 && SPLIT) {
+                if constexpr (!AREG) PECLR_VMCNT(0);
+                if constexpr (!(ABL & 1)) split_store();  // after this step's fragment reads in program (= LDS) order
+                else if constexpr (AREG) { asm volatile("" :: "v"(ar[0]), "v"(ar[NRAW - 1])); }
+                if constexpr (AREG && !(ABL & 9) && ILV) {
+                    // one MFMA, then four of the split's VALU instructions (the two pipes run side by side), a plane store now and then
+#pragma unroll
+                    for (int q = 0; q < 12 * WM; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        if (q % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    }
+                }
+                if constexpr (!AREG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (t + 2 < nk) {
+                    if constexpr (!(ABL & 4)) issue_b(t + 2);
+                    if constexpr (!(ABL & 2)) issue_a(t + 2);
+                }
+            }
+        }
+    };
+    PECLR_VMCNT(0);                                       // (B chunk 0; for nk > 1 also what was just issued)
+    for (int t = 0; t + 1 < nk; ++t) kstep(t, std::true_type{});
+    kstep(nk - 1, std::false_type{});
+
+    // epilogue: wave-private 32 x 32 transposes through LDS (the B buffers, once every wave is done with them), 16 bytes per lane
+    __syncthreads();
+    float* wlds = reinterpret_cast<float*>(lds + wave * (32 * XEPL * 4));
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int mt = m0 + a * 32, nt = n0 + y * 32;
+            float4 dv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = mt + er + 8 * jj;
+                dv[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g.addend && m < g.M) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(g.addend + (size_t)m * g.ldd + nt + ec);
+                    const f32x4 tv = g.stream_out ? __builtin_nontemporal_load(src) : *src;
+                    dv[jj] = make_float4(tv[0], tv[1], tv[2], tv[3]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = acc[a][y][r];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = mt + er + 8 * jj;
+                float4 c = *reinterpret_cast<const float4*>(wlds + (er + 8 * jj) * XEPL + ec);
+                c.x += dv[jj].x; c.y += dv[jj].y; c.z += dv[jj].z; c.w += dv[jj].w;
+                if (m < g.M) {
+                    f32x4* dst = reinterpret_cast<f32x4*>(g.out + (size_t)m * g.ldo + nt + ec);
+                    const f32x4 tv = {c.x, c.y, c.z, c.w};
+                    if (g.stream_out) __builtin_nontemporal_store(tv, dst);
+                    else *dst = tv;
+                }
+            }
+        }
+}
+
+// ---- weight packing: W[N][K] fp32 (or its transpose) -> fragment-ordered bf16 planes.  One workgroup per
+// (128 columns, 16 k) chunk, thread = (column, k-half): 8 k-values -> 16 bytes in each of the chunk's planes.
+struct PackDesc {           // device table entry (8 x int64)
+    int64_t src, dst;       // fp32 matrix, packed output
+    int64_t n, k;           // logical B_t[n][k] extents (n multiple of 128, k multiple of 16)
+    int64_t ld;             // leading dimension of src (floats)
+    int64_t transposed;     // 0: B_t[n][k] = src[n * ld + k];  1: B_t[n][k] = src[k * ld + n]
+    int64_t chunk_begin;    // first chunk of this matrix in the launch
+    int64_t pad;
+};
+
+__global__ __launch_bounds__(256) void x6_pack_kernel(const PackDesc* descs, int count) {
+    int d = 0;
+    while (d + 1 < count && (int64_t)blockIdx.x >= descs[d + 1].chunk_begin) ++d;
+    const PackDesc e = descs[d];
+    const int chunk = (int)(blockIdx.x - e.chunk_begin);
+    const int nks = (int)(e.k / PK);
+    const int ct = chunk / nks, ks = chunk % nks;
+    const int col = threadIdx.x & 127, kh = threadIdx.x >> 7;
+    const int n = ct * PN + col, k0 = ks * PK + 8 * kh;
+    const float* src = reinterpret_cast<const float*>(e.src);
+    float v[8];
+    if (e.transposed) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = src[(size_t)(k0 + q) * e.ld + n];
+    } else {
+        const float4 lo = *reinterpret_cast<const float4*>(src + (size_t)n * e.ld + k0);
+        const float4 hi = *reinterpret_cast<const float4*>(src + (size_t)n * e.ld + k0 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    }
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) split3(v[q], h[q], m[q], l[q]);
+    unsigned char* dst = reinterpret_cast<unsigned char*>(e.dst) + (size_t)chunk * CHUNK + ((col >> 5) * 3) * 1024 +
+                         ((col & 31) + 32 * kh) * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]), pack_hi(h[4], h[5]), pack_hi(h[6], h[7]));
+    *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]), pack_hi(m[4], m[5]), pack_hi(m[6], m[7]));
+    *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]), pack_hi(l[4], l[5]), pack_hi(l[6], l[7]));
+}
+
+}  // namespace
+}  // namespace peclr
+
+using namespace peclr;
+
+extern "C" int64_t peclr_x6_pack_bytes(int N, int K) {
+    if (N <= 0 || K <= 0 || N % PN || K % PK) return 0;
+    return (int64_t)N * K * 6;
+}
+
+extern "C" int peclr_x6_pack_f32(const void* desc_table, int count, int total_chunks, peclr_stream_t stream) {
+    if (!desc_table) return PECLR_ERR_NULL;
+    if (count <= 0 || total_chunks <= 0) return PECLR_ERR_SHAPE;
+    hipLaunchKernelGGL(x6_pack_kernel, dim3(total_chunks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const PackDesc*>(desc_table), count);
+    return launch_status();
+}
+
+extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K) {
+    // 128-row tiles run three workgroups per CU (768 slots), 256-row tiles two (512 slots) at half the tiles and half the
+    // B traffic per flop; pick the one with fewer (rounds of slots) x (rows per tile) -- the workgroup rounds a launch
+    // quantises into are what separates the two on ResNet's shapes (tools/exp/gemm_x6p_probe.py) -- and 256 on a tie
+    if (M <= 0 || N <= 0 || N % PN) return 0;
+    const long t128 = (long)((M + 127) / 128) * (N / PN), t256 = (long)((M + 255) / 256) * (N / PN);
+    const long c128 = ((t128 + 767) / 768) * 128, c256 = ((t256 + 511) / 512) * 256;
+    return c128 < c256 ? 128 : 256;
+}
+
+extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
+                                  const float* addend, int ldd, int tile_rows, peclr_stream_t stream) {
+    if (!A || !Bp || !C) return PECLR_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0 || N % PN || K % PK) return PECLR_ERR_SHAPE;
+    if (lda % 4 || lda < K || ldc % 4 || ldc < N || (addend && (ldd % 4 || ldd < N))) return PECLR_ERR_SHAPE;
+    if (!aligned16(A) || !aligned16(Bp) || !aligned16(C) || (addend && !aligned16(addend))) return PECLR_ERR_ALIGN;
+    if (tile_rows == 0) tile_rows = peclr_gemm_x6p_tile_rows(M, N, K);
+    if (tile_rows != 128 && tile_rows != 256) return PECLR_ERR_UNSUPPORTED;
+    X6PArgs g;
+    g.A = A; g.Bp = Bp; g.addend = addend; g.out = C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldc; g.ldd = ldd;
+    g.stream_out = (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
+    const int nrb = (M + tile_rows - 1) / tile_rows;
+    const dim3 grid(8 * ((nrb + 7) / 8) * (N / PN));
+    if (tile_rows == 256) hipLaunchKernelGGL(gemm_x6p_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    else hipLaunchKernelGGL(gemm_x6p_kernel<1>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    return launch_status();
+}

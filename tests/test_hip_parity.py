@@ -1740,6 +1740,88 @@ def test_gemm_x6_is_an_fp32_gemm(capi, m, n, k, with_addend):
     assert float((gi.double() - exact).abs().max()) <= 2.0 ** -22 * float(exact.abs().max())
 
 
+@pytest.mark.parametrize("m,n,k,with_addend", [(128 * 70 + 37, 1024, 80, True), (65536 + 8, 256, 128, True), (20000, 512, 144, False),
+                                               (12544, 2048, 512, True), (50176, 256, 1024, False), (300, 128, 16, True),
+                                               (200704, 128, 512, False)])
+def test_gemm_x6p_equals_gemm_x6_bit_for_bit(capi, m, n, k, with_addend):
+    """peclr_gemm_x6p_f32 (weight split once into fragment-ordered planes by peclr_x6_pack_f32, streamed by LDS-DMA;
+    activation rows split by the one wave that owns them) performs the SAME arithmetic as peclr_gemm_x6_f32 -- same
+    exact split, same six products, same accumulation order -- so the two agree bit for bit, for both tile heights,
+    ragged M, with and without the addend, and for planes packed from the transposed storage of the weight (the
+    input-gradient arrangement).  Its accuracy is therefore the one test_gemm_x6_is_an_fp32_gemm establishes; the
+    float64 bar is re-checked here on the adversarial operands all the same."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    a *= torch.exp2(torch.randint(-6, 7, (m, 1), generator=g).float())
+    bt = torch.randn(n, k, generator=g) * 0.05
+    a, bt = a.to(DEV), bt.to(DEV)
+    d = torch.randn(m, n, generator=g).to(DEV) if with_addend else None
+    want = capi.gemm_x6(a, bt, d)
+    packed = capi.X6Planes([(bt, False), (bt.t().contiguous(), True)]).pack()
+    assert packed.planes[0].numel() == 6 * n * k and torch.equal(packed.planes[0], packed.planes[1])
+    for tile_rows in (0, 128, 256):
+        got = capi.gemm_x6p(a, packed.planes[0], n, d, tile_rows=tile_rows)
+        assert torch.equal(got, want), tile_rows
+    ref = a.double() @ bt.double().t() + (d.double() if with_addend else 0)
+    bound = (a.double().abs() @ bt.double().abs().t()) + (d.double().abs() if with_addend else 0)
+    assert ((got.double() - ref).abs() / bound).max().item() <= 2.0 ** -21
+    # a second pack() after the weight changed in place re-splits it (the table holds pointers, not values)
+    bt.mul_(-1.5)
+    packed.pack()
+    assert torch.equal(capi.gemm_x6p(a, packed.planes[0], n, d), capi.gemm_x6(a, bt, d))
+    for bad in ((a, packed.planes[0][:-16], n), (a[:, :-16].contiguous(), packed.planes[0], n)):
+        with pytest.raises(capi.PeclrHipError):
+            capi.gemm_x6p(*bad)
+    with pytest.raises(capi.PeclrHipError):
+        capi.X6Planes([(bt[:100], False)])           # 100 output columns: not a multiple of 128
+
+
+def test_x6_pack_group_follows_the_weights():
+    """bn2d.X6PackGroup: ONE pack launch per optimiser step for every routed 1x1 convolution of an encoder; a member
+    re-packs when its weight was updated in place, replaced, or rewritten by the fused optimiser (raw pointers)."""
+    from peclr_amd import _capi
+    from peclr_amd import bn2d as B
+    from peclr_amd.optim import LARSAdam
+
+    torch.manual_seed(3)
+    convs = [B.Conv2d(256, 128, 1, bias=False), B.Conv2d(128, 512, 1, bias=False), B.Conv2d(64, 256, 1, bias=False)]
+    net = torch.nn.Sequential(*convs).to(DEV).to(memory_format=torch.channels_last)
+    for c in convs:
+        c.hip_gemm = True
+    group = B.X6PackGroup(convs)
+    assert group.convs == convs[:2] and getattr(convs[2], "x6_group", None) is None
+    packs = []
+    real = _capi.X6Planes.pack
+    _capi.X6Planes.pack = lambda self: (packs.append(1), real(self))[1]
+    try:
+        x = torch.randn(64, 256, 28, 28, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+
+        def run():
+            y = convs[1](convs[0](x))
+            w0, w1 = (c.weight.detach().double().view(c.out_channels, c.in_channels) for c in convs[:2])
+            ref = torch.einsum("nchw,oc->nohw", torch.einsum("nchw,oc->nohw", x.detach()[:4].double(), w0), w1)
+            assert float((y[:4].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+            return y
+
+        run()
+        run()
+        assert len(packs) == 1                       # second forward: nothing changed, nothing re-packed
+        with torch.no_grad():
+            convs[1].weight.mul_(0.5)                # in-place update bumps the version counter
+        run()
+        assert len(packs) == 2
+        opt = LARSAdam([{"params": [c.weight for c in convs[:2]], "weight_decay": 0.0}], lr=1e-2, lars=False, fused=True)
+        run().square().mean().backward()
+        opt.step()                                   # writes the parameters through raw pointers
+        run()
+        assert len(packs) == 3
+        convs[0].weight.data = (convs[0].weight.detach() * 2).contiguous(memory_format=torch.channels_last)   # new storage
+        run()
+        assert len(packs) == 4
+    finally:
+        _capi.X6Planes.pack = real
+
+
 @pytest.mark.parametrize("cin,cout,hw,n", [(1024, 256, 14, 256), (256, 1024, 14, 256), (512, 128, 28, 64), (64, 256, 8, 4),
                                            (256, 64, 56, 48)])
 def test_conv1x1_as_gemm_on_the_matrix_cores_matches_float64(cin, cout, hw, n):
