@@ -109,12 +109,18 @@ int peclr_gemm_x6_tn_f32(int M, int N, int K, const float* A, int lda, const flo
  *   first chunk, 0}; B_t[n][k] = src[n * ld + k] (transposed = 0: forward, W[Cout][Cin]) or src[k * ld + n]
  *   (transposed = 1: input gradients, B_t = W^T); n % 128 == 0, k % 16 == 0; chunks per matrix = (n / 128) * (k / 16);
  *   dst holds peclr_x6_pack_bytes(n, k) = 6 n k bytes.  One launch packs every matrix of the table.
- *   peclr_gemm_x6p_f32: C[M,N] = A[M,K] . B_t^T (+ addend); tile_rows 256, 128 or 0 (= peclr_gemm_x6p_tile_rows). */
+ *   peclr_gemm_x6p_f32: C[M,N] = A[M,K] . B_t^T (+ addend); tile_rows 256, 128 or 0 (= peclr_gemm_x6p_tile_rows).
+ *   stat_partial (nullable; needs stat_shift[N]): the training-mode BatchNorm2d statistics of C (the `conv -> bn` pair of
+ *   the torchvision Bottleneck, resnet_model.py:15) from the accumulators, so that no separate pass re-reads the tensor
+ *   the GEMM just wrote: float [ceil(M / tile_rows)][2][N] per-row-block sums of (C - shift) and (C - shift)^2, then one
+ *   row [N] holding the shift -- exactly the `partial` layout of peclr_bn2d_stats, so peclr_bn2d_finalize_f32 (or the
+ *   synchronised route's peclr_bn2d_combine_f64) takes it with n_split = ceil(M / tile_rows).  Fixed summation order. */
 int64_t peclr_x6_pack_bytes(int N, int K);
 int peclr_x6_pack_f32(const void* desc_table, int count, int total_chunks, peclr_stream_t stream);
 int peclr_gemm_x6p_tile_rows(int M, int N, int K);
 int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
-                       const float* addend, int ldd, int tile_rows, peclr_stream_t stream);
+                       const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
+                       peclr_stream_t stream);
 int peclr_gemm_pick_split_k(int M, int N, int K);
 
 /* out[i] = sum_s slabs[s][i] (+ bias[i % cols] if non-null), i < rows*cols. */

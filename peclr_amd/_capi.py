@@ -71,7 +71,7 @@ SIGNATURES = {
     "peclr_x6_pack_bytes": (c_int64, [c_int, c_int]),
     "peclr_x6_pack_f32": (c_int, [_P, c_int, c_int, _P]),
     "peclr_gemm_x6p_tile_rows": (c_int, [c_int, c_int, c_int]),
-    "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P]),
+    "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
@@ -141,11 +141,13 @@ LAUNCH_ORDER = None  # None = off; list of names in launch order (one entry per 
 
 
 class _timed:
-    """`nbytes` / `flops`: the launch's ALGORITHMIC work when it is shape-dependent (summed per name)."""
-    __slots__ = ("name", "s", "e", "nbytes", "flops")
+    """`nbytes` / `flops`: the launch's ALGORITHMIC work when it is shape-dependent (summed per name); `kernel`: the
+    kernel family that runs under this name when the entry point has more than one (bench.py prices a launch against
+    the roof of the kernel that actually ran)."""
+    __slots__ = ("name", "s", "e", "nbytes", "flops", "kernel")
 
-    def __init__(self, name, nbytes=0, flops=0):
-        self.name, self.nbytes, self.flops = name, nbytes, flops
+    def __init__(self, name, nbytes=0, flops=0, kernel=None):
+        self.name, self.nbytes, self.flops, self.kernel = name, nbytes, flops, kernel
 
     def __enter__(self):
         if EVENT_LOG is not None:
@@ -158,7 +160,7 @@ class _timed:
     def __exit__(self, *exc):
         if EVENT_LOG is not None:
             self.e.record()
-            EVENT_LOG.setdefault(self.name, []).append((self.s, self.e, self.nbytes, self.flops))
+            EVENT_LOG.setdefault(self.name, []).append((self.s, self.e, self.nbytes, self.flops, self.kernel))
         return False
 
 
@@ -192,10 +194,10 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Ten
     return out
 
 
-def slab_reduce(slabs: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+def slab_reduce(slabs: torch.Tensor, bias: Optional[torch.Tensor] = None, tag: str = "slab_reduce") -> torch.Tensor:
     s, rows, cols = slabs.shape
     out = torch.empty((rows, cols), device=slabs.device, dtype=torch.float32)
-    with _timed("slab_reduce"):
+    with _timed(tag, 4 * (s + 1) * rows * cols, kernel="slab_reduce_kernel"):
         rc = lib().peclr_slab_reduce_f32(_ptr(slabs), s, rows, cols, _ptr(bias), out.data_ptr(), _stream())
     _check(rc, "peclr_slab_reduce_f32")
     return out
@@ -368,7 +370,7 @@ def gemm_add(layout: int, a: torch.Tensor, b: torch.Tensor, addend: torch.Tensor
     if k != k2 or tuple(addend.shape) != (m, n):
         raise PeclrHipError(f"gemm_add: shapes {tuple(a.shape)} x {tuple(b.shape)} + {tuple(addend.shape)} (layout {layout})")
     out = torch.empty((m, n), device=a.device, dtype=torch.float32)
-    with _timed(tag, 4 * (m * k + k * n + 2 * m * n), 2 * m * n * k):
+    with _timed(tag, 4 * (m * k + k * n + 2 * m * n), 2 * m * n * k, kernel="gemm_f32 (v_mfma_f32)"):
         rc = lib().peclr_gemm_add_f32(layout, m, n, k, _ptr(a), a.shape[1], _ptr(b), b.shape[1], out.data_ptr(), n,
                                       _ptr(addend), n, _stream())
     _check(rc, "peclr_gemm_add_f32")
@@ -384,7 +386,7 @@ def gemm_x6(a: torch.Tensor, b_t: torch.Tensor, addend: Optional[torch.Tensor] =
         raise PeclrHipError(f"gemm_x6: shapes {tuple(a.shape)} x {tuple(b_t.shape)}^T")
     if out is None:
         out = torch.empty((m, n), device=a.device, dtype=torch.float32)
-    with _timed(tag, 4 * (m * k + k * n + (2 if addend is not None else 1) * m * n), 2 * m * n * k):
+    with _timed(tag, 4 * (m * k + k * n + (2 if addend is not None else 1) * m * n), 2 * m * n * k, kernel="gemm_x6_nt128_kernel"):
         rc = lib().peclr_gemm_x6_f32(m, n, k, _ptr(a), k, _ptr(b_t), k, _ptr(out), n, _ptr(addend), n, _stream())
     _check(rc, "peclr_gemm_x6_f32")
     return out
@@ -420,25 +422,34 @@ class X6Planes:
         self.nbytes = sum(p.numel() for p in self.planes) + 4 * sum(w.numel() for w in self._sources)
 
     def pack(self):
-        with _timed("x6_pack", self.nbytes):
+        with _timed("x6_pack", self.nbytes, kernel="x6_pack_kernel"):
             rc = lib().peclr_x6_pack_f32(self.table.data_ptr(), self.count, self.chunks, _stream())
         _check(rc, "peclr_x6_pack_f32")
         return self
 
 
 def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[torch.Tensor] = None, tag: str = "gemm_x6p",
-             tile_rows: int = 0) -> torch.Tensor:
+             tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None):
     """C (fp32) [M, n] = A[M, K] . B_t^T (+ addend) with B_t given as packed planes (X6Planes): fp32 accuracy on the
-    bf16 matrix cores, the weight operand split once per step (peclr_gemm_x6p_f32)."""
+    bf16 matrix cores, the weight operand split once per step (peclr_gemm_x6p_f32).
+    stat_shift (fp32 [n]): also return the training-mode BatchNorm statistics of C as `(partial, n_split)` in the layout
+    of peclr_bn2d_stats (sums of (C - shift) and its square per row block; the shift in the last row) -> (C, partial, n_split)."""
     m, k = a.shape
     if planes.dtype != torch.uint8 or planes.numel() != 6 * n * k or (addend is not None and tuple(addend.shape) != (m, n)):
         raise PeclrHipError(f"gemm_x6p: A {tuple(a.shape)}, planes of {planes.numel()} bytes for B_t[{n}, {k}]")
     out = torch.empty((m, n), device=a.device, dtype=torch.float32)
-    with _timed(tag, 4 * (m * k + (2 if addend is not None else 1) * m * n) + 6 * k * n, 2 * m * n * k):
+    partial, ns = None, 0
+    if stat_shift is not None:
+        if stat_shift.numel() != n:
+            raise PeclrHipError(f"gemm_x6p: stat_shift has {stat_shift.numel()} entries for {n} columns")
+        tile_rows = tile_rows or lib().peclr_gemm_x6p_tile_rows(m, n, k)
+        ns = (m + tile_rows - 1) // tile_rows
+        partial = torch.empty((2 * ns + 1, n), device=a.device, dtype=torch.float32)
+    with _timed(tag, 4 * (m * k + (2 if addend is not None else 1) * m * n) + 6 * k * n, 2 * m * n * k, kernel="gemm_x6p_kernel"):
         rc = lib().peclr_gemm_x6p_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
-                                      tile_rows, _stream())
+                                      tile_rows, _ptr(stat_shift), _ptr(partial), _stream())
     _check(rc, "peclr_gemm_x6p_f32")
-    return out
+    return out if stat_shift is None else (out, partial, ns)
 
 
 def gemm_x6_tn(a: torch.Tensor, b: torch.Tensor, tag: str = "gemm_x6_tn") -> torch.Tensor:
@@ -452,10 +463,10 @@ def gemm_x6_tn(a: torch.Tensor, b: torch.Tensor, tag: str = "gemm_x6_tn") -> tor
     if ns < 1:
         raise PeclrHipError(f"gemm_x6_tn: unsupported shape M={m} N={n} K={k}")
     slabs = torch.empty((ns, m, n), device=a.device, dtype=torch.float32)
-    with _timed(tag, 4 * (k * m + k * n + ns * m * n), 2 * m * n * k):
+    with _timed(tag, 4 * (k * m + k * n + ns * m * n), 2 * m * n * k, kernel="gemm_x6_tn128_kernel"):
         rc = lib().peclr_gemm_x6_tn_f32(m, n, k, _ptr(a), m, _ptr(b), n, slabs.data_ptr(), ns, _stream())
     _check(rc, "peclr_gemm_x6_tn_f32")
-    return slabs[0] if ns == 1 else slab_reduce(slabs)
+    return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
 
 
 def gemm_add_half(a: torch.Tensor, b_t: torch.Tensor, addend: Optional[torch.Tensor], tag: str = "gemm_add") -> torch.Tensor:
@@ -519,7 +530,8 @@ def _sync_totals(partial, ns, c, rows, group):
     return local, total
 
 
-def _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group=None):
+def _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group=None, sync_shift=None,
+                      pre=None):
     """stats -> finalize: (save [mean, invstd], scale_shift) for x [N,C,H,W] NHWC; updates the running
     statistics in training mode."""
     n, c, h, w = x.shape
@@ -530,15 +542,23 @@ def _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, 
     save = torch.empty((2, c), device=dev, dtype=torch.float32)
     ss = torch.empty((2, c), device=dev, dtype=torch.float32)
     part_ptr, ns = None, 0
-    if training:
+    sync = sync_group is not None
+    if training and pre is not None:
+        # the producer of x (a GEMM epilogue) already summed the statistics per row block: `pre` = (partial, n_split,
+        # shift it used) in peclr_bn2d_stats' layout; nothing re-reads x here
+        partial, ns, shift = pre
+        if tuple(partial.shape) != (2 * ns + 1, c):
+            raise PeclrHipError(f"bn2d: precomputed statistics of shape {tuple(partial.shape)} for C = {c}, n_split = {ns}")
+        part_ptr = _ptr(partial, what="bn2d partial statistics")
+    elif training:
         ns = bn2d_n_split(r, c, io)
         partial = torch.empty((2 * ns + 1, c), device=dev, dtype=torch.float32)
         part_ptr = partial.data_ptr()
-        sync = sync_group is not None
-        if sync and running_mean is None:
+        if sync and running_mean is None and sync_shift is None:
             raise PeclrHipError("synchronised BatchNorm needs running statistics (their mean is the common shift)")
-        # synchronised: every rank must subtract the SAME shift before summing -> the (replicated) running mean
-        shift = running_mean.detach().clone() if sync else None
+        # synchronised: every rank must subtract the SAME shift before summing -> the (replicated) running mean, or the
+        # copy of it the caller kept (re-run of a checkpointed block: the running statistics have moved since)
+        shift = (sync_shift if sync_shift is not None else running_mean.detach().clone()) if sync else None
         with _timed("bn2d_stats", e * r * c):
             rc = lib().peclr_bn2d_stats(xp, io, r, c, _ptr(shift), part_ptr, ns, _stream())
         _check(rc, "peclr_bn2d_stats")
@@ -561,7 +581,7 @@ def _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, 
 
 
 def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, relu,
-             want_mask=False, sync_group=None):
+             want_mask=False, sync_group=None, sync_shift=None, pre=None):
     """want_mask: also write the 1-bit ReLU mask ([R, C/32] int32) the backward reads instead of y.
     sync_group: a process group -> training statistics are those of the rows of ALL its ranks
     (mean/var of the global batch, as one device holding the concatenated batch would compute)."""
@@ -570,7 +590,7 @@ def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training,
     dev = x.device
     xp = _nhwc_ptr(x, "bn2d x")
     io, e = _IO[x.dtype]
-    save, ss = _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group)
+    save, ss = _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group, sync_shift, pre)
     y = torch.empty_like(x, memory_format=torch.channels_last)
     mask = torch.empty((r, c // 32), device=dev, dtype=torch.int32) if (want_mask and relu and c % 32 == 0) else None
     with _timed("bn2d_apply", (3 if residual is not None else 2) * e * r * c + (r * c // 8 if mask is not None else 0)):
@@ -624,7 +644,8 @@ def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres, sync_group=Non
     return dx, dparams[0], dparams[1], dres
 
 
-def bn2d_avgpool_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group=None):
+def bn2d_avgpool_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group=None,
+                     sync_shift=None, pre=None):
     """Encoder tail: mean over H x W of relu(bn(x) + residual) as fp32 [N, C]; the activation itself is not
     written.  Returns (pooled, relu mask, save, scale_shift)."""
     n, c, h, w = x.shape
@@ -632,7 +653,7 @@ def bn2d_avgpool_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, t
     if c % 32 or residual is None:
         raise PeclrHipError("fused BN + add + ReLU + average pool needs a residual and C % 32 == 0")
     io, e = _IO[x.dtype]
-    save, ss = _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group)
+    save, ss = _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group, sync_shift, pre)
     pooled = torch.empty((n, c), device=x.device, dtype=torch.float32)
     mask = torch.empty((r, c // 32), device=x.device, dtype=torch.int32)
     with _timed("bn2d_apply_avgpool", 2 * e * r * c + r * c // 8 + 4 * n * c):
@@ -681,11 +702,11 @@ def bn2d_avgpool_bwd(d_pooled, x, mask, save, ss, training, sync_group=None):
     return dx, dparams[0], dparams[1], dres
 
 
-def bn2d_pool_fwd(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group=None):
+def bn2d_pool_fwd(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group=None, sync_shift=None):
     """Stem: y = maxpool3x3/2(relu(bn(x))) in one pass; returns (y, tap codes, save, scale_shift)."""
     n, c, h, w = x.shape
     io, e = _IO[x.dtype]
-    save, ss = _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group)
+    save, ss = _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group, sync_shift)
     ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     y = torch.empty((n, c, ph, pw), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
     x_at_max = torch.empty_like(y)

@@ -72,6 +72,7 @@ _GEMM_X6 = os.environ.get("PECLR_GEMM_X6", "1") != "0"    # A/B switch: fp32 GEM
 _X6_MIN_K = int(os.environ.get("PECLR_GEMM_X6_MIN_K", "128"))   # in-step A/B: 128 beats 256 by 0.1-0.4 ms, 64 is HBM-bound
 
 
+_BN_STATS_IN_GEMM = os.environ.get("PECLR_BN_STATS_IN_GEMM", "1") != "0"   # A/B switch: BatchNorm statistics in the GEMM epilogue
 _GEMM_X6P = os.environ.get("PECLR_GEMM_X6P", "1") != "0"  # A/B switch: weight planes packed once per step (peclr_gemm_x6p_f32)
 
 
@@ -87,10 +88,9 @@ class X6PackGroup:
         self.convs = [c for c in convs if self.member(c)]
         self._x6 = None
         self._ptrs = None
-        self._stamp = {}
-        self._at = {id(c): 2 * i for i, c in enumerate(self.convs)}
-        for c in self.convs:
-            c.x6_group = self
+        self._stamp = [None] * len(self.convs)
+        for i, c in enumerate(self.convs):   # (position kept on the module: a deep copy of the model keeps group and members consistent)
+            c.x6_group, c.x6_index = self, i
 
     @staticmethod
     def member(conv) -> bool:
@@ -111,18 +111,19 @@ class X6PackGroup:
             self._x6 = _capi.X6Planes(specs)
             self._ptrs = ptrs
         self._x6.pack()
-        for c in self.convs:
-            self._stamp[id(c)] = self._key(c)
+        self._stamp = [self._key(c) for c in self.convs]
 
     def planes(self, conv):
         """(forward planes of W [Cout, Cin], input-gradient planes of W^T), fresh."""
-        stale = self._stamp.get(id(conv)) != self._key(conv)
-        if not stale and conv is self.convs[0] and torch.cuda.is_current_stream_capturing():
+        at = conv.x6_index
+        if at >= len(self.convs) or self.convs[at] is not conv:
+            raise _capi.PeclrHipError("X6PackGroup: convolution is not a member of its group (call enable_hip_batchnorm again)")
+        stale = self._stamp[at] != self._key(conv)
+        if not stale and at == 0 and torch.cuda.is_current_stream_capturing():
             stale = True
         if stale:
             self.pack()
-        at = self._at[id(conv)]
-        return self._x6.planes[at], self._x6.planes[at + 1]
+        return self._x6.planes[2 * at], self._x6.planes[2 * at + 1]
 
 
 def _x6_planes(conv):
@@ -136,15 +137,16 @@ def _x6_planes(conv):
 
 class _BN2dAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool):
+    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool, pre=None):
         training = bn.training or not bn.track_running_stats
         # the ReLU mask can be recomputed from x unless a residual was added before it; then the
         # forward writes a 1-bit mask (or, for C % 32 != 0, the backward re-reads y)
         need_mask = relu and residual is not None
-        rm, rv, nbt = bn._stat_buffers(training)
+        rm, rv, nbt, shift = bn._stat_buffers(training)
         y, save, ss, mask = _capi.bn2d_fwd(x, residual, weight, bias, rm, rv, nbt, training, bn.eps,
                                            bn.momentum if bn.momentum is not None else 0.1, relu, want_mask=need_mask,
-                                           sync_group=bn.sync_group if training else None)
+                                           sync_group=bn.sync_group if training else None, sync_shift=shift,
+                                           pre=pre if training else None)
         keep = mask if mask is not None else (y if need_mask else None)
         ctx.save_for_backward(x, save, ss, *([keep] if keep is not None else []))
         ctx.cfg = (training, relu, residual is not None, keep is not None, mask is not None)
@@ -162,7 +164,7 @@ class _BN2dAct(torch.autograd.Function):
                                                  has_res and ctx.needs_input_grad[3], sync_group=ctx.sync_group)
         if has_res and dres is None and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dgamma, dbeta, dres, None, None
+        return dx, dgamma, dbeta, dres, None, None, None
 
 
 class _BN2dReluPool(torch.autograd.Function):
@@ -172,9 +174,9 @@ class _BN2dReluPool(torch.autograd.Function):
     def forward(ctx, x, weight, bias, bn: "FusedBatchNormAct2d"):
         training = bn.training or not bn.track_running_stats
         sync = bn.sync_group if training else None
-        rm, rv, nbt = bn._stat_buffers(training)
+        rm, rv, nbt, shift = bn._stat_buffers(training)
         y, x_at_max, code, save, ss = _capi.bn2d_pool_fwd(x, weight, bias, rm, rv, nbt, training, bn.eps,
-                                                bn.momentum if bn.momentum is not None else 0.1, sync_group=sync)
+                                                bn.momentum if bn.momentum is not None else 0.1, sync_group=sync, sync_shift=shift)
         ctx.save_for_backward(x, x_at_max, code, save, ss)
         ctx.cfg = (training, sync)
         return y
@@ -194,12 +196,13 @@ class _BN2dAddReluAvgPool(torch.autograd.Function):
     and the backward forms the pool's broadcast gradient on the fly."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d"):
+    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", pre=None):
         training = bn.training or not bn.track_running_stats
         sync = bn.sync_group if training else None
-        rm, rv, nbt = bn._stat_buffers(training)
+        rm, rv, nbt, shift = bn._stat_buffers(training)
         pooled, mask, save, ss = _capi.bn2d_avgpool_fwd(x, residual, weight, bias, rm, rv, nbt, training, bn.eps,
-                                                        bn.momentum if bn.momentum is not None else 0.1, sync_group=sync)
+                                                        bn.momentum if bn.momentum is not None else 0.1, sync_group=sync,
+                                                        sync_shift=shift, pre=pre if training else None)
         ctx.save_for_backward(x, mask, save, ss)
         ctx.cfg = (training, sync)
         return pooled
@@ -210,7 +213,7 @@ class _BN2dAddReluAvgPool(torch.autograd.Function):
         training, sync = ctx.cfg
         dx, dgamma, dbeta, dres = _capi.bn2d_avgpool_bwd(d_pooled.float().contiguous(), x, mask, save, ss, training,
                                                          sync_group=sync)
-        return dx, dgamma, dbeta, dres, None
+        return dx, dgamma, dbeta, dres, None, None
 
 
 # ---- weight gradients on a side stream.  In the backward pass a convolution's weight gradient (MFMA-bound) is
@@ -222,12 +225,15 @@ class _BN2dAddReluAvgPool(torch.autograd.Function):
 # `wgrad_join()`, which the caller runs after backward, once the main stream has waited for the side stream.
 # Under hipGraph capture the side stream becomes a parallel branch of the graph.
 class _WgradOverlap:
-    stream = None        # torch.cuda.Stream or None (= off: everything on the current stream, through autograd)
+    stream = None        # torch.cuda.Stream or None (= mode off: everything on the current stream, through autograd)
+    armed = False        # the mode only acts between `arm_wgrad_overlap()` (before a forward pass whose backward the
+    #                      caller will follow with `wgrad_join()`) and that join: any other forward / backward in the
+    #                      process -- a plain `loss.backward(); opt.step()` -- goes through autograd as usual
     parked: list = []    # (parameter, gradient computed on the side stream, tensors it read)
 
 
 def enable_wgrad_overlap(enabled: bool = True):
-    """Switch the side-stream weight gradients on (a dedicated stream is created on first use) or off."""
+    """Create (or drop) the side stream of the side-stream weight gradients; they act only while armed."""
     if enabled and _WgradOverlap.stream is None:
         _WgradOverlap.stream = torch.cuda.Stream()
     elif not enabled:
@@ -235,9 +241,21 @@ def enable_wgrad_overlap(enabled: bool = True):
         _WgradOverlap.stream = None
 
 
-def wgrad_join():
+def arm_wgrad_overlap():
+    """Before a forward pass whose backward will be followed by `wgrad_join()` (the Trainer does both)."""
+    _WgradOverlap.armed = _WgradOverlap.stream is not None
+
+
+def _overlap_stream():
+    return _WgradOverlap.stream if _WgradOverlap.armed else None
+
+
+def wgrad_join(on_joined=None):
     """After backward: wait for the side stream, then give every parked gradient to its parameter
-    (`.grad = g`, or `.grad += g` when one is already there: accumulation windows, all-reduce bucket views)."""
+    (`.grad = g`, or `.grad += g` when one is already there: accumulation windows, all-reduce bucket views), call
+    `on_joined(parameter)` for each (the all-reduce buckets count their members off there: these gradients never pass
+    AccumulateGrad, so no post-accumulate hook fires for them), and disarm."""
+    _WgradOverlap.armed = False
     if not _WgradOverlap.parked:
         return
     torch.cuda.current_stream().wait_stream(_WgradOverlap.stream)
@@ -247,6 +265,8 @@ def wgrad_join():
                 param.grad = g
             else:
                 param.grad.add_(g)
+            if on_joined is not None:
+                on_joined(param)
     _WgradOverlap.parked.clear()
 
 
@@ -257,7 +277,7 @@ def _conv_wgrad(gy: Tensor, x: Tensor, weight: Tensor, stride, padding, param=No
         g = torch.ops.aten.convolution_backward(gy, x, weight.to(x.dtype), None, list(stride), list(padding), [1, 1], False,
                                                 [0, 0], 1, [False, True, False])[1]
         return g.to((param if param is not None else weight).dtype)
-    st = _WgradOverlap.stream
+    st = _overlap_stream()
     if st is None or param is None or not gy.is_cuda:
         return run()
     st.wait_stream(torch.cuda.current_stream())          # gy (and x) are ready where the side stream picks up
@@ -321,7 +341,7 @@ def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
         ref = param if param is not None else weight
         return dw.as_strided(ref.shape, ref.stride())       # same memory, the parameter's (channels_last) strides
 
-    st = _WgradOverlap.stream
+    st = _overlap_stream()
     if st is None or param is None:
         return run()
     st.wait_stream(torch.cuda.current_stream())
@@ -331,6 +351,20 @@ def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
     return None
 
 
+def _stat_shift_for(bn, cout: int):
+    """The shift a GEMM epilogue subtracts before it sums the statistics `bn` will finalize (None: `bn` cannot take
+    statistics from its producer -- not a fused training-mode BatchNorm of that width, or no running mean to centre on).
+    The running mean is the natural centre (the sums are exact in the shift; it only has to be near the batch mean, and
+    identical on every rank under synchronised statistics); the re-run of a checkpointed block under synchronised
+    statistics re-uses the copy its first run took."""
+    if (not isinstance(bn, FusedBatchNormAct2d) or not bn.hip or not bn.affine or bn.num_features != cout
+            or bn.running_mean is None or not bn.training or not bn.running_mean.is_cuda):
+        return None
+    if _RECOMPUTING and bn.sync_group is not None and getattr(bn, "_sync_shift", None) is not None:
+        return bn._sync_shift
+    return bn.running_mean
+
+
 class _Conv1x1Gemm(torch.autograd.Function):
     """1x1 / stride-1 convolution of an NHWC fp32 tensor as the GEMM it is, on the bf16 matrix cores at fp32 accuracy:
     forward y[R, Cout] = x[R, Cin] . W^T and / or the input gradient dx[R, Cin] = dy[R, Cout] . W, each where `_x6_pays`
@@ -338,7 +372,9 @@ class _Conv1x1Gemm(torch.autograd.Function):
     both operands split per workgroup: peclr_gemm_x6_f32); the other direction and small weight gradients stay on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, use_fwd: bool, use_bwd: bool):
+    def forward(ctx, x, weight, conv, use_fwd: bool, use_bwd: bool, stats=None):
+        """stats: None, or [bn] -- the BatchNorm2d that consumes the output; the GEMM epilogue then sums its statistics
+        and the list comes back as [partial, n_split, shift, bn] (left untouched when that is not possible)."""
         ctx.save_for_backward(x, weight)
         planes = _x6_planes(conv) if (use_fwd or use_bwd) else None
         ctx.cfg = (conv, use_bwd, planes)
@@ -347,7 +383,11 @@ class _Conv1x1Gemm(torch.autograd.Function):
         n, cin, h, w = x.shape
         cout = weight.shape[0]
         x2 = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
-        if planes is not None:
+        shift = _stat_shift_for(stats[0], cout) if (stats and planes is not None and _BN_STATS_IN_GEMM) else None
+        if shift is not None:
+            y, partial, ns = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd", stat_shift=shift)
+            stats[:] = [partial, ns, shift, stats[0]]
+        elif planes is not None:
             y = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd")
         else:
             y = _capi.gemm_x6(x2, weight.detach().reshape(cout, cin), tag="conv1x1_fwd")
@@ -378,7 +418,14 @@ class _Conv1x1Gemm(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
+
+
+def _attach_stats(y: Tensor, stats):
+    """Hand the statistics a GEMM epilogue summed to the BatchNorm that consumes `y` (FusedBatchNormAct2d.forward looks for them)."""
+    if stats is not None and len(stats) == 4:
+        y._peclr_bn_stats = tuple(stats)
+    return y
 
 
 class Conv2d(nn.Conv2d):
@@ -387,7 +434,9 @@ class Conv2d(nn.Conv2d):
 
     hip_gemm = False   # enable_hip_batchnorm: fp32 1x1 / stride-1 convolutions as GEMMs on the bf16 matrix cores
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, stats_for=None) -> Tensor:
+        """stats_for: the BatchNorm2d that consumes the output -- when this convolution runs as an in-tree GEMM its
+        epilogue sums that layer's training statistics (one pass over the activation less)."""
         if (self.hip_gemm and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")
                 and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1
                 and self.bias is None and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
@@ -397,8 +446,9 @@ class Conv2d(nn.Conv2d):
             use_wgrad = (_x6_wgrad_pays(rows, self.out_channels, self.in_channels) and torch.is_grad_enabled()
                          and self.weight.requires_grad)
             if use_fwd or use_bwd or use_wgrad:
-                return _Conv1x1Gemm.apply(x, self.weight, self, use_fwd, use_bwd)
-        if (_WgradOverlap.stream is not None and x.is_cuda and torch.is_grad_enabled() and self.bias is None
+                stats = [stats_for] if (stats_for is not None and use_fwd) else None
+                return _attach_stats(_Conv1x1Gemm.apply(x, self.weight, self, use_fwd, use_bwd, stats), stats)
+        if (_overlap_stream() is not None and x.is_cuda and torch.is_grad_enabled() and self.bias is None
                 and self.groups == 1 and self.dilation == (1, 1) and isinstance(self.padding, tuple)
                 and x.is_contiguous(memory_format=torch.channels_last) and self.weight.requires_grad):
             w = self.weight
@@ -416,7 +466,7 @@ class _ForkConv1x1(torch.autograd.Function):
     identity gradient added in the epilogue.  Small shapes' forward and weight gradient stay on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv):
+    def forward(ctx, x, weight, conv, stats=None):
         ctx.save_for_backward(x, weight)
         ctx.param = weight if isinstance(weight, nn.Parameter) else None
         n, cin, h, w = x.shape
@@ -428,7 +478,11 @@ class _ForkConv1x1(torch.autograd.Function):
         ctx.use_bwd = use_bwd
         if use_fwd:
             x2 = x.permute(0, 2, 3, 1).reshape(r, cin)
-            if ctx.planes is not None:
+            shift = _stat_shift_for(stats[0], cmid) if (stats and ctx.planes is not None and _BN_STATS_IN_GEMM) else None
+            if shift is not None:
+                y, partial, ns = _capi.gemm_x6p(x2, ctx.planes[0], cmid, tag="conv1x1_fwd", stat_shift=shift)
+                stats[:] = [partial, ns, shift, stats[0]]
+            elif ctx.planes is not None:
                 y = _capi.gemm_x6p(x2, ctx.planes[0], cmid, tag="conv1x1_fwd")
             else:
                 y = _capi.gemm_x6(x2, weight.detach().reshape(cmid, cin), tag="conv1x1_fwd")
@@ -466,10 +520,10 @@ class _ForkConv1x1(torch.autograd.Function):
             else:
                 out = _capi.gemm_add(_capi.GEMM_NN, a, weight.reshape(cmid, cin), d, tag="conv1x1_dgrad_add")
             dx = out.view(n, h, w, cin).permute(0, 3, 1, 2)       # back to a channels_last NCHW tensor
-        return dx, dw, None
+        return dx, dw, None, None
 
 
-def fork_conv1x1(conv: nn.Conv2d, x: Tensor):
+def fork_conv1x1(conv: nn.Conv2d, x: Tensor, stats_for=None):
     """`(conv(x), x)` with the fused input gradient when `conv.hip_fork` is set (enable_hip_batchnorm does
     it for the bottlenecks' first 1x1 convolution) and the activations are channels_last on a HIP device,
     fp32 (no autocast) or bf16 (under bf16 autocast); the stock ops otherwise."""
@@ -482,8 +536,10 @@ def fork_conv1x1(conv: nn.Conv2d, x: Tensor):
           and x.is_contiguous(memory_format=torch.channels_last)
           and conv.weight.shape[0] % 8 == 0 and conv.weight.shape[1] % 8 == 0)
     if ok:
-        return _ForkConv1x1.apply(x, conv.weight, conv)
-    return conv(x), x
+        stats = [stats_for] if stats_for is not None else None
+        out, identity = _ForkConv1x1.apply(x, conv.weight, conv, stats)
+        return _attach_stats(out, stats), identity
+    return (conv(x, stats_for=stats_for) if isinstance(conv, Conv2d) else conv(x)), x
 
 
 class FusedBatchNormAct2d(nn.BatchNorm2d):
@@ -501,12 +557,18 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
         self.sync_group = None
 
     def _stat_buffers(self, training: bool):
-        """Running statistics the kernels should update -- none while a checkpointed block is being re-run in
-        the backward pass (the first run already moved them), unless they are needed as the common shift of
-        synchronised statistics."""
-        if training and _RECOMPUTING and self.sync_group is None:
-            return None, None, None
-        return self.running_mean, self.running_var, self.num_batches_tracked
+        """(running_mean, running_var, num_batches_tracked, sync_shift) for the kernels.  The running statistics are
+        NOT handed over while a checkpointed block is being re-run in the backward pass (the first run already moved
+        them).  Synchronised statistics subtract a common shift -- the replicated running mean -- before summing: the
+        first run keeps the copy it used, and the re-run gets that copy (the running mean has moved since) so that it
+        reproduces the first run's statistics exactly and updates nothing."""
+        sync = training and self.sync_group is not None
+        if training and _RECOMPUTING:
+            return None, None, None, (getattr(self, "_sync_shift", None) if sync else None)
+        shift = None
+        if sync:
+            shift = self._sync_shift = self.running_mean.detach().clone()
+        return self.running_mean, self.running_var, self.num_batches_tracked, shift
 
     def forward(self, x: Tensor, residual: Optional[Tensor] = None, relu: Optional[bool] = None) -> Tensor:
         relu = self.default_relu if relu is None else relu
@@ -516,9 +578,14 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
                 raise _capi.PeclrHipError("fused BatchNorm2d needs affine=True and a fixed momentum")
             if pool:
                 return _BN2dReluPool.apply(x, self.weight, self.bias, self)
+            # statistics its producer already summed (a GEMM epilogue, `conv_stats_for`), valid for THIS layer in training
+            pre = getattr(x, "_peclr_bn_stats", None)
+            if pre is not None and (pre[3] is not self or not (self.training or not self.track_running_stats)):
+                pre = None
+            pre = pre[:3] if pre is not None else None
             if self.tail_avgpool and relu and residual is not None and self.num_features % 32 == 0:
-                return _BN2dAddReluAvgPool.apply(x, self.weight, self.bias, residual, self)
-            return _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu)
+                return _BN2dAddReluAvgPool.apply(x, self.weight, self.bias, residual, self, pre)
+            return _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre)
         if self.sync_group is not None and self.training:
             raise _capi.PeclrHipError("synchronised statistics are implemented by the HIP kernels only (hip=True)")
         if self.training and _RECOMPUTING:   # re-run of a checkpointed block: batch statistics, buffers untouched

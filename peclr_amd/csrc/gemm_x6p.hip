@@ -44,6 +44,11 @@ struct X6PArgs {
     float* out;
     int M, N, K, lda, ldo, ldd;
     int stream_out;
+    // optional BatchNorm statistics of the OUTPUT (the convolution's BatchNorm2d in training mode): per workgroup row
+    // block, per column, sum and sum of squares of (C - shift) over the block's rows -> stat_partial[row block][2][N],
+    // plus the shift itself in row [n row blocks] -- the layout peclr_bn2d_finalize_f32 combines
+    const float* stat_shift;
+    float* stat_partial;
 };
 
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
@@ -217,6 +222,36 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     // epilogue: wave-private 32 x 32 transposes through LDS (the B buffers, once every wave is done with them), 16 bytes per lane
     __syncthreads();
     float* wlds = reinterpret_cast<float*>(lds + wave * (32 * XEPL * 4));
+    if (g.stat_partial) {
+        // column statistics of this workgroup's TM x 128 block straight from the accumulators: a lane holds column
+        // y * 32 + i for 16 rows per MFMA tile; the two k-halves of a column meet through one cross-lane add, the four
+        // waves (different rows, same columns) through 4 KiB of LDS, added in a fixed order
+        float* sl = reinterpret_cast<float*>(lds + 4 * (32 * XEPL * 4));          // [wave][2][128]
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const float k0 = g.stat_shift[n0 + y * 32 + i];
+            float sum = 0.f, sq = 0.f;
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[a][y][r] - k0;
+                    if (m0 + a * 32 + mfma32_row(r, kh) < g.M) { sum += d; sq = fmaf(d, d, sq); }
+                }
+            sum += __shfl_xor(sum, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (kh == 0) { sl[(wave * 2) * 128 + y * 32 + i] = sum; sl[(wave * 2 + 1) * 128 + y * 32 + i] = sq; }
+        }
+        __syncthreads();
+        {
+            const int which = tid >> 7, col = tid & 127;
+            const float v = ((sl[(0 * 2 + which) * 128 + col] + sl[(1 * 2 + which) * 128 + col]) +
+                             sl[(2 * 2 + which) * 128 + col]) + sl[(3 * 2 + which) * 128 + col];
+            g.stat_partial[((size_t)row_block * 2 + which) * g.N + n0 + col] = v;
+            if (row_block == 0 && which == 0)
+                g.stat_partial[(size_t)((g.M + TM - 1) / TM) * 2 * g.N + n0 + col] = g.stat_shift[n0 + col];
+        }
+    }
     const int er = lane >> 3, ec = (lane & 7) * 4;
 #pragma unroll
     for (int a = 0; a < WM; ++a)
@@ -320,8 +355,9 @@ extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K) {
 }
 
 extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
-                                  const float* addend, int ldd, int tile_rows, peclr_stream_t stream) {
-    if (!A || !Bp || !C) return PECLR_ERR_NULL;
+                                  const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
+                                  peclr_stream_t stream) {
+    if (!A || !Bp || !C || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || N % PN || K % PK) return PECLR_ERR_SHAPE;
     if (lda % 4 || lda < K || ldc % 4 || ldc < N || (addend && (ldd % 4 || ldd < N))) return PECLR_ERR_SHAPE;
     if (!aligned16(A) || !aligned16(Bp) || !aligned16(C) || (addend && !aligned16(addend))) return PECLR_ERR_ALIGN;
@@ -331,6 +367,7 @@ extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, 
     g.A = A; g.Bp = Bp; g.addend = addend; g.out = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldc; g.ldd = ldd;
     g.stream_out = (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
+    g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     const int nrb = (M + tile_rows - 1) / tile_rows;
     const dim3 grid(8 * ((nrb + 7) / 8) * (N / PN));
     if (tile_rows == 256) hipLaunchKernelGGL(gemm_x6p_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);

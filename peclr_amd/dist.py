@@ -159,13 +159,13 @@ class GradReducer:
         for b in self.buckets:
             for p, v in zip(b.params, b.views):
                 p.grad = v
-                self._owner[p] = b
+                self._owner[id(p)] = b
                 p.register_post_accumulate_grad_hook(self._hook)
 
     def _hook(self, p):
         if not self._armed or self.world == 1:
             return
-        b = self._owner[p]
+        b = self._owner[id(p)]
         b.pending -= 1
         if b.pending == 0:
             b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -174,9 +174,9 @@ class GradReducer:
         """Arm the hooks for the coming backward.  `unused`: parameters that will NOT receive a
         gradient in it (e.g. encoder.final_layer.*), so their buckets do not wait for them."""
         self._armed = True
-        skip = set(unused)
+        skip = {id(p) for p in unused}
         for b in self.buckets:
-            b.pending = sum(1 for p in b.params if p not in skip)
+            b.pending = sum(1 for p in b.params if id(p) not in skip)
             b.handle = None
 
     def finish(self):

@@ -113,11 +113,12 @@ class BaseModel(_Base):
             schedule = CosineAnnealingLR(optimizer, T_max=total_steps)
         return [optimizer], [{"scheduler": schedule, "interval": "step", "frequency": 1}]
 
-    # ---- epoch-end hooks (a11).  The monitored quantity is the TRAINING epoch's mean loss
-    # (base_model.py:111-115); the supervised models' "loss_3d" branch is not on this path.
+    # ---- epoch-end hooks (a11).  The monitored quantity is the TRAINING epoch's mean loss -- "loss_3d" when the step
+    # dict has one (the supervised subclasses of the reference inherit this hook), "loss" otherwise (base_model.py:111-115).
     def training_epoch_end(self, outputs: List[dict]):
         self.train_metrics_epoch = _epoch_mean(outputs)
-        self.log("checkpoint_saving_loss", self.train_metrics_epoch["loss"])
+        monitored = "loss_3d" if "loss_3d" in self.train_metrics_epoch else "loss"
+        self.log("checkpoint_saving_loss", self.train_metrics_epoch[monitored])
 
     def validation_epoch_end(self, outputs: List[dict]):
         self.validation_metrics_epoch = _epoch_mean(outputs)

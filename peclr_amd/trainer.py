@@ -138,6 +138,12 @@ class Trainer:
         model.sync_bn_group = group  # projection-head BatchNorm1d (ops.head_align)
 
     def _autocast(self):
+        """Context of every forward pass the trainer runs (also arms the side-stream weight gradients for it: the
+        trainer follows each of its backward passes with `_join_wgrad`)."""
+        if self.overlap_wgrad:
+            from . import bn2d as _bn2d
+
+            _bn2d.arm_wgrad_overlap()
         if self.precision == "fp32":
             return contextlib.nullcontext()
         dev = "cuda" if next(self.model.parameters()).is_cuda else "cpu"
@@ -173,16 +179,32 @@ class Trainer:
 
     def _check_uniform_batch(self, batch):
         """N > 1: the all-gather of the embeddings has a fixed shape and the positive-pair index map uses
-        the local pair count on global rows, so every rank must hold the same number of pairs.  Checked
-        (one tiny MIN/MAX all-reduce) whenever this rank's count changes; a ragged last batch that differs
-        across ranks is an error here instead of a hang or silently mis-paired positives."""
+        the local pair count on global rows, so every rank must hold the same number of pairs.  One tiny MAX
+        all-reduce of [n, -n] on EVERY eager micro-batch and on every rank (a rank-local "only when my count
+        changed" shortcut would leave the rank with the short batch alone in the collective): a ragged batch
+        that differs across ranks raises on every rank instead of hanging or silently mis-pairing positives."""
         if self.world_size == 1:
             return
         n = int(batch["transformed_image1"].shape[0])
-        if n == self._uniform_n:
-            return
         pdist.assert_uniform(n, self.process_group, batch["transformed_image1"].device, "pairs per rank")
         self._uniform_n = n
+
+    def _ranks_agree_on_replay(self, fits: bool, is_final_batch: bool) -> bool:
+        """Graph mode at N > 1: replay only if the batch fits the captured shapes on EVERY rank.  Decided with one
+        MIN all-reduce where a ragged batch can occur (the epoch's final batch: every rank is at its final batch, so
+        the collective is symmetric); elsewhere a batch that does not fit is an error raised before any collective."""
+        if self.world_size == 1 or self.reducer is None:
+            return fits
+        if not is_final_batch:
+            if not fits:
+                raise RuntimeError("a batch whose shapes differ from the captured graph's arrived before the epoch's final "
+                                   "batch: with data parallelism only the final batch of an epoch may be ragged")
+            return True
+        dev = next(self.model.parameters()).device
+        flag = torch.tensor([int(fits)], device="cpu" if torch.distributed.get_backend(self.process_group) == "gloo" else dev,
+                            dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
+        return bool(int(flag))
 
     def zero_grad(self):
         if self.reducer is not None:
@@ -226,7 +248,7 @@ class Trainer:
         if self.overlap_wgrad:
             from . import bn2d as _bn2d
 
-            _bn2d.wgrad_join()
+            _bn2d.wgrad_join(self.reducer._hook if self.reducer is not None else None)
 
     def _no_fp16_graphs(self):
         if self.precision == "fp16" and not self._device_scaler():
@@ -499,7 +521,7 @@ class Trainer:
         content of the accumulators; the micro-batch graph is then captured (a capture records, it does not run)."""
         out = self.training_micro_step(batch, batch_idx, is_final_batch)
         params = [p for p in self.model.parameters() if p.requires_grad]
-        carried = {p: p.grad for p in params if p.grad is not None}      # empty if that batch closed a window
+        carried = {id(p): p.grad for p in params if p.grad is not None}  # empty if that batch closed a window
         for p in params:
             p.grad = None
         self._static_batch = self._clone_batch(batch)
@@ -512,7 +534,7 @@ class Trainer:
             self._join_wgrad()
         pairs = [(p, p.grad) for p in params if p.grad is not None]
         self._micro_src = [g for _, g in pairs]
-        self._micro_acc = [carried[p] if p in carried else torch.zeros_like(g) for p, g in pairs]
+        self._micro_acc = [carried[id(p)] if id(p) in carried else torch.zeros_like(g) for p, g in pairs]
         for (p, _), a in zip(pairs, self._micro_acc):
             p.grad = a
         self._micro_pairs = [(p, a) for (p, _), a in zip(pairs, self._micro_acc)]
@@ -545,8 +567,8 @@ class Trainer:
             else:
                 self.capture_split_graphs(batch, warmup=1)
             return self._capture_eager_out
-        if sig != self._graph_sig:
-            # off-shape (ragged last) batch: eager step.  The gradients of the previous replay are still
+        if not self._ranks_agree_on_replay(sig == self._graph_sig, is_final_batch):
+            # off-shape (ragged last) batch on some rank: eager step on all of them.  The gradients of the previous replay are still
             # in place (a captured backward OVERWRITES its buffers, nothing zeroes them), so the eager
             # backward must not accumulate onto them.
             if self.reducer is None:

@@ -106,6 +106,12 @@ def worker(rank, world, port, out_dir):
     ragged = {k: v[: N_LOCAL - rank] for k, v in batch.items()}
     with pytest.raises(RuntimeError, match="differs across data-parallel ranks"):
         tr._check_uniform_batch(ragged)
+    # ... also when the counts were equal before and only ONE rank's changes (rank 0 keeps its usual batch): the check
+    # is a collective every rank enters on every micro-batch, not only the ranks whose own count moved
+    tr._check_uniform_batch(batch)
+    with pytest.raises(RuntimeError, match="differs across data-parallel ranks"):
+        tr._check_uniform_batch(ragged if rank == 1 else batch)
+    tr._check_uniform_batch(batch)
     # a full optimiser step keeps the replicas identical
     tr.optimizer.step()
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])

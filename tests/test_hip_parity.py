@@ -555,6 +555,37 @@ def solo_group(tmp_path_factory):
         td.destroy_process_group()
 
 
+def test_checkpointed_block_with_synchronised_statistics_moves_the_running_statistics_once(solo_group):
+    """Activation checkpointing re-runs a block's forward in the backward pass.  With synchronised statistics the
+    kernels need the (replicated) running mean as the common shift of their sums, so the re-run must get the copy
+    the first run used -- and must not update running_mean / running_var / num_batches_tracked a second time."""
+    from peclr_amd import bn2d as B
+    from peclr_amd import resnet
+
+    torch.manual_seed(11)
+    res = {}
+    for ckpt in (False, True):
+        torch.manual_seed(11)
+        block = resnet.Bottleneck(64, 16, norm_layer=B.FusedBatchNormAct2d).to(DEV).to(memory_format=torch.channels_last).train()
+        with torch.no_grad():
+            for bn in (block.bn1, block.bn2, block.bn3):
+                bn.running_mean.uniform_(-0.2, 0.2)
+        B.enable_hip_batchnorm(block, sync_group=solo_group)
+        block.checkpoint = ckpt
+        x = torch.randn(8, 64, 12, 12, generator=torch.Generator().manual_seed(1)).to(DEV).contiguous(memory_format=torch.channels_last)
+        x.requires_grad_()
+        block(x).square().mean().backward()
+        res[ckpt] = ([t.clone() for bn in (block.bn1, block.bn2, block.bn3) for t in (bn.running_mean, bn.running_var)],
+                     [int(bn.num_batches_tracked) for bn in (block.bn1, block.bn2, block.bn3)], x.grad.clone(),
+                     [p.grad.clone() for p in block.parameters()])
+    assert res[True][1] == res[False][1] == [1, 1, 1]
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    assert torch.allclose(res[True][2], res[False][2], rtol=0, atol=1e-6 * float(res[False][2].abs().max()) + 1e-9)
+    for a, b in zip(res[True][3], res[False][3]):
+        assert torch.allclose(a, b, rtol=0, atol=2e-5 * float(b.abs().max()) + 1e-9)
+
+
 @pytest.mark.parametrize("shape", [(4, 64, 8, 8), (3, 2048, 2, 2), (16, 64, 56, 56), (6, 256, 5, 7)])
 @pytest.mark.parametrize("relu,res", [(True, True), (False, False)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
@@ -769,7 +800,7 @@ def test_training_step_with_flat_grad_buckets_matches_plain():
             assert len(tr.reducer.buckets) > 3
             w = model.encoder.features[0].weight
             assert w.grad.stride() == w.stride() and w.is_contiguous(memory_format=torch.channels_last)
-            assert w.grad.untyped_storage().data_ptr() == tr.reducer._owner[w].flat.untyped_storage().data_ptr()
+            assert w.grad.untyped_storage().data_ptr() == tr.reducer._owner[id(w)].flat.untyped_storage().data_ptr()
         grads = [p.grad.detach().clone() for n, p in model.named_parameters() if "final_layer" not in n]
         before = [p.detach().clone() for p in model.parameters()]
         tr.optimizer.step()           # fused LARS/Adam straight out of the flat buckets
@@ -1774,6 +1805,76 @@ def test_gemm_x6p_equals_gemm_x6_bit_for_bit(capi, m, n, k, with_addend):
             capi.gemm_x6p(*bad)
     with pytest.raises(capi.PeclrHipError):
         capi.X6Planes([(bt[:100], False)])           # 100 output columns: not a multiple of 128
+
+
+@pytest.mark.parametrize("cin,cmid,hw", [(512, 128, 28), (1024, 256, 14), (2048, 512, 7), (256, 64, 56)])
+def test_batchnorm_statistics_from_the_gemm_epilogue_equal_the_separate_pass(cin, cmid, hw):
+    """conv1x1 -> BatchNorm2d pairs whose convolution runs as peclr_gemm_x6p_f32: the GEMM epilogue sums the layer's
+    training statistics from its accumulators (per row block, fixed order, centred on the running mean) and
+    peclr_bn2d_finalize_f32 takes them -- no pass re-reads the tensor the GEMM just wrote.  At ResNet-50's four
+    bottleneck shapes (2 x 128 views; the layer1 shape is not routed and must be unaffected): block output, input
+    gradient, parameter gradients and running statistics of the fused route against the separate peclr_bn2d_stats pass
+    and against torch in float64."""
+    from peclr_amd import _capi
+    from peclr_amd import bn2d as B
+    from peclr_amd import resnet
+
+    n = 256
+    g = torch.Generator().manual_seed(cin + hw)
+    x0 = (torch.randn(n, cin, hw, hw, generator=g) * 0.7 + 0.3).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, cin, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    res, launches = {}, {}
+    for fused in (False, True):
+        torch.manual_seed(7)
+        block = resnet.Bottleneck(cin, cmid, norm_layer=B.FusedBatchNormAct2d).to(DEV).to(memory_format=torch.channels_last).train()
+        with torch.no_grad():
+            for bn in (block.bn1, block.bn2, block.bn3):
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.3, 0.3)
+                bn.running_mean.uniform_(-0.1, 0.1)
+        B.enable_hip_batchnorm(block)
+        B._BN_STATS_IN_GEMM = fused
+        rm_start = block.bn1.running_mean.clone()
+        _capi.EVENT_LOG = {}
+        try:
+            x = x0.clone().requires_grad_()
+            y = block(x)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            launches[fused] = {k: len(v) for k, v in _capi.EVENT_LOG.items()}
+        finally:
+            _capi.EVENT_LOG = None
+            B._BN_STATS_IN_GEMM = True
+        res[fused] = (y.detach(), x.grad.clone(), [p.grad.clone() for p in block.parameters()],
+                      [(bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)) for bn in (block.bn1, block.bn2, block.bn3)],
+                      block, rm_start)
+    routed = B._x6_pays(n * hw * hw, cmid, cin)
+    assert launches[False]["bn2d_stats"] == 3
+    assert launches[True]["bn2d_stats"] == (1 if routed else 3), launches[True]      # bn2 sits behind MIOpen's 3x3
+    assert launches[True]["bn2d_finalize"] == 3
+    # fused against unfused: the same sums in another order and about another centre -> fp32 round-off apart in the
+    # forward.  In the backward a pre-activation within that round-off of zero may land on the other side of a ReLU
+    # (a handful of the 1e7 elements), which moves the gradient AT those elements by O(1): everything else agrees.
+    a, b = res[True][0], res[False][0]
+    assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max())
+    # (each such element reaches a 3 x 3 x Cin neighbourhood of the input gradient through the convolutions, so the
+    # comparison of the backward is norm-wise; the strict bars are on the forward output and on the statistics)
+    a, b = res[True][1], res[False][1]
+    assert float((a - b).norm()) <= 2e-2 * float(b.norm())
+    for a, b in zip(res[True][2], res[False][2]):
+        assert float((a - b).norm()) <= 2e-2 * float(b.norm()) + 1e-7
+    for (m1, v1, k1), (m0, v0, k0) in zip(res[True][3], res[False][3]):
+        assert k1 == k0 == 1
+        assert float((m1 - m0).abs().max()) <= 1e-6 and float((v1 - v0).abs().max()) <= 1e-6 * float(v0.abs().max()) + 1e-7
+    # the statistics themselves against float64 (where the tensor is small enough for that): bn1 normalises conv1(x); its
+    # running statistics moved from their start (running_var 1) by 0.1 of the batch mean / unbiased variance
+    if hw <= 14:
+        block, rm_start = res[True][4], res[True][5]
+        w1 = block.conv1.weight.detach().double().view(cmid, cin)
+        y1 = torch.einsum("nchw,oc->nohw", x0.double(), w1)
+        mean, var = y1.mean((0, 2, 3)), y1.var((0, 2, 3), unbiased=True)
+        assert float((res[True][3][0][0].double() - (0.9 * rm_start.double() + 0.1 * mean)).abs().max()) <= 2e-6
+        assert float((res[True][3][0][1].double() - (0.9 + 0.1 * var)).abs().max()) <= 2e-6 * float(var.max()) + 1e-6
 
 
 def test_x6_pack_group_follows_the_weights():

@@ -323,6 +323,22 @@ def _tiny_batches(n, count, seed=0, size=32):
     return batches
 
 
+def test_training_epoch_end_monitors_loss_3d_when_the_step_reports_one():
+    """base_model.py:111-115: `checkpoint_saving_loss` is the epoch mean of "loss_3d" if the step dicts carry that key
+    (the supervised subclasses of the reference inherit the hook), of "loss" otherwise."""
+    from peclr_amd.module import BaseModel
+
+    model = BaseModel.__new__(BaseModel)
+    torch.nn.Module.__init__(model)
+    logged = {}
+    model.log = lambda key, value, **kw: logged.__setitem__(key, float(value))
+    outs = [{"loss": torch.tensor(1.0), "loss_3d": torch.tensor(5.0)}, {"loss": torch.tensor(3.0), "loss_3d": torch.tensor(9.0)}]
+    model.training_epoch_end(outs)
+    assert logged["checkpoint_saving_loss"] == 7.0 and float(model.train_metrics_epoch["loss"]) == 2.0
+    model.training_epoch_end([{"loss": torch.tensor(1.0)}, {"loss": torch.tensor(3.0)}])
+    assert logged["checkpoint_saving_loss"] == 2.0
+
+
 def test_accumulation_steps_on_the_final_batch_of_the_epoch():
     """Lightning 1.0.8: `should_accumulate = not (accumulation_done or is_final_batch)` -- 5 batches with
     accumulate_grad_batches=2 are 3 optimiser steps per epoch (2 + 2 + 1), the trailing partial window is

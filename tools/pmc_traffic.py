@@ -6,6 +6,7 @@ counters, are reported in KiB, need SEPARATE passes (TCC slots), and on gfx950 F
 exactly half the bytes of a wide coalesced streaming read -> doubled here; WRITE_SIZE is taken as is
 (uncalibrated).  Usage:
     python tools/pmc_traffic.py <fetch_pass.db> <write_pass.db> <kernel-substring> [out.json]
+    python tools/pmc_traffic.py --table <fetch_pass.db> <write_pass.db> <manifest.json> <out.json>     (every bench tag)
 """
 import json
 import sqlite3
@@ -21,36 +22,26 @@ def per_launch(db, counter, needle):
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
-# bench.py kernel name -> substring of the HIP kernel symbol
-BENCH_KERNELS = {
-    "gemm_k1_fwd": None, "bn_relu_fwd": "bn_relu_fwd_kernel", "align_fwd": "align_fwd_kernel",
-    "ntxent_fwd": "ntxent_kernel<false>", "ntxent_finalize": "ntxent_finalize_kernel",
-    "ntxent_bwd": "ntxent_kernel<true>", "slab_reduce": "slab_reduce_kernel", "align_bwd": "align_bwd_kernel",
-    "bn_relu_bwd": "bn_relu_bwd_kernel", "lars_sumsq": "sumsq_kernel", "lars_adam_update": "lars_adam_kernel",
-    "bn2d_stats": "bn2d_stats_kernel", "bn2d_finalize": "bn2d_stats_finalize_kernel", "bn2d_apply": "bn2d_apply_kernel",
-    "bn2d_bwd_reduce": "bn2d_bwd_reduce_kernel", "bn2d_bwd_finalize": "bn2d_bwd_finalize_kernel",
-    "bn2d_bwd_apply": "bn2d_bwd_apply_kernel",
-    "bn2d_pool_apply": "bn2d_pool_apply_kernel", "bn2d_pool_bwd_reduce": "bn2d_pool_bwd_reduce_kernel",
-    "bn2d_pool_bwd_apply": "bn2d_pool_bwd_apply_kernel", "bn2d_apply_avgpool": "bn2d_apply_avgpool_kernel",
-    "conv1x1_dgrad_add": "gemm_f32_nn128_kernel",
-}
+def table(fetch_db, write_db, manifest, out_path):
+    """Per bench tag: the FETCH / WRITE counters of exactly the launches the bench timed under that tag (both passes are
+    aligned with the launch manifest, as tools/pmc_mfma.py does), so `traffic` and the bench's `algorithmic_bytes`
+    describe the same launches.  Keyed by tag; `symbol` is the kernel that ran."""
+    sys.path.insert(0, __file__.rsplit("/", 1)[0])
+    from pmc_mfma import align
 
-
-def table(fetch_db, write_db, out_path):
+    order = json.load(open(manifest))["order"]
+    f, w = align(fetch_db, order), align(write_db, order)
     out = {}
-    for bench_name, needle in BENCH_KERNELS.items():
-        if needle is None:
+    for tag in f:
+        fv, wv = f[tag]["counters"].get("FETCH_SIZE"), w.get(tag, {}).get("counters", {}).get("WRITE_SIZE")
+        if not fv or not wv:
             continue
-        f, nf = per_launch(fetch_db, "FETCH_SIZE", needle)
-        w, nw = per_launch(write_db, "WRITE_SIZE", needle)
-        if f is None or w is None:
-            continue
-        out[bench_name] = {"symbol": needle, "launches_sampled": [nf, nw], "FETCH_SIZE_KiB_raw": round(f, 2),
-                           "WRITE_SIZE_KiB_raw": round(w, 2),
-                           "traffic_bytes_per_launch": round((2 * f + w) * 1024)}
-    out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py; per-launch means; "
-                    "FETCH_SIZE doubled (gfx950 tallies wide coalesced reads at half), WRITE_SIZE as reported "
-                    "(MI355X_MICROARCH.md section HBM)")
+        fk, wk = sum(fv) / len(fv), sum(wv) / len(wv)
+        out[tag] = {"symbol": f[tag]["symbol"], "launches_sampled": [len(fv), len(wv)], "FETCH_SIZE_KiB_raw": round(fk, 2),
+                    "WRITE_SIZE_KiB_raw": round(wk, 2), "traffic_bytes_per_launch": round((2 * fk + wk) * 1024)}
+    out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py --graph 0; per-launch means over "
+                    "the launches of each bench tag (launch manifest); FETCH_SIZE doubled (gfx950 tallies wide coalesced reads "
+                    "at half), WRITE_SIZE as reported (MI355X_MICROARCH.md section HBM)")
     with open(out_path, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out, indent=1))
@@ -58,7 +49,7 @@ def table(fetch_db, write_db, out_path):
 
 def main():
     if sys.argv[1] == "--table":
-        return table(sys.argv[2], sys.argv[3], sys.argv[4])
+        return table(*sys.argv[2:6])
     fetch_db, write_db, needle = sys.argv[1:4]
     fetch_kib, nf = per_launch(fetch_db, "FETCH_SIZE", needle)
     write_kib, nw = per_launch(write_db, "WRITE_SIZE", needle)

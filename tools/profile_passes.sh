@@ -1,10 +1,10 @@
 #!/bin/bash
-# rocprofv3 passes behind profiles/r02_* and profiles/pmc_traffic.json: kernel trace + two SQ counter passes + the two
+# rocprofv3 passes behind profiles/r03_* and profiles/pmc_traffic.json: kernel trace + two SQ counter passes + the two
 # HBM-traffic passes (FETCH_SIZE and WRITE_SIZE need separate passes: TCC slots) (8 SQ slots per pass; counters
 # only with --kernel-trace, never with the sys/hip/hsa trace domains), for (a) the labelled MFMA probe and
 # (b) the eager default bench.  Run from the repo root on the MI355X box:  bash tools/profile_passes.sh <outdir>
 set -u
-OUT=${1:-gpurun_out/r02_prof}
+OUT=${1:-gpurun_out/r03_prof}
 ROOT=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -32,7 +32,7 @@ run bench_pmc_b "$PMC_B" $BENCH
 run bench_pmc_fetch "FETCH_SIZE" $BENCH
 run bench_pmc_write "WRITE_SIZE" $BENCH
 cd "$ROOT"
-python tools/pmc_traffic.py --table "$OUT/bench_pmc_fetch/p_results.db" "$OUT/bench_pmc_write/p_results.db" "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.txt" 2>&1
+python tools/pmc_traffic.py --table "$OUT/bench_pmc_fetch/p_results.db" "$OUT/bench_pmc_write/p_results.db" "$OUT/bench_pmc_fetch/manifest.json" "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.txt" 2>&1
 python tools/pmc_mfma.py "$OUT/probe_trace/p_results.db" "$OUT/probe_trace/manifest.json" "$OUT/probe_mfma.json" \
   "$OUT/probe_pmc_a/p_results.db" "$OUT/probe_pmc_b/p_results.db" > "$OUT/probe_mfma.txt" 2>&1
 python tools/pmc_mfma.py "$OUT/bench_trace/p_results.db" "$OUT/bench_trace/manifest.json" "$OUT/bench_mfma.json" \
