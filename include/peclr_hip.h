@@ -107,7 +107,8 @@ int peclr_gemm_x6_tn_f32(int M, int N, int K, const float* A, int lda, const flo
  * activation operand in the kernel (once per 128 output columns, by the one wave that owns the row).
  *   desc_table: DEVICE array of `count` entries of 8 int64 {src fp32 matrix, dst planes, n, k, ld (floats), transposed,
  *   first chunk, 0}; B_t[n][k] = src[n * ld + k] (transposed = 0: forward, W[Cout][Cin]) or src[k * ld + n]
- *   (transposed = 1: input gradients, B_t = W^T); n % 128 == 0, k % 16 == 0; chunks per matrix = (n / 128) * (k / 16);
+ *   (transposed = 1: input gradients, B_t = W^T) or, for a T-tap filter W[Cout][T][Cin] read for its input gradient,
+ *   transposed = T: B_t[ci][tap * Cout + co] = src[(co * T + tap) * ld + ci]; n % 128 == 0, k % 16 == 0; chunks per matrix = (n / 128) * (k / 16);
  *   dst holds peclr_x6_pack_bytes(n, k) = 6 n k bytes.  One launch packs every matrix of the table.
  *   peclr_gemm_x6p_f32: C[M,N] = A[M,K] . B_t^T (+ addend); tile_rows 256, 128 or 0 (= peclr_gemm_x6p_tile_rows).
  *   stat_partial (nullable; needs stat_shift[N]): the training-mode BatchNorm2d statistics of C (the `conv -> bn` pair of
@@ -121,6 +122,16 @@ int peclr_gemm_x6p_tile_rows(int M, int N, int K);
 int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                        const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
                        peclr_stream_t stream);
+/* 3x3 / stride-1 / padding-1 convolution of an NHWC fp32 tensor (the middle convolution of the torchvision Bottleneck,
+ * resnet_model.py:15) as an implicit GEMM on the same kernel: rows = output pixels, K = 9 * Cin ordered (tap, channel); the
+ * activation rows of a k-step come from the pixel the tap points at (zeros outside the image: `zeros` = >= 64 bytes of
+ * zeros), the weights from planes packed out of W[Cout][3][3][Cin] (channels_last storage) seen as [Cout][9 * Cin].
+ * flip = 1 computes the INPUT GRADIENT dX = conv(dY, flipped filter): pass dY as X, Cin := Cout, Cout := Cin and planes
+ * packed with `transposed` = 9 (B_t[ci][tap * Cout + co] = W[co][tap][ci]).  addend, tile_rows and the BatchNorm
+ * statistics outputs as in peclr_gemm_x6p_f32.  Cin % 16 == 0, Cout % 128 == 0.                                      */
+int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* X, const void* Bp, float* Y,
+                          const float* addend, int flip, int tile_rows, const float* zeros, const float* stat_shift,
+                          float* stat_partial, peclr_stream_t stream);
 int peclr_gemm_pick_split_k(int M, int N, int K);
 
 /* out[i] = sum_s slabs[s][i] (+ bias[i % cols] if non-null), i < rows*cols. */

@@ -72,6 +72,7 @@ SIGNATURES = {
     "peclr_x6_pack_f32": (c_int, [_P, c_int, c_int, _P]),
     "peclr_gemm_x6p_tile_rows": (c_int, [c_int, c_int, c_int]),
     "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P, _P, _P]),
+    "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
@@ -407,12 +408,13 @@ class X6Planes:
             _ptr(w, what="x6 weight")
             if w.dim() != 2:
                 raise PeclrHipError("X6Planes: 2-D weight matrices expected")
-            n, k = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+            t = int(transposed)                     # 0 plain, 1 transposed, T > 1: T-tap filter [Cout * T, Cin] for its input gradient
+            n, k = (w.shape[1], w.shape[0]) if t else (w.shape[0], w.shape[1])
             nbytes = lib().peclr_x6_pack_bytes(n, k)
             if nbytes <= 0:
                 raise PeclrHipError(f"X6Planes: B_t[{n}, {k}] needs n % 128 == 0 and k % 16 == 0")
             planes = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-            rows.append([w.data_ptr(), planes.data_ptr(), n, k, w.stride(0), int(bool(transposed)), chunk, 0])
+            rows.append([w.data_ptr(), planes.data_ptr(), n, k, w.stride(0), t, chunk, 0])
             chunk += (n // 128) * (k // 16)
             self.planes.append(planes)
             self.shapes.append((n, k))
@@ -450,6 +452,42 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
                                       tile_rows, _ptr(stat_shift), _ptr(partial), _stream())
     _check(rc, "peclr_gemm_x6p_f32")
     return out if stat_shift is None else (out, partial, ns)
+
+
+_ZEROS = {}
+
+
+def _zeros(device):
+    z = _ZEROS.get(device)
+    if z is None:
+        z = _ZEROS[device] = torch.zeros(64, device=device, dtype=torch.float32)
+    return z
+
+
+def conv3x3_x6p(x: torch.Tensor, planes: torch.Tensor, cout: int, flip: bool = False, addend: Optional[torch.Tensor] = None,
+                tag: str = "conv3x3_x6p", tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None):
+    """3x3 / stride-1 / padding-1 convolution of an NHWC (channels_last) fp32 tensor x [N, Cin, H, W] as an implicit GEMM on
+    the bf16 matrix cores at fp32 accuracy (peclr_conv3x3_x6p_f32); `planes` = X6Planes of W seen as [Cout, 9 * Cin]
+    (flip=False) or, for the input gradient (flip=True, x = dY), of [Cout_w * 9, Cin_w] packed with transposed = 9.
+    Returns y [N, cout, H, W] channels_last (and (partial, n_split) when stat_shift is given)."""
+    nb, cin, h, w = x.shape
+    xp = _nhwc_ptr(x, "conv3x3 x", torch.float32)
+    if planes.dtype != torch.uint8 or planes.numel() != 6 * cout * 9 * cin:
+        raise PeclrHipError(f"conv3x3_x6p: planes of {planes.numel()} bytes for [{cout}, 9 * {cin}]")
+    y = torch.empty((nb, cout, h, w), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    m = nb * h * w
+    partial, ns = None, 0
+    if stat_shift is not None:
+        tile_rows = tile_rows or lib().peclr_gemm_x6p_tile_rows(m, cout, 9 * cin)
+        ns = (m + tile_rows - 1) // tile_rows
+        partial = torch.empty((2 * ns + 1, cout), device=x.device, dtype=torch.float32)
+    ap = _nhwc_ptr(addend, "conv3x3 addend", torch.float32) if addend is not None else None
+    with _timed(tag, 4 * (m * cin + (2 if addend is not None else 1) * m * cout) + 54 * cin * cout, 18 * m * cin * cout,
+                kernel="gemm_x6p_kernel (3x3)"):
+        rc = lib().peclr_conv3x3_x6p_f32(nb, h, w, cin, cout, xp, _ptr(planes, torch.uint8), y.data_ptr(), ap, int(flip), tile_rows,
+                                         _zeros(x.device).data_ptr(), _ptr(stat_shift), _ptr(partial), _stream())
+    _check(rc, "peclr_conv3x3_x6p_f32")
+    return y if stat_shift is None else (y, partial, ns)
 
 
 def gemm_x6_tn(a: torch.Tensor, b: torch.Tensor, tag: str = "gemm_x6_tn") -> torch.Tensor:

@@ -95,8 +95,10 @@ class X6PackGroup:
     @staticmethod
     def member(conv) -> bool:
         cout, cin = conv.out_channels, conv.in_channels
-        return (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
-                and conv.bias is None and cout >= 128 and cin >= 128 and cout % 128 == 0 and cin % 128 == 0)
+        shape_ok = ((conv.kernel_size == (1, 1) and conv.padding == (0, 0)) or
+                    (conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1)))
+        return (shape_ok and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None and cout >= 128 and cin >= 128
+                and cout % 128 == 0 and cin % 128 == 0)
 
     def _key(self, conv):
         return (conv.weight.data_ptr(), conv.weight._version, _capi.WEIGHTS_EPOCH)
@@ -106,8 +108,16 @@ class X6PackGroup:
         if self._x6 is None or ptrs != self._ptrs:
             specs = []
             for c in self.convs:
-                w2 = c.weight.detach().reshape(c.out_channels, c.in_channels)
-                specs += [(w2, False), (w2, True)]
+                if c.kernel_size == (3, 3):
+                    # [Cout][3][3][Cin] as it lies in (channels_last) memory: forward B_t = [Cout, 9 Cin]; input gradient
+                    # B_t[ci][tap * Cout + co] = W[co][tap][ci]
+                    w4 = c.weight.detach().permute(0, 2, 3, 1)
+                    if not w4.is_contiguous():
+                        raise _capi.PeclrHipError("X6PackGroup: 3x3 weights must be channels_last (NHWC encoder)")
+                    specs += [(w4.reshape(c.out_channels, 9 * c.in_channels), False), (w4.reshape(c.out_channels * 9, c.in_channels), 9)]
+                else:
+                    w2 = c.weight.detach().reshape(c.out_channels, c.in_channels)
+                    specs += [(w2, False), (w2, True)]
             self._x6 = _capi.X6Planes(specs)
             self._ptrs = ptrs
         self._x6.pack()
@@ -421,6 +431,38 @@ class _Conv1x1Gemm(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+_CONV3X3_X6 = os.environ.get("PECLR_CONV3X3_X6", "1") != "0"   # A/B switch: 3x3 stride-1 convolutions as implicit x6p GEMMs
+
+
+class _Conv3x3Gemm(torch.autograd.Function):
+    """3x3 / stride-1 / padding-1 convolution of an NHWC fp32 tensor as an implicit GEMM on the bf16 matrix cores at
+    fp32 accuracy (peclr_conv3x3_x6p_f32: rows = output pixels, K = 9 Cin in (tap, channel) order, the activation rows
+    of a k-step read from the pixel its tap points at, the filter from planes packed once per step): forward and input
+    gradient (the same kernel on the flipped filter); the weight gradient stays on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight, conv, stats=None):
+        ctx.save_for_backward(x, weight)
+        planes = _x6_planes(conv)
+        ctx.cfg = (conv, planes)
+        cout = weight.shape[0]
+        shift = _stat_shift_for(stats[0], cout) if (stats and _BN_STATS_IN_GEMM) else None
+        if shift is not None:
+            y, partial, ns = _capi.conv3x3_x6p(x, planes[0], cout, tag="conv3x3_fwd", tile_rows=256, stat_shift=shift)
+            stats[:] = [partial, ns, shift, stats[0]]
+            return y
+        return _capi.conv3x3_x6p(x, planes[0], cout, tag="conv3x3_fwd", tile_rows=256)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        conv, planes = ctx.cfg
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        dw = _conv_wgrad(gy, x, weight, (1, 1), (1, 1), conv.weight) if ctx.needs_input_grad[1] else None
+        dx = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=256) if ctx.needs_input_grad[0] else None
+        return dx, dw, None, None
+
+
 def _attach_stats(y: Tensor, stats):
     """Hand the statistics a GEMM epilogue summed to the BatchNorm that consumes `y` (FusedBatchNormAct2d.forward looks for them)."""
     if stats is not None and len(stats) == 4:
@@ -448,6 +490,11 @@ class Conv2d(nn.Conv2d):
             if use_fwd or use_bwd or use_wgrad:
                 stats = [stats_for] if (stats_for is not None and use_fwd) else None
                 return _attach_stats(_Conv1x1Gemm.apply(x, self.weight, self, use_fwd, use_bwd, stats), stats)
+        if (self.hip_gemm and _CONV3X3_X6 and _GEMM_X6P and getattr(self, "x6_group", None) is not None and self.kernel_size == (3, 3)
+                and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x.dim() == 4
+                and x.is_contiguous(memory_format=torch.channels_last) and x.shape[0] * x.shape[2] * x.shape[3] >= 8192):
+            stats = [stats_for] if stats_for is not None else None
+            return _attach_stats(_Conv3x3Gemm.apply(x, self.weight, self, stats), stats)
         if (_overlap_stream() is not None and x.is_cuda and torch.is_grad_enabled() and self.bias is None
                 and self.groups == 1 and self.dilation == (1, 1) and isinstance(self.padding, tuple)
                 and x.is_contiguous(memory_format=torch.channels_last) and self.weight.requires_grad):
@@ -610,8 +657,8 @@ def enable_hip_batchnorm(module: nn.Module, enabled: bool = True, sync_group=Non
             n += 1
         elif getattr(m, "fork_entry", False):   # bottleneck conv1 (resnet.Bottleneck marks it)
             m.hip_fork = enabled
-        if isinstance(m, Conv2d) and m.kernel_size == (1, 1) and m.stride == (1, 1):
-            m.hip_gemm = enabled                # fp32 1x1 convolutions as GEMMs where that is faster (`_x6_pays`)
+        if isinstance(m, Conv2d) and m.kernel_size in ((1, 1), (3, 3)) and m.stride == (1, 1):
+            m.hip_gemm = enabled                # fp32 1x1 (where `_x6_pays`) and 3x3 stride-1 convolutions as in-tree GEMMs
             m.x6_group = None
     if enabled:                                 # their weights are split into bf16 planes once per step, all in one launch
         X6PackGroup([m for m in module.modules() if isinstance(m, Conv2d) and (m.hip_gemm or getattr(m, "hip_fork", False))])

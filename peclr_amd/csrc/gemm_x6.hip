@@ -1,9 +1,9 @@
 // fp32 GEMM on the bf16 matrix cores: C[M,N] = A[M,K] . B[N,K]^T (+ addend[M,N]), fp32 in, fp32 out.
 //
 // gfx950 multiplies bf16 16x faster than fp32 (v_mfma_f32_32x32x16_bf16: 32 768 flop in 32 cycles; v_mfma_f32_32x32x2_f32:
-// 4 096 flop in 64).  An fp32 number splits EXACTLY into three bf16 numbers by truncation,
-//     h = x & 0xFFFF0000,  m = (x - h) & 0xFFFF0000,  l = (x - h) - m        (x == h + m + l; 8 + 8 + 8 significand bits)
-// so a.b = sum of nine bf16 products; the three smallest (m.l, l.m, l.l: <= 2^-24 |a.b|, the size of ONE fp32 rounding)
+// 4 096 flop in 64).  An fp32 number splits EXACTLY into three bf16 numbers,
+//     h = bf16(x),  m = bf16(x - h),  l = (x - h) - m        (round to nearest; x == h + m + l; 8 + 8 + 8 significand bits)
+// so a.b = sum of nine bf16 products; the three smallest (m.l, l.m, l.l: <= 2^-27 |a.b|, zero-mean, below ONE fp32 rounding)
 // are dropped and the other six run on the bf16 MFMA with fp32 accumulation:
 //     a.b ~= h.h + (h.m + m.h) + (h.l + l.h + m.m)
 // Six MFMAs of 32 cycles replace eight of 64 per 32x32x16 block: 2.67x the fp32 MFMA rate at fp32 accuracy (measured
@@ -13,7 +13,7 @@
 // mean the run has diverged; parts below the bf16 denormal range (|x| < 2^-133) are flushed.
 //
 // Kernel: 128 x 128 tile, 4 waves x (2 x 2) MFMA tiles, K-tile = 32 fp32.  Both operands are K-contiguous ("NT"): a
-// thread loads 16-byte words of 4 consecutive k, splits them in registers (and / sub / perm: 5.5 VALU ops per element,
+// thread loads 16-byte words of 4 consecutive k, splits them in registers (cvt_pk / shift / sub: 5.5 VALU ops per element,
 // ~40 % of the MFMA time, on the other pipe) and writes three bf16 planes per operand to LDS (row pitch 80 bytes:
 // ds_read_b128 fragments of 8 k-values, bank-conflict free).  One 60 KiB LDS image, next K-tile staged in registers,
 // 2 workgroups per CU.  Epilogue as in gemm_f32_nn128_kernel: wave-private 32 x 32 transposes through LDS so that
@@ -43,26 +43,14 @@ struct X6Args {
     int stream_out;
 };
 
-// x -> (h, m, l), exact.  The results keep their value in the HIGH 16 bits (a bf16 is the top half of an fp32).
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-    h = __float_as_uint(x) & 0xFFFF0000u;
-    const float r1 = x - __uint_as_float(h);
-    m = __float_as_uint(r1) & 0xFFFF0000u;
-    l = __float_as_uint(r1 - __uint_as_float(m));   // <= 8 significant bits: its low half is zero
-}
-__device__ __forceinline__ unsigned pack_hi(unsigned lo_elem, unsigned hi_elem) {   // {hi_elem[31:16], lo_elem[31:16]}
-    return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302u);
-}
-// one float4 (4 consecutive k) -> 8 bytes in each of the three planes
+// one float4 (4 consecutive k) -> 8 bytes in each of the three planes (common.hpp split3_pk: exact, round to nearest)
 __device__ __forceinline__ void split_store(bf16_t* planes, int offset, const float4& v, int plane = PLANE) {
-    unsigned h[4], m[4], l[4];
-    split3(v.x, h[0], m[0], l[0]);
-    split3(v.y, h[1], m[1], l[1]);
-    split3(v.z, h[2], m[2], l[2]);
-    split3(v.w, h[3], m[3], l[3]);
-    *reinterpret_cast<uint2*>(planes + offset) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
-    *reinterpret_cast<uint2*>(planes + plane + offset) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
-    *reinterpret_cast<uint2*>(planes + 2 * plane + offset) = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
+    unsigned h[2], m[2], l[2];
+    split3_pk(v.x, v.y, h[0], m[0], l[0]);
+    split3_pk(v.z, v.w, h[1], m[1], l[1]);
+    *reinterpret_cast<uint2*>(planes + offset) = make_uint2(h[0], h[1]);
+    *reinterpret_cast<uint2*>(planes + plane + offset) = make_uint2(m[0], m[1]);
+    *reinterpret_cast<uint2*>(planes + 2 * plane + offset) = make_uint2(l[0], l[1]);
 }
 __device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, f32x16 acc) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);

@@ -1,7 +1,7 @@
 // fp32 GEMM on the bf16 matrix cores, second generation: C[M,N] = A[M,K] . W[N,K]^T (+ addend), fp32 in / fp32 out,
 // with the WEIGHT operand split once per optimiser step instead of once per workgroup.
 //
-// Same arithmetic as gemm_x6.hip (x == h + m + l exactly, three bf16 numbers by truncation; six of the nine partial
+// Same arithmetic as gemm_x6.hip (x == h + m + l exactly, three bf16 numbers, common.hpp split3_pk; six of the nine partial
 // products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, smallest first), different data path:
 //
 //   * W is a parameter: it changes once per step and is used by thousands of workgroups (forward, input gradient,
@@ -49,17 +49,13 @@ struct X6PArgs {
     // plus the shift itself in row [n row blocks] -- the layout peclr_bn2d_finalize_f32 combines
     const float* stat_shift;
     float* stat_partial;
+    // TAPS = 9 (3x3 convolution, stride 1, padding 1, as an implicit GEMM over NHWC rows): A is the activation [M = N*H*W][lda
+    // = Cin], K = 9 * Cin ordered (tap, channel), tap = 3 * a + b reads the pixel at (+a-1, +b-1) -- (1-a, 1-b) when
+    // `flip` (the input gradient's correlation with the flipped filter) -- or zeros outside the image
+    int H, W, flip;
+    const float* zeros;                  // >= 64 bytes of zeros (source of the padding pixels)
 };
 
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-    h = __float_as_uint(x) & 0xFFFF0000u;
-    const float r1 = x - __uint_as_float(h);
-    m = __float_as_uint(r1) & 0xFFFF0000u;
-    l = __float_as_uint(r1 - __uint_as_float(m));
-}
-__device__ __forceinline__ unsigned pack_hi(unsigned lo_elem, unsigned hi_elem) {
-    return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302u);
-}
 __device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, f32x16 acc) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
@@ -78,7 +74,7 @@ __device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_offset)
 // AREG: the fp32 rows travel global -> registers (inline-asm loads, hand-counted) instead of global -> LDS (DMA) -> registers
 // ABL: ablation switches for tools/exp/x6p_ablate.hip (0 in the library): 1 no split / plane stores in the loop, 2 no raw-row
 // loads either, 4 no B DMA in the loop, 8 no MFMAs (bits combine)
-template <int WM, int ABL = 0, bool AREG = true, bool ILV = true>
+template <int WM, int ABL = 0, bool AREG = true, bool ILV = true, int TAPS = 1>
 __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     constexpr int RM = 32 * WM;                          // rows per wave
     constexpr int TM = 4 * RM;                           // rows per workgroup
@@ -118,12 +114,24 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
 
     // this lane's fp32 source: rows (lane >> 2) + 16 c of the wave's block, k-quad lane & 3 (rows past M re-read row M - 1)
     const float* asrc[NRAW];
+    unsigned tapmask[NRAW];                               // TAPS = 9: bit tap = that tap's pixel lies inside the image
 #pragma unroll
     for (int c = 0; c < NRAW; ++c) {
         int row = m0 + 16 * c + (lane >> 2);
         row = row < g.M ? row : g.M - 1;
         asrc[c] = g.A + (size_t)row * g.lda + 4 * (lane & 3);
+        tapmask[c] = 0;
+        if constexpr (TAPS == 9) {
+            const int ow = row % g.W, oh = (row / g.W) % g.H;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dh = g.flip ? 1 - tap / 3 : tap / 3 - 1, dw = g.flip ? 1 - tap % 3 : tap % 3 - 1;
+                if ((unsigned)(oh + dh) < (unsigned)g.H && (unsigned)(ow + dw) < (unsigned)g.W) tapmask[c] |= 1u << tap;
+            }
+        }
     }
+    const float* const zsrc = TAPS == 9 ? g.zeros + 4 * (lane & 3) : nullptr;
+    const int kpt = TAPS == 9 ? g.lda / PK : 0;            // k-steps per tap
     auto issue_b = [&](int t) {                           // wave's three pieces of chunk t -> buffer t % NB
         const unsigned char* s = bsrc + (size_t)t * CHUNK;
         const unsigned d = b_a + (t % NB) * CHUNK;
@@ -132,10 +140,20 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     };
     f32x4 ar[NRAW];                                       // AREG: the next k-step's rows, in flight / landed
     auto issue_a = [&](int t) {
+        long off = (long)t * PK;                          // floats from the row's first channel
+        int tap = 0;
+        if constexpr (TAPS == 9) {
+            tap = t / kpt;
+            const int a = tap / 3, b = tap - 3 * a;
+            const int dh = g.flip ? 1 - a : a - 1, dw = g.flip ? 1 - b : b - 1;
+            off = (long)(dh * g.W + dw) * g.lda + (t - tap * kpt) * PK;
+        }
 #pragma unroll
         for (int c = 0; c < NRAW; ++c) {
-            if constexpr (AREG) ar[c] = *reinterpret_cast<const f32x4*>(asrc[c] + t * PK);
-            else dma16(asrc[c] + t * PK, raw_a + c * 1024);
+            const float* src = asrc[c] + off;
+            if constexpr (TAPS == 9) src = (tapmask[c] >> tap) & 1u ? src : zsrc;
+            if constexpr (AREG) ar[c] = *reinterpret_cast<const f32x4*>(src);
+            else dma16(src, raw_a + c * 1024);
         }
     };
     // rows of the k-step just landed -> three planes [k-half][row][8 k] (this lane: row 16 c + (lane >> 2),
@@ -147,13 +165,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
             f32x4 v;
             if constexpr (AREG) v = ar[c];
             else v = *reinterpret_cast<const f32x4*>(raw + c * 1024 + lane * 16);
-            unsigned h[4], m[4], l[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) split3(v[q], h[q], m[q], l[q]);
+            unsigned h[2], m[2], l[2];
+            split3_pk(v[0], v[1], h[0], m[0], l[0]);
+            split3_pk(v[2], v[3], h[1], m[1], l[1]);
             unsigned char* d = planes + poff + c * 256;
-            *reinterpret_cast<uint2*>(d) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
-            *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
-            *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
+            *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
+            *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(m[0], m[1]);
+            *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(l[0], l[1]);
         }
     };
 
@@ -292,7 +310,9 @@ struct PackDesc {           // device table entry (8 x int64)
     int64_t src, dst;       // fp32 matrix, packed output
     int64_t n, k;           // logical B_t[n][k] extents (n multiple of 128, k multiple of 16)
     int64_t ld;             // leading dimension of src (floats)
-    int64_t transposed;     // 0: B_t[n][k] = src[n * ld + k];  1: B_t[n][k] = src[k * ld + n]
+    int64_t transposed;     // 0: B_t[n][k] = src[n * ld + k];  1: B_t[n][k] = src[k * ld + n];  T > 1 (a T-tap filter
+                            // W[Cout][T][Cin] read for its input gradient, n = ci, k = tap * Cout + co, Cout = k extent / T):
+                            // B_t[n][k] = src[((k % Cout) * T + k / Cout) * ld + n]
     int64_t chunk_begin;    // first chunk of this matrix in the launch
     int64_t pad;
 };
@@ -308,7 +328,14 @@ __global__ __launch_bounds__(256) void x6_pack_kernel(const PackDesc* descs, int
     const int n = ct * PN + col, k0 = ks * PK + 8 * kh;
     const float* src = reinterpret_cast<const float*>(e.src);
     float v[8];
-    if (e.transposed) {
+    if (e.transposed > 1) {
+        const int taps = (int)e.transposed, cout = (int)(e.k / taps);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q, tap = k / cout, co = k - tap * cout;
+            v[q] = src[((size_t)co * taps + tap) * e.ld + n];
+        }
+    } else if (e.transposed) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = src[(size_t)(k0 + q) * e.ld + n];
     } else {
@@ -316,14 +343,14 @@ __global__ __launch_bounds__(256) void x6_pack_kernel(const PackDesc* descs, int
         const float4 hi = *reinterpret_cast<const float4*>(src + (size_t)n * e.ld + k0 + 4);
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
     }
-    unsigned h[8], m[8], l[8];
+    unsigned h[4], m[4], l[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) split3(v[q], h[q], m[q], l[q]);
+    for (int q = 0; q < 4; ++q) split3_pk(v[2 * q], v[2 * q + 1], h[q], m[q], l[q]);
     unsigned char* dst = reinterpret_cast<unsigned char*>(e.dst) + (size_t)chunk * CHUNK + ((col >> 5) * 3) * 1024 +
                          ((col & 31) + 32 * kh) * 16;
-    *reinterpret_cast<uint4*>(dst) = make_uint4(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]), pack_hi(h[4], h[5]), pack_hi(h[6], h[7]));
-    *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]), pack_hi(m[4], m[5]), pack_hi(m[6], m[7]));
-    *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]), pack_hi(l[4], l[5]), pack_hi(l[6], l[7]));
+    *reinterpret_cast<uint4*>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
 }  // namespace
@@ -354,6 +381,40 @@ extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K) {
     return c128 < c256 ? 128 : 256;
 }
 
+extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K);
+
+static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t stream) {
+    const int nrb = (g.M + tile_rows - 1) / tile_rows;
+    const dim3 grid(8 * ((nrb + 7) / 8) * (g.N / PN));
+    if (taps == 9) {
+        if (tile_rows == 256) hipLaunchKernelGGL((gemm_x6p_kernel<2, 0, true, true, 9>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_x6p_kernel<1, 0, true, true, 9>), grid, dim3(256), 0, stream, g);
+    } else {
+        if (tile_rows == 256) hipLaunchKernelGGL(gemm_x6p_kernel<2>, grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL(gemm_x6p_kernel<1>, grid, dim3(256), 0, stream, g);
+    }
+    return launch_status();
+}
+
+extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* X, const void* Bp, float* Y,
+                                     const float* addend, int flip, int tile_rows, const float* zeros,
+                                     const float* stat_shift, float* stat_partial, peclr_stream_t stream) {
+    if (!X || !Bp || !Y || !zeros || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
+    if (NB <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cout % PN || Cin % PK) return PECLR_ERR_SHAPE;
+    if ((long)NB * H * W > 0x7FFFFFFFL / 2) return PECLR_ERR_SHAPE;
+    if (!aligned16(X) || !aligned16(Bp) || !aligned16(Y) || !aligned16(zeros) || (addend && !aligned16(addend))) return PECLR_ERR_ALIGN;
+    const int M = NB * H * W;
+    if (tile_rows == 0) tile_rows = peclr_gemm_x6p_tile_rows(M, Cout, 9 * Cin);
+    if (tile_rows != 128 && tile_rows != 256) return PECLR_ERR_UNSUPPORTED;
+    X6PArgs g;
+    g.A = X; g.Bp = Bp; g.addend = addend; g.out = Y;
+    g.M = M; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout;
+    g.stream_out = (size_t)M * Cout * sizeof(float) > ((size_t)64 << 20);
+    g.stat_shift = stat_shift; g.stat_partial = stat_partial;
+    g.H = H; g.W = W; g.flip = flip ? 1 : 0; g.zeros = zeros;
+    return launch_x6p(g, tile_rows, 9, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                                   const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
                                   peclr_stream_t stream) {
@@ -368,9 +429,6 @@ extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, 
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldc; g.ldd = ldd;
     g.stream_out = (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
-    const int nrb = (M + tile_rows - 1) / tile_rows;
-    const dim3 grid(8 * ((nrb + 7) / 8) * (N / PN));
-    if (tile_rows == 256) hipLaunchKernelGGL(gemm_x6p_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
-    else hipLaunchKernelGGL(gemm_x6p_kernel<1>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
-    return launch_status();
+    g.H = g.W = 1; g.flip = 0; g.zeros = nullptr;
+    return launch_x6p(g, tile_rows, 1, static_cast<hipStream_t>(stream));
 }

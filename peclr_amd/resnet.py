@@ -97,7 +97,7 @@ class Bottleneck(nn.Module):
         if self.downsample is not None:
             identity = self.downsample(identity)
         out = _bn(self.bn1, out, relu=True)
-        out = _bn(self.bn2, self.conv2(out), relu=True)
+        out = _bn(self.bn2, _conv(self.conv2, out, self.bn2), relu=True)
         return _bn(self.bn3, _conv(self.conv3, out, self.bn3), identity, relu=True)
 
 
