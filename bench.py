@@ -577,6 +577,16 @@ def main():
                                       for b in trainer.reducer.buckets],
                      "collectives_per_step": "all_gather z [2N,128] fp32 + all_gather [row_lse | stats16 | loss] + "
                                              f"{len(trainer.reducer.buckets)} bucket all_reduce(SUM)",
+                     # what every collective of one step moves, for checking a SCALE record against (per rank: bytes this rank
+                     # contributes; an all-gather delivers world x that to every rank, a ring all-reduce moves
+                     # 2 (world - 1) / world of the bucket per rank)
+                     "collective_bytes_per_step": {
+                         "all_gather_z_per_rank": 2 * args.pairs * 128 * 4,
+                         "all_gather_lse_stats_loss_per_rank": (2 * args.pairs + 17) * 4,
+                         "bucket_all_reduce": [int(b.flat.numel() * b.flat.element_size()) for b in trainer.reducer.buckets],
+                         "all_reduce_total": int(sum(b.flat.numel() * b.flat.element_size() for b in trainer.reducer.buckets)),
+                         "ring_bytes_on_the_wire_per_rank": int(2 * (world - 1) / world * sum(
+                             b.flat.numel() * b.flat.element_size() for b in trainer.reducer.buckets))},
                      "note": "no scaling curve has been measured by the builder (1 GPU per lease); per-N values "
                              "are the driver's"}
     if rank == 0:

@@ -65,11 +65,23 @@ def init_from_env(backend: Optional[str] = None) -> int:
     return local
 
 
+# Test hook: issue every collective even on a one-rank group (where each is the identity).  A single-GPU box cannot host
+# two RCCL ranks (RCCL refuses two ranks per device), so this is how the RCCL branches -- all_gather_into_tensor, the
+# asynchronous bucket all-reduce between hipGraph replays -- get executed with a live RCCL communicator there
+# (tests/test_dist_rccl_gpu.py).  Off in production.
+FORCE_COLLECTIVES = False
+
+
+def collectives_active(group=None) -> bool:
+    """More than one rank -- or the one-rank test hook above with a live process group."""
+    return world_size(group) > 1 or (FORCE_COLLECTIVES and dist.is_initialized())
+
+
 def all_gather_cat(t: Tensor, group=None) -> Tensor:
     """[rows, ...] on every rank -> [world*rows, ...], rank-major.  Not differentiable (the callers
     carry their own closed-form backward)."""
     world = world_size(group)
-    if world == 1:
+    if world == 1 and not (FORCE_COLLECTIVES and dist.is_initialized()):
         return t
     t = t.contiguous()
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
@@ -163,12 +175,15 @@ class GradReducer:
                 p.register_post_accumulate_grad_hook(self._hook)
 
     def _hook(self, p):
-        if not self._armed or self.world == 1:
+        if not self._armed or not self._reduces():
             return
         b = self._owner[id(p)]
         b.pending -= 1
         if b.pending == 0:
             b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _reduces(self) -> bool:
+        return self.world > 1 or (FORCE_COLLECTIVES and dist.is_initialized())
 
     def prepare(self, unused: Iterable[torch.nn.Parameter] = ()):
         """Arm the hooks for the coming backward.  `unused`: parameters that will NOT receive a
@@ -181,7 +196,7 @@ class GradReducer:
 
     def finish(self):
         """Wait for every in-flight bucket; reduce any bucket whose hooks never completed."""
-        if self.world > 1:
+        if self._reduces():
             for b in self.buckets:
                 if b.handle is None:
                     b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -193,7 +208,7 @@ class GradReducer:
     def all_reduce_now(self):
         """Reduce every bucket (no hooks involved): the path used after a captured backward, whose
         gradients were copied into the buckets."""
-        if self.world > 1:
+        if self._reduces():
             handles = [dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
             for h in handles:
                 h.wait()
@@ -201,7 +216,7 @@ class GradReducer:
     def launch(self, buckets: Iterable[_Bucket]) -> list:
         """Start the SUM all-reduce of some buckets asynchronously (RCCL's own stream picks up after the work
         already queued on the current stream); returns handles to `wait()` on before the optimiser step."""
-        if self.world == 1:
+        if not self._reduces():
             return []
         return [dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in buckets]
 

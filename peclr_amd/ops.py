@@ -134,12 +134,13 @@ class _NTXent(torch.autograd.Function):
         mr = z_local.shape[0]
         world = pdist.world_size(group)
         rank = pdist.rank(group)
-        z_all = pdist.all_gather_cat(z_local, group) if world > 1 else z_local
+        multi = pdist.collectives_active(group)
+        z_all = pdist.all_gather_cat(z_local, group) if multi else z_local
         mg = z_all.shape[0]
         stats_in = row_stats if (row_stats is not None and row_stats.numel() > 0) else None
         out17, row_lse, sim = _capi.ntxent_fwd(z_local, rank * mr, z_all, n_pairs, 1.0 / temperature, 1.0 / mg,
                                                stats_in, n_pairs, want_sim)
-        if world > 1:
+        if multi:
             # one collective carries every rank's log-denominators, its partial loss AND its 16 projection
             # statistics (means over this rank's samples; equal pair counts per rank, so the mean of the
             # rank means is the global-batch mean a single device would report)

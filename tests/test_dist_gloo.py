@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 from tests import _capi_double
 
-N_LOCAL, DIN, HID = 4, 24, 32
+N_LOCAL, DIN, HID = int(os.environ.get("PECLR_TEST_N_LOCAL", "4")), 24, 32
 
 
 def free_port():
@@ -117,19 +117,26 @@ def worker(rank, world, port, out_dir):
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
-    assert torch.equal(gathered[0], gathered[1])
+    assert all(torch.equal(gathered[0], t) for t in gathered[1:])
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_two_ranks_equal_one_rank(tmp_path, monkeypatch):
-    world = 2
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,n_local", [(2, 4), (8, 2)])
+def test_ranks_equal_one_rank(tmp_path, monkeypatch, world, n_local):
+    """2 ranks x 4 pairs and 8 ranks x 2 pairs (the node size of BASELINE.json's configs 3 and 5: partner map, packed
+    lse / statistics gather and bucket plan at the real world size) against one process on the concatenated batch."""
+    global N_LOCAL
+    monkeypatch.setenv("PECLR_TEST_N_LOCAL", str(n_local))     # the spawned workers re-import this module
+    N_LOCAL = n_local
     mp.spawn(worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
     r0 = torch.load(os.path.join(tmp_path, "r0.pt"))
     r1 = torch.load(os.path.join(tmp_path, "r1.pt"))
-    assert torch.equal(r0["loss"], r1["loss"])  # every rank holds the global loss
-    for n in r0["grads"]:
-        assert torch.equal(r0["grads"][n], r1["grads"][n]), n  # SUM-reduced: identical everywhere
+    for r in range(1, world):
+        rk = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        assert torch.equal(r0["loss"], rk["loss"])  # every rank holds the global loss
+        for n in r0["grads"]:
+            assert torch.equal(r0["grads"][n], rk["grads"][n]), (r, n)  # SUM-reduced: identical everywhere
 
     # single process on the concatenated batch, rows reordered to the reference layout [all v1; all v2]
     _capi_double.install(monkeypatch)
