@@ -59,6 +59,9 @@ def assert_step_matches_oracle(model, batch, tag):
     assert d["z_max_abs_delta"] <= 1e-5, (tag, d["z_max_abs_delta"])
     assert d["stats_max_abs_delta"] <= 1e-5, (tag, d["stats_max_abs_delta"])
     assert d["dh_rel"] <= 3e-5, (tag, d["dh_max_abs_delta"], d["dh_scale"])
+    # the oracle takes the HIP path's side of a rectifier decision only where the pre-activation is within 1e-5 of zero
+    # (oracle.projection_head_fwd): that may concern a handful of the M x 512 hidden units, never a population
+    assert d["relu_tie_count"] <= 8, (tag, "rectifier ties settled by the implementation", d["relu_tie_count"])
     # the head's parameter gradients as well (they came out of the same backward)
     ph = model.projection_head
     ref = d["oracle"]
@@ -168,11 +171,72 @@ def test_c4_resnet152_accum16_graph_equals_eager_and_oracle():
     # float atomics, and 152 un-trained layers of train-mode BatchNorm amplify that run-to-run noise on the way
     # down (measured: ~1e-2 norm-wise between two identical eager runs, where ResNet-18 shows ~1e-5).  A replay
     # that dropped or doubled a micro-batch would be off by >= 1/16 = 6e-2 on top of that.
+    # (round 3: with the 1x1 weight gradients and the 3x3 forward / input gradients on deterministic in-tree kernels the
+    # eager loop repeats itself to ~2e-3 where round 2 measured 1e-2; the exact comparison -- MIOpen's deterministic
+    # solvers, 100x slower -- is test_accumulation_graph_equals_eager_exactly_with_deterministic_convolutions below)
     noise = deviation(se, se2)
     dev = deviation(se, sg)
     assert dev <= max(4.0 * noise, 1e-3), (dev, noise)
-    assert dev <= 5e-2, (dev, noise)                     # a dropped / doubled micro-batch: >= 6e-2 on top of the noise
+    assert dev <= 1e-2, (dev, noise)                     # one of 16 micro-batches mis-scaled by 50 %: 3e-2
     print(f"C4 accumulated-gradient deviation: graph vs eager {dev:.3e}, eager vs eager {noise:.3e}")
+
+
+def test_accumulation_graph_equals_eager_exactly_with_deterministic_convolutions():
+    """The accumulation logic of C4 (k micro-batches per optimiser step: loss / k, gradients added, one step) with
+    every source of run-to-run noise removed: MIOpen's deterministic attribute (torch.backends.cudnn.deterministic)
+    makes the library's weight gradients fixed-order too -- two orders of magnitude slower, hence ResNet-50 on 2 x 16
+    views @96 and k = 4 here.  Then the eager window repeats itself bit for bit, and the k hipGraph replays accumulate the
+    eager window's gradient to fp32 round-off (they add the same k gradients in the same order, through an accumulator
+    buffer instead of autograd's in-place accumulation)."""
+    from peclr_amd import Trainer
+
+    k, pairs = 4, 16
+    was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        base = build("50", pairs, accum=k)
+        micro = [synthetic_batch(pairs, 96, 200 + i) for i in range(k)]
+
+        def run(graph):
+            model = copy.deepcopy(base)
+            tr = Trainer(max_epochs=100, accumulate_grad_batches=k).attach(model)
+            tr.zero_grad()
+            snap = {}
+            real_step = tr.optimizer.step
+
+            def spy_step(*a, **kw):
+                snap["grads"] = [p.grad.detach().clone() for p in model.parameters() if p.grad is not None]
+                snap["calls"] = snap.get("calls", 0) + 1
+                return real_step(*a, **kw)
+
+            tr.optimizer.step = spy_step
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                if graph:
+                    tr.capture_micro_graph(micro[0], warmup_windows=1)
+                    snap.clear()
+                    for i in range(k):
+                        tr.replay_micro(micro[i])
+                else:
+                    for i in range(k):
+                        tr.training_micro_step(micro[0], i)
+                    snap.clear()
+                    for i in range(k):
+                        tr.training_micro_step(micro[i], k + i)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            return snap
+
+        se, se2, sg = run(False), run(False), run(True)
+        assert se["calls"] == se2["calls"] == sg["calls"] == 1
+        for a, b in zip(se["grads"], se2["grads"]):
+            assert torch.equal(a, b)                                  # the comparison arm is exact
+        num = sum(float((a - b).double().pow(2).sum()) for a, b in zip(se["grads"], sg["grads"]))
+        den = sum(float(a.double().pow(2).sum()) for a in se["grads"])
+        assert (num / den) ** 0.5 <= 1e-5, (num / den) ** 0.5       # a mis-scaled micro-batch of 4: >= 1e-1
+    finally:
+        torch.backends.cudnn.deterministic = was
 
 
 # ------------------------------------------------------------------ C5: 448x448 inputs, 8 x (2 x 64) split, bf16
