@@ -132,6 +132,18 @@ int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void*
 int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* X, const void* Bp, float* Y,
                           const float* addend, int flip, int tile_rows, const float* zeros, const float* stat_shift,
                           float* stat_partial, peclr_stream_t stream);
+/* Weight gradients, second generation: C[M, taps * N] = sum_k A[k, M] . B[k shifted by the tap, N], the contraction over the
+ * ROWS of two NHWC activations (A = dY [R, Cout], B = X [R, Cin]).  taps = 1: dW = dY^T X of a 1x1 convolution.  taps = 9:
+ * the nine [Cout, Cin] products of a 3x3 / stride-1 / padding-1 convolution's weight gradient, X read at the pixel each
+ * tap points at (H x W images, K = images * H * W rows; zeros outside the image: `zeros` = >= 64 bytes of zeros), written
+ * as columns tap * N + n -- the [Cout][3][3][Cin] storage of a channels_last weight.  K is split over
+ * peclr_gemm_x6t_slabs(M, N, K, taps) workgroup rows, each writing one fp32 slab [M][taps * N]; peclr_slab_reduce_f32 adds
+ * them in a fixed order (deterministic).  256 x 256 output tiles where the problem has them (an operand row is split once
+ * per 256 columns of the other operand), k-step 16 with double-buffered planes.  M, N, lda, ldb multiples of 4.  Replaces
+ * MIOpen's fp32 weight gradients of the Bottleneck's convolutions (resnet_model.py:15).                                  */
+int peclr_gemm_x6t_slabs(int M, int N, int K, int taps);
+int peclr_gemm_x6t_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs, int n_slabs,
+                       int taps, int H, int W, const float* zeros, peclr_stream_t stream);
 int peclr_gemm_pick_split_k(int M, int N, int K);
 
 /* out[i] = sum_s slabs[s][i] (+ bias[i % cols] if non-null), i < rows*cols. */

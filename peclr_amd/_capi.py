@@ -72,6 +72,8 @@ SIGNATURES = {
     "peclr_x6_pack_f32": (c_int, [_P, c_int, c_int, _P]),
     "peclr_gemm_x6p_tile_rows": (c_int, [c_int, c_int, c_int]),
     "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P, _P, _P]),
+    "peclr_gemm_x6t_slabs": (c_int, [c_int, c_int, c_int, c_int]),
+    "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
@@ -504,6 +506,26 @@ def gemm_x6_tn(a: torch.Tensor, b: torch.Tensor, tag: str = "gemm_x6_tn") -> tor
     with _timed(tag, 4 * (k * m + k * n + ns * m * n), 2 * m * n * k, kernel="gemm_x6_tn128_kernel"):
         rc = lib().peclr_gemm_x6_tn_f32(m, n, k, _ptr(a), m, _ptr(b), n, slabs.data_ptr(), ns, _stream())
     _check(rc, "peclr_gemm_x6_tn_f32")
+    return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
+
+
+def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, tag: str = "gemm_x6t") -> torch.Tensor:
+    """C[M, taps * N] (fp32) = sum over rows of A[K, M]^T . B[K (shifted by the tap), N] -- the weight gradient of a 1x1
+    (taps = 1) or 3x3 / stride-1 / padding-1 (taps = 9, hw = (H, W) of the images the rows are the pixels of) convolution
+    on NHWC storage, on the bf16 matrix cores at fp32 accuracy (peclr_gemm_x6t_f32 + peclr_slab_reduce_f32: fixed-order
+    split-K, deterministic)."""
+    (k, m), (k2, n) = a.shape, b.shape
+    if k != k2 or taps not in (1, 9) or (taps == 9 and hw is None):
+        raise PeclrHipError(f"gemm_x6t: shapes {tuple(a.shape)}^T x {tuple(b.shape)}, taps {taps}")
+    h, w = hw if hw is not None else (1, 1)
+    ns = lib().peclr_gemm_x6t_slabs(m, n, k, taps)
+    if ns < 1:
+        raise PeclrHipError(f"gemm_x6t: unsupported shape M={m} N={n} K={k}")
+    slabs = torch.empty((ns, m, taps * n), device=a.device, dtype=torch.float32)
+    with _timed(tag, 4 * (k * m + k * n + ns * m * n * taps), 2 * m * n * k * taps, kernel="gemm_x6t_kernel"):
+        rc = lib().peclr_gemm_x6t_f32(m, n, k, _ptr(a), a.stride(0), _ptr(b), b.stride(0), slabs.data_ptr(), ns, taps, h, w,
+                                      _zeros(a.device).data_ptr(), _stream())
+    _check(rc, "peclr_gemm_x6t_f32")
     return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
 
 

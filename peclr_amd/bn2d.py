@@ -73,6 +73,7 @@ _X6_MIN_K = int(os.environ.get("PECLR_GEMM_X6_MIN_K", "128"))   # in-step A/B: 1
 
 
 _BN_STATS_IN_GEMM = os.environ.get("PECLR_BN_STATS_IN_GEMM", "1") != "0"   # A/B switch: BatchNorm statistics in the GEMM epilogue
+_GEMM_X6T = os.environ.get("PECLR_GEMM_X6T", "1") != "0"  # A/B switch: weight gradients on the 256 x 256-tile kernel (peclr_gemm_x6t_f32)
 _GEMM_X6P = os.environ.get("PECLR_GEMM_X6P", "1") != "0"  # A/B switch: weight planes packed once per step (peclr_gemm_x6p_f32)
 
 
@@ -347,7 +348,8 @@ def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
 
     def run():
         gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
-        dw = _capi.gemm_x6_tn(gy2, x2, tag="conv1x1_wgrad")
+        dw = (_capi.gemm_x6t(gy2, x2, tag="conv1x1_wgrad") if _GEMM_X6T and cout >= 128 and cin >= 128
+              else _capi.gemm_x6_tn(gy2, x2, tag="conv1x1_wgrad"))
         ref = param if param is not None else weight
         return dw.as_strided(ref.shape, ref.stride())       # same memory, the parameter's (channels_last) strides
 

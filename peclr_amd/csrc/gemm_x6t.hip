@@ -1,0 +1,248 @@
+// Weight gradients on the bf16 matrix cores at fp32 accuracy, second generation: C[M, N] = sum_k A[k, M] . B[k (+ shift), N]
+// with the contraction over the ROWS of two NHWC activations (dW = dY^T X for 1x1 convolutions; for a 3x3 convolution one
+// such product per filter tap, X read at the pixel the tap points at).
+//
+// Both operands are activations, so both have to be split (x == h + m + l, common.hpp) inside the kernel; what this
+// kernel changes against gemm_x6_tn128_kernel is how often and where:
+//   * 256 x 256 output tiles (8 waves as 4 x 2, each 64 x 128 = 2 x 4 MFMA tiles, six products each): an operand row is split
+//     once per 256 output columns of the other operand instead of once per 128 -- 1.8 VALU instructions per MFMA, the
+//     ratio of the forward kernel (gemm_x6p.hip), where the 128 x 128 kernel has 3.7.  128-wide problems take 128 x 256,
+//     256 x 128 or 128 x 128 tiles (wave tiles 32 x 128, 64 x 64, 32 x 64) of the same code.
+//   * k-step 16 with DOUBLE-buffered planes and one barrier per step: the split / plane stores of step t + 1 run under
+//     the MFMAs of step t (the old kernel alternated a multiply phase and a store phase).
+//   * a thread owns a 4 (k) x 4 (columns) block: four 16-byte loads, columns paired over k by the packed conversion
+//     (the transpose costs nothing), 8-byte stores.  Plane layout [k-half][32-column tile][slot][8 k] with
+//     slot(i) = (i & 3) * 8 + ((i >> 2) ^ ((i >> 1) & 1) * 4): the sixteen lanes of a store instruction (eight column chunks
+//     x two k-quads) fill 128 contiguous bytes, the sixteen lanes of a fragment read hit sixteen distinct 16-byte
+//     slots -- both conflict-free.
+// K is split over gridDim.y workgroup rows writing fp32 slabs [split][M][ldc] that peclr_slab_reduce_f32 adds in a fixed
+// order (deterministic).  taps = 9: gridDim.z = 9, B rows shifted by the tap's pixel offset (zeros outside the image),
+// output columns tap * N + n (the [Cout][3][3][Cin] layout of a channels_last weight).
+#include "common.hpp"
+
+namespace peclr {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TK = 16;
+
+struct X6TArgs {
+    const float* A;                  // [K][lda]: M columns used
+    const float* B;                  // [K][ldb]: N columns used
+    float* slabs;                    // [splits][M][ldc]
+    int M, N, K, lda, ldb, ldc;
+    int kchunk;                      // rows per split (multiple of 16)
+    int taps, H, W;                  // taps = 9: 3x3 filter taps in gridDim.z, image extents of the rows
+    const float* zeros;
+};
+
+__device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ int slot_of(int i) { return (i & 3) * 8 + ((i >> 2) ^ (((i >> 1) & 1) << 2)); }
+
+// MT x NT: 32 x 32 MFMA tiles per wave; waves 4 (M) x 2 (N): workgroup tile 128 MT x 64 NT
+template <int MT, int NT, int TAPS>
+__global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
+    constexpr int TM = 128 * MT, TN = 64 * NT;
+    constexpr int HALF_A = TM * 16, HALF_B = TN * 16;         // bytes of one k-half of a plane
+    constexpr int PL_A = 2 * HALF_A, PL_B = 2 * HALF_B;
+    constexpr int BUF = 3 * (PL_A + PL_B);                    // one k-step of both operands
+    constexpr int XEPL = 36;
+    static_assert(2 * BUF >= 8 * 32 * XEPL * 4, "epilogue transposes live in the plane buffers");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, kh = lane >> 5;
+    const int nct = (g.N + TN - 1) / TN;
+    const int m0 = (int)(blockIdx.x / nct) * TM, n0 = (int)(blockIdx.x % nct) * TN;
+    const int kbeg = blockIdx.y * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (kend - kbeg + TK - 1) / TK;
+    const int tap = TAPS == 9 ? blockIdx.z : 0;
+    const int dh = TAPS == 9 ? tap / 3 - 1 : 0, dw = TAPS == 9 ? tap % 3 - 1 : 0;
+
+    // ---- this thread's block of the split: operand (A for the first TM threads' worth of blocks, then B), column chunk
+    // (4 columns), k-quad (4 rows).  Lane bits: [2:0] chunk within a 32-column tile, [3] k-quad & 1, [4] k-half, [5] tile
+    // parity; a wave covers 64 columns.
+    const int blk_col64 = wave;                               // 64-column group index over A's then B's columns
+    const bool is_a = blk_col64 < TM / 64;
+    const bool active = blk_col64 < (TM + TN) / 64;
+    const int cgrp = is_a ? blk_col64 : blk_col64 - TM / 64;
+    const int chunk = (lane & 7) + 8 * (lane >> 5);           // 0..15 within the 64-column group
+    const int kq = (lane >> 3) & 3;
+    const int col = cgrp * 64 + 4 * chunk;                    // first of this thread's 4 columns inside the tile
+    const float* src = is_a ? g.A + m0 + col : g.B + n0 + col;
+    const int ld = is_a ? g.lda : g.ldb;
+    const bool col_ok = active && (is_a ? m0 + col < g.M : n0 + col < g.N);
+    // plane store address of column col + j: tile (col >> 5), slot of ((col & 31) + j), k-quad half
+    const int tile = col >> 5, cin = col & 31;
+    const int st_base = (kq >> 1) * (is_a ? HALF_A : HALF_B) + tile * 512 + (kq & 1) * 8 + (is_a ? 0 : 3 * PL_A);
+    const int st_plane = is_a ? PL_A : PL_B;
+
+    f32x4 ld4[4];
+    // TAPS = 9: pixel (oh, ow) of the first row of this thread's next block, advanced by 16 rows per k-step (no divisions in
+    // the loop); gload() is called with t = 0, 1, 2, ... in order
+    int ow_t = 0, oh_t = 0;
+    if constexpr (TAPS == 9) {
+        const int k = kbeg + 4 * kq;
+        ow_t = k % g.W;
+        oh_t = (k / g.W) % g.H;
+    }
+    auto gload = [&](int t) {                                 // rows kbeg + 16 t + 4 kq + q of this thread's 4 columns
+        int ow = ow_t, oh = oh_t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = kbeg + t * TK + 4 * kq + q;
+            const float* p = src + (size_t)k * ld;
+            bool ok = col_ok && k < kend;
+            if constexpr (TAPS == 9) {
+                if (!is_a) {                                  // B row = the pixel (dh, dw) away, zeros outside the image
+                    ok = ok && (unsigned)(oh + dh) < (unsigned)g.H && (unsigned)(ow + dw) < (unsigned)g.W;
+                    p += (long)(dh * g.W + dw) * ld;
+                }
+                if (++ow == g.W) { ow = 0; oh = oh + 1 == g.H ? 0 : oh + 1; }
+            }
+            p = ok ? p : g.zeros;
+            ld4[q] = *reinterpret_cast<const f32x4*>(p);
+        }
+        if constexpr (TAPS == 9) {
+            ow_t += TK;
+#pragma unroll
+            for (int it = 0; it < 3; ++it)                    // W >= 7: at most three image rows per 16 pixels
+                if (ow_t >= g.W) { ow_t -= g.W; oh_t = oh_t + 1 == g.H ? 0 : oh_t + 1; }
+        }
+    };
+    auto split_store = [&](int buf) {
+        if (!active) return;
+        unsigned char* base = lds + buf * BUF + st_base;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned h[2], m[2], l[2];
+            split3_pk(ld4[0][j], ld4[1][j], h[0], m[0], l[0]);
+            split3_pk(ld4[2][j], ld4[3][j], h[1], m[1], l[1]);
+            unsigned char* d = base + slot_of(cin + j) * 16;
+            *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
+            *reinterpret_cast<uint2*>(d + st_plane) = make_uint2(m[0], m[1]);
+            *reinterpret_cast<uint2*>(d + 2 * st_plane) = make_uint2(l[0], l[1]);
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int y = 0; y < NT; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][y][r] = 0.f;
+
+    const int fa = kh * HALF_A + (wm * MT) * 512 + slot_of(i) * 16;                  // + a * 512 + plane * PL_A
+    const int fb = 3 * PL_A + kh * HALF_B + (wn * NT) * 512 + slot_of(i) * 16;       // + y * 512 + plane * PL_B
+
+    if (nk > 0) {
+        gload(0);
+        split_store(0);
+        if (nk > 1) gload(1);
+    }
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* bufp = lds + (t & 1) * BUF;
+        uint4 af[MT][3];
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const uint4*>(bufp + fa + a * 512 + p * PL_A);
+        constexpr int NH = NT > 2 ? 2 : 1, YH = NT / NH;          // B fragments in two halves (registers)
+#pragma unroll
+        for (int half = 0; half < NH; ++half) {
+            uint4 bf[YH][3];
+#pragma unroll
+            for (int y = 0; y < YH; ++y)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[y][p] = *reinterpret_cast<const uint4*>(bufp + fb + (half * YH + y) * 512 + p * PL_B);
+#define PECLR_X6(P, Q)                                                                        \
+    _Pragma("unroll") for (int y = 0; y < YH; ++y) _Pragma("unroll") for (int a = 0; a < MT; ++a) \
+        acc[a][half * YH + y] = mma(af[a][P], bf[y][Q], acc[a][half * YH + y]);
+            PECLR_X6(2, 0) PECLR_X6(0, 2) PECLR_X6(1, 1) PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)
+#undef PECLR_X6
+            if (half == 0 && t + 1 < nk) {
+                split_store((t + 1) & 1);                 // rows of step t + 1 (loaded during step t - 1) -> the other buffer
+                if (t + 2 < nk) gload(t + 2);
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: wave-private 32 x 32 transposes through LDS, 16-byte stores into this split's slab
+    float* out = g.slabs + (size_t)blockIdx.y * g.M * g.ldc + (TAPS == 9 ? tap * g.N : 0);
+    float* wlds = reinterpret_cast<float*>(lds) + wave * (32 * XEPL);
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int y = 0; y < NT; ++y) {
+            const int mt = m0 + (wm * MT + a) * 32, nt = n0 + (wn * NT + y) * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = acc[a][y][r];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = mt + er + 8 * jj, n = nt + ec;
+                const float4 c = *reinterpret_cast<const float4*>(wlds + (er + 8 * jj) * XEPL + ec);
+                if (m < g.M && n < g.N) *reinterpret_cast<float4*>(out + (size_t)m * g.ldc + n) = c;
+            }
+        }
+}
+
+inline void pick_tile(int M, int N, int& mt, int& nt) {
+    mt = M >= 256 ? 2 : 1;          // workgroup tile 128 mt x 64 nt
+    nt = N >= 256 ? 4 : 2;
+}
+
+}  // namespace
+}  // namespace peclr
+
+using namespace peclr;
+
+// Number of K splits (= slabs): about one workgroup (8 waves) per CU, at least 16 k-steps per workgroup.
+extern "C" int peclr_gemm_x6t_slabs(int M, int N, int K, int taps) {
+    if (M <= 0 || N <= 0 || K <= 0 || (taps != 1 && taps != 9)) return 0;
+    int mt, nt;
+    pick_tile(M, N, mt, nt);
+    const long tiles = (long)((M + 128 * mt - 1) / (128 * mt)) * ((N + 64 * nt - 1) / (64 * nt)) * taps;
+    long s = (256 + tiles - 1) / tiles;
+    const long max_s = (K + 16 * TK - 1) / (16 * TK);
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    const int kchunk = (int)(((K + s - 1) / s + TK - 1) / TK * TK);
+    return (K + kchunk - 1) / kchunk;
+}
+
+extern "C" int peclr_gemm_x6t_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs,
+                                  int n_slabs, int taps, int H, int W, const float* zeros, peclr_stream_t stream) {
+    if (!A || !B || !slabs || !zeros) return PECLR_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0 || n_slabs < 1 || (taps != 1 && taps != 9)) return PECLR_ERR_SHAPE;
+    if (M % 4 || N % 4 || lda % 4 || ldb % 4 || lda < M || ldb < N) return PECLR_ERR_SHAPE;
+    if (taps == 9 && (H <= 0 || W < 6 || K % (H * W))) return PECLR_ERR_SHAPE;
+    if (!aligned16(A) || !aligned16(B) || !aligned16(slabs) || !aligned16(zeros)) return PECLR_ERR_ALIGN;
+    if (n_slabs != peclr_gemm_x6t_slabs(M, N, K, taps)) return PECLR_ERR_WORKSPACE;
+    X6TArgs g;
+    g.A = A; g.B = B; g.slabs = slabs;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = taps * N;
+    g.kchunk = ((K + n_slabs - 1) / n_slabs + TK - 1) / TK * TK;
+    g.taps = taps; g.H = H; g.W = W; g.zeros = zeros;
+    int mt, nt;
+    pick_tile(M, N, mt, nt);
+    const dim3 grid(((M + 128 * mt - 1) / (128 * mt)) * ((N + 64 * nt - 1) / (64 * nt)), n_slabs, taps);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define PECLR_LAUNCH(MT_, NT_)                                                                                  \
+    do {                                                                                                        \
+        if (taps == 9) hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, 9>), grid, dim3(512), 0, s, g);            \
+        else hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, 1>), grid, dim3(512), 0, s, g);                      \
+    } while (0)
+    if (mt == 2 && nt == 4) PECLR_LAUNCH(2, 4);
+    else if (mt == 2) PECLR_LAUNCH(2, 2);
+    else if (nt == 4) PECLR_LAUNCH(1, 4);
+    else PECLR_LAUNCH(1, 2);
+#undef PECLR_LAUNCH
+    return launch_status();
+}

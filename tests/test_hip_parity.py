@@ -1992,9 +1992,10 @@ def test_conv1x1_as_gemm_on_the_matrix_cores_matches_float64(cin, cout, hw, n):
     x = torch.randn(n, cin, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
     gy = torch.randn(n, cout, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
     calls = []
-    real, real_tn = _capi.gemm_x6, _capi.gemm_x6_tn
+    real, real_tn, real_t = _capi.gemm_x6, _capi.gemm_x6_tn, _capi.gemm_x6t
     _capi.gemm_x6 = lambda *a, **k: (calls.append(k.get("tag")), real(*a, **k))[1]
     _capi.gemm_x6_tn = lambda *a, **k: (calls.append(k.get("tag")), real_tn(*a, **k))[1]
+    _capi.gemm_x6t = lambda *a, **k: (calls.append(k.get("tag")), real_t(*a, **k))[1]
     res = {}
     try:
         for mode in (False, True):
@@ -2005,7 +2006,7 @@ def test_conv1x1_as_gemm_on_the_matrix_cores_matches_float64(cin, cout, hw, n):
             y.backward(gy)
             res[mode] = (y.detach(), xx.grad.clone(), conv.weight.grad.clone())
     finally:
-        _capi.gemm_x6, _capi.gemm_x6_tn = real, real_tn
+        _capi.gemm_x6, _capi.gemm_x6_tn, _capi.gemm_x6t = real, real_tn, real_t
     rows = n * hw * hw
     want_calls = [t for t, ok in (("conv1x1_fwd", B._x6_pays(rows, cout, cin)), ("conv1x1_wgrad", B._x6_wgrad_pays(rows, cout, cin)),
                                   ("conv1x1_dgrad", B._x6_pays(rows, cin, cout))) if ok]
@@ -2031,6 +2032,47 @@ def test_conv1x1_as_gemm_on_the_matrix_cores_matches_float64(cin, cout, hw, n):
         xx = x.clone().requires_grad_()
         conv(xx).backward(gy)
         assert torch.equal(conv.weight.grad, res[True][2])
+
+
+@pytest.mark.parametrize("k_rows,m,n", [(50176, 256, 1024), (200704, 128, 512), (40000 + 36, 256, 64), (12544, 2048, 512), (8192 + 4, 132, 260),
+                                        (3000, 512, 128), (20000 + 8, 384, 640)])
+def test_gemm_x6t_matches_float64_and_is_deterministic(capi, k_rows, m, n):
+    """peclr_gemm_x6t_f32 + peclr_slab_reduce_f32 (weight gradients, second generation: 256 x 256 / 128 x 256 / 256 x 128 /
+    128 x 128 output tiles, k-step 16, double-buffered planes): C[M,N] = A[K,M]^T . B[K,N] over the rows, ragged K, M and
+    N, every tile shape.  fp32 accuracy against float64 -- the bar of the first-generation kernel, whose error it may not
+    exceed by more than round-off -- and bit-identical from run to run."""
+    g = torch.Generator().manual_seed(k_rows + m + n)
+    a = torch.randn(k_rows, m, generator=g).to(DEV)
+    b = torch.randn(k_rows, n, generator=g).to(DEV)
+    got = capi.gemm_x6t(a, b)
+    assert got.shape == (m, n)
+    ref = a.double().t() @ b.double()
+    bound = a.double().abs().t() @ b.double().abs()
+    err = ((got.double() - ref).abs() / bound).max().item()
+    old = ((capi.gemm_x6_tn(a, b).double() - ref).abs() / bound).max().item()
+    assert err <= 2.0 ** -20 and err <= 1.5 * old + 2.0 ** -26, (err, old)
+    assert torch.equal(capi.gemm_x6t(a, b), got)
+
+
+@pytest.mark.parametrize("nb,c,hw", [(6, 128, 9), (4, 256, 7), (256, 256, 14), (40, 512, 7)])
+def test_gemm_x6t_nine_taps_is_the_3x3_weight_gradient(capi, nb, c, hw):
+    """peclr_gemm_x6t_f32 with taps = 9: the nine [Cout, Cin] products of a 3x3 / stride-1 / padding-1 convolution's weight
+    gradient, X read at the pixel each tap points at (zeros outside the image), written in the [Cout][3][3][Cin] order of a
+    channels_last weight.  Against torch's float64 convolution_backward and next to MIOpen's fp32 result."""
+    g = torch.Generator().manual_seed(c + hw)
+    x = torch.randn(nb, c, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(nb, c, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(c, c, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+    r = nb * hw * hw
+    got = capi.gemm_x6t(gy.permute(0, 2, 3, 1).reshape(r, c), x.permute(0, 2, 3, 1).reshape(r, c), taps=9, hw=(hw, hw))
+    dw = got.view(c, 3, 3, c).permute(0, 3, 1, 2)
+    args = (None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])
+    ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), *args)[1]
+    mi = torch.ops.aten.convolution_backward(gy, x, w, *args)[1]
+    scale = float(ref.abs().max())
+    e_new, e_mi = float((dw.double() - ref).abs().max()) / scale, float((mi.double() - ref).abs().max()) / scale
+    assert e_new <= max(4 * e_mi, 2e-6), (e_new, e_mi)
+    assert torch.equal(capi.gemm_x6t(gy.permute(0, 2, 3, 1).reshape(r, c), x.permute(0, 2, 3, 1).reshape(r, c), taps=9, hw=(hw, hw)), got)
 
 
 @pytest.mark.parametrize("k_rows,m,n", [(50176, 256, 1024), (200704, 128, 512), (40000 + 36, 256, 64), (12544, 2048, 512), (8192 + 4, 132, 260)])
