@@ -193,7 +193,7 @@ def kernel_table(event_log, m_rows, m_global, din, hid, n_params):
 
 # launches of peclr_gemm_x6_f32 / _tn_f32 (fp32 operands split into three bf16 numbers, six products on the bf16 MFMA):
 # their MFMA roof is the dense bf16 peak / 6 fp32-equivalent flop/s, not the v_mfma_f32 peak
-X6_TAGS = {"conv1x1_fwd", "conv1x1_dgrad", "conv1x1_dgrad_add_x6", "conv1x1_wgrad", "gemm_x6", "gemm_x6p", "gemm_x6_tn", "conv3x3_fwd", "conv3x3_dgrad", "gemm_x6t"}
+X6_TAGS = {"conv1x1_fwd", "conv1x1_dgrad", "conv1x1_dgrad_add_x6", "conv1x1_wgrad", "gemm_x6", "gemm_x6p", "gemm_x6_tn", "conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "gemm_x6t"}
 
 
 def mfma_peak(name):

@@ -377,6 +377,28 @@ def _stat_shift_for(bn, cout: int):
     return bn.running_mean
 
 
+def _wgrad_3x3_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
+    """d(weight) of a 3x3 / stride-1 / padding-1 convolution: nine dY^T X products with X read at the pixel each tap points
+    at, all in one launch that splits dY once for the nine taps (peclr_gemm_x6t_f32, taps = 9; fp32 accuracy, fixed-order
+    split-K: deterministic), written in the weight's own channels_last storage order [Cout][3][3][Cin]."""
+    n, cin, h, w = x.shape
+    cout = gy.shape[1]
+
+    def run():
+        gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
+        dw = _capi.gemm_x6t(gy2, x2, taps=9, hw=(h, w), tag="conv3x3_wgrad")
+        return dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2)      # = a channels_last [Cout, Cin, 3, 3] tensor
+
+    st = _overlap_stream()
+    if st is None or param is None:
+        return run()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = run()
+    _WgradOverlap.parked.append((param, g, (gy, x)))
+    return None
+
+
 class _Conv1x1Gemm(torch.autograd.Function):
     """1x1 / stride-1 convolution of an NHWC fp32 tensor as the GEMM it is, on the bf16 matrix cores at fp32 accuracy:
     forward y[R, Cout] = x[R, Cin] . W^T and / or the input gradient dx[R, Cin] = dy[R, Cout] . W, each where `_x6_pays`
@@ -433,6 +455,7 @@ class _Conv1x1Gemm(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+_CONV3X3_WGRAD_X6 = os.environ.get("PECLR_CONV3X3_WGRAD_X6", "1") != "0"   # A/B switch: 3x3 weight gradients in-tree (nine taps, one launch)
 _CONV3X3_X6 = os.environ.get("PECLR_CONV3X3_X6", "1") != "0"   # A/B switch: 3x3 stride-1 convolutions as implicit x6p GEMMs
 
 
@@ -440,7 +463,8 @@ class _Conv3x3Gemm(torch.autograd.Function):
     """3x3 / stride-1 / padding-1 convolution of an NHWC fp32 tensor as an implicit GEMM on the bf16 matrix cores at
     fp32 accuracy (peclr_conv3x3_x6p_f32: rows = output pixels, K = 9 Cin in (tap, channel) order, the activation rows
     of a k-step read from the pixel its tap points at, the filter from planes packed once per step): forward and input
-    gradient (the same kernel on the flipped filter); the weight gradient stays on MIOpen."""
+    gradient (the same kernel on the flipped filter); the weight gradient as nine dY^T X products in one launch
+    (`_wgrad_3x3_x6`)."""
 
     @staticmethod
     def forward(ctx, x, weight, conv, stats=None):
@@ -460,7 +484,11 @@ class _Conv3x3Gemm(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         conv, planes = ctx.cfg
         gy = gy.contiguous(memory_format=torch.channels_last)
-        dw = _conv_wgrad(gy, x, weight, (1, 1), (1, 1), conv.weight) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            in_tree = (_GEMM_X6T and _CONV3X3_WGRAD_X6 and weight.is_contiguous(memory_format=torch.channels_last)
+                       and x.shape[3] >= 6 and x.shape[1] % 4 == 0 and gy.shape[1] % 4 == 0)
+            dw = _wgrad_3x3_x6(gy, x, weight, conv.weight) if in_tree else _conv_wgrad(gy, x, weight, (1, 1), (1, 1), conv.weight)
         dx = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=256) if ctx.needs_input_grad[0] else None
         return dx, dw, None, None
 

@@ -193,6 +193,145 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
         }
 }
 
+// ---- 3x3 weight gradient, all nine taps in one workgroup.  With one product per tap (gemm_x6t_kernel<.., 9>) the dY
+// operand is split nine times over; here a workgroup (8 waves as 4 x 2) owns a 128 (Cout) x 64 (Cin) block of ALL nine taps:
+// per k-step dY's 128 columns are split ONCE, X's 64 columns once per tap (rows shifted by the tap, zeros outside the
+// image), and every wave runs 9 x 6 MFMAs into nine 32 x 32 accumulators (144 registers) -- 2.2 VALU instructions per MFMA
+// instead of 3.7.  Eleven 64-column groups of planes per k-step (dY: 2, X: one per tap), 6 KiB each, double-buffered
+// (132 KiB); waves 0-2 split two groups per step, the others one.
+__global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
+    constexpr int GRP = 3 * 2 * 64 * 16;                      // bytes of one 64-column group: [plane][k-half][tile][slot][16]
+    constexpr int NG = 11, BUF = NG * GRP;
+    constexpr int XEPL = 36;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, kh = lane >> 5;
+    const int nct = (g.N + 63) / 64;
+    const int m0 = (int)(blockIdx.x / nct) * 128, n0 = (int)(blockIdx.x % nct) * 64;
+    const int kbeg = blockIdx.y * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (kend - kbeg + TK - 1) / TK;
+
+    const int chunk = (lane & 7) + 8 * (lane >> 5), kq = (lane >> 3) & 3;
+    const int cin = 4 * (chunk & 7), tile = chunk >> 3;
+    const int st_off = (kq >> 1) * 1024 + tile * 512 + (kq & 1) * 8;     // inside a group's plane
+    // group gi: 0, 1 = dY columns m0 + 64 gi ...; 2 + tap = X columns n0 ..., rows shifted by the tap
+    const int g1 = wave, g2 = wave + 8;                        // this wave's groups (g2 only for waves 0..2)
+    const bool two = g2 < NG;
+    struct Src { const float* p; int ld, dh, dw; bool ok, is_a; };
+    auto src_of = [&](int gi) {
+        Src s;
+        s.is_a = gi < 2;
+        const int tap = gi - 2;
+        s.dh = s.is_a ? 0 : tap / 3 - 1;
+        s.dw = s.is_a ? 0 : tap % 3 - 1;
+        const int c = 4 * chunk + (s.is_a ? 64 * gi : 0);
+        s.ld = s.is_a ? g.lda : g.ldb;
+        s.p = s.is_a ? g.A + m0 + c : g.B + n0 + c;
+        s.ok = s.is_a ? m0 + c < g.M : n0 + c < g.N;
+        return s;
+    };
+    const Src s1 = src_of(g1), s2 = src_of(two ? g2 : g1);
+    int ow_t, oh_t;
+    {
+        const int k = kbeg + 4 * kq;
+        ow_t = k % g.W;
+        oh_t = (k / g.W) % g.H;
+    }
+    f32x4 la[4], lb[4];
+    auto gload1 = [&](const Src& s, int t, f32x4 (&r)[4]) {
+        int ow = ow_t, oh = oh_t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = kbeg + t * TK + 4 * kq + q;
+            bool ok = s.ok && k < kend;
+            if (!s.is_a) ok = ok && (unsigned)(oh + s.dh) < (unsigned)g.H && (unsigned)(ow + s.dw) < (unsigned)g.W;
+            const float* p = s.p + ((long)k + (s.is_a ? 0 : s.dh * g.W + s.dw)) * s.ld;
+            r[q] = *reinterpret_cast<const f32x4*>(ok ? p : g.zeros);
+            if (++ow == g.W) { ow = 0; oh = oh + 1 == g.H ? 0 : oh + 1; }
+        }
+    };
+    auto gload = [&](int t) {
+        gload1(s1, t, la);
+        if (two) gload1(s2, t, lb);
+        ow_t += TK;
+#pragma unroll
+        for (int it = 0; it < 3; ++it)
+            if (ow_t >= g.W) { ow_t -= g.W; oh_t = oh_t + 1 == g.H ? 0 : oh_t + 1; }
+    };
+    auto store1 = [&](int buf, int gi, const f32x4 (&r)[4]) {
+        unsigned char* base = lds + buf * BUF + gi * GRP + st_off;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned h[2], m[2], l[2];
+            split3_pk(r[0][j], r[1][j], h[0], m[0], l[0]);
+            split3_pk(r[2][j], r[3][j], h[1], m[1], l[1]);
+            unsigned char* d = base + slot_of(cin + j) * 16;
+            *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
+            *reinterpret_cast<uint2*>(d + 2048) = make_uint2(m[0], m[1]);
+            *reinterpret_cast<uint2*>(d + 4096) = make_uint2(l[0], l[1]);
+        }
+    };
+    auto split_store = [&](int buf) {
+        store1(buf, g1, la);
+        if (two) store1(buf, g2, lb);
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+    const int fa = (wm >> 1) * GRP + kh * 1024 + (wm & 1) * 512 + slot_of(i) * 16;       // + plane * 2048
+    const int fb = 2 * GRP + kh * 1024 + wn * 512 + slot_of(i) * 16;                      // + tap * GRP + plane * 2048
+
+    if (nk > 0) {
+        gload(0);
+        split_store(0);
+        if (nk > 1) gload(1);
+    }
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* bufp = lds + (t & 1) * BUF;
+        uint4 af[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const uint4*>(bufp + fa + p * 2048);
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            uint4 bf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const uint4*>(bufp + fb + tp * GRP + p * 2048);
+            acc[tp] = mma(af[2], bf[0], acc[tp]);
+            acc[tp] = mma(af[0], bf[2], acc[tp]);
+            acc[tp] = mma(af[1], bf[1], acc[tp]);
+            acc[tp] = mma(af[1], bf[0], acc[tp]);
+            acc[tp] = mma(af[0], bf[1], acc[tp]);
+            acc[tp] = mma(af[0], bf[0], acc[tp]);
+            if (tp == 2 && t + 1 < nk) {
+                split_store((t + 1) & 1);
+                if (t + 2 < nk) gload(t + 2);
+            }
+        }
+        __syncthreads();
+    }
+
+    float* out = g.slabs + (size_t)blockIdx.y * g.M * g.ldc;
+    float* wlds = reinterpret_cast<float*>(lds) + wave * (32 * XEPL);
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+    const int mt = m0 + wm * 32, nt = n0 + wn * 32;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = acc[tp][r];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int m = mt + er + 8 * jj, n = nt + ec;
+            const float4 c = *reinterpret_cast<const float4*>(wlds + (er + 8 * jj) * XEPL + ec);
+            if (m < g.M && n < g.N) *reinterpret_cast<float4*>(out + (size_t)m * g.ldc + tp * g.N + n) = c;
+        }
+    }
+}
+
 inline void pick_tile(int M, int N, int& mt, int& nt) {
     mt = M >= 256 ? 2 : 1;          // workgroup tile 128 mt x 64 nt
     nt = N >= 256 ? 4 : 2;
@@ -208,7 +347,8 @@ extern "C" int peclr_gemm_x6t_slabs(int M, int N, int K, int taps) {
     if (M <= 0 || N <= 0 || K <= 0 || (taps != 1 && taps != 9)) return 0;
     int mt, nt;
     pick_tile(M, N, mt, nt);
-    const long tiles = (long)((M + 128 * mt - 1) / (128 * mt)) * ((N + 64 * nt - 1) / (64 * nt)) * taps;
+    const long tiles = taps == 9 ? (long)((M + 127) / 128) * ((N + 63) / 64)      // all nine taps in one workgroup
+                                 : (long)((M + 128 * mt - 1) / (128 * mt)) * ((N + 64 * nt - 1) / (64 * nt));
     long s = (256 + tiles - 1) / tiles;
     const long max_s = (K + 16 * TK - 1) / (16 * TK);
     if (s > max_s) s = max_s;
@@ -232,8 +372,12 @@ extern "C" int peclr_gemm_x6t_f32(int M, int N, int K, const float* A, int lda, 
     g.taps = taps; g.H = H; g.W = W; g.zeros = zeros;
     int mt, nt;
     pick_tile(M, N, mt, nt);
-    const dim3 grid(((M + 128 * mt - 1) / (128 * mt)) * ((N + 64 * nt - 1) / (64 * nt)), n_slabs, taps);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (taps == 9) {
+        hipLaunchKernelGGL(gemm_x6w_kernel, dim3(((M + 127) / 128) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
+        return launch_status();
+    }
+    const dim3 grid(((M + 128 * mt - 1) / (128 * mt)) * ((N + 64 * nt - 1) / (64 * nt)), n_slabs, taps);
 #define PECLR_LAUNCH(MT_, NT_)                                                                                  \
     do {                                                                                                        \
         if (taps == 9) hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, 9>), grid, dim3(512), 0, s, g);            \
