@@ -414,10 +414,10 @@ class X6Planes:
             n, k = (w.shape[1], w.shape[0]) if t else (w.shape[0], w.shape[1])
             nbytes = lib().peclr_x6_pack_bytes(n, k)
             if nbytes <= 0:
-                raise PeclrHipError(f"X6Planes: B_t[{n}, {k}] needs n % 128 == 0 and k % 16 == 0")
+                raise PeclrHipError(f"X6Planes: B_t[{n}, {k}] needs n % 64 == 0 and k % 16 == 0")
             planes = torch.empty(nbytes, device=dev, dtype=torch.uint8)
             rows.append([w.data_ptr(), planes.data_ptr(), n, k, w.stride(0), t, chunk, 0])
-            chunk += (n // 128) * (k // 16)
+            chunk += ((n + 127) // 128) * (k // 16)
             self.planes.append(planes)
             self.shapes.append((n, k))
         self._sources = [w for w, _ in specs]          # keep the storage alive
@@ -439,7 +439,7 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
     stat_shift (fp32 [n]): also return the training-mode BatchNorm statistics of C as `(partial, n_split)` in the layout
     of peclr_bn2d_stats (sums of (C - shift) and its square per row block; the shift in the last row) -> (C, partial, n_split)."""
     m, k = a.shape
-    if planes.dtype != torch.uint8 or planes.numel() != 6 * n * k or (addend is not None and tuple(addend.shape) != (m, n)):
+    if planes.dtype != torch.uint8 or planes.numel() != 6 * ((n + 127) // 128 * 128) * k or (addend is not None and tuple(addend.shape) != (m, n)):
         raise PeclrHipError(f"gemm_x6p: A {tuple(a.shape)}, planes of {planes.numel()} bytes for B_t[{n}, {k}]")
     out = torch.empty((m, n), device=a.device, dtype=torch.float32)
     partial, ns = None, 0
@@ -474,7 +474,7 @@ def conv3x3_x6p(x: torch.Tensor, planes: torch.Tensor, cout: int, flip: bool = F
     Returns y [N, cout, H, W] channels_last (and (partial, n_split) when stat_shift is given)."""
     nb, cin, h, w = x.shape
     xp = _nhwc_ptr(x, "conv3x3 x", torch.float32)
-    if planes.dtype != torch.uint8 or planes.numel() != 6 * cout * 9 * cin:
+    if planes.dtype != torch.uint8 or planes.numel() != 6 * ((cout + 127) // 128 * 128) * 9 * cin:
         raise PeclrHipError(f"conv3x3_x6p: planes of {planes.numel()} bytes for [{cout}, 9 * {cin}]")
     y = torch.empty((nb, cout, h, w), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     m = nb * h * w

@@ -96,9 +96,11 @@ class X6PackGroup:
     @staticmethod
     def member(conv) -> bool:
         cout, cin = conv.out_channels, conv.in_channels
-        shape_ok = ((conv.kernel_size == (1, 1) and conv.padding == (0, 0)) or
-                    (conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1)))
-        return (shape_ok and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None and cout >= 128 and cin >= 128
+        if conv.stride != (1, 1) or conv.groups != 1 or conv.bias is not None:
+            return False
+        if conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1):
+            return cout >= 64 and cin >= 64 and cout % 64 == 0 and cin % 64 == 0        # 64-column tiles for layer1
+        return (conv.kernel_size == (1, 1) and conv.padding == (0, 0) and cout >= 128 and cin >= 128
                 and cout % 128 == 0 and cin % 128 == 0)
 
     def _key(self, conv):
@@ -487,7 +489,8 @@ class _Conv3x3Gemm(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             in_tree = (_GEMM_X6T and _CONV3X3_WGRAD_X6 and weight.is_contiguous(memory_format=torch.channels_last)
-                       and x.shape[3] >= 6 and x.shape[1] % 4 == 0 and gy.shape[1] % 4 == 0)
+                       and x.shape[3] >= 6 and x.shape[1] % 4 == 0 and gy.shape[1] % 4 == 0
+                       and gy.shape[1] >= 128)       # (64 output channels leave half of the 128-row tile empty: MIOpen is faster)
             dw = _wgrad_3x3_x6(gy, x, weight, conv.weight) if in_tree else _conv_wgrad(gy, x, weight, (1, 1), (1, 1), conv.weight)
         dx = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=256) if ctx.needs_input_grad[0] else None
         return dx, dw, None, None

@@ -74,7 +74,8 @@ __device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_offset)
 // AREG: the fp32 rows travel global -> registers (inline-asm loads, hand-counted) instead of global -> LDS (DMA) -> registers
 // ABL: ablation switches for tools/exp/x6p_ablate.hip (0 in the library): 1 no split / plane stores in the loop, 2 no raw-row
 // loads either, 4 no B DMA in the loop, 8 no MFMAs (bits combine)
-template <int WM, int ABL = 0, bool AREG = true, bool ILV = true, int TAPS = 1>
+// NTL: 32-column MFMA tiles per wave (4 -> 128 output columns per workgroup; 2 -> 64, for 64-channel layers: half a packed chunk)
+template <int WM, int ABL = 0, bool AREG = true, bool ILV = true, int TAPS = 1, int NTL = 4>
 __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     constexpr int RM = 32 * WM;                          // rows per wave
     constexpr int TM = 4 * RM;                           // rows per workgroup
@@ -94,21 +95,26 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     unsigned char* const planes = lds + PL0 + wave * WAVE_PL;
     unsigned char* const raw = lds + RAW0 + wave * (RM * 64);
     const unsigned raw_a = __builtin_amdgcn_readfirstlane(lds0 + RAW0 + wave * (RM * 64));
-    const unsigned b_a = __builtin_amdgcn_readfirstlane(lds0 + (3 * wave) * 1024);
+    const unsigned b_a = __builtin_amdgcn_readfirstlane(lds0);
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);             // wave-uniform copy in an SGPR (LDS-DMA targets)
 
-    const int nct = g.N / PN;
+    constexpr int PNL = 32 * NTL;                        // output columns per workgroup
+    const int nct = (g.N + PNL - 1) / PNL;
     const int j = blockIdx.x / 8;
     const int row_block = 8 * (j / nct) + (int)(blockIdx.x % 8);      // all column tiles of a row block on one XCD
     if (row_block * TM >= g.M) return;
-    const int m0 = row_block * TM + wave * RM, ct = j % nct, n0 = ct * PN;
+    const int m0 = row_block * TM + wave * RM, ct = j % nct, n0 = ct * PNL;
     const int nk = g.K / PK;
-    const unsigned char* bsrc = static_cast<const unsigned char*>(g.Bp) + (size_t)ct * nk * CHUNK + (3 * wave) * 1024 + lane * 16;
+    // packed chunk of this column tile (NTL = 2: the first or second half of a 128-column chunk's twelve pieces)
+    const int piece0 = NTL == 4 ? 0 : (ct & 1) * 6;
+    const unsigned char* bsrc = static_cast<const unsigned char*>(g.Bp) + (size_t)(NTL == 4 ? ct : ct >> 1) * nk * CHUNK +
+                                piece0 * 1024 + lane * 16;
 
-    f32x16 acc[WM][4];
+    f32x16 acc[WM][NTL];
 #pragma unroll
     for (int a = 0; a < WM; ++a)
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+        for (int y = 0; y < NTL; ++y)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][y][r] = 0.f;
 
@@ -132,11 +138,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     }
     const float* const zsrc = TAPS == 9 ? g.zeros + 4 * (lane & 3) : nullptr;
     const int kpt = TAPS == 9 ? g.lda / PK : 0;            // k-steps per tap
-    auto issue_b = [&](int t) {                           // wave's three pieces of chunk t -> buffer t % NB
+    auto issue_b = [&](int t) {                           // this wave's pieces (of 3 NTL) of chunk t -> buffer t % NB
         const unsigned char* s = bsrc + (size_t)t * CHUNK;
         const unsigned d = b_a + (t % NB) * CHUNK;
+        if constexpr (NTL == 4) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) dma16(s + q * 1024, d + q * 1024);
+            for (int q = 0; q < 3; ++q) dma16(s + (3 * wave_s + q) * 1024, d + (3 * wave_s + q) * 1024);
+        } else {                                          // six pieces: waves 0, 1 two each, waves 2, 3 one
+            dma16(s + wave_s * 1024, d + wave_s * 1024);
+            if (wave_s < 2) dma16(s + (4 + wave_s) * 1024, d + (4 + wave_s) * 1024);
+        }
     };
     f32x4 ar[NRAW];                                       // AREG: the next k-step's rows, in flight / landed
     auto issue_a = [&](int t) {
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
             for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const uint4*>(planes + p * PLANE + foff + a * 512);
         const unsigned char* bt = lds + (t % NB) * CHUNK + lane * 16;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < NTL / 2; ++half) {
             uint4 bf[2][3];
 #pragma unroll
             for (int y = 0; y < 2; ++y)
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         // waves (different rows, same columns) through 4 KiB of LDS, added in a fixed order
         float* sl = reinterpret_cast<float*>(lds + 4 * (32 * XEPL * 4));          // [wave][2][128]
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
+        for (int y = 0; y < NTL; ++y) {
             const float k0 = g.stat_shift[n0 + y * 32 + i];
             float sum = 0.f, sq = 0.f;
 #pragma unroll
@@ -263,18 +274,20 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         __syncthreads();
         {
             const int which = tid >> 7, col = tid & 127;
+            if (col < PNL) {
             const float v = ((sl[(0 * 2 + which) * 128 + col] + sl[(1 * 2 + which) * 128 + col]) +
                              sl[(2 * 2 + which) * 128 + col]) + sl[(3 * 2 + which) * 128 + col];
             g.stat_partial[((size_t)row_block * 2 + which) * g.N + n0 + col] = v;
             if (row_block == 0 && which == 0)
                 g.stat_partial[(size_t)((g.M + TM - 1) / TM) * 2 * g.N + n0 + col] = g.stat_shift[n0 + col];
+            }
         }
     }
     const int er = lane >> 3, ec = (lane & 7) * 4;
 #pragma unroll
     for (int a = 0; a < WM; ++a)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
+        for (int y = 0; y < NTL; ++y) {
             const int mt = m0 + a * 32, nt = n0 + y * 32;
             float4 dv[4];
 #pragma unroll
@@ -323,12 +336,15 @@ __global__ __launch_bounds__(256) void x6_pack_kernel(const PackDesc* descs, int
     const PackDesc e = descs[d];
     const int chunk = (int)(blockIdx.x - e.chunk_begin);
     const int nks = (int)(e.k / PK);
-    const int ct = chunk / nks, ks = chunk % nks;
+    const int ct = chunk / nks, ks = chunk % nks;            // (chunks per matrix: ceil(n / 128) * (k / 16))
     const int col = threadIdx.x & 127, kh = threadIdx.x >> 7;
     const int n = ct * PN + col, k0 = ks * PK + 8 * kh;
     const float* src = reinterpret_cast<const float*>(e.src);
     float v[8];
-    if (e.transposed > 1) {
+    if (n >= e.n) {                                           // padding columns of the last chunk (n a multiple of 64 only)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.f;
+    } else if (e.transposed > 1) {
         const int taps = (int)e.transposed, cout = (int)(e.k / taps);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -359,8 +375,8 @@ __global__ __launch_bounds__(256) void x6_pack_kernel(const PackDesc* descs, int
 using namespace peclr;
 
 extern "C" int64_t peclr_x6_pack_bytes(int N, int K) {
-    if (N <= 0 || K <= 0 || N % PN || K % PK) return 0;
-    return (int64_t)N * K * 6;
+    if (N <= 0 || K <= 0 || N % 64 || K % PK) return 0;      // (N is padded to whole 128-column chunks with zero columns)
+    return (int64_t)((N + PN - 1) / PN * PN) * K * 6;
 }
 
 extern "C" int peclr_x6_pack_f32(const void* desc_table, int count, int total_chunks, peclr_stream_t stream) {
@@ -375,8 +391,9 @@ extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K) {
     // 128-row tiles run three workgroups per CU (768 slots), 256-row tiles two (512 slots) at half the tiles and half the
     // B traffic per flop; pick the one with fewer (rounds of slots) x (rows per tile) -- the workgroup rounds a launch
     // quantises into are what separates the two on ResNet's shapes (tools/exp/gemm_x6p_probe.py) -- and 256 on a tie
-    if (M <= 0 || N <= 0 || N % PN) return 0;
-    const long t128 = (long)((M + 127) / 128) * (N / PN), t256 = (long)((M + 255) / 256) * (N / PN);
+    if (M <= 0 || N <= 0 || N % 64) return 0;
+    const long nct = N % PN ? N / 64 : N / PN;
+    const long t128 = (long)((M + 127) / 128) * nct, t256 = (long)((M + 255) / 256) * nct;
     const long c128 = ((t128 + 767) / 768) * 128, c256 = ((t256 + 511) / 512) * 256;
     return c128 < c256 ? 128 : 256;
 }
@@ -385,14 +402,19 @@ extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K);
 
 static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t stream) {
     const int nrb = (g.M + tile_rows - 1) / tile_rows;
-    const dim3 grid(8 * ((nrb + 7) / 8) * (g.N / PN));
+    const bool narrow = g.N % PN != 0;                    // 64-column tiles (N a multiple of 64 only)
+    const dim3 grid(8 * ((nrb + 7) / 8) * (narrow ? g.N / 64 : g.N / PN));
+#define PECLR_LAUNCH(WM_, TAPS_)                                                                                      \
+    do {                                                                                                              \
+        if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, true, TAPS_, 2>), grid, dim3(256), 0, stream, g); \
+        else hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, true, TAPS_, 4>), grid, dim3(256), 0, stream, g);       \
+    } while (0)
     if (taps == 9) {
-        if (tile_rows == 256) hipLaunchKernelGGL((gemm_x6p_kernel<2, 0, true, true, 9>), grid, dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((gemm_x6p_kernel<1, 0, true, true, 9>), grid, dim3(256), 0, stream, g);
+        if (tile_rows == 256) PECLR_LAUNCH(2, 9); else PECLR_LAUNCH(1, 9);
     } else {
-        if (tile_rows == 256) hipLaunchKernelGGL(gemm_x6p_kernel<2>, grid, dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL(gemm_x6p_kernel<1>, grid, dim3(256), 0, stream, g);
+        if (tile_rows == 256) PECLR_LAUNCH(2, 1); else PECLR_LAUNCH(1, 1);
     }
+#undef PECLR_LAUNCH
     return launch_status();
 }
 
@@ -400,7 +422,7 @@ extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, co
                                      const float* addend, int flip, int tile_rows, const float* zeros,
                                      const float* stat_shift, float* stat_partial, peclr_stream_t stream) {
     if (!X || !Bp || !Y || !zeros || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
-    if (NB <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cout % PN || Cin % PK) return PECLR_ERR_SHAPE;
+    if (NB <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cout % 64 || Cin % PK) return PECLR_ERR_SHAPE;
     if ((long)NB * H * W > 0x7FFFFFFFL / 2) return PECLR_ERR_SHAPE;
     if (!aligned16(X) || !aligned16(Bp) || !aligned16(Y) || !aligned16(zeros) || (addend && !aligned16(addend))) return PECLR_ERR_ALIGN;
     const int M = NB * H * W;
@@ -419,7 +441,7 @@ extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, 
                                   const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
                                   peclr_stream_t stream) {
     if (!A || !Bp || !C || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
-    if (M <= 0 || N <= 0 || K <= 0 || N % PN || K % PK) return PECLR_ERR_SHAPE;
+    if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % PK) return PECLR_ERR_SHAPE;
     if (lda % 4 || lda < K || ldc % 4 || ldc < N || (addend && (ldd % 4 || ldd < N))) return PECLR_ERR_SHAPE;
     if (!aligned16(A) || !aligned16(Bp) || !aligned16(C) || (addend && !aligned16(addend))) return PECLR_ERR_ALIGN;
     if (tile_rows == 0) tile_rows = peclr_gemm_x6p_tile_rows(M, N, K);

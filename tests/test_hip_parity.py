@@ -1877,7 +1877,7 @@ def test_batchnorm_statistics_from_the_gemm_epilogue_equal_the_separate_pass(cin
         assert float((res[True][3][0][1].double() - (0.9 + 0.1 * var)).abs().max()) <= 2e-6 * float(var.max()) + 1e-6
 
 
-@pytest.mark.parametrize("c,hw,n", [(128, 28, 24), (256, 14, 64), (512, 7, 200), (128, 9, 104)])
+@pytest.mark.parametrize("c,hw,n", [(128, 28, 24), (256, 14, 64), (512, 7, 200), (128, 9, 104), (64, 56, 8), (192, 12, 60)])
 def test_conv3x3_as_an_implicit_gemm_on_the_matrix_cores_matches_float64(c, hw, n):
     """bn2d.Conv2d(hip_gemm) for 3x3 / stride-1 / padding-1 convolutions of NHWC fp32 tensors: forward and input
     gradient as peclr_conv3x3_x6p_f32 (implicit GEMM over (tap, channel), zero padding by source selection, filter planes
@@ -1907,7 +1907,8 @@ def test_conv3x3_as_an_implicit_gemm_on_the_matrix_cores_matches_float64(c, hw, 
         finally:
             _capi.EVENT_LOG = None
         res[mode] = (y.detach(), xx.grad.clone(), conv.weight.grad.clone())
-    assert tags[False] == [] and tags[True] == ["conv3x3_dgrad", "conv3x3_fwd", "conv3x3_wgrad", "wgrad_slab_reduce", "x6_pack"], tags
+    want = ["conv3x3_dgrad", "conv3x3_fwd"] + (["conv3x3_wgrad", "wgrad_slab_reduce"] if c >= 128 else []) + ["x6_pack"]
+    assert tags[False] == [] and tags[True] == want, tags
     assert res[True][0].is_contiguous(memory_format=torch.channels_last) and res[True][1].is_contiguous(memory_format=torch.channels_last)
     sub = slice(0, min(n, 6))
     w64 = conv.weight.detach().double()
@@ -1935,7 +1936,8 @@ def test_conv3x3_as_an_implicit_gemm_on_the_matrix_cores_matches_float64(c, hw, 
     y2 = conv(xx)
     y2.backward(gy)
     assert torch.equal(y2, res[True][0]) and torch.equal(xx.grad, res[True][1])
-    assert torch.equal(conv.weight.grad, 2 * res[True][2])            # (accumulated onto the first gradient: fixed-order slabs)
+    if c >= 128:
+        assert torch.equal(conv.weight.grad, 2 * res[True][2])        # (accumulated onto the first gradient: fixed-order slabs)
 
 
 def test_x6_pack_group_follows_the_weights():
@@ -2060,7 +2062,7 @@ def test_gemm_x6t_matches_float64_and_is_deterministic(capi, k_rows, m, n):
     assert torch.equal(capi.gemm_x6t(a, b), got)
 
 
-@pytest.mark.parametrize("nb,c,hw", [(6, 128, 9), (4, 256, 7), (256, 256, 14), (40, 512, 7)])
+@pytest.mark.parametrize("nb,c,hw", [(6, 128, 9), (4, 256, 7), (256, 256, 14), (40, 512, 7), (5, 64, 10)])
 def test_gemm_x6t_nine_taps_is_the_3x3_weight_gradient(capi, nb, c, hw):
     """peclr_gemm_x6t_f32 with taps = 9: the nine [Cout, Cin] products of a 3x3 / stride-1 / padding-1 convolution's weight
     gradient, X read at the pixel each tap points at (zeros outside the image), written in the [Cout][3][3][Cin] order of a

@@ -27,7 +27,7 @@ def timeit(fn, reps=8):
     return ts[len(ts) // 2]
 
 
-SHAPES = [(256, 128, 28), (256, 256, 14), (256, 512, 7)] if len(sys.argv) < 2 else [(8, 128, 9), (5, 256, 6)]
+SHAPES = [(256, 64, 56), (256, 128, 28), (256, 256, 14), (256, 512, 7)] if len(sys.argv) < 2 else [(8, 128, 9), (5, 256, 6), (6, 64, 10)]
 for n, c, hw in SHAPES:
     g = torch.Generator(device="cuda").manual_seed(c + hw)
     x = torch.randn(n, c, hw, hw, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)

@@ -17,9 +17,9 @@ def timeit(fn, reps=8):
 small = len(sys.argv) > 1
 R2, R3, R4 = 256 * 28 * 28, 256 * 14 * 14, 256 * 7 * 7
 S1 = [(R2, 128, 512), (R2, 512, 128), (R3, 256, 1024), (R3, 1024, 256), (R4, 512, 2048), (R4, 2048, 512), (R2, 128, 256)]
-S3 = [(256, 128, 28), (256, 256, 14), (256, 512, 7)]
+S3 = [(256, 64, 56), (256, 128, 28), (256, 256, 14), (256, 512, 7)]
 if small:
-    S1 = [(4100, 128, 256), (8192 + 4, 132, 260), (3000, 512, 128)]; S3 = [(6, 128, 9), (4, 256, 7)]
+    S1 = [(4100, 128, 256), (8192 + 4, 132, 260), (3000, 512, 128)]; S3 = [(6, 128, 9), (4, 256, 7), (5, 64, 10)]
 for k, m, n in S1:
     g = torch.Generator(device="cuda").manual_seed(k + m + n)
     a = torch.randn(k, m, device="cuda", generator=g); b = torch.randn(k, n, device="cuda", generator=g)
