@@ -380,9 +380,10 @@ def try_graph_child():
 
 
 def fp32_gemm_check(device):
-    """Untimed, before the timed region: the error of peclr_gemm_x6_f32 / _tn_f32 (fp32 operands as three bf16 numbers,
-    six MFMA products) and of the v_mfma_f32 kernel against float64 on the same fp32 data, relative to the output
-    scale -- the bench line carries the evidence that its fp32 GEMMs are fp32-accurate."""
+    """Untimed, before the timed region: the error of the six-product kernels that carry the backbone's GEMM-shaped fp32 work
+    (fp32 operands as three bf16 numbers, six MFMA products: peclr_gemm_x6p_f32 forward / input gradient,
+    peclr_conv3x3_x6p_f32, peclr_gemm_x6t_f32 weight gradients) and of the v_mfma_f32 kernel against float64 on the same
+    fp32 data, relative to the output scale -- the bench line carries the evidence that its fp32 GEMMs are fp32-accurate."""
     from peclr_amd import _capi
 
     g = torch.Generator(device=device).manual_seed(1234)
@@ -391,10 +392,17 @@ def fp32_gemm_check(device):
     bt = torch.randn(n, k, device=device, generator=g) * 0.05
     ref = a.double() @ bt.double().t()
     scale = float(ref.abs().max())
-    err = lambda t: float((t.double() - ref).abs().max()) / scale  # noqa: E731
-    at = a.t().contiguous()                                         # [K, M]: the TN kernel contracts over rows
-    return {"shape": [m, n, k], "x6_max_err_over_scale": err(_capi.gemm_x6(a, bt)),
-            "x6_tn_max_err_over_scale": err(_capi.gemm_x6_tn(at, bt.t().contiguous())),
+    err = lambda t, r=ref, s=scale: float((t.double() - r).abs().max()) / s  # noqa: E731
+    at = a.t().contiguous()                                         # [K, M]: the weight-gradient kernels contract over rows
+    planes = _capi.X6Planes([(bt, False)]).pack().planes[0]
+    x = torch.randn(8, 256, 14, 14, device=device, generator=g).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(256, 256, 3, 3, device=device, generator=g) * 0.03).contiguous(memory_format=torch.channels_last)
+    p3 = _capi.X6Planes([(w.permute(0, 2, 3, 1).reshape(256, 9 * 256), False)]).pack().planes[0]
+    y3 = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    return {"shape": [m, n, k], "x6p_max_err_over_scale": err(_capi.gemm_x6p(a, planes, n)),
+            "x6t_max_err_over_scale": err(_capi.gemm_x6t(at, bt.t().contiguous())),
+            "conv3x3_x6p_max_err_over_scale": float((_capi.conv3x3_x6p(x, p3, 256).double() - y3).abs().max()) / float(y3.abs().max()),
+            "conv3x3_miopen_max_err_over_scale": float((torch.nn.functional.conv2d(x, w, padding=1).double() - y3).abs().max()) / float(y3.abs().max()),
             "v_mfma_f32_max_err_over_scale": err(_capi.gemm(_capi.GEMM_NT, a, bt)), "reference": "float64 on the same fp32 inputs"}
 
 
@@ -631,8 +639,8 @@ def main():
                                   "one hipGraph replay per step (whole step captured)" if use_graph else
                                   "eager launches" + (f" ({graph_note})" if graph_note else "")),
                        "graph_fallback": graph_note,   # None unless --graph auto had to fall back to eager launches
-                       # fp32 runs: the GEMM-shaped backbone work (1x1 convolutions forward / input gradient / weight gradient from K = 128 on,
-                       # the fused entry gradient) runs on the bf16 matrix cores at fp32 ACCURACY: every fp32 operand is split
+                       # fp32 runs: the GEMM-shaped backbone work (1x1 convolutions from K = 128 on and 3x3 stride-1 convolutions: forward,
+                       # input gradient, weight gradient; the fused entry gradient) runs on the bf16 matrix cores at fp32 ACCURACY: every fp32 operand is split
                        # exactly into three bf16 numbers and six of the nine partial products are accumulated in fp32
                        # (peclr_gemm_x6_f32; error vs float64 <= the v_mfma_f32 kernel's, tests/test_hip_parity.py)
                        "fp32_gemm": (("exact 3-way bf16 split, 6 MFMA products, fp32 accumulate (fp32 accuracy)"
@@ -649,9 +657,10 @@ def main():
             "fp32_gemm_check": x6_check,
             "roofline": roof,
             "kernels": kernels,
-            "backbone": {"note": "whole encoder, 3x forward conv FLOPs over the step time, against the v_mfma_f32 / bf16 MFMA peak: "
-                                 "3x3 / 7x7 / layer1 convolutions on PyTorch-ROCm/MIOpen, the other fp32 1x1 convolutions "
-                                 "hand-written (config.fp32_gemm)",
+            "backbone": {"note": "whole encoder, 3x forward conv FLOPs over the step time, against the v_mfma_f32 / bf16 MFMA peak; fp32: "
+                                 "the stride-1 1x1 (layers 2-4) and 3x3 (layers 1-4) convolutions run on the in-tree six-product "
+                                 "kernels (config.fp32_gemm), the 7x7 stem, the strided convolutions and layer1's 1x1 on "
+                                 "PyTorch-ROCm/MIOpen",
                          "flops_per_step_per_gpu": step_flops, "achieved": round(ach_tf, 2), "peak": peak_tf,
                          "unit": "TFLOP/s", "frac": round(ach_tf / peak_tf, 4)},
             "hand_written_us_per_step": round(sum(k["avg_us"] * k["launches"] / table_steps

@@ -23,7 +23,7 @@ static void launch(const X6PArgs& g, hipStream_t st) {
 }
 
 int main() {
-    const int shapes[][3] = {{4096, 2048, 512}, {8192, 2048, 512}, {16384, 2048, 512}, {12544, 2048, 512}};
+    const int shapes[][3] = {{16384, 2048, 512}, {50176, 256, 1024}};
     float *A, *C, *W; unsigned char *Bp, *junk;
     CK(hipMalloc(&A, (size_t)200704 * 2048 * 4)); CK(hipMalloc(&C, (size_t)200704 * 2048 * 4));
     CK(hipMalloc(&W, (size_t)2048 * 2048 * 4)); CK(hipMalloc(&Bp, (size_t)2048 * 2048 * 6)); CK(hipMalloc(&junk, 512u << 20));

@@ -64,6 +64,25 @@ def main():
         gab, wbt, gdb = ga.bfloat16(), wb.t().contiguous().bfloat16(), gd.bfloat16()
         calls.append((f"conv1x1_dgrad_add_bf16@{r}x{cmid}x{cin}",
                       lambda gab=gab, wbt=wbt, gdb=gdb: _capi.gemm_add_bf16(gab, wbt, gdb, tag="conv1x1_dgrad_add")))
+    # round 3: the six-product GEMM family at ResNet-50's shapes -- 1x1 forward / input gradient (peclr_gemm_x6p_f32, with and
+    # without the residual-gradient addend), 3x3 forward (peclr_conv3x3_x6p_f32), weight gradients (peclr_gemm_x6t_f32)
+    for r, n, k in ((200704, 128, 512), (200704, 512, 128), (50176, 256, 1024), (50176, 1024, 256), (12544, 512, 2048), (12544, 2048, 512)):
+        xa, wt = torch.randn(r, k, device=dev), torch.randn(n, k, device=dev) * 0.05
+        pk = _capi.X6Planes([(wt, False)]).pack()
+        calls.append((f"gemm_x6p@{r}x{n}x{k}", lambda xa=xa, pk=pk, n=n: _capi.gemm_x6p(xa, pk.planes[0], n, tag="gemm_x6p")))
+        if n > k:
+            gd = torch.randn(r, n, device=dev)
+            calls.append((f"gemm_x6p_add@{r}x{n}x{k}", lambda xa=xa, pk=pk, n=n, gd=gd: _capi.gemm_x6p(xa, pk.planes[0], n, gd, tag="gemm_x6p")))
+        ga, gb = torch.randn(r, n, device=dev), torch.randn(r, k, device=dev)
+        calls.append((f"gemm_x6t@{r}x{n}x{k}", lambda ga=ga, gb=gb: _capi.gemm_x6t(ga, gb, tag="gemm_x6t")))
+    for c, hw in ((64, 56), (128, 28), (256, 14), (512, 7)):
+        x4 = torch.randn(256, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+        w4 = (torch.randn(c, c, 3, 3, device=dev) * 0.03).contiguous(memory_format=torch.channels_last)
+        pk = _capi.X6Planes([(w4.permute(0, 2, 3, 1).reshape(c, 9 * c), False)]).pack()
+        calls.append((f"conv3x3_x6p@256x{c}x{hw}", lambda x4=x4, pk=pk, c=c: _capi.conv3x3_x6p(x4, pk.planes[0], c, tile_rows=256, tag="conv3x3_x6p")))
+        if c >= 128:
+            x2 = x4.permute(0, 2, 3, 1).reshape(-1, c)
+            calls.append((f"conv3x3_wgrad@256x{c}x{hw}", lambda x2=x2, hw=hw: _capi.gemm_x6t(x2, x2, taps=9, hw=(hw, hw), tag="conv3x3_wgrad")))
     for _, fn in calls:            # untimed warm-up (module load, first-touch)
         fn()
     torch.cuda.synchronize()

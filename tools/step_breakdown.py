@@ -20,7 +20,9 @@ CATS = OrderedDict([
     ("MIOpen zero-fill / cast for split-K weight gradients", lambda n: "SubTensorOp" in n or "fillBufferAligned" in n),
     ("hand-written: BatchNorm2d glue (bn2d_*)", lambda n: "peclr" in n and "bn2d_" in n),
     ("hand-written: fused dgrad + residual GEMM (128x128)", lambda n: "peclr" in n and "gemm_f32_nn128" in n),
-    ("hand-written: fp32 GEMMs on the bf16 matrix cores (1x1 convolutions, fused dgrad)", lambda n: "peclr" in n and "gemm_x6" in n),
+    ("hand-written: 3x3 convolutions on the bf16 matrix cores (forward, input gradient: gemm_x6p <.., 9>; weight gradient: gemm_x6w)",
+     lambda n: "peclr" in n and ("gemm_x6w" in n or ("gemm_x6p_kernel" in n and ", 9, " in n))),
+    ("hand-written: fp32 GEMMs on the bf16 matrix cores (1x1 convolutions, fused dgrad, weight gradients)", lambda n: "peclr" in n and "gemm_x6" in n),
     ("hand-written: head GEMMs / bf16 GEMM", lambda n: "peclr" in n and "gemm_" in n),
     ("hand-written: BN1d+ReLU, align, NT-Xent", lambda n: "peclr" in n and any(k in n for k in ("bn_relu", "align_", "ntxent", "slab_reduce"))),
     ("hand-written: LARS / Adam", lambda n: "peclr" in n and ("sumsq" in n or "lars_adam" in n)),
