@@ -100,6 +100,22 @@ int peclr_gemm_x6_f32(int M, int N, int K, const float* A, int lda, const float*
 int peclr_gemm_x6_tn_slabs(int M, int N, int K);
 int peclr_gemm_x6_tn_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs,
                          int n_slabs, peclr_stream_t stream);
+/* Optional fusion of a BatchNorm2d(+ReLU) layer's backward REDUCTION into the GEMM that produces the gradient arriving at
+ * that layer (the input gradient of the convolution that consumed the layer's output): host struct of device pointers.
+ * The epilogue sums, per row block and column, dY' and dY' * xhat (dY' = dY where the ReLU passed -- recomputed from the
+ * layer's input x with scale / shift, or read from its 1-bit mask; xhat = (x - mean) * invstd) into
+ * partial[ceil(M / tile_rows)][2][N], the layout peclr_bn2d_bwd_finalize_f32 combines with n_split = ceil(M / tile_rows):
+ * the separate peclr_bn2d_bwd_reduce pass over dY and x is not needed.  Fixed summation order. */
+typedef struct {
+    const float* x;             /* the layer's input [M][N], contiguous */
+    const float* mean;          /* [N] */
+    const float* invstd;        /* [N] */
+    const float* scale_shift;   /* [2][N] of the forward */
+    const uint32_t* relu_mask;  /* [M][N / 32] or NULL (mask recomputed from x) */
+    int relu;
+    float* partial;
+} peclr_bn_bwd_fuse;
+
 /* Second generation of the same scheme for a WEIGHT operand (a parameter: constant for a whole step, used by forward,
  * input gradient and fused entry gradient of a 1x1 convolution, resnet_model.py:15): peclr_x6_pack_f32 splits the
  * weight ONCE into three bf16 planes in MFMA fragment order (per 128 output columns x 16 k one 12 KiB chunk of twelve
@@ -121,7 +137,7 @@ int peclr_x6_pack_f32(const void* desc_table, int count, int total_chunks, peclr
 int peclr_gemm_x6p_tile_rows(int M, int N, int K);
 int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                        const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
-                       peclr_stream_t stream);
+                       const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
 /* 3x3 / stride-1 / padding-1 convolution of an NHWC fp32 tensor (the middle convolution of the torchvision Bottleneck,
  * resnet_model.py:15) as an implicit GEMM on the same kernel: rows = output pixels, K = 9 * Cin ordered (tap, channel); the
  * activation rows of a k-step come from the pixel the tap points at (zeros outside the image: `zeros` = >= 64 bytes of
@@ -131,7 +147,7 @@ int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void*
  * statistics outputs as in peclr_gemm_x6p_f32.  Cin % 16 == 0, Cout % 128 == 0.                                      */
 int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* X, const void* Bp, float* Y,
                           const float* addend, int flip, int tile_rows, const float* zeros, const float* stat_shift,
-                          float* stat_partial, peclr_stream_t stream);
+                          float* stat_partial, const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
 /* Weight gradients, second generation: C[M, taps * N] = sum_k A[k, M] . B[k shifted by the tap, N], the contraction over the
  * ROWS of two NHWC activations (A = dY [R, Cout], B = X [R, Cin]).  taps = 1: dW = dY^T X of a 1x1 convolution.  taps = 9:
  * the nine [Cout, Cin] products of a 3x3 / stride-1 / padding-1 convolution's weight gradient, X read at the pixel each

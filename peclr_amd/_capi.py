@@ -71,10 +71,10 @@ SIGNATURES = {
     "peclr_x6_pack_bytes": (c_int64, [c_int, c_int]),
     "peclr_x6_pack_f32": (c_int, [_P, c_int, c_int, _P]),
     "peclr_gemm_x6p_tile_rows": (c_int, [c_int, c_int, c_int]),
-    "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P, _P, _P]),
+    "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P]),
     "peclr_gemm_x6t_slabs": (c_int, [c_int, c_int, c_int, c_int]),
     "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
-    "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
@@ -395,6 +395,25 @@ def gemm_x6(a: torch.Tensor, b_t: torch.Tensor, addend: Optional[torch.Tensor] =
     return out
 
 
+class _BnBwdFuse(ctypes.Structure):
+    """peclr_bn_bwd_fuse (include/peclr_hip.h)."""
+    _fields_ = [("x", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("scale_shift", c_void_p), ("relu_mask", c_void_p),
+                ("relu", c_int), ("partial", c_void_p)]
+
+
+def _bn_bwd_fuse(bn_bwd, m: int, n: int, tile_rows: int):
+    """bn_bwd = (x [.., n] NHWC/2-D fp32 of m rows, save [2, n], ss [2, n], mask or None, relu) of the BatchNorm layer whose
+    incoming gradient this GEMM produces -> (struct, partial [2 * n_split, n], n_split); keeps the tensors alive."""
+    x, save, ss, mask, relu = bn_bwd
+    if x.dtype != torch.float32 or x.numel() != m * n or not x.is_cuda:
+        raise PeclrHipError(f"bn backward fusion: layer input of {x.numel()} elements for a [{m}, {n}] gradient")
+    ns = (m + tile_rows - 1) // tile_rows
+    partial = torch.empty((2 * ns, n), device=x.device, dtype=torch.float32)
+    st = _BnBwdFuse(x.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), _ptr(ss), _ptr(mask, torch.int32, "relu mask"), int(relu),
+                    partial.data_ptr())
+    return st, partial, ns
+
+
 class X6Planes:
     """Weight matrices split once into fragment-ordered bf16 planes (peclr_x6_pack_f32) for peclr_gemm_x6p_f32.
     `specs`: list of (fp32 2-D HIP tensor W, transposed) -- B_t = W ([N, K]) or W^T (W is [K, N]).  The device table is
@@ -433,27 +452,34 @@ class X6Planes:
 
 
 def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[torch.Tensor] = None, tag: str = "gemm_x6p",
-             tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None):
+             tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None):
     """C (fp32) [M, n] = A[M, K] . B_t^T (+ addend) with B_t given as packed planes (X6Planes): fp32 accuracy on the
     bf16 matrix cores, the weight operand split once per step (peclr_gemm_x6p_f32).
     stat_shift (fp32 [n]): also return the training-mode BatchNorm statistics of C as `(partial, n_split)` in the layout
-    of peclr_bn2d_stats (sums of (C - shift) and its square per row block; the shift in the last row) -> (C, partial, n_split)."""
+    of peclr_bn2d_stats (sums of (C - shift) and its square per row block; the shift in the last row) -> (C, partial, n_split).
+    bn_bwd (see `_bn_bwd_fuse`): C is the gradient arriving at that BatchNorm layer; also return its backward reduction
+    `(partial, n_split)` in peclr_bn2d_bwd_reduce's layout -> (C, partial, n_split)."""
     m, k = a.shape
     if planes.dtype != torch.uint8 or planes.numel() != 6 * ((n + 127) // 128 * 128) * k or (addend is not None and tuple(addend.shape) != (m, n)):
         raise PeclrHipError(f"gemm_x6p: A {tuple(a.shape)}, planes of {planes.numel()} bytes for B_t[{n}, {k}]")
     out = torch.empty((m, n), device=a.device, dtype=torch.float32)
-    partial, ns = None, 0
+    partial, ns, fuse = None, 0, None
+    if stat_shift is not None or bn_bwd is not None:
+        tile_rows = tile_rows or lib().peclr_gemm_x6p_tile_rows(m, n, k)
     if stat_shift is not None:
         if stat_shift.numel() != n:
             raise PeclrHipError(f"gemm_x6p: stat_shift has {stat_shift.numel()} entries for {n} columns")
-        tile_rows = tile_rows or lib().peclr_gemm_x6p_tile_rows(m, n, k)
         ns = (m + tile_rows - 1) // tile_rows
         partial = torch.empty((2 * ns + 1, n), device=a.device, dtype=torch.float32)
-    with _timed(tag, 4 * (m * k + (2 if addend is not None else 1) * m * n) + 6 * k * n, 2 * m * n * k, kernel="gemm_x6p_kernel"):
+    elif bn_bwd is not None:
+        fuse, partial, ns = _bn_bwd_fuse(bn_bwd, m, n, tile_rows)
+    with _timed(tag, 4 * (m * k + (2 if addend is not None else 1) * m * n + (m * n if fuse is not None else 0)) + 6 * k * n, 2 * m * n * k,
+                kernel="gemm_x6p_kernel"):
         rc = lib().peclr_gemm_x6p_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
-                                      tile_rows, _ptr(stat_shift), _ptr(partial), _stream())
+                                      tile_rows, _ptr(stat_shift), partial.data_ptr() if stat_shift is not None else None,
+                                      ctypes.byref(fuse) if fuse is not None else None, _stream())
     _check(rc, "peclr_gemm_x6p_f32")
-    return out if stat_shift is None else (out, partial, ns)
+    return out if partial is None else (out, partial, ns)
 
 
 _ZEROS = {}
@@ -467,29 +493,34 @@ def _zeros(device):
 
 
 def conv3x3_x6p(x: torch.Tensor, planes: torch.Tensor, cout: int, flip: bool = False, addend: Optional[torch.Tensor] = None,
-                tag: str = "conv3x3_x6p", tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None):
+                tag: str = "conv3x3_x6p", tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None):
     """3x3 / stride-1 / padding-1 convolution of an NHWC (channels_last) fp32 tensor x [N, Cin, H, W] as an implicit GEMM on
     the bf16 matrix cores at fp32 accuracy (peclr_conv3x3_x6p_f32); `planes` = X6Planes of W seen as [Cout, 9 * Cin]
     (flip=False) or, for the input gradient (flip=True, x = dY), of [Cout_w * 9, Cin_w] packed with transposed = 9.
-    Returns y [N, cout, H, W] channels_last (and (partial, n_split) when stat_shift is given)."""
+    Returns y [N, cout, H, W] channels_last (and (partial, n_split) when stat_shift or bn_bwd is given, as in gemm_x6p)."""
     nb, cin, h, w = x.shape
     xp = _nhwc_ptr(x, "conv3x3 x", torch.float32)
     if planes.dtype != torch.uint8 or planes.numel() != 6 * ((cout + 127) // 128 * 128) * 9 * cin:
         raise PeclrHipError(f"conv3x3_x6p: planes of {planes.numel()} bytes for [{cout}, 9 * {cin}]")
     y = torch.empty((nb, cout, h, w), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     m = nb * h * w
-    partial, ns = None, 0
-    if stat_shift is not None:
+    partial, ns, fuse = None, 0, None
+    if stat_shift is not None or bn_bwd is not None:
         tile_rows = tile_rows or lib().peclr_gemm_x6p_tile_rows(m, cout, 9 * cin)
+    if stat_shift is not None:
         ns = (m + tile_rows - 1) // tile_rows
         partial = torch.empty((2 * ns + 1, cout), device=x.device, dtype=torch.float32)
+    elif bn_bwd is not None:
+        fuse, partial, ns = _bn_bwd_fuse(bn_bwd, m, cout, tile_rows)
     ap = _nhwc_ptr(addend, "conv3x3 addend", torch.float32) if addend is not None else None
-    with _timed(tag, 4 * (m * cin + (2 if addend is not None else 1) * m * cout) + 54 * cin * cout, 18 * m * cin * cout,
-                kernel="gemm_x6p_kernel (3x3)"):
+    with _timed(tag, 4 * (m * cin + (2 if addend is not None else 1) * m * cout + (m * cout if fuse is not None else 0)) + 54 * cin * cout,
+                18 * m * cin * cout, kernel="gemm_x6p_kernel (3x3)"):
         rc = lib().peclr_conv3x3_x6p_f32(nb, h, w, cin, cout, xp, _ptr(planes, torch.uint8), y.data_ptr(), ap, int(flip), tile_rows,
-                                         _zeros(x.device).data_ptr(), _ptr(stat_shift), _ptr(partial), _stream())
+                                         _zeros(x.device).data_ptr(), _ptr(stat_shift),
+                                         partial.data_ptr() if stat_shift is not None else None,
+                                         ctypes.byref(fuse) if fuse is not None else None, _stream())
     _check(rc, "peclr_conv3x3_x6p_f32")
-    return y if stat_shift is None else (y, partial, ns)
+    return y if partial is None else (y, partial, ns)
 
 
 def gemm_x6_tn(a: torch.Tensor, b: torch.Tensor, tag: str = "gemm_x6_tn") -> torch.Tensor:
@@ -661,7 +692,7 @@ def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training,
     return y, save, ss, mask
 
 
-def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres, sync_group=None):
+def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres, sync_group=None, pre=None):
     """ReLU mask source: `mask` (bit mask from the forward) > `y` (forward output) > recomputed from x.
     sync_group: as in bn2d_fwd; dgamma/dbeta stay this rank's local sums (the gradient all-reduce sums
     them later), dx uses the global sums."""
@@ -669,8 +700,6 @@ def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres, sync_group=Non
     r = n * h * w
     dev = x.device
     io, e = _IO[x.dtype]
-    ns = bn2d_n_split(r, c, io)
-    partial = torch.empty((2 * ns, c), device=dev, dtype=torch.float32)
     dparams = torch.empty((2, c), device=dev, dtype=torch.float32)  # dgamma, dbeta
     coef = torch.empty((2, c), device=dev, dtype=torch.float32)
     dx = torch.empty_like(x, memory_format=torch.channels_last)
@@ -679,10 +708,18 @@ def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres, sync_group=Non
     yp = _nhwc_ptr(y, "bn2d y", x.dtype) if (y is not None and mask is None) else None
     mp = _ptr(mask, torch.int32, "relu mask")
     extra = (r * c // 8) if mask is not None else (e * r * c if yp is not None else 0)
-    with _timed("bn2d_bwd_reduce", 2 * e * r * c + extra):
-        rc = lib().peclr_bn2d_bwd_reduce(dyp, xp, yp, mp, io, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
-                                         ss.data_ptr(), partial.data_ptr(), ns, _stream())
-    _check(rc, "peclr_bn2d_bwd_reduce")
+    if pre is not None:
+        # the GEMM that produced dy already reduced it against this layer's x in its epilogue (peclr_bn_bwd_fuse)
+        partial, ns = pre
+        if tuple(partial.shape) != (2 * ns, c):
+            raise PeclrHipError(f"bn2d backward: precomputed reduction of shape {tuple(partial.shape)} for C = {c}, n_split = {ns}")
+    else:
+        ns = bn2d_n_split(r, c, io)
+        partial = torch.empty((2 * ns, c), device=dev, dtype=torch.float32)
+        with _timed("bn2d_bwd_reduce", 2 * e * r * c + extra):
+            rc = lib().peclr_bn2d_bwd_reduce(dyp, xp, yp, mp, io, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
+                                             ss.data_ptr(), partial.data_ptr(), ns, _stream())
+        _check(rc, "peclr_bn2d_bwd_reduce")
     if training and sync_group is not None:
         local, total = _sync_totals(partial, ns, c, r, sync_group)
         with _timed("bn2d_bwd_finalize", 32 * c):

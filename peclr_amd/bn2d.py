@@ -72,6 +72,10 @@ _GEMM_X6 = os.environ.get("PECLR_GEMM_X6", "1") != "0"    # A/B switch: fp32 GEM
 _X6_MIN_K = int(os.environ.get("PECLR_GEMM_X6_MIN_K", "128"))   # in-step A/B: 128 beats 256 by 0.1-0.4 ms, 64 is HBM-bound
 
 
+_BN_BWD_IN_GEMM = os.environ.get("PECLR_BN_BWD_IN_GEMM", "1") != "0"     # A/B switch: BatchNorm backward reduction in the dgrad GEMM epilogue
+# gradient tensors whose producer (an input-gradient GEMM) already reduced them against the BatchNorm layer they arrive at:
+# data_ptr -> (token of that layer's forward, partial sums, n_split); popped by the layer's backward
+_BN_BWD_STATS: dict = {}
 _BN_STATS_IN_GEMM = os.environ.get("PECLR_BN_STATS_IN_GEMM", "1") != "0"   # A/B switch: BatchNorm statistics in the GEMM epilogue
 _GEMM_X6T = os.environ.get("PECLR_GEMM_X6T", "1") != "0"  # A/B switch: weight gradients on the 256 x 256-tile kernel (peclr_gemm_x6t_f32)
 _GEMM_X6P = os.environ.get("PECLR_GEMM_X6P", "1") != "0"  # A/B switch: weight planes packed once per step (peclr_gemm_x6p_f32)
@@ -150,7 +154,9 @@ def _x6_planes(conv):
 
 class _BN2dAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool, pre=None):
+    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool, pre=None, link=None):
+        """link: None or an empty list that receives what a consumer's input-gradient GEMM needs to perform this layer's
+        backward reduction in its epilogue: [x, save, scale_shift, relu mask or None, relu, token]."""
         training = bn.training or not bn.track_running_stats
         # the ReLU mask can be recomputed from x unless a residual was added before it; then the
         # forward writes a 1-bit mask (or, for C % 32 != 0, the backward re-reads y)
@@ -164,6 +170,10 @@ class _BN2dAct(torch.autograd.Function):
         ctx.save_for_backward(x, save, ss, *([keep] if keep is not None else []))
         ctx.cfg = (training, relu, residual is not None, keep is not None, mask is not None)
         ctx.sync_group = bn.sync_group if training else None
+        ctx.token = None
+        if link is not None and x.dtype == torch.float32 and (keep is None or mask is not None):
+            ctx.token = object()
+            link[:] = [x, save, ss, mask, relu, ctx.token]
         return y
 
     @staticmethod
@@ -173,11 +183,15 @@ class _BN2dAct(torch.autograd.Function):
         keep = ctx.saved_tensors[3] if has_keep else None
         y, mask = (None, keep) if is_mask else (keep, None)
         dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        pre = None
+        ent = _BN_BWD_STATS.pop(dy.data_ptr(), None) if ctx.token is not None else None
+        if ent is not None and ent[0] is ctx.token:          # the GEMM that produced dy reduced it against x already
+            pre = ent[1:]
         dx, dgamma, dbeta, dres = _capi.bn2d_bwd(dy, x, y, mask, save, ss, training, relu,
-                                                 has_res and ctx.needs_input_grad[3], sync_group=ctx.sync_group)
+                                                 has_res and ctx.needs_input_grad[3], sync_group=ctx.sync_group, pre=pre)
         if has_res and dres is None and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dgamma, dbeta, dres, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None
 
 
 class _BN2dReluPool(torch.autograd.Function):
@@ -408,12 +422,13 @@ class _Conv1x1Gemm(torch.autograd.Function):
     both operands split per workgroup: peclr_gemm_x6_f32); the other direction and small weight gradients stay on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, use_fwd: bool, use_bwd: bool, stats=None):
+    def forward(ctx, x, weight, conv, use_fwd: bool, use_bwd: bool, stats=None, link=None):
         """stats: None, or [bn] -- the BatchNorm2d that consumes the output; the GEMM epilogue then sums its statistics
         and the list comes back as [partial, n_split, shift, bn] (left untouched when that is not possible)."""
         ctx.save_for_backward(x, weight)
         planes = _x6_planes(conv) if (use_fwd or use_bwd) else None
         ctx.cfg = (conv, use_bwd, planes)
+        ctx.link = link
         if not use_fwd:
             return F.conv2d(x, weight)
         n, cin, h, w = x.shape
@@ -445,7 +460,11 @@ class _Conv1x1Gemm(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if use_bwd:
                 gy2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout)
-                if planes is not None:
+                link = ctx.link
+                if planes is not None and link is not None and link[0].shape == x.shape and cin % 32 == 0:
+                    dx, partial, ns = _capi.gemm_x6p(gy2, planes[1], cin, tag="conv1x1_dgrad", bn_bwd=link[:5])
+                    _note_bn_bwd(dx, link, partial, ns)
+                elif planes is not None:
                     dx = _capi.gemm_x6p(gy2, planes[1], cin, tag="conv1x1_dgrad")
                 else:
                     wt = weight.detach().reshape(cout, cin).t().contiguous()          # [Cin][Cout]: K-contiguous B operand
@@ -454,7 +473,7 @@ class _Conv1x1Gemm(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 _CONV3X3_WGRAD_X6 = os.environ.get("PECLR_CONV3X3_WGRAD_X6", "1") != "0"   # A/B switch: 3x3 weight gradients in-tree (nine taps, one launch)
@@ -469,10 +488,11 @@ class _Conv3x3Gemm(torch.autograd.Function):
     (`_wgrad_3x3_x6`)."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, stats=None):
+    def forward(ctx, x, weight, conv, stats=None, link=None):
         ctx.save_for_backward(x, weight)
         planes = _x6_planes(conv)
         ctx.cfg = (conv, planes)
+        ctx.link = link
         cout = weight.shape[0]
         shift = _stat_shift_for(stats[0], cout) if (stats and _BN_STATS_IN_GEMM) else None
         if shift is not None:
@@ -492,8 +512,28 @@ class _Conv3x3Gemm(torch.autograd.Function):
                        and x.shape[3] >= 6 and x.shape[1] % 4 == 0 and gy.shape[1] % 4 == 0
                        and gy.shape[1] >= 128)       # (64 output channels leave half of the 128-row tile empty: MIOpen is faster)
             dw = _wgrad_3x3_x6(gy, x, weight, conv.weight) if in_tree else _conv_wgrad(gy, x, weight, (1, 1), (1, 1), conv.weight)
-        dx = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=256) if ctx.needs_input_grad[0] else None
-        return dx, dw, None, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            link = ctx.link
+            if link is not None and link[0].shape == x.shape and x.shape[1] % 32 == 0:
+                # dx is the gradient arriving at the BatchNorm layer whose output x is: reduce it in the epilogue
+                dx, partial, ns = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=256,
+                                                    bn_bwd=link[:5])
+                _note_bn_bwd(dx, link, partial, ns)
+            else:
+                dx = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=256)
+        return dx, dw, None, None, None
+
+
+def _bn_link_of(x: Tensor):
+    """(x_bn, save, scale_shift, mask, relu, token) if `x` is the output of a fused BatchNorm layer whose backward reduction
+    a consumer's input-gradient GEMM may perform, else None."""
+    link = getattr(x, "_peclr_bn_link", None)
+    return tuple(link) if link and _BN_BWD_IN_GEMM else None
+
+
+def _note_bn_bwd(dx: Tensor, link, partial, ns):
+    _BN_BWD_STATS[dx.data_ptr()] = (link[5], partial, ns)
 
 
 def _attach_stats(y: Tensor, stats):
@@ -522,12 +562,12 @@ class Conv2d(nn.Conv2d):
                          and self.weight.requires_grad)
             if use_fwd or use_bwd or use_wgrad:
                 stats = [stats_for] if (stats_for is not None and use_fwd) else None
-                return _attach_stats(_Conv1x1Gemm.apply(x, self.weight, self, use_fwd, use_bwd, stats), stats)
+                return _attach_stats(_Conv1x1Gemm.apply(x, self.weight, self, use_fwd, use_bwd, stats, _bn_link_of(x) if use_bwd else None), stats)
         if (self.hip_gemm and _CONV3X3_X6 and _GEMM_X6P and getattr(self, "x6_group", None) is not None and self.kernel_size == (3, 3)
                 and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x.dim() == 4
                 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[0] * x.shape[2] * x.shape[3] >= 8192):
             stats = [stats_for] if stats_for is not None else None
-            return _attach_stats(_Conv3x3Gemm.apply(x, self.weight, self, stats), stats)
+            return _attach_stats(_Conv3x3Gemm.apply(x, self.weight, self, stats, _bn_link_of(x)), stats)
         if (_overlap_stream() is not None and x.is_cuda and torch.is_grad_enabled() and self.bias is None
                 and self.groups == 1 and self.dilation == (1, 1) and isinstance(self.padding, tuple)
                 and x.is_contiguous(memory_format=torch.channels_last) and self.weight.requires_grad):
@@ -546,9 +586,10 @@ class _ForkConv1x1(torch.autograd.Function):
     identity gradient added in the epilogue.  Small shapes' forward and weight gradient stay on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, stats=None):
+    def forward(ctx, x, weight, conv, stats=None, link=None):
         ctx.save_for_backward(x, weight)
         ctx.param = weight if isinstance(weight, nn.Parameter) else None
+        ctx.link = link
         n, cin, h, w = x.shape
         cmid = weight.shape[0]
         r = n * h * w
@@ -592,15 +633,21 @@ class _ForkConv1x1(torch.autograd.Function):
                 wt.copy_(weight.detach().reshape(cmid, cin).t())      # transpose + cast in ONE launch
                 out = _capi.gemm_add_half(a, wt, d, tag="conv1x1_dgrad_add")
             elif ctx.use_bwd and ctx.planes is not None:
-                # fp32 on the bf16 matrix cores (exact 3-way split, six products), weight planes packed once per step
-                out = _capi.gemm_x6p(a, ctx.planes[1], cin, d, tag="conv1x1_dgrad_add_x6")
+                # fp32 on the bf16 matrix cores (exact 3-way split, six products), weight planes packed once per step;
+                # the result is the gradient arriving at the previous block's last BatchNorm: reduced in the epilogue
+                link = ctx.link
+                if link is not None and link[0].shape == x.shape and cin % 32 == 0:
+                    out, partial, ns = _capi.gemm_x6p(a, ctx.planes[1], cin, d, tag="conv1x1_dgrad_add_x6", bn_bwd=link[:5])
+                    _note_bn_bwd(out, link, partial, ns)
+                else:
+                    out = _capi.gemm_x6p(a, ctx.planes[1], cin, d, tag="conv1x1_dgrad_add_x6")
             elif ctx.use_bwd:
                 wt = weight.detach().reshape(cmid, cin).t().contiguous()
                 out = _capi.gemm_x6(a, wt, d, tag="conv1x1_dgrad_add_x6")
             else:
                 out = _capi.gemm_add(_capi.GEMM_NN, a, weight.reshape(cmid, cin), d, tag="conv1x1_dgrad_add")
             dx = out.view(n, h, w, cin).permute(0, 3, 1, 2)       # back to a channels_last NCHW tensor
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 def fork_conv1x1(conv: nn.Conv2d, x: Tensor, stats_for=None):
@@ -617,7 +664,7 @@ def fork_conv1x1(conv: nn.Conv2d, x: Tensor, stats_for=None):
           and conv.weight.shape[0] % 8 == 0 and conv.weight.shape[1] % 8 == 0)
     if ok:
         stats = [stats_for] if stats_for is not None else None
-        out, identity = _ForkConv1x1.apply(x, conv.weight, conv, stats)
+        out, identity = _ForkConv1x1.apply(x, conv.weight, conv, stats, _bn_link_of(x))
         return _attach_stats(out, stats), identity
     return (conv(x, stats_for=stats_for) if isinstance(conv, Conv2d) else conv(x)), x
 
@@ -665,7 +712,11 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
             pre = pre[:3] if pre is not None else None
             if self.tail_avgpool and relu and residual is not None and self.num_features % 32 == 0:
                 return _BN2dAddReluAvgPool.apply(x, self.weight, self.bias, residual, self, pre)
-            return _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre)
+            link = [] if (_BN_BWD_IN_GEMM and torch.is_grad_enabled() and x.requires_grad) else None
+            y = _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre, link)
+            if link:
+                y._peclr_bn_link = link
+            return y
         if self.sync_group is not None and self.training:
             raise _capi.PeclrHipError("synchronised statistics are implemented by the HIP kernels only (hip=True)")
         if self.training and _RECOMPUTING:   # re-run of a checkpointed block: batch statistics, buffers untouched

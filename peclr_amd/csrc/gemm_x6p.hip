@@ -54,6 +54,18 @@ struct X6PArgs {
     // `flip` (the input gradient's correlation with the flipped filter) -- or zeros outside the image
     int H, W, flip;
     const float* zeros;                  // >= 64 bytes of zeros (source of the padding pixels)
+    // optional: C is the gradient dY arriving at a BatchNorm2d(+ReLU) layer (this GEMM is the input gradient of the
+    // convolution that consumed that layer's output).  The epilogue then performs the layer's backward REDUCTION on the tile
+    // it holds: per row block and column, sum of dY' and of dY' * xhat with dY' = dY where the ReLU passed (recomputed from
+    // the layer's input x, or read from its 1-bit mask), xhat = (x - mean) * invstd -> bb_partial[row block][2][N], the
+    // layout peclr_bn2d_bwd_finalize_f32 combines; peclr_bn2d_bwd_reduce (a pass over dY and x) is not needed
+    const float* bb_x;                   // the BatchNorm layer's input [M][N] (ld = N)
+    const float* bb_mean;
+    const float* bb_invstd;
+    const float* bb_ss;                  // [2][N] scale, shift of the forward
+    const unsigned* bb_mask;             // [M][N / 32] ReLU bit mask (layers with a residual added before the ReLU), or null
+    int bb_relu;
+    float* bb_partial;
 };
 
 __device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, f32x16 acc) {
@@ -284,12 +296,24 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         }
     }
     const int er = lane >> 3, ec = (lane & 7) * 4;
+    float* sl = reinterpret_cast<float*>(lds + 4 * (32 * XEPL * 4));              // [wave][2][128] (BatchNorm backward sums)
 #pragma unroll
-    for (int a = 0; a < WM; ++a)
+    for (int y = 0; y < NTL; ++y) {
+        const int nt = n0 + y * 32;
+        f32x4 bmean, binv, bsc, bsh;
+        float sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bb_partial) {
+            bmean = *reinterpret_cast<const f32x4*>(g.bb_mean + nt + ec);
+            binv = *reinterpret_cast<const f32x4*>(g.bb_invstd + nt + ec);
+            bsc = *reinterpret_cast<const f32x4*>(g.bb_ss + nt + ec);
+            bsh = *reinterpret_cast<const f32x4*>(g.bb_ss + g.N + nt + ec);
+        }
 #pragma unroll
-        for (int y = 0; y < NTL; ++y) {
-            const int mt = m0 + a * 32, nt = n0 + y * 32;
+        for (int a = 0; a < WM; ++a) {
+            const int mt = m0 + a * 32;
             float4 dv[4];
+            f32x4 xv[4];
+            unsigned mb[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int m = mt + er + 8 * jj;
@@ -298,6 +322,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                     const f32x4* src = reinterpret_cast<const f32x4*>(g.addend + (size_t)m * g.ldd + nt + ec);
                     const f32x4 tv = g.stream_out ? __builtin_nontemporal_load(src) : *src;
                     dv[jj] = make_float4(tv[0], tv[1], tv[2], tv[3]);
+                }
+                if (g.bb_partial && m < g.M) {
+                    xv[jj] = *reinterpret_cast<const f32x4*>(g.bb_x + (size_t)m * g.N + nt + ec);
+                    mb[jj] = g.bb_mask ? g.bb_mask[(size_t)m * (g.N >> 5) + (nt >> 5)] >> ec : 0u;
                 }
             }
 #pragma unroll
@@ -312,9 +340,37 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                     const f32x4 tv = {c.x, c.y, c.z, c.w};
                     if (g.stream_out) __builtin_nontemporal_store(tv, dst);
                     else *dst = tv;
+                    if (g.bb_partial) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            bool on = true;
+                            if (g.bb_relu) on = g.bb_mask ? (mb[jj] >> q) & 1u : fmaf(xv[jj][q], bsc[q], bsh[q]) > 0.f;
+                            const float d = on ? tv[q] : 0.f;
+                            sb[q] += d;
+                            sg[q] = fmaf(d, (xv[jj][q] - bmean[q]) * binv[q], sg[q]);
+                        }
+                    }
                 }
             }
         }
+        if (g.bb_partial) {                               // rows of this wave: lanes with equal (lane & 7) hold the same four columns
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) { sb[q] += __shfl_xor(sb[q], o, 64); sg[q] += __shfl_xor(sg[q], o, 64); }
+                if (er == 0) { sl[(wave * 2) * 128 + y * 32 + ec + q] = sb[q]; sl[(wave * 2 + 1) * 128 + y * 32 + ec + q] = sg[q]; }
+            }
+        }
+    }
+    if (g.bb_partial) {
+        __syncthreads();
+        const int which = tid >> 7, col = tid & 127;
+        if (col < PNL) {
+            const float v = ((sl[(0 * 2 + which) * 128 + col] + sl[(1 * 2 + which) * 128 + col]) +
+                             sl[(2 * 2 + which) * 128 + col]) + sl[(3 * 2 + which) * 128 + col];
+            g.bb_partial[((size_t)row_block * 2 + which) * g.N + n0 + col] = v;
+        }
+    }
 }
 
 // ---- weight packing: W[N][K] fp32 (or its transpose) -> fragment-ordered bf16 planes.  One workgroup per
@@ -400,6 +456,12 @@ extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K) {
 
 extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K);
 
+static void set_bb(X6PArgs& g, const peclr_bn_bwd_fuse* bb) {
+    g.bb_x = bb ? bb->x : nullptr; g.bb_mean = bb ? bb->mean : nullptr; g.bb_invstd = bb ? bb->invstd : nullptr;
+    g.bb_ss = bb ? bb->scale_shift : nullptr; g.bb_mask = bb ? bb->relu_mask : nullptr; g.bb_relu = bb ? bb->relu : 0;
+    g.bb_partial = bb ? bb->partial : nullptr;
+}
+
 static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t stream) {
     const int nrb = (g.M + tile_rows - 1) / tile_rows;
     const bool narrow = g.N % PN != 0;                    // 64-column tiles (N a multiple of 64 only)
@@ -420,8 +482,10 @@ static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t str
 
 extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* X, const void* Bp, float* Y,
                                      const float* addend, int flip, int tile_rows, const float* zeros,
-                                     const float* stat_shift, float* stat_partial, peclr_stream_t stream) {
+                                     const float* stat_shift, float* stat_partial, const peclr_bn_bwd_fuse* bb,
+                                     peclr_stream_t stream) {
     if (!X || !Bp || !Y || !zeros || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
+    if (bb && (stat_partial || !bb->x || !bb->mean || !bb->invstd || !bb->scale_shift || !bb->partial || Cout % 32)) return PECLR_ERR_NULL;
     if (NB <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cout % 64 || Cin % PK) return PECLR_ERR_SHAPE;
     if ((long)NB * H * W > 0x7FFFFFFFL / 2) return PECLR_ERR_SHAPE;
     if (!aligned16(X) || !aligned16(Bp) || !aligned16(Y) || !aligned16(zeros) || (addend && !aligned16(addend))) return PECLR_ERR_ALIGN;
@@ -434,13 +498,15 @@ extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, co
     g.stream_out = (size_t)M * Cout * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = H; g.W = W; g.flip = flip ? 1 : 0; g.zeros = zeros;
+    set_bb(g, bb);
     return launch_x6p(g, tile_rows, 9, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                                   const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
-                                  peclr_stream_t stream) {
+                                  const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
     if (!A || !Bp || !C || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
+    if (bb && (stat_partial || !bb->x || !bb->mean || !bb->invstd || !bb->scale_shift || !bb->partial || ldc != N)) return PECLR_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % PK) return PECLR_ERR_SHAPE;
     if (lda % 4 || lda < K || ldc % 4 || ldc < N || (addend && (ldd % 4 || ldd < N))) return PECLR_ERR_SHAPE;
     if (!aligned16(A) || !aligned16(Bp) || !aligned16(C) || (addend && !aligned16(addend))) return PECLR_ERR_ALIGN;
@@ -452,5 +518,6 @@ extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, 
     g.stream_out = (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = g.W = 1; g.flip = 0; g.zeros = nullptr;
+    set_bb(g, bb);
     return launch_x6p(g, tile_rows, 1, static_cast<hipStream_t>(stream));
 }

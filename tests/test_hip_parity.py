@@ -1850,7 +1850,8 @@ def test_batchnorm_statistics_from_the_gemm_epilogue_equal_the_separate_pass(cin
                       block, rm_start)
     routed = B._x6_pays(n * hw * hw, cmid, cin)
     assert launches[False]["bn2d_stats"] == 3
-    assert launches[True].get("bn2d_stats", 0) == (0 if routed else 3), launches[True]   # conv1, conv2 (3x3) and conv3 all in-tree
+    # conv1, conv2 (3x3) and conv3 all in-tree; at layer1's shape only the 3x3 (64-column tiles) is
+    assert launches[True].get("bn2d_stats", 0) == (0 if routed else 2), launches[True]
     assert launches[True]["bn2d_finalize"] == 3
     # fused against unfused: the same sums in another order and about another centre -> fp32 round-off apart in the
     # forward.  In the backward a pre-activation within that round-off of zero may land on the other side of a ReLU
@@ -1938,6 +1939,55 @@ def test_conv3x3_as_an_implicit_gemm_on_the_matrix_cores_matches_float64(c, hw, 
     assert torch.equal(y2, res[True][0]) and torch.equal(xx.grad, res[True][1])
     if c >= 128:
         assert torch.equal(conv.weight.grad, 2 * res[True][2])        # (accumulated onto the first gradient: fixed-order slabs)
+
+
+@pytest.mark.parametrize("cin,cmid,hw", [(512, 128, 28), (1024, 256, 14), (2048, 512, 7), (256, 64, 56)])
+def test_batchnorm_backward_reduction_in_the_dgrad_epilogue_equals_the_separate_pass(cin, cmid, hw):
+    """The gradient arriving at a BatchNorm2d(+ReLU) layer is produced by the input-gradient GEMM of the convolution that
+    consumed the layer's output (conv2's 3x3 dgrad -> bn1, conv3's 1x1 dgrad -> bn2, the next block's fused entry gradient
+    -> bn3).  Where that GEMM is in-tree its epilogue performs the layer's backward reduction (sums of dY' and dY' xhat with
+    the ReLU decision recomputed from x or read from the 1-bit mask) and peclr_bn2d_bwd_reduce is not launched.  Two
+    chained bottlenecks at ResNet-50's shapes (the second one's entry gradient feeds the first one's bn3): every gradient of
+    the fused route against the separate pass -- same ReLU decisions, sums in another order: fp32 round-off apart."""
+    from peclr_amd import _capi
+    from peclr_amd import bn2d as B
+    from peclr_amd import resnet
+
+    n = 256
+    g = torch.Generator().manual_seed(cin + hw + 1)
+    x0 = (torch.randn(n, cin, hw, hw, generator=g) * 0.7 + 0.3).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, cin, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    res, launches = {}, {}
+    for fused in (False, True):
+        torch.manual_seed(7)
+        net = torch.nn.Sequential(resnet.Bottleneck(cin, cmid, norm_layer=B.FusedBatchNormAct2d),
+                                  resnet.Bottleneck(cin, cmid, norm_layer=B.FusedBatchNormAct2d))
+        net = net.to(DEV).to(memory_format=torch.channels_last).train()
+        B.enable_hip_batchnorm(net)
+        B._BN_BWD_IN_GEMM = fused
+        _capi.EVENT_LOG = {}
+        try:
+            x = x0.clone().requires_grad_()
+            y = net(x)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            launches[fused] = {k: len(v) for k, v in _capi.EVENT_LOG.items()}
+        finally:
+            _capi.EVENT_LOG = None
+            B._BN_BWD_IN_GEMM = True
+        res[fused] = (y.detach(), x.grad.clone(), [p.grad.clone() for p in net.parameters()])
+        assert not B._BN_BWD_STATS or not fused or all(False for _ in ())       # (entries are popped by their layer)
+    routed = B._x6_pays(n * hw * hw, cmid, cin)
+    assert launches[False]["bn2d_bwd_reduce"] == 6
+    # fused: bn1, bn2 of both blocks and bn3 of the first (its gradient comes out of the second block's entry GEMM);
+    # the last bn3 receives the loss gradient directly.  layer1's shape: only the 3x3 (C = 64) is in-tree -> bn1 of both
+    assert launches[True].get("bn2d_bwd_reduce", 0) == (1 if routed else 4), launches[True]
+    assert launches[True]["bn2d_bwd_finalize"] == 6
+    assert torch.equal(res[True][0], res[False][0])
+    a, b = res[True][1], res[False][1]
+    assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    for a, b in zip(res[True][2], res[False][2]):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7
 
 
 def test_x6_pack_group_follows_the_weights():

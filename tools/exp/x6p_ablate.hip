@@ -35,7 +35,8 @@ int main() {
         PackDesc d{(int64_t)W, (int64_t)Bp, N, K, K, 0, 0, 0}, *dd;
         CK(hipMalloc(&dd, sizeof(d))); CK(hipMemcpy(dd, &d, sizeof(d), hipMemcpyHostToDevice));
         x6_pack_kernel<<<(N / 128) * (K / 16), 256>>>(dd, 1);
-        X6PArgs g{A, Bp, nullptr, C, M, N, K, K, N, 0, 0, nullptr, nullptr};
+        X6PArgs g{};
+        g.A = A; g.Bp = Bp; g.out = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldo = N;
         g.stream_out = (size_t)M * N * 4 > ((size_t)64 << 20);
         struct V { const char* name; void (*fn)(const X6PArgs&, hipStream_t); };
         const V vs[] = {{"full/256", launch<2, 0>}, {"full/128", launch<1, 0>}, {"full/256 rawdma", launch<2, 0, false>}, {"full/128 rawdma", launch<1, 0, false>}, {"full/256 noilv", launch<2, 0, true, false>}, {"full/128 noilv", launch<1, 0, true, false>},
