@@ -77,6 +77,7 @@ _BN_BWD_IN_GEMM = os.environ.get("PECLR_BN_BWD_IN_GEMM", "1") != "0"     # A/B s
 # data_ptr -> (token of that layer's forward, partial sums, n_split); popped by the layer's backward
 _BN_BWD_STATS: dict = {}
 _BN_STATS_IN_GEMM = os.environ.get("PECLR_BN_STATS_IN_GEMM", "1") != "0"   # A/B switch: BatchNorm statistics in the GEMM epilogue
+_X6_LAYER1 = os.environ.get("PECLR_X6_LAYER1", "1") != "0"  # A/B switch: layer1's 64-channel 1x1 convolutions (forward / input gradient) in-tree
 _GEMM_X6T = os.environ.get("PECLR_GEMM_X6T", "1") != "0"  # A/B switch: weight gradients on the 256 x 256-tile kernel (peclr_gemm_x6t_f32)
 _GEMM_X6P = os.environ.get("PECLR_GEMM_X6P", "1") != "0"  # A/B switch: weight planes packed once per step (peclr_gemm_x6p_f32)
 
@@ -104,8 +105,8 @@ class X6PackGroup:
             return False
         if conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1):
             return cout >= 64 and cin >= 64 and cout % 64 == 0 and cin % 64 == 0        # 64-column tiles for layer1
-        return (conv.kernel_size == (1, 1) and conv.padding == (0, 0) and cout >= 128 and cin >= 128
-                and cout % 128 == 0 and cin % 128 == 0)
+        return (conv.kernel_size == (1, 1) and conv.padding == (0, 0) and cout >= 64 and cin >= 64
+                and cout % 64 == 0 and cin % 64 == 0)
 
     def _key(self, conv):
         return (conv.weight.data_ptr(), conv.weight._version, _capi.WEIGHTS_EPOCH)
@@ -347,7 +348,14 @@ def _x6_pays(rows: int, n_out: int, k: int) -> bool:
     full and the 128 x 128 tiles fill the chip; the K = 64 and N = 64 shapes of layer1 are HBM-bound either way."""
     # (64-wide outputs -- layer1 -- have a 128 x 64-tile variant in the library that wins in isolation, 256 vs 345 us,
     # and loses 0.4 ms per step inside it, where MIOpen's kernels find their operands in the caches: not routed)
-    return _GEMM_X6 and k >= _X6_MIN_K and k % 4 == 0 and n_out >= 128 and n_out % 4 == 0 and (rows // 128) * (n_out // 128) >= 196
+    if not _GEMM_X6:
+        return False
+    if k >= _X6_MIN_K and k % 4 == 0 and n_out >= 128 and n_out % 4 == 0 and (rows // 128) * (n_out // 128) >= 196:
+        return True
+    # layer1 (64 <-> 256 channels, 8e5 rows): HBM-bound, the GEMM itself is a draw against MIOpen (290 vs 296 us, 269 vs 331,
+    # input gradient 253 vs 322: tools/exp/layer1_probe.py) -- what pays is that the in-tree GEMM also delivers the next
+    # BatchNorm's statistics / performs the previous one's backward reduction, each a pass over up to 822 MB
+    return _X6_LAYER1 and _GEMM_X6P and rows >= 400000 and k >= 64 and k % 16 == 0 and n_out >= 64 and n_out % 64 == 0
 
 
 def _x6_wgrad_pays(rows: int, cout: int, cin: int) -> bool:

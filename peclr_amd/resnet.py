@@ -95,7 +95,11 @@ class Bottleneck(nn.Module):
         # (the 1x1 convolutions that run as in-tree GEMMs sum the statistics of the BatchNorm behind them in their epilogue)
         out, identity = fork_conv1x1(self.conv1, x, stats_for=self.bn1)
         if self.downsample is not None:
-            identity = self.downsample(identity)
+            ds = self.downsample
+            if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[1], FusedBatchNormAct2d):
+                identity = _bn(ds[1], _conv(ds[0], identity, ds[1]))      # (conv -> bn: statistics from the GEMM where in-tree)
+            else:
+                identity = ds(identity)
         out = _bn(self.bn1, out, relu=True)
         out = _bn(self.bn2, _conv(self.conv2, out, self.bn2), relu=True)
         return _bn(self.bn3, _conv(self.conv3, out, self.bn3), identity, relu=True)
