@@ -14,7 +14,8 @@ from typing import Optional
 
 import torch  # must be imported BEFORE the CDLL: the .so binds to torch's libamdhip64.so.7
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpeclr_hip.so")
+# (PECLR_HIP_LIB: another build of the same library, for same-box A/B runs of a kernel change)
+_LIB_PATH = os.environ.get("PECLR_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpeclr_hip.so")
 _LIB = None
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
