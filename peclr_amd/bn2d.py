@@ -77,6 +77,7 @@ _BN_BWD_IN_GEMM = os.environ.get("PECLR_BN_BWD_IN_GEMM", "1") != "0"     # A/B s
 # data_ptr -> (token of that layer's forward, partial sums, n_split); popped by the layer's backward
 _BN_BWD_STATS: dict = {}
 _BN_STATS_IN_GEMM = os.environ.get("PECLR_BN_STATS_IN_GEMM", "1") != "0"   # A/B switch: BatchNorm statistics in the GEMM epilogue
+_X6_LAYER1_FORK = os.environ.get("PECLR_X6_LAYER1_FORK", "1") != "0"  # A/B: layer1's fused entry gradient (K = 64) on the x6p kernel (+ bn3 reduction)
 _X6_LAYER1 = os.environ.get("PECLR_X6_LAYER1", "1") != "0"  # A/B switch: layer1's 64-channel 1x1 convolutions (forward / input gradient) in-tree
 _GEMM_X6T = os.environ.get("PECLR_GEMM_X6T", "1") != "0"  # A/B switch: weight gradients on the 256 x 256-tile kernel (peclr_gemm_x6t_f32)
 _GEMM_X6P = os.environ.get("PECLR_GEMM_X6P", "1") != "0"  # A/B switch: weight planes packed once per step (peclr_gemm_x6p_f32)
@@ -602,7 +603,8 @@ class _ForkConv1x1(torch.autograd.Function):
         cmid = weight.shape[0]
         r = n * h * w
         use_fwd = x.dtype == torch.float32 and _x6_pays(r, cmid, cin)
-        use_bwd = x.dtype == torch.float32 and _GEMM_X6 and cmid >= _X6_MIN_K and (r // 128) * (cin // 128) >= 512
+        use_bwd = (x.dtype == torch.float32 and _GEMM_X6 and (r // 128) * (cin // 128) >= 512
+                   and (cmid >= _X6_MIN_K or (_X6_LAYER1_FORK and _GEMM_X6P and r >= 400000 and cmid >= 64 and cmid % 16 == 0 and cin % 128 == 0)))
         ctx.planes = _x6_planes(conv) if (use_fwd or use_bwd) else None
         ctx.use_bwd = use_bwd
         if use_fwd:
