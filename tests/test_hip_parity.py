@@ -1980,9 +1980,8 @@ def test_batchnorm_backward_reduction_in_the_dgrad_epilogue_equals_the_separate_
     routed = B._x6_pays(n * hw * hw, cmid, cin)
     assert launches[False]["bn2d_bwd_reduce"] == 6
     # fused: bn1, bn2 of both blocks and bn3 of the first (its gradient comes out of the second block's entry GEMM);
-    # the last bn3 receives the loss gradient directly.  layer1's shape: only the 3x3 (C = 64) is in-tree -> bn1 of both
-    want = 1 if cmid >= 128 else 2           # (layer1's entry gradient stays on the v_mfma_f32 kernel: bn3 of the first block too)
-    assert launches[True].get("bn2d_bwd_reduce", 0) == (want if routed else 4), launches[True]
+    # the last bn3 receives the loss gradient directly (layer1's 64-channel shapes included since they are routed)
+    assert launches[True].get("bn2d_bwd_reduce", 0) == (1 if routed else 4), launches[True]
     assert launches[True]["bn2d_bwd_finalize"] == 6
     assert torch.equal(res[True][0], res[False][0])
     a, b = res[True][1], res[False][1]
