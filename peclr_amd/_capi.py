@@ -396,6 +396,9 @@ def gemm_x6(a: torch.Tensor, b_t: torch.Tensor, addend: Optional[torch.Tensor] =
     return out
 
 
+_X6P_TILE_ROWS = int(os.environ.get("PECLR_X6P_TILE_ROWS", "0"))   # experiments: force 128- or 256-row tiles for the 1x1 GEMMs
+
+
 class _BnBwdFuse(ctypes.Structure):
     """peclr_bn_bwd_fuse (include/peclr_hip.h)."""
     _fields_ = [("x", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("scale_shift", c_void_p), ("relu_mask", c_void_p),
@@ -465,6 +468,7 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
         raise PeclrHipError(f"gemm_x6p: A {tuple(a.shape)}, planes of {planes.numel()} bytes for B_t[{n}, {k}]")
     out = torch.empty((m, n), device=a.device, dtype=torch.float32)
     partial, ns, fuse = None, 0, None
+    tile_rows = tile_rows or _X6P_TILE_ROWS
     if stat_shift is not None or bn_bwd is not None:
         tile_rows = tile_rows or lib().peclr_gemm_x6p_tile_rows(m, n, k)
     if stat_shift is not None:

@@ -486,6 +486,7 @@ class _Conv1x1Gemm(torch.autograd.Function):
 
 
 _CONV3X3_WGRAD_X6 = os.environ.get("PECLR_CONV3X3_WGRAD_X6", "1") != "0"   # A/B switch: 3x3 weight gradients in-tree (nine taps, one launch)
+_CONV3X3_TILE_ROWS = int(os.environ.get("PECLR_CONV3X3_TILE_ROWS", "256"))   # experiments
 _CONV3X3_X6 = os.environ.get("PECLR_CONV3X3_X6", "1") != "0"   # A/B switch: 3x3 stride-1 convolutions as implicit x6p GEMMs
 
 
@@ -505,10 +506,10 @@ class _Conv3x3Gemm(torch.autograd.Function):
         cout = weight.shape[0]
         shift = _stat_shift_for(stats[0], cout) if (stats and _BN_STATS_IN_GEMM) else None
         if shift is not None:
-            y, partial, ns = _capi.conv3x3_x6p(x, planes[0], cout, tag="conv3x3_fwd", tile_rows=256, stat_shift=shift)
+            y, partial, ns = _capi.conv3x3_x6p(x, planes[0], cout, tag="conv3x3_fwd", tile_rows=_CONV3X3_TILE_ROWS, stat_shift=shift)
             stats[:] = [partial, ns, shift, stats[0]]
             return y
-        return _capi.conv3x3_x6p(x, planes[0], cout, tag="conv3x3_fwd", tile_rows=256)
+        return _capi.conv3x3_x6p(x, planes[0], cout, tag="conv3x3_fwd", tile_rows=_CONV3X3_TILE_ROWS)
 
     @staticmethod
     def backward(ctx, gy):
@@ -526,11 +527,11 @@ class _Conv3x3Gemm(torch.autograd.Function):
             link = ctx.link
             if link is not None and link[0].shape == x.shape and x.shape[1] % 32 == 0:
                 # dx is the gradient arriving at the BatchNorm layer whose output x is: reduce it in the epilogue
-                dx, partial, ns = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=256,
+                dx, partial, ns = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=_CONV3X3_TILE_ROWS,
                                                     bn_bwd=link[:5])
                 _note_bn_bwd(dx, link, partial, ns)
             else:
-                dx = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=256)
+                dx = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=_CONV3X3_TILE_ROWS)
         return dx, dw, None, None, None
 
 

@@ -65,8 +65,8 @@ class BasicBlock(nn.Module):
 
     def _run(self, x: Tensor) -> Tensor:
         identity = x if self.downsample is None else self.downsample(x)
-        out = _bn(self.bn1, self.conv1(x), relu=True)
-        return _bn(self.bn2, self.conv2(out), identity, relu=True)
+        out = _bn(self.bn1, _conv(self.conv1, x, self.bn1), relu=True)
+        return _bn(self.bn2, _conv(self.conv2, out, self.bn2), identity, relu=True)
 
 
 class Bottleneck(nn.Module):
