@@ -85,7 +85,7 @@ __device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_offset)
 // WM: 32-row MFMA tiles per wave (2 -> 256 x 128 workgroup tile, 1 -> 128 x 128 for problems with few row blocks)
 // AREG: the fp32 rows travel global -> registers (inline-asm loads, hand-counted) instead of global -> LDS (DMA) -> registers
 // ABL: ablation switches for tools/exp/x6p_ablate.hip (0 in the library): 1 no split / plane stores in the loop, 2 no raw-row
-// loads either, 4 no B DMA in the loop, 8 no MFMAs (bits combine)
+// loads either, 4 no B DMA in the loop, 8 no MFMAs, 16 no barrier, 32 B fragments always from buffer 0 (bits combine)
 // NTL: 32-column MFMA tiles per wave (4 -> 128 output columns per workgroup; 2 -> 64, for 64-channel layers: half a packed chunk)
 template <int WM, int ABL = 0, bool AREG = true, bool ILV = true, int TAPS = 1, int NTL = 4>
 __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
@@ -214,14 +214,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     // one k-step; SPLIT: the rows of step t + 1 are split and stored (t + 1 < nk), interleaved with the first half's MFMAs
     auto kstep = [&](int t, auto split_next) {
         constexpr bool SPLIT = decltype(split_next)::value;
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         uint4 af[WM][3];
 #pragma unroll
         for (int a = 0; a < WM; ++a)
 #pragma unroll
             for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const uint4*>(planes + p * PLANE + foff + a * 512);
-        const unsigned char* bt = lds + (t % NB) * CHUNK + lane * 16;
+        const unsigned char* bt = lds + ((ABL & 32) ? 0 : (t % NB)) * CHUNK + lane * 16;
 #pragma unroll
         for (int half = 0; half < NTL / 2; ++half) {
             uint4 bf[2][3];

@@ -750,7 +750,7 @@ def test_encoder_wrapper_fused_stem_equals_stock_on_gpu():
             assert pf.grad is None and "final_layer" in n
             continue
         # Norm-wise: two IDENTICAL stock runs already differ by 3.4e-3 of the largest element here (MIOpen's
-        # atomically accumulated weight gradients through small-batch BN, tools/exp/stem_diag.py), and a
+        # atomically accumulated weight gradients through small-batch BN), and a
         # pre-activation within rounding of zero may land on the other side of a ReLU in the other
         # implementation, which shows up as an isolated outlier element.
         err = float((ps.grad - pf.grad).norm()) / max(1e-6, float(ps.grad.norm()))

@@ -23,12 +23,12 @@ static void launch(const X6PArgs& g, hipStream_t st) {
 }
 
 int main() {
-    const int shapes[][3] = {{16384, 2048, 512}, {50176, 256, 1024}};
+    const int shapes[][3] = {{16384, 2048, 512}, {16384, 2048, 4096}};
     float *A, *C, *W; unsigned char *Bp, *junk;
     CK(hipMalloc(&A, (size_t)200704 * 2048 * 4)); CK(hipMalloc(&C, (size_t)200704 * 2048 * 4));
-    CK(hipMalloc(&W, (size_t)2048 * 2048 * 4)); CK(hipMalloc(&Bp, (size_t)2048 * 2048 * 6)); CK(hipMalloc(&junk, 512u << 20));
+    CK(hipMalloc(&W, (size_t)2048 * 4096 * 4)); CK(hipMalloc(&Bp, (size_t)2048 * 4096 * 6)); CK(hipMalloc(&junk, 512u << 20));
     fill<<<4096, 256>>>(A, (size_t)200704 * 2048, 1, 1.f);
-    fill<<<4096, 256>>>(W, (size_t)2048 * 2048, 2, 0.05f);
+    fill<<<4096, 256>>>(W, (size_t)2048 * 4096, 2, 0.05f);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& sh : shapes) {
         const int M = sh[0], N = sh[1], K = sh[2];
@@ -39,13 +39,10 @@ int main() {
         g.A = A; g.Bp = Bp; g.out = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldo = N;
         g.stream_out = (size_t)M * N * 4 > ((size_t)64 << 20);
         struct V { const char* name; void (*fn)(const X6PArgs&, hipStream_t); };
-        const V vs[] = {{"full/256", launch<2, 0>}, {"full/128", launch<1, 0>}, {"full/256 rawdma", launch<2, 0, false>}, {"full/128 rawdma", launch<1, 0, false>}, {"full/256 noilv", launch<2, 0, true, false>}, {"full/128 noilv", launch<1, 0, true, false>},
-                        {"nosplit/256", launch<2, 1>}, {"nosplit/128", launch<1, 1>},
-                        {"nosplit+noraw/256", launch<2, 3>}, {"nosplit+noraw/128", launch<1, 3>},
-                        {"noBdma/256", launch<2, 4>}, {"noBdma/128", launch<1, 4>},
+        const V vs[] = {{"full/256", launch<2, 0>}, {"full/128", launch<1, 0>},
                         {"mfma only/256", launch<2, 7>}, {"mfma only/128", launch<1, 7>},
-                        {"no mfma/256", launch<2, 8>}, {"no mfma/128", launch<1, 8>},
-                        {"dma only/256", launch<2, 9>}, {"dma only/128", launch<1, 9>}};
+                        {"mfma only, no barrier/256", launch<2, 23>}, {"mfma only, no barrier/128", launch<1, 23>},
+                        {"mfma only, no barrier, one B buffer/256", launch<2, 55>}, {"mfma only, no barrier, one B buffer/128", launch<1, 55>}};
         printf("M=%d N=%d K=%d  (ideal MFMA time %.1f us)\n", M, N, K, 2.0 * M * N * K * 6 / 2.5e15 * 1e6);
         for (auto& v : vs) {
             std::vector<float> ts;
