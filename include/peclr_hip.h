@@ -160,6 +160,13 @@ int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* 
 int peclr_gemm_x6t_slabs(int M, int N, int K, int taps);
 int peclr_gemm_x6t_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs, int n_slabs,
                        int taps, int H, int W, const float* zeros, peclr_stream_t stream);
+/* Forward of the STRIDE-2 convolutions of a ResNet layer's first block on the same kernel: taps = 9 the 3x3 / padding-1
+ * convolution, taps = 1 the 1x1 downsample convolution; X [NB, H, W, Cin] NHWC (H, W even), Y [NB, H/2, W/2, Cout]; output pixel
+ * (oh, ow) reads input pixel (2 oh + dh, 2 ow + dw).  Planes packed as for the stride-1 forward; optional BatchNorm
+ * statistics of Y.  (Input and weight gradients of these convolutions stay on MIOpen.)                                  */
+int peclr_conv_s2_x6p_f32(int NB, int H, int W, int Cin, int Cout, int taps, const float* X, const void* Bp, float* Y,
+                          int tile_rows, const float* zeros, const float* stat_shift, float* stat_partial,
+                          peclr_stream_t stream);
 int peclr_gemm_pick_split_k(int M, int N, int K);
 
 /* out[i] = sum_s slabs[s][i] (+ bias[i % cols] if non-null), i < rows*cols. */

@@ -75,6 +75,7 @@ SIGNATURES = {
     "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P]),
     "peclr_gemm_x6t_slabs": (c_int, [c_int, c_int, c_int, c_int]),
     "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "peclr_conv_s2_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
@@ -526,6 +527,29 @@ def conv3x3_x6p(x: torch.Tensor, planes: torch.Tensor, cout: int, flip: bool = F
                                          ctypes.byref(fuse) if fuse is not None else None, _stream())
     _check(rc, "peclr_conv3x3_x6p_f32")
     return y if partial is None else (y, partial, ns)
+
+
+def conv_s2_x6p(x: torch.Tensor, planes: torch.Tensor, cout: int, taps: int, tag: str = "conv_s2_x6p", tile_rows: int = 0,
+                stat_shift: Optional[torch.Tensor] = None):
+    """Forward of a stride-2 convolution (taps = 9: 3x3 / padding 1; taps = 1: 1x1) of an NHWC fp32 tensor x [N, Cin, H, W]
+    (H, W even) on the six-product kernel (peclr_conv_s2_x6p_f32) -> y [N, cout, H/2, W/2] channels_last (and
+    (partial, n_split) of the output's BatchNorm statistics when stat_shift is given)."""
+    nb, cin, h, w = x.shape
+    xp = _nhwc_ptr(x, "conv_s2 x", torch.float32)
+    if planes.dtype != torch.uint8 or planes.numel() != 6 * ((cout + 127) // 128 * 128) * taps * cin or h % 2 or w % 2:
+        raise PeclrHipError(f"conv_s2_x6p: planes of {planes.numel()} bytes for [{cout}, {taps} * {cin}], input {h} x {w}")
+    y = torch.empty((nb, cout, h // 2, w // 2), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    m = nb * (h // 2) * (w // 2)
+    partial, ns = None, 0
+    if stat_shift is not None:
+        tile_rows = tile_rows or lib().peclr_gemm_x6p_tile_rows(m, cout, taps * cin)
+        ns = (m + tile_rows - 1) // tile_rows
+        partial = torch.empty((2 * ns + 1, cout), device=x.device, dtype=torch.float32)
+    with _timed(tag, 4 * (nb * h * w * cin + m * cout) + 6 * taps * cin * cout, 2 * m * taps * cin * cout, kernel="gemm_x6p_kernel (stride 2)"):
+        rc = lib().peclr_conv_s2_x6p_f32(nb, h, w, cin, cout, taps, xp, _ptr(planes, torch.uint8), y.data_ptr(), tile_rows,
+                                         _zeros(x.device).data_ptr(), _ptr(stat_shift), _ptr(partial), _stream())
+    _check(rc, "peclr_conv_s2_x6p_f32")
+    return y if stat_shift is None else (y, partial, ns)
 
 
 def gemm_x6_tn(a: torch.Tensor, b: torch.Tensor, tag: str = "gemm_x6_tn") -> torch.Tensor:

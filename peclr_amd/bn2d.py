@@ -102,8 +102,8 @@ class X6PackGroup:
     @staticmethod
     def member(conv) -> bool:
         cout, cin = conv.out_channels, conv.in_channels
-        if conv.stride != (1, 1) or conv.groups != 1 or conv.bias is not None:
-            return False
+        if conv.stride not in ((1, 1), (2, 2)) or conv.groups != 1 or conv.bias is not None:
+            return False            # (stride 2: the forward only, `_ConvS2Gemm`)
         if conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1):
             return cout >= 64 and cin >= 64 and cout % 64 == 0 and cin % 64 == 0        # 64-column tiles for layer1
         return (conv.kernel_size == (1, 1) and conv.padding == (0, 0) and cout >= 64 and cin >= 64
@@ -535,6 +535,40 @@ class _Conv3x3Gemm(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
+_CONV_S2_X6 = os.environ.get("PECLR_CONV_S2_X6", "1") != "0"   # A/B switch: forward of the stride-2 convolutions in-tree
+
+
+class _ConvS2Gemm(torch.autograd.Function):
+    """Stride-2 3x3 (padding 1) / 1x1 convolution of an NHWC fp32 tensor: forward on the six-product kernel
+    (peclr_conv_s2_x6p_f32: the k-step's tap and the stride select the source pixel; BatchNorm statistics of the output
+    in the epilogue), input and weight gradient on MIOpen (the transposed convolution is a scatter)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, conv, stats=None):
+        ctx.save_for_backward(x, weight)
+        ctx.conv = conv
+        planes = _x6_planes(conv)
+        cout, taps = weight.shape[0], weight.shape[2] * weight.shape[3]
+        shift = _stat_shift_for(stats[0], cout) if (stats and _BN_STATS_IN_GEMM) else None
+        if shift is not None:
+            y, partial, ns = _capi.conv_s2_x6p(x, planes[0], cout, taps, tag="conv_s2_fwd", stat_shift=shift)
+            stats[:] = [partial, ns, shift, stats[0]]
+            return y
+        return _capi.conv_s2_x6p(x, planes[0], cout, taps, tag="conv_s2_fwd")
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        conv = ctx.conv
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        pad = list(conv.padding)
+        dw = _conv_wgrad(gy, x, weight, (2, 2), pad, conv.weight) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [2, 2], pad, [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        return dx, dw, None, None
+
+
 def _bn_link_of(x: Tensor):
     """(x_bn, save, scale_shift, mask, relu, token) if `x` is the output of a fused BatchNorm layer whose backward reduction
     a consumer's input-gradient GEMM may perform, else None."""
@@ -573,7 +607,14 @@ class Conv2d(nn.Conv2d):
             if use_fwd or use_bwd or use_wgrad:
                 stats = [stats_for] if (stats_for is not None and use_fwd) else None
                 return _attach_stats(_Conv1x1Gemm.apply(x, self.weight, self, use_fwd, use_bwd, stats, _bn_link_of(x) if use_bwd else None), stats)
+        if (self.hip_gemm and _CONV_S2_X6 and _GEMM_X6P and getattr(self, "x6_group", None) is not None and self.stride == (2, 2)
+                and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x.dim() == 4
+                and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+                and x.shape[0] * x.shape[2] * x.shape[3] >= 32768):
+            stats = [stats_for] if stats_for is not None else None
+            return _attach_stats(_ConvS2Gemm.apply(x, self.weight, self, stats), stats)
         if (self.hip_gemm and _CONV3X3_X6 and _GEMM_X6P and getattr(self, "x6_group", None) is not None and self.kernel_size == (3, 3)
+                and self.stride == (1, 1)
                 and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x.dim() == 4
                 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[0] * x.shape[2] * x.shape[3] >= 8192):
             stats = [stats_for] if stats_for is not None else None
@@ -752,7 +793,7 @@ def enable_hip_batchnorm(module: nn.Module, enabled: bool = True, sync_group=Non
             n += 1
         elif getattr(m, "fork_entry", False):   # bottleneck conv1 (resnet.Bottleneck marks it)
             m.hip_fork = enabled
-        if isinstance(m, Conv2d) and m.kernel_size in ((1, 1), (3, 3)) and m.stride == (1, 1):
+        if isinstance(m, Conv2d) and m.kernel_size in ((1, 1), (3, 3)) and m.stride in ((1, 1), (2, 2)):
             m.hip_gemm = enabled                # fp32 1x1 (where `_x6_pays`) and 3x3 stride-1 convolutions as in-tree GEMMs
             m.x6_group = None
     if enabled:                                 # their weights are split into bf16 planes once per step, all in one launch

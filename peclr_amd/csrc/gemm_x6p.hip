@@ -53,6 +53,10 @@ struct X6PArgs {
     // = Cin], K = 9 * Cin ordered (tap, channel), tap = 3 * a + b reads the pixel at (+a-1, +b-1) -- (1-a, 1-b) when
     // `flip` (the input gradient's correlation with the flipped filter) -- or zeros outside the image
     int H, W, flip;
+    // stride = 2 (forward only): the rows are the pixels of an H x W OUTPUT image, the activation has 2H' x 2W' = Hin x Win
+    // pixels; output pixel (oh, ow) reads input pixel (2 oh + dh, 2 ow + dw) -- the strided 3x3 of a layer's first block
+    // (TAPS = 9) and its 1x1 downsample convolution (TAPS = 1, dh = dw = 0)
+    int stride, Hin, Win;
     const float* zeros;                  // >= 64 bytes of zeros (source of the padding pixels)
     // optional: C is the gradient dY arriving at a BatchNorm2d(+ReLU) layer (this GEMM is the input gradient of the
     // convolution that consumed that layer's output).  The epilogue then performs the layer's backward REDUCTION on the tile
@@ -139,12 +143,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         row = row < g.M ? row : g.M - 1;
         asrc[c] = g.A + (size_t)row * g.lda + 4 * (lane & 3);
         tapmask[c] = 0;
-        if constexpr (TAPS == 9) {
-            const int ow = row % g.W, oh = (row / g.W) % g.H;
+        if (TAPS == 9 || g.stride == 2) {
+            const int ow = row % g.W, oh = (row / g.W) % g.H, img = row / (g.W * g.H);
+            const int ih = g.stride * oh, iw = g.stride * ow;                 // centre pixel in the input image
+            if (g.stride == 2) asrc[c] = g.A + ((size_t)(img * g.Hin + ih) * g.Win + iw) * g.lda + 4 * (lane & 3);
+            if constexpr (TAPS == 9) {
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dh = g.flip ? 1 - tap / 3 : tap / 3 - 1, dw = g.flip ? 1 - tap % 3 : tap % 3 - 1;
-                if ((unsigned)(oh + dh) < (unsigned)g.H && (unsigned)(ow + dw) < (unsigned)g.W) tapmask[c] |= 1u << tap;
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dh = g.flip ? 1 - tap / 3 : tap / 3 - 1, dw = g.flip ? 1 - tap % 3 : tap % 3 - 1;
+                    if ((unsigned)(ih + dh) < (unsigned)g.Hin && (unsigned)(iw + dw) < (unsigned)g.Win) tapmask[c] |= 1u << tap;
+                }
             }
         }
     }
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
             tap = t / kpt;
             const int a = tap / 3, b = tap - 3 * a;
             const int dh = g.flip ? 1 - a : a - 1, dw = g.flip ? 1 - b : b - 1;
-            off = (long)(dh * g.W + dw) * g.lda + (t - tap * kpt) * PK;
+            off = (long)(dh * g.Win + dw) * g.lda + (t - tap * kpt) * PK;
         }
 #pragma unroll
         for (int c = 0; c < NRAW; ++c) {
@@ -480,6 +488,26 @@ static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t str
     return launch_status();
 }
 
+extern "C" int peclr_conv_s2_x6p_f32(int NB, int H, int W, int Cin, int Cout, int taps, const float* X, const void* Bp, float* Y,
+                                     int tile_rows, const float* zeros, const float* stat_shift, float* stat_partial,
+                                     peclr_stream_t stream) {
+    if (!X || !Bp || !Y || !zeros || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
+    if (NB <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2 || Cin <= 0 || Cout <= 0 || Cout % 64 || Cin % PK || (taps != 1 && taps != 9))
+        return PECLR_ERR_SHAPE;
+    if (!aligned16(X) || !aligned16(Bp) || !aligned16(Y) || !aligned16(zeros)) return PECLR_ERR_ALIGN;
+    const int Ho = H / 2, Wo = W / 2, M = NB * Ho * Wo;
+    if (tile_rows == 0) tile_rows = peclr_gemm_x6p_tile_rows(M, Cout, taps * Cin);
+    if (tile_rows != 128 && tile_rows != 256) return PECLR_ERR_UNSUPPORTED;
+    X6PArgs g;
+    g.A = X; g.Bp = Bp; g.addend = nullptr; g.out = Y;
+    g.M = M; g.N = Cout; g.K = taps * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout;
+    g.stream_out = (size_t)M * Cout * sizeof(float) > ((size_t)64 << 20);
+    g.stat_shift = stat_shift; g.stat_partial = stat_partial;
+    g.H = Ho; g.W = Wo; g.flip = 0; g.zeros = zeros; g.stride = 2; g.Hin = H; g.Win = W;
+    set_bb(g, nullptr);
+    return launch_x6p(g, tile_rows, taps, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* X, const void* Bp, float* Y,
                                      const float* addend, int flip, int tile_rows, const float* zeros,
                                      const float* stat_shift, float* stat_partial, const peclr_bn_bwd_fuse* bb,
@@ -497,7 +525,7 @@ extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, co
     g.M = M; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout;
     g.stream_out = (size_t)M * Cout * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
-    g.H = H; g.W = W; g.flip = flip ? 1 : 0; g.zeros = zeros;
+    g.H = H; g.W = W; g.flip = flip ? 1 : 0; g.zeros = zeros; g.stride = 1; g.Hin = H; g.Win = W;
     set_bb(g, bb);
     return launch_x6p(g, tile_rows, 9, static_cast<hipStream_t>(stream));
 }
@@ -517,7 +545,7 @@ extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, 
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldc; g.ldd = ldd;
     g.stream_out = (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
-    g.H = g.W = 1; g.flip = 0; g.zeros = nullptr;
+    g.H = g.W = 1; g.flip = 0; g.zeros = nullptr; g.stride = 1; g.Hin = g.Win = 1;
     set_bb(g, bb);
     return launch_x6p(g, tile_rows, 1, static_cast<hipStream_t>(stream));
 }

@@ -1990,6 +1990,46 @@ def test_batchnorm_backward_reduction_in_the_dgrad_epilogue_equals_the_separate_
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7
 
 
+@pytest.mark.parametrize("cin,cout,k,hw,n", [(256, 128, 3, 56, 16), (128, 128, 3, 28, 48), (256, 512, 1, 56, 12), (1024, 2048, 1, 14, 200)])
+def test_stride_2_convolution_forward_in_tree_matches_float64(cin, cout, k, hw, n):
+    """bn2d.Conv2d(hip_gemm) for the stride-2 convolutions of a layer's first block (3x3 / padding 1 and the 1x1
+    downsample): forward on peclr_conv_s2_x6p_f32 (rows = output pixels, source pixel (2 oh + dh, 2 ow + dw)), input and
+    weight gradient on MIOpen.  Forward against float64 next to MIOpen's fp32 result; gradients equal MIOpen's own."""
+    from peclr_amd import _capi
+    from peclr_amd import bn2d as B
+
+    g = torch.Generator().manual_seed(cin + cout + hw)
+    conv = B.Conv2d(cin, cout, k, stride=2, padding=k // 2, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    net = torch.nn.Sequential(conv)
+    x = torch.randn(n, cin, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, cout, hw // 2, hw // 2, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    res, tags = {}, {}
+    for mode in (False, True):
+        B.enable_hip_batchnorm(net, mode)
+        conv.weight.grad = None
+        xx = x.clone().requires_grad_()
+        _capi.EVENT_LOG = {}
+        try:
+            y = conv(xx)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            tags[mode] = sorted(_capi.EVENT_LOG)
+        finally:
+            _capi.EVENT_LOG = None
+        res[mode] = (y.detach(), xx.grad.clone(), conv.weight.grad.clone())
+    assert tags[False] == [] and tags[True] == ["conv_s2_fwd", "x6_pack"], tags
+    assert res[True][0].shape == res[False][0].shape and res[True][0].is_contiguous(memory_format=torch.channels_last)
+    sub = slice(0, min(n, 6))
+    y_ref = torch.nn.functional.conv2d(x[sub].double(), conv.weight.detach().double(), stride=2, padding=k // 2)
+    scale = float(y_ref.abs().max())
+    e_new = float((res[True][0][sub].double() - y_ref).abs().max()) / scale
+    e_old = float((res[False][0][sub].double() - y_ref).abs().max()) / scale
+    assert e_new <= max(4 * e_old, 4e-6), (e_new, e_old)
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-5 * float(res[False][0].abs().max())
+    for a, b in ((res[True][1], res[False][1]), (res[True][2], res[False][2])):       # MIOpen either way (atomics: round-off apart)
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+
+
 def test_x6_pack_group_follows_the_weights():
     """bn2d.X6PackGroup: ONE pack launch per optimiser step for every routed 1x1 convolution of an encoder; a member
     re-packs when its weight was updated in place, replaced, or rewritten by the fused optimiser (raw pointers)."""

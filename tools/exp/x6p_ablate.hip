@@ -36,7 +36,7 @@ int main() {
         CK(hipMalloc(&dd, sizeof(d))); CK(hipMemcpy(dd, &d, sizeof(d), hipMemcpyHostToDevice));
         x6_pack_kernel<<<(N / 128) * (K / 16), 256>>>(dd, 1);
         X6PArgs g{};
-        g.A = A; g.Bp = Bp; g.out = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldo = N;
+        g.A = A; g.Bp = Bp; g.out = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldo = N; g.stride = 1;
         g.stream_out = (size_t)M * N * 4 > ((size_t)64 << 20);
         struct V { const char* name; void (*fn)(const X6PArgs&, hipStream_t); };
         const V vs[] = {{"full/256", launch<2, 0>}, {"full/128", launch<1, 0>},
