@@ -347,6 +347,46 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
+// Many slabs, few elements (the split-K weight gradients: 64-256 slabs of 64 K - 1 M elements): one thread per 16-byte word
+// walking all slabs leaves most of the chip idle (64 workgroups for a 128 x 512 gradient).  Here a workgroup owns 64
+// consecutive words and its four waves each sum every fourth slab (eight loads in flight), then the four partial sums are
+// added in a fixed order through LDS: 4x the workgroups, 4x shorter dependent chains.  Deterministic (fixed order per shape).
+__global__ __launch_bounds__(256) void slab_reduce4_kernel(const float* __restrict__ slabs, int n_slabs, size_t count4,
+                                                           int cols, const float* __restrict__ bias, float* __restrict__ out) {
+    __shared__ float4 part[4][64];
+    const int e = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const size_t v = (size_t)blockIdx.x * 64 + e;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v < count4) {
+        const float4* p = reinterpret_cast<const float4*>(slabs) + v;
+        int k = sg;
+        for (; k + 28 < n_slabs; k += 32) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(k + 4 * u) * count4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += t[u].x; s.y += t[u].y; s.z += t[u].z; s.w += t[u].w; }
+        }
+        for (; k < n_slabs; k += 4) {
+            const float4 t = p[(size_t)k * count4];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+    }
+    part[sg][e] = s;
+    __syncthreads();
+    if (sg == 0 && v < count4) {
+        float4 r = part[0][e];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) { r.x += part[q][e].x; r.y += part[q][e].y; r.z += part[q][e].z; r.w += part[q][e].w; }
+        if (bias) {
+            const int c = (int)((v * 4) % (size_t)cols);
+            const float4 b = *reinterpret_cast<const float4*>(bias + c);
+            r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w;
+        }
+        reinterpret_cast<float4*>(out)[v] = r;
+    }
+}
+
 inline int kchunk_for(int K, int split_k) {
     const int per = (K + split_k - 1) / split_k;
     return ((per + BK - 1) / BK) * BK;
@@ -437,6 +477,11 @@ extern "C" int peclr_slab_reduce_f32(const float* slabs, int n_slabs, int rows, 
     if (n_slabs < 1 || rows <= 0 || cols <= 0) return PECLR_ERR_SHAPE;
     if (cols % 4 || !aligned16(slabs) || !aligned16(out) || (bias && !aligned16(bias))) return PECLR_ERR_ALIGN;
     const size_t count4 = (size_t)rows * cols / 4;
+    if (n_slabs >= 8 && count4 <= ((size_t)1 << 22)) {      // the split-K weight gradients
+        hipLaunchKernelGGL(slab_reduce4_kernel, dim3((unsigned)((count4 + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           slabs, n_slabs, count4, cols, bias, out);
+        return launch_status();
+    }
     int blocks = (int)((count4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs,

@@ -55,6 +55,21 @@ def test_gemm_nt(capi, m, n, k, split):
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * np.sqrt(k))  # ~eps * sqrt(k) * |a.b| terms
 
 
+@pytest.mark.parametrize("slabs,rows,cols", [(2, 5, 12), (7, 33, 20), (8, 3, 4), (9, 65, 260), (36, 128, 512), (64, 64, 64),
+                                             (147, 64, 36), (256, 256, 1024)])
+def test_slab_reduce(capi, slabs, rows, cols):
+    """peclr_slab_reduce_f32, both kernels (one thread per word for a few slabs; four waves per 64 words for the many
+    slabs of a split-K weight gradient): against float64, with and without the bias, and the same bits on every run."""
+    x, bias = rnd((slabs, rows, cols), 31), rnd((cols,), 32)
+    ref = x.astype(np.float64).sum(0)
+    d = dev(x)
+    got = host(capi.slab_reduce(d))
+    np.testing.assert_allclose(got, ref, rtol=0, atol=4e-7 * slabs * np.abs(x).max())
+    got_b = host(capi.slab_reduce(d, dev(bias)))
+    np.testing.assert_allclose(got_b, ref + bias, rtol=0, atol=4e-7 * slabs * np.abs(x).max())
+    assert np.array_equal(got, host(capi.slab_reduce(d)))
+
+
 @pytest.mark.parametrize("m,n,k", [(256, 2048, 512), (12, 48, 96), (6, 96, 128), (100, 260, 132)])
 def test_gemm_nn_tn(capi, m, n, k):
     a, b = rnd((m, k), 4), rnd((k, n), 5)
