@@ -155,15 +155,19 @@ int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* 
  * as columns tap * N + n -- the [Cout][3][3][Cin] storage of a channels_last weight.  K is split over
  * peclr_gemm_x6t_slabs(M, N, K, taps) workgroup rows, each writing one fp32 slab [M][taps * N]; peclr_slab_reduce_f32 adds
  * them in a fixed order (deterministic).  256 x 256 output tiles where the problem has them (an operand row is split once
- * per 256 columns of the other operand), k-step 16 with double-buffered planes.  M, N, lda, ldb multiples of 4.  Replaces
- * MIOpen's fp32 weight gradients of the Bottleneck's convolutions (resnet_model.py:15).                                  */
+ * per 256 columns of the other operand), k-step 16 with double-buffered planes; 64-wide sides (layer1) get 64 x 256 /
+ * 256 x 64 / 64 x 128 tiles and, for taps = 9, a 64 x 64 block with the taps in two halves.  stride = 2 (the first block of
+ * layers 2-4): A's K rows are the H x W OUTPUT pixels, B's 4 K rows the pixels of the 2H x 2W inputs, read at
+ * (2 oh + dh, 2 ow + dw) (taps = 1: the 1x1 shortcut, dh = dw = 0; taps = 9: padding 1).  M, N, lda, ldb multiples of 4;
+ * W >= 6 when taps = 9 or stride = 2.  Replaces MIOpen's fp32 weight gradients of the Bottleneck's convolutions
+ * (resnet_model.py:15).                                                                                                  */
 int peclr_gemm_x6t_slabs(int M, int N, int K, int taps);
 int peclr_gemm_x6t_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs, int n_slabs,
-                       int taps, int H, int W, const float* zeros, peclr_stream_t stream);
+                       int taps, int H, int W, int stride, const float* zeros, peclr_stream_t stream);
 /* Forward of the STRIDE-2 convolutions of a ResNet layer's first block on the same kernel: taps = 9 the 3x3 / padding-1
  * convolution, taps = 1 the 1x1 downsample convolution; X [NB, H, W, Cin] NHWC (H, W even), Y [NB, H/2, W/2, Cout]; output pixel
  * (oh, ow) reads input pixel (2 oh + dh, 2 ow + dw).  Planes packed as for the stride-1 forward; optional BatchNorm
- * statistics of Y.  (Input and weight gradients of these convolutions stay on MIOpen.)                                  */
+ * statistics of Y.  (Weight gradients: peclr_gemm_x6t_f32 with stride = 2; the input gradient stays on MIOpen.)         */
 int peclr_conv_s2_x6p_f32(int NB, int H, int W, int Cin, int Cout, int taps, const float* X, const void* Bp, float* Y,
                           int tile_rows, const float* zeros, const float* stat_shift, float* stat_partial,
                           peclr_stream_t stream);

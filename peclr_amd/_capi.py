@@ -74,7 +74,7 @@ SIGNATURES = {
     "peclr_gemm_x6p_tile_rows": (c_int, [c_int, c_int, c_int]),
     "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P]),
     "peclr_gemm_x6t_slabs": (c_int, [c_int, c_int, c_int, c_int]),
-    "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "peclr_conv_s2_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
@@ -569,21 +569,22 @@ def gemm_x6_tn(a: torch.Tensor, b: torch.Tensor, tag: str = "gemm_x6_tn") -> tor
     return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
 
 
-def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, tag: str = "gemm_x6t") -> torch.Tensor:
+def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, stride: int = 1, tag: str = "gemm_x6t") -> torch.Tensor:
     """C[M, taps * N] (fp32) = sum over rows of A[K, M]^T . B[K (shifted by the tap), N] -- the weight gradient of a 1x1
-    (taps = 1) or 3x3 / stride-1 / padding-1 (taps = 9, hw = (H, W) of the images the rows are the pixels of) convolution
-    on NHWC storage, on the bf16 matrix cores at fp32 accuracy (peclr_gemm_x6t_f32 + peclr_slab_reduce_f32: fixed-order
-    split-K, deterministic)."""
+    (taps = 1) or 3x3 / padding-1 (taps = 9, hw = (H, W) of the images A's rows are the pixels of) convolution on NHWC
+    storage, on the bf16 matrix cores at fp32 accuracy (peclr_gemm_x6t_f32 + peclr_slab_reduce_f32: fixed-order split-K,
+    deterministic).  stride = 2: A = dY over the H x W output pixels, B = X over the 2H x 2W input pixels (4 K rows)."""
     (k, m), (k2, n) = a.shape, b.shape
-    if k != k2 or taps not in (1, 9) or (taps == 9 and hw is None):
-        raise PeclrHipError(f"gemm_x6t: shapes {tuple(a.shape)}^T x {tuple(b.shape)}, taps {taps}")
+    if k * stride * stride != k2 or taps not in (1, 9) or stride not in (1, 2) or ((taps == 9 or stride == 2) and hw is None):
+        raise PeclrHipError(f"gemm_x6t: shapes {tuple(a.shape)}^T x {tuple(b.shape)}, taps {taps}, stride {stride}")
     h, w = hw if hw is not None else (1, 1)
     ns = lib().peclr_gemm_x6t_slabs(m, n, k, taps)
     if ns < 1:
         raise PeclrHipError(f"gemm_x6t: unsupported shape M={m} N={n} K={k}")
     slabs = torch.empty((ns, m, taps * n), device=a.device, dtype=torch.float32)
-    with _timed(tag, 4 * (k * m + k * n + ns * m * n * taps), 2 * m * n * k * taps, kernel="gemm_x6t_kernel"):
-        rc = lib().peclr_gemm_x6t_f32(m, n, k, _ptr(a), a.stride(0), _ptr(b), b.stride(0), slabs.data_ptr(), ns, taps, h, w,
+    with _timed(tag, 4 * (k * m + k2 * n // (stride * stride) * (1 if taps == 1 else stride * stride) + ns * m * n * taps),
+                2 * m * n * k * taps, kernel="gemm_x6t_kernel"):
+        rc = lib().peclr_gemm_x6t_f32(m, n, k, _ptr(a), a.stride(0), _ptr(b), b.stride(0), slabs.data_ptr(), ns, taps, h, w, stride,
                                       _zeros(a.device).data_ptr(), _stream())
     _check(rc, "peclr_gemm_x6t_f32")
     return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")

@@ -359,10 +359,15 @@ def _x6_pays(rows: int, n_out: int, k: int) -> bool:
     return _X6_LAYER1 and _GEMM_X6P and rows >= 400000 and k >= 64 and k % 16 == 0 and n_out >= 64 and n_out % 64 == 0
 
 
+_X6_LAYER1_WGRAD = os.environ.get("PECLR_X6_LAYER1_WGRAD", "1") != "0"   # A/B switch: layer1's 64-wide weight gradients in-tree
+
+
 def _x6_wgrad_pays(rows: int, cout: int, cin: int) -> bool:
-    """peclr_gemm_x6_tn_f32 against MIOpen's fp32 1x1 weight gradient (tools/exp/conv1x1_probe.py): 150-205 us against
-    208-267 from layer2 on; with 64 output or input channels (layer1) half of every 128-wide tile would be empty."""
-    return _GEMM_X6 and cout >= 128 and cin >= 128 and cout % 4 == 0 and cin % 4 == 0 and rows >= 8192
+    """peclr_gemm_x6t_f32 against MIOpen's fp32 1x1 weight gradient (tools/exp/conv1x1_probe.py, wgrad_probe.py): 150-205 us
+    against 208-267 from layer2 on; the 64-wide gradients of layer1 (HBM-bound: 8e5 rows of 64 + 256 channels) on 64 x 256 /
+    256 x 64 / 64 x 128 tiles."""
+    wide = 128 if not (_GEMM_X6T and _X6_LAYER1_WGRAD) else 64
+    return _GEMM_X6 and cout >= wide and cin >= wide and cout % 4 == 0 and cin % 4 == 0 and rows >= 8192
 
 
 def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
@@ -373,8 +378,7 @@ def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
 
     def run():
         gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
-        dw = (_capi.gemm_x6t(gy2, x2, tag="conv1x1_wgrad") if _GEMM_X6T and cout >= 128 and cin >= 128
-              else _capi.gemm_x6_tn(gy2, x2, tag="conv1x1_wgrad"))
+        dw = _capi.gemm_x6t(gy2, x2, tag="conv1x1_wgrad") if _GEMM_X6T else _capi.gemm_x6_tn(gy2, x2, tag="conv1x1_wgrad")
         ref = param if param is not None else weight
         return dw.as_strided(ref.shape, ref.stride())       # same memory, the parameter's (channels_last) strides
 
@@ -402,17 +406,21 @@ def _stat_shift_for(bn, cout: int):
     return bn.running_mean
 
 
-def _wgrad_3x3_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
-    """d(weight) of a 3x3 / stride-1 / padding-1 convolution: nine dY^T X products with X read at the pixel each tap points
-    at, all in one launch that splits dY once for the nine taps (peclr_gemm_x6t_f32, taps = 9; fp32 accuracy, fixed-order
-    split-K: deterministic), written in the weight's own channels_last storage order [Cout][3][3][Cin]."""
+def _wgrad_3x3_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, stride: int = 1, taps: int = 9):
+    """d(weight) of a 3x3 / padding-1 convolution (stride 1 or 2): nine dY^T X products with X read at the pixel each tap
+    points at, all in one launch that splits dY once for the nine taps (peclr_gemm_x6t_f32, taps = 9; fp32 accuracy,
+    fixed-order split-K: deterministic), written in the weight's own channels_last storage order [Cout][3][3][Cin].
+    taps = 1 with stride 2: the 1x1 / stride-2 shortcut convolution (X read at every second pixel)."""
     n, cin, h, w = x.shape
-    cout = gy.shape[1]
+    cout, ho, wo = gy.shape[1:]
 
     def run():
-        gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
-        dw = _capi.gemm_x6t(gy2, x2, taps=9, hw=(h, w), tag="conv3x3_wgrad")
-        return dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2)      # = a channels_last [Cout, Cin, 3, 3] tensor
+        gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
+        dw = _capi.gemm_x6t(gy2, x2, taps=taps, hw=(ho, wo), stride=stride, tag="conv3x3_wgrad" if taps == 9 else "conv1x1_wgrad")
+        if taps == 9:
+            return dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2)      # = a channels_last [Cout, Cin, 3, 3] tensor
+        ref = param if param is not None else weight
+        return dw.as_strided(ref.shape, ref.stride())               # [Cout][Cin] in memory either way
 
     st = _overlap_stream()
     if st is None or param is None:
@@ -520,7 +528,7 @@ class _Conv3x3Gemm(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             in_tree = (_GEMM_X6T and _CONV3X3_WGRAD_X6 and weight.is_contiguous(memory_format=torch.channels_last)
                        and x.shape[3] >= 6 and x.shape[1] % 4 == 0 and gy.shape[1] % 4 == 0
-                       and gy.shape[1] >= 128)       # (64 output channels leave half of the 128-row tile empty: MIOpen is faster)
+                       and gy.shape[1] >= (64 if _X6_LAYER1_WGRAD else 128))   # (64 output channels: the 64 x 64 block with two tap halves)
             dw = _wgrad_3x3_x6(gy, x, weight, conv.weight) if in_tree else _conv_wgrad(gy, x, weight, (1, 1), (1, 1), conv.weight)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -536,12 +544,14 @@ class _Conv3x3Gemm(torch.autograd.Function):
 
 
 _CONV_S2_X6 = os.environ.get("PECLR_CONV_S2_X6", "1") != "0"   # A/B switch: forward of the stride-2 convolutions in-tree
+_CONV_S2_WGRAD_X6 = os.environ.get("PECLR_CONV_S2_WGRAD_X6", "1") != "0"   # A/B switch: their weight gradients in-tree
 
 
 class _ConvS2Gemm(torch.autograd.Function):
     """Stride-2 3x3 (padding 1) / 1x1 convolution of an NHWC fp32 tensor: forward on the six-product kernel
     (peclr_conv_s2_x6p_f32: the k-step's tap and the stride select the source pixel; BatchNorm statistics of the output
-    in the epilogue), input and weight gradient on MIOpen (the transposed convolution is a scatter)."""
+    in the epilogue), weight gradient on peclr_gemm_x6t_f32 with stride 2, input gradient on MIOpen (the transposed
+    convolution is a scatter)."""
 
     @staticmethod
     def forward(ctx, x, weight, conv, stats=None):
@@ -562,7 +572,14 @@ class _ConvS2Gemm(torch.autograd.Function):
         conv = ctx.conv
         gy = gy.contiguous(memory_format=torch.channels_last)
         pad = list(conv.padding)
-        dw = _conv_wgrad(gy, x, weight, (2, 2), pad, conv.weight) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            taps = weight.shape[2] * weight.shape[3]
+            in_tree = (_GEMM_X6T and _CONV_S2_WGRAD_X6 and weight.is_contiguous(memory_format=torch.channels_last)
+                       and x.shape[2] == 2 * gy.shape[2] and x.shape[3] == 2 * gy.shape[3] and gy.shape[3] >= 6
+                       and x.shape[1] % 4 == 0 and gy.shape[1] % 4 == 0 and gy.shape[1] >= 64 and x.shape[1] >= 64)
+            dw = (_wgrad_3x3_x6(gy, x, weight, conv.weight, stride=2, taps=taps) if in_tree
+                  else _conv_wgrad(gy, x, weight, (2, 2), pad, conv.weight))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [2, 2], pad, [1, 1], False, [0, 0], 1, [True, False, False])[0]

@@ -33,7 +33,8 @@ struct X6TArgs {
     float* slabs;                    // [splits][M][ldc]
     int M, N, K, lda, ldb, ldc;
     int kchunk;                      // rows per split (multiple of 16)
-    int taps, H, W;                  // taps = 9: 3x3 filter taps in gridDim.z, image extents of the rows
+    int taps, H, W;                  // taps = 9: the nine 3x3 filter taps; H x W: image extents of A's rows (output pixels)
+    int stride;                      // 2: B's rows are the pixels of 2H x 2W images, read at (2 oh + dh, 2 ow + dw)
     const float* zeros;
 };
 
@@ -42,10 +43,17 @@ __device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, f32x16 acc
 }
 __device__ __forceinline__ int slot_of(int i) { return (i & 3) * 8 + ((i >> 2) ^ (((i >> 1) & 1) << 2)); }
 
-// MT x NT: 32 x 32 MFMA tiles per wave; waves 4 (M) x 2 (N): workgroup tile 128 MT x 64 NT
-template <int MT, int NT, int TAPS>
+// MT x NT: 32 x 32 MFMA tiles per wave; waves WGM (M) x 8 / WGM (N): workgroup tile 32 WGM MT x 256 / WGM NT (4 x 2 waves:
+// 128 MT x 64 NT; 2 x 4 waves for the 64-row gradients of layer1: 64 MT x 128 NT).  GEO: B's rows are the pixels of the
+// stride-2 convolution's input (a 1x1 / stride-2 shortcut), found from the output pixel each row of A is.
+// PF: k-steps of global loads in flight per thread (register stages).  (Measured on the 64-wide gradients, whose k-steps
+// are short: PF = 2 changes nothing -- hipcc's wait-count pass still drains every load before the split -- and PF = 4
+// costs the second workgroup per CU its registers, 262 -> 298 us.  PF = 1 everywhere.)
+template <int MT, int NT, int WGM, bool GEO, int PF>
 __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
-    constexpr int TM = 128 * MT, TN = 64 * NT;
+    constexpr int WGN = 8 / WGM;
+    constexpr int TM = 32 * WGM * MT, TN = 32 * WGN * NT;
+    static_assert((TM + TN) / 64 <= 8 && TM % 64 == 0 && TN % 64 == 0, "one 64-column group of the split per wave");
     constexpr int HALF_A = TM * 16, HALF_B = TN * 16;         // bytes of one k-half of a plane
     constexpr int PL_A = 2 * HALF_A, PL_B = 2 * HALF_B;
     constexpr int BUF = 3 * (PL_A + PL_B);                    // one k-step of both operands
@@ -53,14 +61,12 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
     static_assert(2 * BUF >= 8 * 32 * XEPL * 4, "epilogue transposes live in the plane buffers");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int i = lane & 31, kh = lane >> 5;
     const int nct = (g.N + TN - 1) / TN;
     const int m0 = (int)(blockIdx.x / nct) * TM, n0 = (int)(blockIdx.x % nct) * TN;
     const int kbeg = blockIdx.y * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     const int nk = (kend - kbeg + TK - 1) / TK;
-    const int tap = TAPS == 9 ? blockIdx.z : 0;
-    const int dh = TAPS == 9 ? tap / 3 - 1 : 0, dw = TAPS == 9 ? tap % 3 - 1 : 0;
 
     // ---- this thread's block of the split: operand (A for the first TM threads' worth of blocks, then B), column chunk
     // (4 columns), k-quad (4 rows).  Lane bits: [2:0] chunk within a 32-column tile, [3] k-quad & 1, [4] k-half, [5] tile
@@ -80,40 +86,38 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
     const int st_base = (kq >> 1) * (is_a ? HALF_A : HALF_B) + tile * 512 + (kq & 1) * 8 + (is_a ? 0 : 3 * PL_A);
     const int st_plane = is_a ? PL_A : PL_B;
 
-    f32x4 ld4[4];
-    // TAPS = 9: pixel (oh, ow) of the first row of this thread's next block, advanced by 16 rows per k-step (no divisions in
+    f32x4 ld4[PF][4];
+    // GEO: pixel (oh, ow) of the first row of this thread's next block, advanced by 16 rows per k-step (no divisions in
     // the loop); gload() is called with t = 0, 1, 2, ... in order
     int ow_t = 0, oh_t = 0;
-    if constexpr (TAPS == 9) {
+    if constexpr (GEO) {
         const int k = kbeg + 4 * kq;
         ow_t = k % g.W;
         oh_t = (k / g.W) % g.H;
     }
-    auto gload = [&](int t) {                                 // rows kbeg + 16 t + 4 kq + q of this thread's 4 columns
+    auto gload = [&](int t, f32x4 (&ld4)[4]) {                // rows kbeg + 16 t + 4 kq + q of this thread's 4 columns
         int ow = ow_t, oh = oh_t;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = kbeg + t * TK + 4 * kq + q;
             const float* p = src + (size_t)k * ld;
-            bool ok = col_ok && k < kend;
-            if constexpr (TAPS == 9) {
-                if (!is_a) {                                  // B row = the pixel (dh, dw) away, zeros outside the image
-                    ok = ok && (unsigned)(oh + dh) < (unsigned)g.H && (unsigned)(ow + dw) < (unsigned)g.W;
-                    p += (long)(dh * g.W + dw) * ld;
-                }
+            const bool ok = col_ok && k < kend;
+            if constexpr (GEO) {
+                // B row = input pixel (2 oh, 2 ow) of the same image: 4 (k - oh W - ow) rows of whole images before it
+                if (!is_a) p = src + (size_t)(4 * (k - oh * g.W - ow) + 4 * oh * g.W + 2 * ow) * ld;
                 if (++ow == g.W) { ow = 0; oh = oh + 1 == g.H ? 0 : oh + 1; }
             }
             p = ok ? p : g.zeros;
             ld4[q] = *reinterpret_cast<const f32x4*>(p);
         }
-        if constexpr (TAPS == 9) {
+        if constexpr (GEO) {
             ow_t += TK;
 #pragma unroll
             for (int it = 0; it < 3; ++it)                    // W >= 7: at most three image rows per 16 pixels
                 if (ow_t >= g.W) { ow_t -= g.W; oh_t = oh_t + 1 == g.H ? 0 : oh_t + 1; }
         }
     };
-    auto split_store = [&](int buf) {
+    auto split_store = [&](int buf, const f32x4 (&ld4)[4]) {
         if (!active) return;
         unsigned char* base = lds + buf * BUF + st_base;
 #pragma unroll
@@ -139,13 +143,20 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
     const int fa = kh * HALF_A + (wm * MT) * 512 + slot_of(i) * 16;                  // + a * 512 + plane * PL_A
     const int fb = 3 * PL_A + kh * HALF_B + (wn * NT) * 512 + slot_of(i) * 16;       // + y * 512 + plane * PL_B
 
+    // step u lives in register stage u % PF: loaded PF steps ahead, split into the planes one step ahead
     if (nk > 0) {
-        gload(0);
-        split_store(0);
-        if (nk > 1) gload(1);
+        gload(0, ld4[0]);
+        split_store(0, ld4[0]);
+#pragma unroll
+        for (int u = 1; u <= PF; ++u)
+            if (u < nk) gload(u, ld4[u % PF]);
     }
     __syncthreads();
-    for (int t = 0; t < nk; ++t) {
+    for (int t0 = 0; t0 < nk; t0 += PF)
+#pragma unroll
+    for (int st = 0; st < PF; ++st) {
+        const int t = t0 + st;
+        if (t >= nk) break;                                   // (uniform)
         const unsigned char* bufp = lds + (t & 1) * BUF;
         uint4 af[MT][3];
 #pragma unroll
@@ -166,15 +177,15 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
             PECLR_X6(2, 0) PECLR_X6(0, 2) PECLR_X6(1, 1) PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)
 #undef PECLR_X6
             if (half == 0 && t + 1 < nk) {
-                split_store((t + 1) & 1);                 // rows of step t + 1 (loaded during step t - 1) -> the other buffer
-                if (t + 2 < nk) gload(t + 2);
+                split_store((t + 1) & 1, ld4[(st + 1) % PF]);       // rows of step t + 1 -> the other buffer
+                if (t + 1 + PF < nk) gload(t + 1 + PF, ld4[(st + 1) % PF]);
             }
         }
         __syncthreads();
     }
 
     // epilogue: wave-private 32 x 32 transposes through LDS, 16-byte stores into this split's slab
-    float* out = g.slabs + (size_t)blockIdx.y * g.M * g.ldc + (TAPS == 9 ? tap * g.N : 0);
+    float* out = g.slabs + (size_t)blockIdx.y * g.M * g.ldc;
     float* wlds = reinterpret_cast<float*>(lds) + wave * (32 * XEPL);
     const int er = lane >> 3, ec = (lane & 7) * 4;
 #pragma unroll
@@ -199,30 +210,38 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
 // image), and every wave runs 9 x 6 MFMAs into nine 32 x 32 accumulators (144 registers) -- 2.2 VALU instructions per MFMA
 // instead of 3.7.  Eleven 64-column groups of planes per k-step (dY: 2, X: one per tap), 6 KiB each, double-buffered
 // (132 KiB); waves 0-2 split two groups per step, the others one.
+// WGM = 2 (the 64-channel convolutions of layer1): a 64 (Cout) x 64 (Cin) block, one group of dY, waves 2 x 2 x two tap
+// halves (taps 0-4 and 5-8: five and four accumulators).
+// stride 2 (the first block of layers 2-4): X's rows are the pixels of the 2H x 2W input, read at (2 oh + dh, 2 ow + dw).
+template <int WGM>
 __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
     constexpr int GRP = 3 * 2 * 64 * 16;                      // bytes of one 64-column group: [plane][k-half][tile][slot][16]
-    constexpr int NG = 11, BUF = NG * GRP;
+    constexpr int NGA = WGM / 2, NG = NGA + 9, BUF = NG * GRP;
+    constexpr int NACC = WGM == 4 ? 9 : 5;
     constexpr int XEPL = 36;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WGM == 4 ? wave >> 1 : (wave >> 1) & 1, wn = wave & 1;
+    const int tap0 = WGM == 4 ? 0 : (wave >> 2) * 5;          // first tap of this wave
+    const int ntap = WGM == 4 ? 9 : (wave >> 2 ? 4 : 5);
     const int i = lane & 31, kh = lane >> 5;
     const int nct = (g.N + 63) / 64;
-    const int m0 = (int)(blockIdx.x / nct) * 128, n0 = (int)(blockIdx.x % nct) * 64;
+    const int m0 = (int)(blockIdx.x / nct) * (32 * WGM), n0 = (int)(blockIdx.x % nct) * 64;
+    const int sh2 = g.stride == 2;
     const int kbeg = blockIdx.y * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     const int nk = (kend - kbeg + TK - 1) / TK;
 
     const int chunk = (lane & 7) + 8 * (lane >> 5), kq = (lane >> 3) & 3;
     const int cin = 4 * (chunk & 7), tile = chunk >> 3;
     const int st_off = (kq >> 1) * 1024 + tile * 512 + (kq & 1) * 8;     // inside a group's plane
-    // group gi: 0, 1 = dY columns m0 + 64 gi ...; 2 + tap = X columns n0 ..., rows shifted by the tap
-    const int g1 = wave, g2 = wave + 8;                        // this wave's groups (g2 only for waves 0..2)
+    // group gi: 0 .. NGA - 1 = dY columns m0 + 64 gi ...; NGA + tap = X columns n0 ..., rows shifted by the tap
+    const int g1 = wave, g2 = wave + 8;                        // this wave's groups (g2 only for the first NG - 8 waves)
     const bool two = g2 < NG;
     struct Src { const float* p; int ld, dh, dw; bool ok, is_a; };
     auto src_of = [&](int gi) {
         Src s;
-        s.is_a = gi < 2;
-        const int tap = gi - 2;
+        s.is_a = gi < NGA;
+        const int tap = gi - NGA;
         s.dh = s.is_a ? 0 : tap / 3 - 1;
         s.dw = s.is_a ? 0 : tap % 3 - 1;
         const int c = 4 * chunk + (s.is_a ? 64 * gi : 0);
@@ -245,8 +264,11 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
         for (int q = 0; q < 4; ++q) {
             const int k = kbeg + t * TK + 4 * kq + q;
             bool ok = s.ok && k < kend;
-            if (!s.is_a) ok = ok && (unsigned)(oh + s.dh) < (unsigned)g.H && (unsigned)(ow + s.dw) < (unsigned)g.W;
-            const float* p = s.p + ((long)k + (s.is_a ? 0 : s.dh * g.W + s.dw)) * s.ld;
+            const int ih = (oh << sh2) + s.dh, iw = (ow << sh2) + s.dw;          // the input pixel the tap points at
+            if (!s.is_a) ok = ok && (unsigned)ih < (unsigned)(g.H << sh2) && (unsigned)iw < (unsigned)(g.W << sh2);
+            // stride 2: 4 (k - oh W - ow) rows of whole input images before this one's (ih, iw)
+            const long row = s.is_a ? (long)k : sh2 ? 4L * (k - oh * g.W - ow) + ih * 2 * g.W + iw : (long)k + s.dh * g.W + s.dw;
+            const float* p = s.p + row * s.ld;
             r[q] = *reinterpret_cast<const f32x4*>(ok ? p : g.zeros);
             if (++ow == g.W) { ow = 0; oh = oh + 1 == g.H ? 0 : oh + 1; }
         }
@@ -277,13 +299,13 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
         if (two) store1(buf, g2, lb);
     };
 
-    f32x16 acc[9];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
+    for (int tp = 0; tp < NACC; ++tp)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
     const int fa = (wm >> 1) * GRP + kh * 1024 + (wm & 1) * 512 + slot_of(i) * 16;       // + plane * 2048
-    const int fb = 2 * GRP + kh * 1024 + wn * 512 + slot_of(i) * 16;                      // + tap * GRP + plane * 2048
+    const int fb = (NGA + tap0) * GRP + kh * 1024 + wn * 512 + slot_of(i) * 16;           // + tap * GRP + plane * 2048
 
     if (nk > 0) {
         gload(0);
@@ -297,17 +319,19 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const uint4*>(bufp + fa + p * 2048);
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
-            uint4 bf[3];
+        for (int tp = 0; tp < NACC; ++tp) {
+            if (WGM == 4 || tp < ntap) {                      // (wave-uniform: the second tap half has four taps)
+                uint4 bf[3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const uint4*>(bufp + fb + tp * GRP + p * 2048);
-            acc[tp] = mma(af[2], bf[0], acc[tp]);
-            acc[tp] = mma(af[0], bf[2], acc[tp]);
-            acc[tp] = mma(af[1], bf[1], acc[tp]);
-            acc[tp] = mma(af[1], bf[0], acc[tp]);
-            acc[tp] = mma(af[0], bf[1], acc[tp]);
-            acc[tp] = mma(af[0], bf[0], acc[tp]);
-            if (tp == 2 && t + 1 < nk) {
+                for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const uint4*>(bufp + fb + tp * GRP + p * 2048);
+                acc[tp] = mma(af[2], bf[0], acc[tp]);
+                acc[tp] = mma(af[0], bf[2], acc[tp]);
+                acc[tp] = mma(af[1], bf[1], acc[tp]);
+                acc[tp] = mma(af[1], bf[0], acc[tp]);
+                acc[tp] = mma(af[0], bf[1], acc[tp]);
+                acc[tp] = mma(af[0], bf[0], acc[tp]);
+            }
+            if (tp == (WGM == 4 ? 2 : 1) && t + 1 < nk) {
                 split_store((t + 1) & 1);
                 if (t + 2 < nk) gload(t + 2);
             }
@@ -320,36 +344,44 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
     const int er = lane >> 3, ec = (lane & 7) * 4;
     const int mt = m0 + wm * 32, nt = n0 + wn * 32;
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
+    for (int tp = 0; tp < NACC; ++tp) {
+        if (WGM != 4 && tp >= ntap) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = acc[tp][r];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int m = mt + er + 8 * jj, n = nt + ec;
             const float4 c = *reinterpret_cast<const float4*>(wlds + (er + 8 * jj) * XEPL + ec);
-            if (m < g.M && n < g.N) *reinterpret_cast<float4*>(out + (size_t)m * g.ldc + tp * g.N + n) = c;
+            if (m < g.M && n < g.N) *reinterpret_cast<float4*>(out + (size_t)m * g.ldc + (tap0 + tp) * g.N + n) = c;
         }
     }
 }
 
-inline void pick_tile(int M, int N, int& mt, int& nt) {
-    mt = M >= 256 ? 2 : 1;          // workgroup tile 128 mt x 64 nt
-    nt = N >= 256 ? 4 : 2;
+constexpr int PF_SKINNY = 1;
+struct TilePick { int mt, nt, wgm; };
+// 1x1: workgroup tile 32 wgm mt x 256 / wgm nt.  64-wide sides (layer1) get tiles that are 64 wide on that side.
+inline TilePick pick_tile(int M, int N) {
+    if (M <= 64) return {1, N >= 256 ? 2 : 1, 2};                  // 64 x 256 / 64 x 128
+    if (N <= 64) return {M >= 256 ? 2 : 1, 1, 4};                  // 256 x 64 / 128 x 64
+    return {M >= 256 ? 2 : 1, N >= 256 ? 4 : 2, 4};                // 256 x 256 / 256 x 128 / 128 x 256 / 128 x 128
 }
+inline int tile_m(const TilePick& t) { return 32 * t.wgm * t.mt; }
+inline int tile_n(const TilePick& t) { return 32 * (8 / t.wgm) * t.nt; }
 
 }  // namespace
 }  // namespace peclr
 
 using namespace peclr;
 
-// Number of K splits (= slabs): about one workgroup (8 waves) per CU, at least 16 k-steps per workgroup.
+// Number of K splits (= slabs): about one workgroup (8 waves) per CU -- two where the planes of two fit the LDS (the
+// HBM-bound 64-wide gradients) --, at least 16 k-steps per workgroup.
 extern "C" int peclr_gemm_x6t_slabs(int M, int N, int K, int taps) {
     if (M <= 0 || N <= 0 || K <= 0 || (taps != 1 && taps != 9)) return 0;
-    int mt, nt;
-    pick_tile(M, N, mt, nt);
-    const long tiles = taps == 9 ? (long)((M + 127) / 128) * ((N + 63) / 64)      // all nine taps in one workgroup
-                                 : (long)((M + 128 * mt - 1) / (128 * mt)) * ((N + 64 * nt - 1) / (64 * nt));
-    long s = (256 + tiles - 1) / tiles;
+    const TilePick t = pick_tile(M, N);
+    const int tm = taps == 9 ? (M <= 64 ? 64 : 128) : tile_m(t), tn = taps == 9 ? 64 : tile_n(t);    // 3x3: all nine taps in one workgroup
+    const long tiles = (long)((M + tm - 1) / tm) * ((N + tn - 1) / tn);
+    const long wgs = taps == 1 && tm + tn <= 320 ? 512 : 256;
+    long s = (wgs + tiles - 1) / tiles;
     const long max_s = (K + 16 * TK - 1) / (16 * TK);
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -357,36 +389,45 @@ extern "C" int peclr_gemm_x6t_slabs(int M, int N, int K, int taps) {
     return (K + kchunk - 1) / kchunk;
 }
 
+// stride 2: A's K rows are the H x W output pixels of a stride-2 convolution (1x1 without padding, or 3x3 with padding 1),
+// B's 4 K rows the 2H x 2W input pixels.
 extern "C" int peclr_gemm_x6t_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs,
-                                  int n_slabs, int taps, int H, int W, const float* zeros, peclr_stream_t stream) {
+                                  int n_slabs, int taps, int H, int W, int stride, const float* zeros, peclr_stream_t stream) {
     if (!A || !B || !slabs || !zeros) return PECLR_ERR_NULL;
-    if (M <= 0 || N <= 0 || K <= 0 || n_slabs < 1 || (taps != 1 && taps != 9)) return PECLR_ERR_SHAPE;
+    if (M <= 0 || N <= 0 || K <= 0 || n_slabs < 1 || (taps != 1 && taps != 9) || (stride != 1 && stride != 2)) return PECLR_ERR_SHAPE;
     if (M % 4 || N % 4 || lda % 4 || ldb % 4 || lda < M || ldb < N) return PECLR_ERR_SHAPE;
-    if (taps == 9 && (H <= 0 || W < 6 || K % (H * W))) return PECLR_ERR_SHAPE;
+    if ((taps == 9 || stride == 2) && (H <= 0 || W < 6 || K % (H * W))) return PECLR_ERR_SHAPE;
+    if (stride == 2 && (long)K * 4 > 0x7fffffffL) return PECLR_ERR_SHAPE;
     if (!aligned16(A) || !aligned16(B) || !aligned16(slabs) || !aligned16(zeros)) return PECLR_ERR_ALIGN;
     if (n_slabs != peclr_gemm_x6t_slabs(M, N, K, taps)) return PECLR_ERR_WORKSPACE;
     X6TArgs g;
     g.A = A; g.B = B; g.slabs = slabs;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = taps * N;
     g.kchunk = ((K + n_slabs - 1) / n_slabs + TK - 1) / TK * TK;
-    g.taps = taps; g.H = H; g.W = W; g.zeros = zeros;
-    int mt, nt;
-    pick_tile(M, N, mt, nt);
+    g.taps = taps; g.H = H; g.W = W; g.stride = stride; g.zeros = zeros;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (taps == 9) {
-        hipLaunchKernelGGL(gemm_x6w_kernel, dim3(((M + 127) / 128) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
+        if (M <= 64) hipLaunchKernelGGL(gemm_x6w_kernel<2>, dim3(((M + 63) / 64) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
+        else hipLaunchKernelGGL(gemm_x6w_kernel<4>, dim3(((M + 127) / 128) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
         return launch_status();
     }
-    const dim3 grid(((M + 128 * mt - 1) / (128 * mt)) * ((N + 64 * nt - 1) / (64 * nt)), n_slabs, taps);
-#define PECLR_LAUNCH(MT_, NT_)                                                                                  \
-    do {                                                                                                        \
-        if (taps == 9) hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, 9>), grid, dim3(512), 0, s, g);            \
-        else hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, 1>), grid, dim3(512), 0, s, g);                      \
+    const TilePick t = pick_tile(M, N);
+    const dim3 grid(((M + tile_m(t) - 1) / tile_m(t)) * ((N + tile_n(t) - 1) / tile_n(t)), n_slabs);
+#define PECLR_LAUNCH(MT_, NT_, WGM_, PF_)                                                                            \
+    do {                                                                                                             \
+        if (stride == 2) hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, true, PF_>), grid, dim3(512), 0, s, g); \
+        else hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, false, PF_>), grid, dim3(512), 0, s, g);            \
     } while (0)
-    if (mt == 2 && nt == 4) PECLR_LAUNCH(2, 4);
-    else if (mt == 2) PECLR_LAUNCH(2, 2);
-    else if (nt == 4) PECLR_LAUNCH(1, 4);
-    else PECLR_LAUNCH(1, 2);
+    if (t.wgm == 2) {
+        if (t.nt == 2) PECLR_LAUNCH(1, 2, 2, PF_SKINNY);
+        else PECLR_LAUNCH(1, 1, 2, PF_SKINNY);
+    } else if (t.nt == 1) {
+        if (t.mt == 2) PECLR_LAUNCH(2, 1, 4, PF_SKINNY);
+        else PECLR_LAUNCH(1, 1, 4, PF_SKINNY);
+    } else if (t.mt == 2 && t.nt == 4) PECLR_LAUNCH(2, 4, 4, 1);
+    else if (t.mt == 2) PECLR_LAUNCH(2, 2, 4, 1);
+    else if (t.nt == 4) PECLR_LAUNCH(1, 4, 4, 1);
+    else PECLR_LAUNCH(1, 2, 4, 1);
 #undef PECLR_LAUNCH
     return launch_status();
 }

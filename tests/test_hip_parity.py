@@ -1923,7 +1923,7 @@ def test_conv3x3_as_an_implicit_gemm_on_the_matrix_cores_matches_float64(c, hw, 
         finally:
             _capi.EVENT_LOG = None
         res[mode] = (y.detach(), xx.grad.clone(), conv.weight.grad.clone())
-    want = ["conv3x3_dgrad", "conv3x3_fwd"] + (["conv3x3_wgrad", "wgrad_slab_reduce"] if c >= 128 else []) + ["x6_pack"]
+    want = ["conv3x3_dgrad", "conv3x3_fwd", "conv3x3_wgrad", "wgrad_slab_reduce", "x6_pack"]    # (64 channels: the 64 x 64 block)
     assert tags[False] == [] and tags[True] == want, tags
     assert res[True][0].is_contiguous(memory_format=torch.channels_last) and res[True][1].is_contiguous(memory_format=torch.channels_last)
     sub = slice(0, min(n, 6))
@@ -2008,8 +2008,9 @@ def test_batchnorm_backward_reduction_in_the_dgrad_epilogue_equals_the_separate_
 @pytest.mark.parametrize("cin,cout,k,hw,n", [(256, 128, 3, 56, 16), (128, 128, 3, 28, 48), (256, 512, 1, 56, 12), (1024, 2048, 1, 14, 200)])
 def test_stride_2_convolution_forward_in_tree_matches_float64(cin, cout, k, hw, n):
     """bn2d.Conv2d(hip_gemm) for the stride-2 convolutions of a layer's first block (3x3 / padding 1 and the 1x1
-    downsample): forward on peclr_conv_s2_x6p_f32 (rows = output pixels, source pixel (2 oh + dh, 2 ow + dw)), input and
-    weight gradient on MIOpen.  Forward against float64 next to MIOpen's fp32 result; gradients equal MIOpen's own."""
+    downsample): forward on peclr_conv_s2_x6p_f32 (rows = output pixels, source pixel (2 oh + dh, 2 ow + dw)), weight
+    gradient on peclr_gemm_x6t_f32 with stride 2, input gradient on MIOpen.  Forward and weight gradient against float64
+    next to MIOpen's fp32 results; the input gradient equals MIOpen's own."""
     from peclr_amd import _capi
     from peclr_amd import bn2d as B
 
@@ -2032,7 +2033,8 @@ def test_stride_2_convolution_forward_in_tree_matches_float64(cin, cout, k, hw, 
         finally:
             _capi.EVENT_LOG = None
         res[mode] = (y.detach(), xx.grad.clone(), conv.weight.grad.clone())
-    assert tags[False] == [] and tags[True] == ["conv_s2_fwd", "x6_pack"], tags
+    wgrad = "conv3x3_wgrad" if k == 3 else "conv1x1_wgrad"
+    assert tags[False] == [] and tags[True] == sorted(["conv_s2_fwd", "x6_pack", wgrad, "wgrad_slab_reduce"]), tags
     assert res[True][0].shape == res[False][0].shape and res[True][0].is_contiguous(memory_format=torch.channels_last)
     sub = slice(0, min(n, 6))
     y_ref = torch.nn.functional.conv2d(x[sub].double(), conv.weight.detach().double(), stride=2, padding=k // 2)
@@ -2041,8 +2043,14 @@ def test_stride_2_convolution_forward_in_tree_matches_float64(cin, cout, k, hw, 
     e_old = float((res[False][0][sub].double() - y_ref).abs().max()) / scale
     assert e_new <= max(4 * e_old, 4e-6), (e_new, e_old)
     assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-5 * float(res[False][0].abs().max())
-    for a, b in ((res[True][1], res[False][1]), (res[True][2], res[False][2])):       # MIOpen either way (atomics: round-off apart)
-        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+    a, b = res[True][1], res[False][1]                                                # MIOpen either way (atomics: round-off apart)
+    assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+    dw_ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), conv.weight.detach().double(), None, [2, 2], [k // 2] * 2, [1, 1],
+                                                 False, [0, 0], 1, [False, True, False])[1]
+    scale = float(dw_ref.abs().max())
+    e_new, e_old = (float((res[m][2].double() - dw_ref).abs().max()) / scale for m in (True, False))
+    assert e_new <= max(4 * e_old, 2e-6), (e_new, e_old)
+    assert res[True][2].stride() == conv.weight.stride()
 
 
 def test_x6_pack_group_follows_the_weights():
@@ -2148,11 +2156,12 @@ def test_conv1x1_as_gemm_on_the_matrix_cores_matches_float64(cin, cout, hw, n):
 
 
 @pytest.mark.parametrize("k_rows,m,n", [(50176, 256, 1024), (200704, 128, 512), (40000 + 36, 256, 64), (12544, 2048, 512), (8192 + 4, 132, 260),
-                                        (3000, 512, 128), (20000 + 8, 384, 640)])
+                                        (3000, 512, 128), (20000 + 8, 384, 640), (30000 + 4, 64, 256), (30000, 64, 64), (9000, 60, 132),
+                                        (20000 + 12, 128, 64), (10000, 36, 300), (10000, 300, 36)])
 def test_gemm_x6t_matches_float64_and_is_deterministic(capi, k_rows, m, n):
     """peclr_gemm_x6t_f32 + peclr_slab_reduce_f32 (weight gradients, second generation: 256 x 256 / 128 x 256 / 256 x 128 /
-    128 x 128 output tiles, k-step 16, double-buffered planes): C[M,N] = A[K,M]^T . B[K,N] over the rows, ragged K, M and
-    N, every tile shape.  fp32 accuracy against float64 -- the bar of the first-generation kernel, whose error it may not
+    128 x 128 output tiles and the 64 x 256 / 64 x 128 / 256 x 64 / 128 x 64 tiles of 64-wide gradients, k-step 16,
+    double-buffered planes): C[M,N] = A[K,M]^T . B[K,N] over the rows, ragged K, M and N, every tile shape.  fp32 accuracy against float64 -- the bar of the first-generation kernel, whose error it may not
     exceed by more than round-off -- and bit-identical from run to run."""
     g = torch.Generator().manual_seed(k_rows + m + n)
     a = torch.randn(k_rows, m, generator=g).to(DEV)
@@ -2167,7 +2176,7 @@ def test_gemm_x6t_matches_float64_and_is_deterministic(capi, k_rows, m, n):
     assert torch.equal(capi.gemm_x6t(a, b), got)
 
 
-@pytest.mark.parametrize("nb,c,hw", [(6, 128, 9), (4, 256, 7), (256, 256, 14), (40, 512, 7), (5, 64, 10)])
+@pytest.mark.parametrize("nb,c,hw", [(6, 128, 9), (4, 256, 7), (256, 256, 14), (40, 512, 7), (5, 64, 10), (3, 36, 11), (4, 64, 56)])
 def test_gemm_x6t_nine_taps_is_the_3x3_weight_gradient(capi, nb, c, hw):
     """peclr_gemm_x6t_f32 with taps = 9: the nine [Cout, Cin] products of a 3x3 / stride-1 / padding-1 convolution's weight
     gradient, X read at the pixel each tap points at (zeros outside the image), written in the [Cout][3][3][Cin] order of a
@@ -2186,6 +2195,32 @@ def test_gemm_x6t_nine_taps_is_the_3x3_weight_gradient(capi, nb, c, hw):
     e_new, e_mi = float((dw.double() - ref).abs().max()) / scale, float((mi.double() - ref).abs().max()) / scale
     assert e_new <= max(4 * e_mi, 2e-6), (e_new, e_mi)
     assert torch.equal(capi.gemm_x6t(gy.permute(0, 2, 3, 1).reshape(r, c), x.permute(0, 2, 3, 1).reshape(r, c), taps=9, hw=(hw, hw)), got)
+
+
+@pytest.mark.parametrize("nb,cin,cout,ho,taps", [(6, 128, 128, 9, 9), (3, 64, 64, 14, 9), (4, 256, 512, 7, 1), (5, 64, 128, 6, 1),
+                                                 (2, 256, 256, 14, 9), (3, 132, 68, 7, 9), (16, 64, 256, 28, 1), (9, 64, 36, 10, 9)])
+def test_gemm_x6t_stride_2_is_the_strided_weight_gradient(capi, nb, cin, cout, ho, taps):
+    """peclr_gemm_x6t_f32 with stride = 2: the weight gradient of a 3x3 / padding-1 / stride-2 convolution (taps = 9) and of
+    the 1x1 / stride-2 shortcut (taps = 1) -- dY over the H x W output pixels, X over the 2H x 2W input pixels, read at
+    (2 oh + dh, 2 ow + dw).  Against torch's float64 convolution_backward and next to MIOpen's fp32 result; same bits on
+    every run."""
+    g = torch.Generator().manual_seed(cin + cout + ho)
+    hi = 2 * ho
+    ks, pad = (3, 1) if taps == 9 else (1, 0)
+    x = torch.randn(nb, cin, hi, hi, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(nb, cout, ho, ho, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(cout, cin, ks, ks, device=DEV).contiguous(memory_format=torch.channels_last)
+    run = lambda: capi.gemm_x6t(gy.permute(0, 2, 3, 1).reshape(nb * ho * ho, cout), x.permute(0, 2, 3, 1).reshape(nb * hi * hi, cin),
+                                taps=taps, hw=(ho, ho), stride=2)
+    got = run()
+    dw = got.view(cout, ks, ks, cin).permute(0, 3, 1, 2)
+    args = (None, [2, 2], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])
+    ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), *args)[1]
+    mi = torch.ops.aten.convolution_backward(gy, x, w, *args)[1]
+    scale = float(ref.abs().max())
+    e_new, e_mi = float((dw.double() - ref).abs().max()) / scale, float((mi.double() - ref).abs().max()) / scale
+    assert e_new <= max(4 * e_mi, 2e-6), (e_new, e_mi)
+    assert torch.equal(run(), got)
 
 
 @pytest.mark.parametrize("k_rows,m,n", [(50176, 256, 1024), (200704, 128, 512), (40000 + 36, 256, 64), (12544, 2048, 512), (8192 + 4, 132, 260)])

@@ -642,7 +642,7 @@ def test_device_loss_scaler_is_hip_only_and_cpu_runs_keep_torch_grad_scaler():
         opt.attach_scaler(object())
 
 
-def test_x6_routing_rules_and_cpu_fallback():
+def test_x6_routing_rules_and_cpu_fallback(monkeypatch):
     """Which fp32 1x1 products go to peclr_gemm_x6_f32 / _tn_f32 (measured thresholds, bn2d._x6_pays /
     _x6_wgrad_pays), and that a bn2d.Conv2d with hip_gemm set is the stock convolution on tensors the HIP path does
     not take (CPU, NCHW, strided, 3x3)."""
@@ -657,7 +657,11 @@ def test_x6_routing_rules_and_cpu_fallback():
     assert not B._x6_pays(48 * 56 * 56, 64, 256) and not B._x6_pays(r56, 256, 24) and not B._x6_pays(r56, 32, 256)
     assert not B._x6_pays(16 * 14 * 14, 1024, 256)                                                        # too few tiles
     assert B._x6_wgrad_pays(r28, 128, 512) and B._x6_wgrad_pays(r7, 512, 2048)
-    assert not B._x6_wgrad_pays(r56, 64, 256) and not B._x6_wgrad_pays(r56, 256, 64) and not B._x6_wgrad_pays(4096, 256, 1024)
+    assert B._x6_wgrad_pays(r56, 64, 256) and B._x6_wgrad_pays(r56, 256, 64)      # layer1: the 64-wide tiles of peclr_gemm_x6t_f32
+    assert not B._x6_wgrad_pays(r56, 32, 256) and not B._x6_wgrad_pays(4096, 256, 1024)
+    monkeypatch.setattr(B, "_X6_LAYER1_WGRAD", False)
+    assert not B._x6_wgrad_pays(r56, 64, 256) and not B._x6_wgrad_pays(r56, 256, 64) and B._x6_wgrad_pays(r28, 128, 512)
+    monkeypatch.setattr(B, "_X6_LAYER1_WGRAD", True)
     torch.manual_seed(0)
     conv = B.Conv2d(256, 512, 1, bias=False)
     ref = torch.nn.Conv2d(256, 512, 1, bias=False)
