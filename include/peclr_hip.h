@@ -138,6 +138,14 @@ int peclr_gemm_x6p_tile_rows(int M, int N, int K);
 int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                        const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
                        const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
+/* The same product when the addend is the COMPACT input gradient of a 1x1 / stride-2 convolution: the M rows are the pixels
+ * of H x W images (H, W even, M a multiple of H * W), addend_half = [images][H / 2][W / 2][ldd], and only the rows at even
+ * (h, w) add addend_half[(h / 2, w / 2)].  This is the entry gradient of a ResNet layer's first block -- dY1 . W1 (main
+ * branch) + the shortcut's transposed convolution -- without the 4x larger, three-quarters-zero tensor MIOpen's strided
+ * input gradient writes and the addend pass reads (resnet_model.py:15; torchvision Bottleneck.downsample).               */
+int peclr_gemm_x6p_s2add_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
+                             const float* addend_half, int ldd, int H, int W, int tile_rows, const peclr_bn_bwd_fuse* bn_bwd,
+                             peclr_stream_t stream);
 /* 3x3 / stride-1 / padding-1 convolution of an NHWC fp32 tensor (the middle convolution of the torchvision Bottleneck,
  * resnet_model.py:15) as an implicit GEMM on the same kernel: rows = output pixels, K = 9 * Cin ordered (tap, channel); the
  * activation rows of a k-step come from the pixel the tap points at (zeros outside the image: `zeros` = >= 64 bytes of

@@ -73,6 +73,7 @@ SIGNATURES = {
     "peclr_x6_pack_f32": (c_int, [_P, c_int, c_int, _P]),
     "peclr_gemm_x6p_tile_rows": (c_int, [c_int, c_int, c_int]),
     "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P]),
+    "peclr_gemm_x6p_s2add_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "peclr_gemm_x6t_slabs": (c_int, [c_int, c_int, c_int, c_int]),
     "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "peclr_conv_s2_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
@@ -457,16 +458,21 @@ class X6Planes:
 
 
 def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[torch.Tensor] = None, tag: str = "gemm_x6p",
-             tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None):
+             tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None, addend_s2=None):
     """C (fp32) [M, n] = A[M, K] . B_t^T (+ addend) with B_t given as packed planes (X6Planes): fp32 accuracy on the
     bf16 matrix cores, the weight operand split once per step (peclr_gemm_x6p_f32).
     stat_shift (fp32 [n]): also return the training-mode BatchNorm statistics of C as `(partial, n_split)` in the layout
     of peclr_bn2d_stats (sums of (C - shift) and its square per row block; the shift in the last row) -> (C, partial, n_split).
     bn_bwd (see `_bn_bwd_fuse`): C is the gradient arriving at that BatchNorm layer; also return its backward reduction
-    `(partial, n_split)` in peclr_bn2d_bwd_reduce's layout -> (C, partial, n_split)."""
+    `(partial, n_split)` in peclr_bn2d_bwd_reduce's layout -> (C, partial, n_split).
+    addend_s2 = (H, W): the rows are the pixels of H x W images and `addend` [M / 4, n] holds every second pixel only (the
+    compact input gradient of a 1x1 / stride-2 convolution): added at the even (h, w) rows (peclr_gemm_x6p_s2add_f32)."""
     m, k = a.shape
-    if planes.dtype != torch.uint8 or planes.numel() != 6 * ((n + 127) // 128 * 128) * k or (addend is not None and tuple(addend.shape) != (m, n)):
+    add_rows = m if addend_s2 is None else m // 4
+    if planes.dtype != torch.uint8 or planes.numel() != 6 * ((n + 127) // 128 * 128) * k or (addend is not None and tuple(addend.shape) != (add_rows, n)):
         raise PeclrHipError(f"gemm_x6p: A {tuple(a.shape)}, planes of {planes.numel()} bytes for B_t[{n}, {k}]")
+    if addend_s2 is not None and (addend is None or stat_shift is not None):
+        raise PeclrHipError("gemm_x6p: addend_s2 needs the compact addend (and has no statistics output)")
     out = torch.empty((m, n), device=a.device, dtype=torch.float32)
     partial, ns, fuse = None, 0, None
     tile_rows = tile_rows or _X6P_TILE_ROWS
@@ -479,12 +485,18 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
         partial = torch.empty((2 * ns + 1, n), device=a.device, dtype=torch.float32)
     elif bn_bwd is not None:
         fuse, partial, ns = _bn_bwd_fuse(bn_bwd, m, n, tile_rows)
-    with _timed(tag, 4 * (m * k + (2 if addend is not None else 1) * m * n + (m * n if fuse is not None else 0)) + 6 * k * n, 2 * m * n * k,
+    add_elems = 0 if addend is None else addend.numel()
+    with _timed(tag, 4 * (m * k + m * n + add_elems + (m * n if fuse is not None else 0)) + 6 * k * n, 2 * m * n * k,
                 kernel="gemm_x6p_kernel"):
-        rc = lib().peclr_gemm_x6p_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
-                                      tile_rows, _ptr(stat_shift), partial.data_ptr() if stat_shift is not None else None,
-                                      ctypes.byref(fuse) if fuse is not None else None, _stream())
-    _check(rc, "peclr_gemm_x6p_f32")
+        if addend_s2 is not None:
+            rc = lib().peclr_gemm_x6p_s2add_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
+                                                int(addend_s2[0]), int(addend_s2[1]), tile_rows,
+                                                ctypes.byref(fuse) if fuse is not None else None, _stream())
+        else:
+            rc = lib().peclr_gemm_x6p_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
+                                          tile_rows, _ptr(stat_shift), partial.data_ptr() if stat_shift is not None else None,
+                                          ctypes.byref(fuse) if fuse is not None else None, _stream())
+    _check(rc, "peclr_gemm_x6p_s2add_f32" if addend_s2 is not None else "peclr_gemm_x6p_f32")
     return out if partial is None else (out, partial, ns)
 
 

@@ -554,9 +554,10 @@ class _ConvS2Gemm(torch.autograd.Function):
     convolution is a scatter)."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, stats=None):
+    def forward(ctx, x, weight, conv, stats=None, compact=False):
         ctx.save_for_backward(x, weight)
         ctx.conv = conv
+        ctx.compact = compact
         planes = _x6_planes(conv)
         cout, taps = weight.shape[0], weight.shape[2] * weight.shape[3]
         shift = _stat_shift_for(stats[0], cout) if (stats and _BN_STATS_IN_GEMM) else None
@@ -582,8 +583,55 @@ class _ConvS2Gemm(torch.autograd.Function):
                   else _conv_wgrad(gy, x, weight, (2, 2), pad, conv.weight))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [2, 2], pad, [1, 1], False, [0, 0], 1, [True, False, False])[0]
-        return dx, dw, None, None
+            if ctx.compact and weight.shape[2] == 1 and not torch.is_anomaly_enabled():
+                # 1x1 shortcut whose input gradient goes straight into the block's fused entry gradient: dY . W over the
+                # OUTPUT pixels only; the consumer adds it at the even pixels (no 4x larger, three-quarters-zero tensor)
+                n, cout, ho, wo = gy.shape
+                dc = _capi.gemm_x6p(gy.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), _x6_planes(conv)[1], x.shape[1], tag="conv_s2_dgrad")
+                dx = _compact_grad(dc, x.shape)
+            else:
+                dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [2, 2], pad, [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        return dx, dw, None, None, None
+
+
+# ---- compact gradient of a 1x1 / stride-2 shortcut.  `_ConvS2Gemm.backward` may only return a tensor of its input's shape,
+# three quarters of which would be zeros that the block's entry-gradient GEMM then reads as its addend.  When the input is
+# the identity output of `_ForkConv1x1` (whose backward is the only consumer of this gradient, and understands the
+# protocol), it returns a zero-stride NaN view of that shape instead -- no memory, and loudly wrong should anything else
+# ever consume or accumulate it -- and parks the real [N, H/2, W/2, C] gradient here under the view's address.
+_S2_DGRAD_COMPACT = os.environ.get("PECLR_S2_DGRAD_COMPACT", "1") != "0"    # A/B switch
+_COMPACT = {}
+_NAN_RING = {}
+
+
+def _compact_grad(dc: Tensor, shape) -> Tensor:
+    ring = _NAN_RING.get(dc.device)
+    if ring is None:
+        ring = _NAN_RING[dc.device] = [torch.full((64,), float("nan"), device=dc.device, dtype=torch.float32), 0]
+    buf, at = ring
+    ring[1] = (at + 1) % 64
+    sentinel = buf[at:at + 1].view(1, 1, 1, 1).expand(shape)
+    _COMPACT[sentinel.data_ptr()] = (dc, tuple(shape))
+    return sentinel
+
+
+def _take_compact(g: Tensor):
+    """The parked compact gradient if `g` is one of `_compact_grad`'s views, else None."""
+    if g is None or g.dim() != 4 or any(g.stride()) or not _COMPACT:
+        return None
+    hit = _COMPACT.get(g.data_ptr())
+    if hit is None or hit[1] != tuple(g.shape):
+        return None
+    del _COMPACT[g.data_ptr()]
+    return hit[0]
+
+
+def _expand_compact(dc: Tensor, shape) -> Tensor:
+    """The dense form (fallback paths): zeros with the compact gradient at the even pixels."""
+    n, c, h, w = shape
+    full = torch.zeros(shape, device=dc.device, dtype=dc.dtype).contiguous(memory_format=torch.channels_last)
+    full[:, :, ::2, ::2] = dc.view(n, h // 2, w // 2, c).permute(0, 3, 1, 2)
+    return full
 
 
 def _bn_link_of(x: Tensor):
@@ -629,7 +677,9 @@ class Conv2d(nn.Conv2d):
                 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
                 and x.shape[0] * x.shape[2] * x.shape[3] >= 32768):
             stats = [stats_for] if stats_for is not None else None
-            return _attach_stats(_ConvS2Gemm.apply(x, self.weight, self, stats), stats)
+            compact = (_S2_DGRAD_COMPACT and self.kernel_size == (1, 1) and getattr(x, "_peclr_compact_ok", False)
+                       and torch.is_grad_enabled() and x.requires_grad)
+            return _attach_stats(_ConvS2Gemm.apply(x, self.weight, self, stats, compact), stats)
         if (self.hip_gemm and _CONV3X3_X6 and _GEMM_X6P and getattr(self, "x6_group", None) is not None and self.kernel_size == (3, 3)
                 and self.stride == (1, 1)
                 and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x.dim() == 4
@@ -654,7 +704,7 @@ class _ForkConv1x1(torch.autograd.Function):
     identity gradient added in the epilogue.  Small shapes' forward and weight gradient stay on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, stats=None, link=None):
+    def forward(ctx, x, weight, conv, stats=None, link=None, flags=None):
         ctx.save_for_backward(x, weight)
         ctx.param = weight if isinstance(weight, nn.Parameter) else None
         ctx.link = link
@@ -666,6 +716,8 @@ class _ForkConv1x1(torch.autograd.Function):
                    and (cmid >= _X6_MIN_K or (_X6_LAYER1_FORK and _GEMM_X6P and r >= 400000 and cmid >= 64 and cmid % 16 == 0 and cin % 128 == 0)))
         ctx.planes = _x6_planes(conv) if (use_fwd or use_bwd) else None
         ctx.use_bwd = use_bwd
+        if flags is not None:       # tells fork_conv1x1 whether the backward takes compact shortcut gradients (the x6p GEMM)
+            flags.append(bool(use_bwd and ctx.planes is not None and h % 2 == 0 and w % 2 == 0))
         if use_fwd:
             x2 = x.permute(0, 2, 3, 1).reshape(r, cin)
             shift = _stat_shift_for(stats[0], cmid) if (stats and ctx.planes is not None and _BN_STATS_IN_GEMM) else None
@@ -693,9 +745,20 @@ class _ForkConv1x1(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             gy = gy.contiguous(memory_format=torch.channels_last)
-            gid = gid.to(x.dtype).contiguous(memory_format=torch.channels_last)
             r = n * h * w
             a = gy.permute(0, 2, 3, 1).reshape(r, cmid)           # NHWC storage seen as [R, Cmid]: a view
+            dc = _take_compact(gid)                               # the shortcut's compact gradient (first block of a layer)
+            if dc is not None and ctx.use_bwd and ctx.planes is not None and x.dtype == torch.float32:
+                link = ctx.link
+                if link is not None and link[0].shape == x.shape and cin % 32 == 0:
+                    out, partial, ns = _capi.gemm_x6p(a, ctx.planes[1], cin, dc, tag="conv1x1_dgrad_add_x6", bn_bwd=link[:5], addend_s2=(h, w))
+                    _note_bn_bwd(out, link, partial, ns)
+                else:
+                    out = _capi.gemm_x6p(a, ctx.planes[1], cin, dc, tag="conv1x1_dgrad_add_x6", addend_s2=(h, w))
+                return out.view(n, h, w, cin).permute(0, 3, 1, 2), dw, None, None, None, None
+            if dc is not None:
+                gid = _expand_compact(dc, x.shape)
+            gid = gid.to(x.dtype).contiguous(memory_format=torch.channels_last)
             d = gid.permute(0, 2, 3, 1).reshape(r, cin)
             if x.dtype in (torch.bfloat16, torch.float16):       # autocast backbone: 16-bit MFMA, fp32 accumulate
                 wt = torch.empty((cin, cmid), device=x.device, dtype=x.dtype)
@@ -716,7 +779,7 @@ class _ForkConv1x1(torch.autograd.Function):
             else:
                 out = _capi.gemm_add(_capi.GEMM_NN, a, weight.reshape(cmid, cin), d, tag="conv1x1_dgrad_add")
             dx = out.view(n, h, w, cin).permute(0, 3, 1, 2)       # back to a channels_last NCHW tensor
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 def fork_conv1x1(conv: nn.Conv2d, x: Tensor, stats_for=None):
@@ -733,7 +796,10 @@ def fork_conv1x1(conv: nn.Conv2d, x: Tensor, stats_for=None):
           and conv.weight.shape[0] % 8 == 0 and conv.weight.shape[1] % 8 == 0)
     if ok:
         stats = [stats_for] if stats_for is not None else None
-        out, identity = _ForkConv1x1.apply(x, conv.weight, conv, stats, _bn_link_of(x))
+        flags = []
+        out, identity = _ForkConv1x1.apply(x, conv.weight, conv, stats, _bn_link_of(x), flags)
+        if flags and flags[0]:
+            identity._peclr_compact_ok = True     # a 1x1 / stride-2 shortcut may hand its input gradient over compact
         return _attach_stats(out, stats), identity
     return (conv(x, stats_for=stats_for) if isinstance(conv, Conv2d) else conv(x)), x
 

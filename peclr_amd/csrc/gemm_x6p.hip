@@ -43,6 +43,10 @@ struct X6PArgs {
     const float* addend;
     float* out;
     int M, N, K, lda, ldo, ldd;
+    // add_h > 0: the rows are the pixels of add_h x add_w images and the addend holds every second pixel only
+    // ([images][add_h / 2][add_w / 2][ldd]: the input gradient of a 1x1 / stride-2 convolution, kept compact): rows at even
+    // (h, w) add addend[(h / 2, w / 2)], the others nothing
+    int add_h, add_w;
     int stream_out;
     // optional BatchNorm statistics of the OUTPUT (the convolution's BatchNorm2d in training mode): per workgroup row
     // block, per column, sum and sum of squares of (C - shift) over the block's rows -> stat_partial[row block][2][N],
@@ -327,9 +331,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                 const int m = mt + er + 8 * jj;
                 dv[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (g.addend && m < g.M) {
-                    const f32x4* src = reinterpret_cast<const f32x4*>(g.addend + (size_t)m * g.ldd + nt + ec);
-                    const f32x4 tv = g.stream_out ? __builtin_nontemporal_load(src) : *src;
-                    dv[jj] = make_float4(tv[0], tv[1], tv[2], tv[3]);
+                    size_t arow = m;
+                    bool has = true;
+                    if (g.add_h) {
+                        const int w = m % g.add_w, hq = m / g.add_w, h = hq % g.add_h, img = hq / g.add_h;
+                        has = ((h | w) & 1) == 0;
+                        arow = ((size_t)img * (g.add_h >> 1) + (h >> 1)) * (g.add_w >> 1) + (w >> 1);
+                    }
+                    if (has) {
+                        const f32x4* src = reinterpret_cast<const f32x4*>(g.addend + arow * g.ldd + nt + ec);
+                        const f32x4 tv = g.stream_out ? __builtin_nontemporal_load(src) : *src;
+                        dv[jj] = make_float4(tv[0], tv[1], tv[2], tv[3]);
+                    }
                 }
                 if (g.bb_partial && m < g.M) {
                     xv[jj] = *reinterpret_cast<const f32x4*>(g.bb_x + (size_t)m * g.N + nt + ec);
@@ -500,7 +513,7 @@ extern "C" int peclr_conv_s2_x6p_f32(int NB, int H, int W, int Cin, int Cout, in
     if (tile_rows != 128 && tile_rows != 256) return PECLR_ERR_UNSUPPORTED;
     X6PArgs g;
     g.A = X; g.Bp = Bp; g.addend = nullptr; g.out = Y;
-    g.M = M; g.N = Cout; g.K = taps * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout;
+    g.M = M; g.N = Cout; g.K = taps * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout; g.add_h = g.add_w = 0;
     g.stream_out = (size_t)M * Cout * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = Ho; g.W = Wo; g.flip = 0; g.zeros = zeros; g.stride = 2; g.Hin = H; g.Win = W;
@@ -522,7 +535,7 @@ extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, co
     if (tile_rows != 128 && tile_rows != 256) return PECLR_ERR_UNSUPPORTED;
     X6PArgs g;
     g.A = X; g.Bp = Bp; g.addend = addend; g.out = Y;
-    g.M = M; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout;
+    g.M = M; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout; g.add_h = g.add_w = 0;
     g.stream_out = (size_t)M * Cout * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = H; g.W = W; g.flip = flip ? 1 : 0; g.zeros = zeros; g.stride = 1; g.Hin = H; g.Win = W;
@@ -530,12 +543,13 @@ extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, co
     return launch_x6p(g, tile_rows, 9, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
+static int gemm_x6p_host(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc, int add_h, int add_w,
                                   const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
                                   const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
     if (!A || !Bp || !C || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
     if (bb && (stat_partial || !bb->x || !bb->mean || !bb->invstd || !bb->scale_shift || !bb->partial || ldc != N)) return PECLR_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % PK) return PECLR_ERR_SHAPE;
+    if (add_h && (!addend || add_h < 2 || add_w < 2 || add_h % 2 || add_w % 2 || M % (add_h * add_w))) return PECLR_ERR_SHAPE;
     if (lda % 4 || lda < K || ldc % 4 || ldc < N || (addend && (ldd % 4 || ldd < N))) return PECLR_ERR_SHAPE;
     if (!aligned16(A) || !aligned16(Bp) || !aligned16(C) || (addend && !aligned16(addend))) return PECLR_ERR_ALIGN;
     if (tile_rows == 0) tile_rows = peclr_gemm_x6p_tile_rows(M, N, K);
@@ -543,9 +557,23 @@ extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, 
     X6PArgs g;
     g.A = A; g.Bp = Bp; g.addend = addend; g.out = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldc; g.ldd = ldd;
+    g.add_h = add_h; g.add_w = add_w;
     g.stream_out = (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = g.W = 1; g.flip = 0; g.zeros = nullptr; g.stride = 1; g.Hin = g.Win = 1;
     set_bb(g, bb);
     return launch_x6p(g, tile_rows, 1, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
+                                  const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
+                                  const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
+    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, 0, 0, addend, ldd, tile_rows, stat_shift, stat_partial, bb, stream);
+}
+
+extern "C" int peclr_gemm_x6p_s2add_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
+                                        const float* addend_half, int ldd, int H, int W, int tile_rows,
+                                        const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
+    if (!addend_half || H <= 0 || W <= 0) return PECLR_ERR_NULL;
+    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, H, W, addend_half, ldd, tile_rows, nullptr, nullptr, bb, stream);
 }

@@ -2005,6 +2005,70 @@ def test_batchnorm_backward_reduction_in_the_dgrad_epilogue_equals_the_separate_
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7
 
 
+@pytest.mark.parametrize("cin,planes,hw,n", [(256, 128, 56, 16), (512, 256, 28, 48), (1024, 512, 14, 200)])
+def test_first_block_entry_gradient_adds_the_shortcut_gradient_compact(cin, planes, hw, n):
+    """First block of layers 2-4: the block input feeds conv1 (1x1) and the 1x1 / stride-2 shortcut.  The shortcut's input
+    gradient stays compact (dYs . Ws over the output pixels: one peclr_gemm_x6p_f32) and the entry-gradient GEMM adds it at
+    the even pixels (peclr_gemm_x6p_s2add_f32) -- against MIOpen's strided input gradient + the dense addend (the
+    PECLR_S2_DGRAD_COMPACT=0 arm): same products, the shortcut's summed in another order.  A preceding block checks that the
+    BatchNorm backward reduction still rides in that epilogue; the parked gradient is consumed."""
+    from peclr_amd import _capi
+    from peclr_amd import bn2d as B
+    from peclr_amd import resnet
+
+    g = torch.Generator().manual_seed(cin + hw + 2)
+    x0 = (torch.randn(n, cin, hw, hw, generator=g) * 0.7 + 0.3).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, 4 * planes, hw // 2, hw // 2, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    res, tags = {}, {}
+    for compact in (False, True):
+        torch.manual_seed(9)
+        ds = torch.nn.Sequential(resnet.conv1x1(cin, 4 * planes, 2), B.FusedBatchNormAct2d(4 * planes))
+        net = torch.nn.Sequential(resnet.Bottleneck(cin, cin // 4, norm_layer=B.FusedBatchNormAct2d),
+                                  resnet.Bottleneck(cin, planes, 2, ds, norm_layer=B.FusedBatchNormAct2d))
+        net = net.to(DEV).to(memory_format=torch.channels_last).train()
+        B.enable_hip_batchnorm(net)
+        B._S2_DGRAD_COMPACT = compact
+        _capi.EVENT_LOG = {}
+        try:
+            x = x0.clone().requires_grad_()
+            y = net(x)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            tags[compact] = {k: len(v) for k, v in _capi.EVENT_LOG.items()}
+        finally:
+            _capi.EVENT_LOG = None
+            B._S2_DGRAD_COMPACT = True
+        assert not B._COMPACT
+        res[compact] = (y.detach(), x.grad.clone(), [p.grad.clone() for p in net.parameters()])
+    assert tags[True].get("conv_s2_dgrad") == 1 and "conv_s2_dgrad" not in tags[False], tags
+    assert tags[True]["conv1x1_dgrad_add_x6"] == tags[False]["conv1x1_dgrad_add_x6"] >= 1, tags
+    assert tags[True].get("bn2d_bwd_reduce", 0) == tags[False].get("bn2d_bwd_reduce", 0)
+    assert torch.equal(res[True][0], res[False][0])
+    a, b = res[True][1], res[False][1]
+    assert torch.isfinite(a).all()
+    assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    for a, b in zip(res[True][2], res[False][2]):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("m,n,k,hw", [(2 * 12 * 12, 128, 64, 12), (5 * 6 * 10, 192, 48, (6, 10)), (3 * 28 * 28, 256, 512, 28)])
+def test_gemm_x6p_strided_addend(capi, m, n, k, hw):
+    """peclr_gemm_x6p_s2add_f32: C = A . B_t^T + (addend_half at the even pixels): equal, bit for bit, to the dense-addend
+    GEMM on the expanded addend."""
+    h, w = (hw, hw) if isinstance(hw, int) else hw
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).to(DEV)
+    bt = (torch.randn(n, k, generator=g) * 0.1).to(DEV)
+    half = torch.randn(m // 4, n, generator=g).to(DEV)
+    imgs = m // (h * w)
+    dense = torch.zeros(imgs, h, w, n, device=DEV)
+    dense[:, ::2, ::2] = half.view(imgs, h // 2, w // 2, n)
+    pk = capi.X6Planes([(bt, False)]).pack()
+    want = capi.gemm_x6p(a, pk.planes[0], n, dense.view(m, n))
+    got = capi.gemm_x6p(a, pk.planes[0], n, half, addend_s2=(h, w))
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("cin,cout,k,hw,n", [(256, 128, 3, 56, 16), (128, 128, 3, 28, 48), (256, 512, 1, 56, 12), (1024, 2048, 1, 14, 200)])
 def test_stride_2_convolution_forward_in_tree_matches_float64(cin, cout, k, hw, n):
     """bn2d.Conv2d(hip_gemm) for the stride-2 convolutions of a layer's first block (3x3 / padding 1 and the 1x1

@@ -676,3 +676,26 @@ def test_x6_routing_rules_and_cpu_fallback(monkeypatch):
         yb.sum().backward()
         assert torch.equal(a.grad, b.grad) and torch.equal(conv.weight.grad, ref.weight.grad)
         conv.weight.grad = ref.weight.grad = None
+
+
+def test_compact_shortcut_gradient_protocol():
+    """bn2d._compact_grad / _take_compact / _expand_compact: the zero-stride NaN view a 1x1 / stride-2 shortcut returns as its
+    input gradient carries the compact [N, H/2, W/2, C] gradient to the entry-gradient GEMM exactly once; anything that is
+    not such a view is left alone, and the dense fallback puts the compact values at the even pixels."""
+    from peclr_amd import bn2d as B
+
+    dc = torch.arange(2 * 2 * 3 * 5, dtype=torch.float32).view(2 * 2 * 3, 5)          # N=2, H/2=2, W/2=3, C=5
+    shape = (2, 5, 4, 6)
+    s1 = B._compact_grad(dc, shape)
+    s2 = B._compact_grad(dc + 1, shape)
+    assert tuple(s1.shape) == shape and not any(s1.stride()) and torch.isnan(s1).all()     # loud if ever added to anything
+    assert s1.data_ptr() != s2.data_ptr()
+    assert B._take_compact(torch.zeros(shape)) is None and B._take_compact(None) is None
+    assert B._take_compact(s1.expand(shape)[:, :3]) is None                                 # another shape: not ours
+    got = B._take_compact(s2)
+    assert torch.equal(got, dc + 1) and B._take_compact(s2) is None                         # consumed
+    full = B._expand_compact(B._take_compact(s1), shape)
+    assert not B._COMPACT and full.is_contiguous(memory_format=torch.channels_last)
+    ref = torch.zeros(shape)
+    ref[:, :, ::2, ::2] = dc.view(2, 2, 3, 5).permute(0, 3, 1, 2)
+    assert torch.equal(full, ref)
