@@ -146,6 +146,14 @@ int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void*
 int peclr_gemm_x6p_s2add_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                              const float* addend_half, int ldd, int H, int W, int tile_rows, const peclr_bn_bwd_fuse* bn_bwd,
                              peclr_stream_t stream);
+/* ... and when the addend is a gradient that still has to pass a ReLU: addend_mask = the 1-bit mask peclr_bn2d_apply wrote
+ * for that ReLU ([M][N / 32] words, bit c % 32 of word c / 32 = output c was positive); addend elements whose bit is clear
+ * count as zero.  This is the entry gradient of a residual block whose shortcut is the identity: dY1 . W1 +
+ * relu'(out) * d(out) -- the second term is what the block's last BatchNorm backward would otherwise write out as the
+ * residual's gradient (4 B per element written, then read back here).  N % 32 == 0.                                       */
+int peclr_gemm_x6p_maskadd_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
+                               const float* addend, int ldd, const unsigned* addend_mask, int tile_rows,
+                               const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
 /* 3x3 / stride-1 / padding-1 convolution of an NHWC fp32 tensor (the middle convolution of the torchvision Bottleneck,
  * resnet_model.py:15) as an implicit GEMM on the same kernel: rows = output pixels, K = 9 * Cin ordered (tap, channel); the
  * activation rows of a k-step come from the pixel the tap points at (zeros outside the image: `zeros` = >= 64 bytes of

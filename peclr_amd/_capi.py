@@ -74,6 +74,7 @@ SIGNATURES = {
     "peclr_gemm_x6p_tile_rows": (c_int, [c_int, c_int, c_int]),
     "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P]),
     "peclr_gemm_x6p_s2add_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "peclr_gemm_x6p_maskadd_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P]),
     "peclr_gemm_x6t_slabs": (c_int, [c_int, c_int, c_int, c_int]),
     "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "peclr_conv_s2_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
@@ -458,7 +459,8 @@ class X6Planes:
 
 
 def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[torch.Tensor] = None, tag: str = "gemm_x6p",
-             tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None, addend_s2=None):
+             tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None, addend_s2=None,
+             addend_mask: Optional[torch.Tensor] = None):
     """C (fp32) [M, n] = A[M, K] . B_t^T (+ addend) with B_t given as packed planes (X6Planes): fp32 accuracy on the
     bf16 matrix cores, the weight operand split once per step (peclr_gemm_x6p_f32).
     stat_shift (fp32 [n]): also return the training-mode BatchNorm statistics of C as `(partial, n_split)` in the layout
@@ -466,13 +468,18 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
     bn_bwd (see `_bn_bwd_fuse`): C is the gradient arriving at that BatchNorm layer; also return its backward reduction
     `(partial, n_split)` in peclr_bn2d_bwd_reduce's layout -> (C, partial, n_split).
     addend_s2 = (H, W): the rows are the pixels of H x W images and `addend` [M / 4, n] holds every second pixel only (the
-    compact input gradient of a 1x1 / stride-2 convolution): added at the even (h, w) rows (peclr_gemm_x6p_s2add_f32)."""
+    compact input gradient of a 1x1 / stride-2 convolution): added at the even (h, w) rows (peclr_gemm_x6p_s2add_f32).
+    addend_mask (int32 [M, n / 32], the 1-bit ReLU mask of peclr_bn2d_apply): addend elements whose bit is clear count as
+    zero (peclr_gemm_x6p_maskadd_f32)."""
     m, k = a.shape
     add_rows = m if addend_s2 is None else m // 4
     if planes.dtype != torch.uint8 or planes.numel() != 6 * ((n + 127) // 128 * 128) * k or (addend is not None and tuple(addend.shape) != (add_rows, n)):
         raise PeclrHipError(f"gemm_x6p: A {tuple(a.shape)}, planes of {planes.numel()} bytes for B_t[{n}, {k}]")
-    if addend_s2 is not None and (addend is None or stat_shift is not None):
-        raise PeclrHipError("gemm_x6p: addend_s2 needs the compact addend (and has no statistics output)")
+    if addend_s2 is not None and (addend is None or stat_shift is not None or addend_mask is not None):
+        raise PeclrHipError("gemm_x6p: addend_s2 needs the compact addend (and has no statistics output / mask)")
+    if addend_mask is not None and (addend is None or stat_shift is not None or n % 32 or addend_mask.dtype != torch.int32
+                                    or addend_mask.numel() != m * (n // 32) or not addend_mask.is_contiguous()):
+        raise PeclrHipError("gemm_x6p: addend_mask is the int32 [M, n / 32] bit mask of a dense addend (no statistics output)")
     out = torch.empty((m, n), device=a.device, dtype=torch.float32)
     partial, ns, fuse = None, 0, None
     tile_rows = tile_rows or _X6P_TILE_ROWS
@@ -485,10 +492,14 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
         partial = torch.empty((2 * ns + 1, n), device=a.device, dtype=torch.float32)
     elif bn_bwd is not None:
         fuse, partial, ns = _bn_bwd_fuse(bn_bwd, m, n, tile_rows)
-    add_elems = 0 if addend is None else addend.numel()
+    add_elems = 0 if addend is None else addend.numel() + (0 if addend_mask is None else addend_mask.numel())
     with _timed(tag, 4 * (m * k + m * n + add_elems + (m * n if fuse is not None else 0)) + 6 * k * n, 2 * m * n * k,
                 kernel="gemm_x6p_kernel"):
-        if addend_s2 is not None:
+        if addend_mask is not None:
+            rc = lib().peclr_gemm_x6p_maskadd_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
+                                                  _ptr(addend_mask, torch.int32), tile_rows,
+                                                  ctypes.byref(fuse) if fuse is not None else None, _stream())
+        elif addend_s2 is not None:
             rc = lib().peclr_gemm_x6p_s2add_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
                                                 int(addend_s2[0]), int(addend_s2[1]), tile_rows,
                                                 ctypes.byref(fuse) if fuse is not None else None, _stream())
@@ -496,7 +507,8 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
             rc = lib().peclr_gemm_x6p_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
                                           tile_rows, _ptr(stat_shift), partial.data_ptr() if stat_shift is not None else None,
                                           ctypes.byref(fuse) if fuse is not None else None, _stream())
-    _check(rc, "peclr_gemm_x6p_s2add_f32" if addend_s2 is not None else "peclr_gemm_x6p_f32")
+    _check(rc, "peclr_gemm_x6p_maskadd_f32" if addend_mask is not None else "peclr_gemm_x6p_s2add_f32" if addend_s2 is not None
+           else "peclr_gemm_x6p_f32")
     return out if partial is None else (out, partial, ns)
 
 

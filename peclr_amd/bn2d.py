@@ -156,7 +156,7 @@ def _x6_planes(conv):
 
 class _BN2dAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool, pre=None, link=None):
+    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool, pre=None, link=None, lazy_res=False):
         """link: None or an empty list that receives what a consumer's input-gradient GEMM needs to perform this layer's
         backward reduction in its epilogue: [x, save, scale_shift, relu mask or None, relu, token]."""
         training = bn.training or not bn.track_running_stats
@@ -173,6 +173,9 @@ class _BN2dAct(torch.autograd.Function):
         ctx.cfg = (training, relu, residual is not None, keep is not None, mask is not None)
         ctx.sync_group = bn.sync_group if training else None
         ctx.token = None
+        # the residual's gradient is relu'(y) * dy: when its only consumer is the block's entry-gradient GEMM (which then
+        # reads dy and the 1-bit mask itself), it is handed over as that pair instead of being written out
+        ctx.lazy_res = bool(lazy_res and mask is not None and x.dtype == torch.float32)
         if link is not None and x.dtype == torch.float32 and (keep is None or mask is not None):
             ctx.token = object()
             link[:] = [x, save, ss, mask, relu, ctx.token]
@@ -189,11 +192,14 @@ class _BN2dAct(torch.autograd.Function):
         ent = _BN_BWD_STATS.pop(dy.data_ptr(), None) if ctx.token is not None else None
         if ent is not None and ent[0] is ctx.token:          # the GEMM that produced dy reduced it against x already
             pre = ent[1:]
+        lazy = ctx.lazy_res and has_res and ctx.needs_input_grad[3] and _LAZY_RESIDUAL_GRAD and not torch.is_anomaly_enabled()
         dx, dgamma, dbeta, dres = _capi.bn2d_bwd(dy, x, y, mask, save, ss, training, relu,
-                                                 has_res and ctx.needs_input_grad[3], sync_group=ctx.sync_group, pre=pre)
-        if has_res and dres is None and ctx.needs_input_grad[3]:
+                                                 has_res and ctx.needs_input_grad[3] and not lazy, sync_group=ctx.sync_group, pre=pre)
+        if lazy:
+            dres = _lazy_grad(("mask", dy, mask), x.shape, x.device)
+        elif has_res and dres is None and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dgamma, dbeta, dres, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None
 
 
 class _BN2dReluPool(torch.autograd.Function):
@@ -594,29 +600,37 @@ class _ConvS2Gemm(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
-# ---- compact gradient of a 1x1 / stride-2 shortcut.  `_ConvS2Gemm.backward` may only return a tensor of its input's shape,
-# three quarters of which would be zeros that the block's entry-gradient GEMM then reads as its addend.  When the input is
-# the identity output of `_ForkConv1x1` (whose backward is the only consumer of this gradient, and understands the
-# protocol), it returns a zero-stride NaN view of that shape instead -- no memory, and loudly wrong should anything else
-# ever consume or accumulate it -- and parks the real [N, H/2, W/2, C] gradient here under the view's address.
-_S2_DGRAD_COMPACT = os.environ.get("PECLR_S2_DGRAD_COMPACT", "1") != "0"    # A/B switch
+# ---- gradients handed to a block's entry-gradient GEMM in another form than a dense tensor.  An autograd function may only
+# return a tensor of its input's shape.  Two producers would write such a tensor only for `_ForkConv1x1.backward` to read it
+# back as its addend: the 1x1 / stride-2 shortcut of a layer's first block (three quarters of its input gradient are zeros:
+# the compact [N, H/2, W/2, C] product is all there is to it) and the last BatchNorm of a block with an identity shortcut
+# (the residual's gradient is relu'(out) * d(out): the GEMM can read d(out) and the 1-bit mask itself).  When their input is
+# the identity output of `_ForkConv1x1` (whose backward is the only consumer of that gradient, and understands the
+# protocol), they return a zero-stride NaN view of the right shape instead -- no memory, and loudly wrong should anything
+# else ever consume or accumulate it -- and park the real payload here under the view's address.
+_S2_DGRAD_COMPACT = os.environ.get("PECLR_S2_DGRAD_COMPACT", "1") != "0"    # A/B switch: the shortcut's compact gradient
+_LAZY_RESIDUAL_GRAD = os.environ.get("PECLR_LAZY_RESIDUAL_GRAD", "1") != "0"   # A/B switch: the identity shortcut's (dy, mask) pair
 _COMPACT = {}
 _NAN_RING = {}
 
 
-def _compact_grad(dc: Tensor, shape) -> Tensor:
-    ring = _NAN_RING.get(dc.device)
+def _lazy_grad(payload, shape, device) -> Tensor:
+    ring = _NAN_RING.get(device)
     if ring is None:
-        ring = _NAN_RING[dc.device] = [torch.full((64,), float("nan"), device=dc.device, dtype=torch.float32), 0]
+        ring = _NAN_RING[device] = [torch.full((64,), float("nan"), device=device, dtype=torch.float32), 0]
     buf, at = ring
     ring[1] = (at + 1) % 64
     sentinel = buf[at:at + 1].view(1, 1, 1, 1).expand(shape)
-    _COMPACT[sentinel.data_ptr()] = (dc, tuple(shape))
+    _COMPACT[sentinel.data_ptr()] = (payload, tuple(shape))
     return sentinel
 
 
-def _take_compact(g: Tensor):
-    """The parked compact gradient if `g` is one of `_compact_grad`'s views, else None."""
+def _compact_grad(dc: Tensor, shape) -> Tensor:
+    return _lazy_grad(("s2", dc), shape, dc.device)
+
+
+def _take_lazy(g: Tensor):
+    """The parked payload -- ("s2", compact gradient) or ("mask", dy, bit mask) -- if `g` is one of `_lazy_grad`'s views."""
     if g is None or g.dim() != 4 or any(g.stride()) or not _COMPACT:
         return None
     hit = _COMPACT.get(g.data_ptr())
@@ -624,6 +638,22 @@ def _take_compact(g: Tensor):
         return None
     del _COMPACT[g.data_ptr()]
     return hit[0]
+
+
+def _take_compact(g: Tensor):
+    hit = _take_lazy(g)
+    return None if hit is None else _dense_of(hit, g.shape) if hit[0] != "s2" else hit[1]
+
+
+def _dense_of(payload, shape) -> Tensor:
+    """The dense gradient a payload stands for (fallback paths)."""
+    if payload[0] == "s2":
+        return _expand_compact(payload[1], shape)
+    _, dy, mask = payload
+    n, c, h, w = shape
+    bits = (mask.view(n * h * w, c // 32, 1) >> torch.arange(32, device=mask.device, dtype=torch.int32)) & 1
+    d = dy.permute(0, 2, 3, 1).reshape(n * h * w, c) * bits.view(n * h * w, c).to(dy.dtype)
+    return d.view(n, h, w, c).permute(0, 3, 1, 2)
 
 
 def _expand_compact(dc: Tensor, shape) -> Tensor:
@@ -717,7 +747,7 @@ class _ForkConv1x1(torch.autograd.Function):
         ctx.planes = _x6_planes(conv) if (use_fwd or use_bwd) else None
         ctx.use_bwd = use_bwd
         if flags is not None:       # tells fork_conv1x1 whether the backward takes compact shortcut gradients (the x6p GEMM)
-            flags.append(bool(use_bwd and ctx.planes is not None and h % 2 == 0 and w % 2 == 0))
+            flags.append(bool(use_bwd and ctx.planes is not None))
         if use_fwd:
             x2 = x.permute(0, 2, 3, 1).reshape(r, cin)
             shift = _stat_shift_for(stats[0], cmid) if (stats and ctx.planes is not None and _BN_STATS_IN_GEMM) else None
@@ -747,17 +777,21 @@ class _ForkConv1x1(torch.autograd.Function):
             gy = gy.contiguous(memory_format=torch.channels_last)
             r = n * h * w
             a = gy.permute(0, 2, 3, 1).reshape(r, cmid)           # NHWC storage seen as [R, Cmid]: a view
-            dc = _take_compact(gid)                               # the shortcut's compact gradient (first block of a layer)
-            if dc is not None and ctx.use_bwd and ctx.planes is not None and x.dtype == torch.float32:
+            lazy = _take_lazy(gid)          # the shortcut's gradient in its compact / (dy, mask) form (see `_lazy_grad`)
+            if lazy is not None and ctx.use_bwd and ctx.planes is not None and x.dtype == torch.float32:
+                if lazy[0] == "s2":
+                    kw = dict(addend=lazy[1], addend_s2=(h, w))
+                else:
+                    kw = dict(addend=lazy[1].contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(r, cin), addend_mask=lazy[2])
                 link = ctx.link
                 if link is not None and link[0].shape == x.shape and cin % 32 == 0:
-                    out, partial, ns = _capi.gemm_x6p(a, ctx.planes[1], cin, dc, tag="conv1x1_dgrad_add_x6", bn_bwd=link[:5], addend_s2=(h, w))
+                    out, partial, ns = _capi.gemm_x6p(a, ctx.planes[1], cin, tag="conv1x1_dgrad_add_x6", bn_bwd=link[:5], **kw)
                     _note_bn_bwd(out, link, partial, ns)
                 else:
-                    out = _capi.gemm_x6p(a, ctx.planes[1], cin, dc, tag="conv1x1_dgrad_add_x6", addend_s2=(h, w))
+                    out = _capi.gemm_x6p(a, ctx.planes[1], cin, tag="conv1x1_dgrad_add_x6", **kw)
                 return out.view(n, h, w, cin).permute(0, 3, 1, 2), dw, None, None, None, None
-            if dc is not None:
-                gid = _expand_compact(dc, x.shape)
+            if lazy is not None:
+                gid = _dense_of(lazy, x.shape)
             gid = gid.to(x.dtype).contiguous(memory_format=torch.channels_last)
             d = gid.permute(0, 2, 3, 1).reshape(r, cin)
             if x.dtype in (torch.bfloat16, torch.float16):       # autocast backbone: 16-bit MFMA, fp32 accumulate
@@ -848,7 +882,9 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
             if self.tail_avgpool and relu and residual is not None and self.num_features % 32 == 0:
                 return _BN2dAddReluAvgPool.apply(x, self.weight, self.bias, residual, self, pre)
             link = [] if (_BN_BWD_IN_GEMM and torch.is_grad_enabled() and x.requires_grad) else None
-            y = _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre, link)
+            lazy_res = (_LAZY_RESIDUAL_GRAD and relu and residual is not None and getattr(residual, "_peclr_compact_ok", False)
+                        and torch.is_grad_enabled() and residual.requires_grad and self.num_features % 32 == 0)
+            y = _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre, link, lazy_res)
             if link:
                 y._peclr_bn_link = link
             return y

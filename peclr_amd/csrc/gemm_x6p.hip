@@ -47,6 +47,9 @@ struct X6PArgs {
     // ([images][add_h / 2][add_w / 2][ldd]: the input gradient of a 1x1 / stride-2 convolution, kept compact): rows at even
     // (h, w) add addend[(h / 2, w / 2)], the others nothing
     int add_h, add_w;
+    // optional 1-bit mask of the addend ([M][N / 32] words, bit c % 32 of word c / 32): addend elements whose bit is clear
+    // count as zero -- the gradient behind a ReLU, rectified here instead of in a pass of its own
+    const unsigned* add_mask;
     int stream_out;
     // optional BatchNorm statistics of the OUTPUT (the convolution's BatchNorm2d in training mode): per workgroup row
     // block, per column, sum and sum of squares of (C - shift) over the block's rows -> stat_partial[row block][2][N],
@@ -341,7 +344,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                     if (has) {
                         const f32x4* src = reinterpret_cast<const f32x4*>(g.addend + arow * g.ldd + nt + ec);
                         const f32x4 tv = g.stream_out ? __builtin_nontemporal_load(src) : *src;
-                        dv[jj] = make_float4(tv[0], tv[1], tv[2], tv[3]);
+                        const unsigned ab = g.add_mask ? g.add_mask[(size_t)m * (g.N >> 5) + (nt >> 5)] >> ec : 0xfu;
+                        dv[jj] = make_float4(ab & 1u ? tv[0] : 0.f, ab & 2u ? tv[1] : 0.f, ab & 4u ? tv[2] : 0.f, ab & 8u ? tv[3] : 0.f);
                     }
                 }
                 if (g.bb_partial && m < g.M) {
@@ -513,7 +517,7 @@ extern "C" int peclr_conv_s2_x6p_f32(int NB, int H, int W, int Cin, int Cout, in
     if (tile_rows != 128 && tile_rows != 256) return PECLR_ERR_UNSUPPORTED;
     X6PArgs g;
     g.A = X; g.Bp = Bp; g.addend = nullptr; g.out = Y;
-    g.M = M; g.N = Cout; g.K = taps * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout; g.add_h = g.add_w = 0;
+    g.M = M; g.N = Cout; g.K = taps * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout; g.add_h = g.add_w = 0; g.add_mask = nullptr;
     g.stream_out = (size_t)M * Cout * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = Ho; g.W = Wo; g.flip = 0; g.zeros = zeros; g.stride = 2; g.Hin = H; g.Win = W;
@@ -535,7 +539,7 @@ extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, co
     if (tile_rows != 128 && tile_rows != 256) return PECLR_ERR_UNSUPPORTED;
     X6PArgs g;
     g.A = X; g.Bp = Bp; g.addend = addend; g.out = Y;
-    g.M = M; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout; g.add_h = g.add_w = 0;
+    g.M = M; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout; g.add_h = g.add_w = 0; g.add_mask = nullptr;
     g.stream_out = (size_t)M * Cout * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = H; g.W = W; g.flip = flip ? 1 : 0; g.zeros = zeros; g.stride = 1; g.Hin = H; g.Win = W;
@@ -544,6 +548,7 @@ extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, co
 }
 
 static int gemm_x6p_host(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc, int add_h, int add_w,
+                         const unsigned* add_mask,
                                   const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
                                   const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
     if (!A || !Bp || !C || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
@@ -557,7 +562,7 @@ static int gemm_x6p_host(int M, int N, int K, const float* A, int lda, const voi
     X6PArgs g;
     g.A = A; g.Bp = Bp; g.addend = addend; g.out = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldc; g.ldd = ldd;
-    g.add_h = add_h; g.add_w = add_w;
+    g.add_h = add_h; g.add_w = add_w; g.add_mask = add_mask;
     g.stream_out = (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = g.W = 1; g.flip = 0; g.zeros = nullptr; g.stride = 1; g.Hin = g.Win = 1;
@@ -568,12 +573,20 @@ static int gemm_x6p_host(int M, int N, int K, const float* A, int lda, const voi
 extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                                   const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
                                   const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
-    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, 0, 0, addend, ldd, tile_rows, stat_shift, stat_partial, bb, stream);
+    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, 0, 0, nullptr, addend, ldd, tile_rows, stat_shift, stat_partial, bb, stream);
 }
 
 extern "C" int peclr_gemm_x6p_s2add_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                                         const float* addend_half, int ldd, int H, int W, int tile_rows,
                                         const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
     if (!addend_half || H <= 0 || W <= 0) return PECLR_ERR_NULL;
-    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, H, W, addend_half, ldd, tile_rows, nullptr, nullptr, bb, stream);
+    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, H, W, nullptr, addend_half, ldd, tile_rows, nullptr, nullptr, bb, stream);
+}
+
+extern "C" int peclr_gemm_x6p_maskadd_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
+                                          const float* addend, int ldd, const unsigned* addend_mask, int tile_rows,
+                                          const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
+    if (!addend || !addend_mask) return PECLR_ERR_NULL;
+    if (N % 32 || ((size_t)addend_mask & 3)) return PECLR_ERR_SHAPE;
+    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, 0, 0, addend_mask, addend, ldd, tile_rows, nullptr, nullptr, bb, stream);
 }

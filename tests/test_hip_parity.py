@@ -2051,6 +2051,64 @@ def test_first_block_entry_gradient_adds_the_shortcut_gradient_compact(cin, plan
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7
 
 
+@pytest.mark.parametrize("cin,cmid,hw,n", [(256, 64, 56, 256), (512, 128, 28, 64), (2048, 512, 7, 256)])
+def test_identity_shortcut_gradient_is_handed_over_as_dy_and_mask(cin, cmid, hw, n):
+    """Blocks with an identity shortcut: the residual's gradient relu'(out) * d(out) is not written out by the last
+    BatchNorm's backward; the entry-gradient GEMM reads d(out) and the 1-bit mask (peclr_gemm_x6p_maskadd_f32).  The same
+    numbers in the same order as the PECLR_LAZY_RESIDUAL_GRAD=0 arm: every gradient bit for bit."""
+    from peclr_amd import _capi
+    from peclr_amd import bn2d as B
+    from peclr_amd import resnet
+
+    g = torch.Generator().manual_seed(cin + hw + 3)
+    x0 = (torch.randn(n, cin, hw, hw, generator=g) * 0.7 + 0.3).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, cin, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    res, log = {}, {}
+    for lazy in (False, True):
+        torch.manual_seed(5)
+        net = torch.nn.Sequential(resnet.Bottleneck(cin, cmid, norm_layer=B.FusedBatchNormAct2d),
+                                  resnet.Bottleneck(cin, cmid, norm_layer=B.FusedBatchNormAct2d))
+        net = net.to(DEV).to(memory_format=torch.channels_last).train()
+        B.enable_hip_batchnorm(net)
+        B._LAZY_RESIDUAL_GRAD = lazy
+        _capi.EVENT_LOG = {}
+        try:
+            x = x0.clone().requires_grad_()
+            y = net(x)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            log[lazy] = {k: sum(e[2] for e in v) for k, v in _capi.EVENT_LOG.items()}      # algorithmic bytes per tag
+        finally:
+            _capi.EVENT_LOG = None
+            B._LAZY_RESIDUAL_GRAD = True
+        assert not B._COMPACT
+        res[lazy] = (y.detach(), x.grad.clone(), [p.grad.clone() for p in net.parameters()])
+    routed = "conv1x1_dgrad_add_x6" in log[False]
+    assert routed or hw == 7
+    if routed:     # two residual gradients less to write
+        assert log[False]["bn2d_bwd_apply"] - log[True]["bn2d_bwd_apply"] == 2 * 4 * n * hw * hw * cin
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 128, 64), (1000, 192, 48), (4096, 256, 512)])
+def test_gemm_x6p_masked_addend(capi, m, n, k):
+    """peclr_gemm_x6p_maskadd_f32: C = A . B_t^T + (addend where the mask bit is set): equal, bit for bit, to the
+    dense-addend GEMM on the masked addend."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).to(DEV)
+    bt = (torch.randn(n, k, generator=g) * 0.1).to(DEV)
+    add = torch.randn(m, n, generator=g).to(DEV)
+    bits = torch.rand(m, n, generator=g).to(DEV) > 0.4
+    words = (bits.view(m, n // 32, 32).to(torch.int64) << torch.arange(32, device=DEV)).sum(-1)
+    mask = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+    pk = capi.X6Planes([(bt, False)]).pack()
+    want = capi.gemm_x6p(a, pk.planes[0], n, add * bits)
+    got = capi.gemm_x6p(a, pk.planes[0], n, add, addend_mask=mask)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("m,n,k,hw", [(2 * 12 * 12, 128, 64, 12), (5 * 6 * 10, 192, 48, (6, 10)), (3 * 28 * 28, 256, 512, 28)])
 def test_gemm_x6p_strided_addend(capi, m, n, k, hw):
     """peclr_gemm_x6p_s2add_f32: C = A . B_t^T + (addend_half at the even pixels): equal, bit for bit, to the dense-addend

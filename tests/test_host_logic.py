@@ -699,3 +699,11 @@ def test_compact_shortcut_gradient_protocol():
     ref = torch.zeros(shape)
     ref[:, :, ::2, ::2] = dc.view(2, 2, 3, 5).permute(0, 3, 1, 2)
     assert torch.equal(full, ref)
+    # the (dy, mask) form of an identity shortcut's gradient: its dense equivalent is dy where the mask bit is set
+    dy = torch.randn(2, 64, 3, 3).contiguous(memory_format=torch.channels_last)
+    bits = torch.rand(2 * 9, 64) > 0.5
+    words = (bits.view(18, 2, 32).to(torch.int64) << torch.arange(32)).sum(-1)
+    mask = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+    s3 = B._lazy_grad(("mask", dy, mask), dy.shape, dy.device)
+    dense = B._take_compact(s3)
+    assert torch.equal(dense, dy * bits.view(2, 3, 3, 64).permute(0, 3, 1, 2)) and not B._COMPACT
