@@ -180,10 +180,20 @@ int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* 
 int peclr_gemm_x6t_slabs(int M, int N, int K, int taps);
 int peclr_gemm_x6t_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs, int n_slabs,
                        int taps, int H, int W, int stride, const float* zeros, peclr_stream_t stream);
+/* Input gradient of the 3x3 / padding-1 / STRIDE-2 convolution of a layer's first block (resnet_model.py:15), on the same
+ * kernel: dY [NB, Ho, Wo, Cout] NHWC -> dX [NB, 2 Ho, 2 Wo, Cin].  Input pixel (2 i + ph, 2 j + pw) receives filter row a only
+ * where ph + 1 - a is even, so the transposed convolution splits into four dense ones, one per parity class (ph, pw), with
+ * 1, 2, 2 and 4 taps (gridDim.y = class): the same 9 Cout multiply-adds per OUTPUT pixel as the forward, none against the
+ * zeros a dilated gradient would hold.  Bp: planes of the filter packed for the input gradient (peclr_x6_pack_f32,
+ * transposed = 9, as for peclr_conv3x3_x6p_f32 with flip).  bn_bwd: dX is the gradient arriving at that BatchNorm layer
+ * (partial: 4 * ceil(NB Ho Wo / tile_rows) row blocks, class by class).  Cin % 64 == 0, Cout % 16 == 0.  Replaces MIOpen's
+ * igemm_bwd on these three convolutions.                                                                                  */
+int peclr_conv3x3_s2_dgrad_x6p_f32(int NB, int Ho, int Wo, int Cout, int Cin, const float* dY, const void* Bp, float* dX,
+                                   int tile_rows, const float* zeros, const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
 /* Forward of the STRIDE-2 convolutions of a ResNet layer's first block on the same kernel: taps = 9 the 3x3 / padding-1
  * convolution, taps = 1 the 1x1 downsample convolution; X [NB, H, W, Cin] NHWC (H, W even), Y [NB, H/2, W/2, Cout]; output pixel
  * (oh, ow) reads input pixel (2 oh + dh, 2 ow + dw).  Planes packed as for the stride-1 forward; optional BatchNorm
- * statistics of Y.  (Weight gradients: peclr_gemm_x6t_f32 with stride = 2; the input gradient stays on MIOpen.)         */
+ * statistics of Y.  (Weight gradients: peclr_gemm_x6t_f32 with stride = 2; input gradients: above / peclr_gemm_x6p_s2add_f32.)  */
 int peclr_conv_s2_x6p_f32(int NB, int H, int W, int Cin, int Cout, int taps, const float* X, const void* Bp, float* Y,
                           int tile_rows, const float* zeros, const float* stat_shift, float* stat_partial,
                           peclr_stream_t stream);

@@ -73,6 +73,7 @@ SIGNATURES = {
     "peclr_x6_pack_f32": (c_int, [_P, c_int, c_int, _P]),
     "peclr_gemm_x6p_tile_rows": (c_int, [c_int, c_int, c_int]),
     "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P]),
+    "peclr_conv3x3_s2_dgrad_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
     "peclr_gemm_x6p_s2add_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "peclr_gemm_x6p_maskadd_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P]),
     "peclr_gemm_x6t_slabs": (c_int, [c_int, c_int, c_int, c_int]),
@@ -408,13 +409,13 @@ class _BnBwdFuse(ctypes.Structure):
                 ("relu", c_int), ("partial", c_void_p)]
 
 
-def _bn_bwd_fuse(bn_bwd, m: int, n: int, tile_rows: int):
+def _bn_bwd_fuse(bn_bwd, m: int, n: int, tile_rows: int, groups: int = 1):
     """bn_bwd = (x [.., n] NHWC/2-D fp32 of m rows, save [2, n], ss [2, n], mask or None, relu) of the BatchNorm layer whose
     incoming gradient this GEMM produces -> (struct, partial [2 * n_split, n], n_split); keeps the tensors alive."""
     x, save, ss, mask, relu = bn_bwd
     if x.dtype != torch.float32 or x.numel() != m * n or not x.is_cuda:
         raise PeclrHipError(f"bn backward fusion: layer input of {x.numel()} elements for a [{m}, {n}] gradient")
-    ns = (m + tile_rows - 1) // tile_rows
+    ns = groups * ((m // groups + tile_rows - 1) // tile_rows)       # (groups: row blocks of each of several equal row sets)
     partial = torch.empty((2 * ns, n), device=x.device, dtype=torch.float32)
     st = _BnBwdFuse(x.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), _ptr(ss), _ptr(mask, torch.int32, "relu mask"), int(relu),
                     partial.data_ptr())
@@ -551,6 +552,29 @@ def conv3x3_x6p(x: torch.Tensor, planes: torch.Tensor, cout: int, flip: bool = F
                                          ctypes.byref(fuse) if fuse is not None else None, _stream())
     _check(rc, "peclr_conv3x3_x6p_f32")
     return y if partial is None else (y, partial, ns)
+
+
+def conv3x3_s2_dgrad_x6p(gy: torch.Tensor, planes: torch.Tensor, cin: int, tag: str = "conv3x3_s2_dgrad", tile_rows: int = 0, bn_bwd=None):
+    """Input gradient of a 3x3 / padding-1 / stride-2 convolution: gy [N, Cout, Ho, Wo] channels_last fp32 -> dx
+    [N, cin, 2 Ho, 2 Wo], one implicit GEMM per parity class of input pixels (1, 2, 2 and 4 of the nine taps:
+    peclr_conv3x3_s2_dgrad_x6p_f32); `planes` as for the stride-1 input gradient ([Cout * 9, Cin] packed with
+    transposed = 9).  bn_bwd: as in gemm_x6p (the BatchNorm layer dx arrives at) -> (dx, partial, n_split)."""
+    nb, cout, ho, wo = gy.shape
+    gp = _nhwc_ptr(gy, "conv_s2 dgrad gy", torch.float32)
+    if planes.dtype != torch.uint8 or planes.numel() != 6 * ((cin + 127) // 128 * 128) * 9 * cout:
+        raise PeclrHipError(f"conv3x3_s2_dgrad_x6p: planes of {planes.numel()} bytes for [{cin}, 9 * {cout}]")
+    dx = torch.empty((nb, cin, 2 * ho, 2 * wo), device=gy.device, dtype=torch.float32, memory_format=torch.channels_last)
+    mc = nb * ho * wo
+    partial, ns, fuse = None, 0, None
+    if bn_bwd is not None:
+        tile_rows = tile_rows or lib().peclr_gemm_x6p_tile_rows(mc, cin, 4 * cout)
+        fuse, partial, ns = _bn_bwd_fuse(bn_bwd, 4 * mc, cin, tile_rows, groups=4)
+    with _timed(tag, 4 * (mc * cout + 4 * mc * cin * (2 if fuse is not None else 1)) + 54 * cin * cout, 18 * mc * cin * cout,
+                kernel="gemm_x6p_kernel (3x3)"):
+        rc = lib().peclr_conv3x3_s2_dgrad_x6p_f32(nb, ho, wo, cout, cin, gp, _ptr(planes, torch.uint8), dx.data_ptr(), tile_rows,
+                                                  _zeros(gy.device).data_ptr(), ctypes.byref(fuse) if fuse is not None else None, _stream())
+    _check(rc, "peclr_conv3x3_s2_dgrad_x6p_f32")
+    return dx if partial is None else (dx, partial, ns)
 
 
 def conv_s2_x6p(x: torch.Tensor, planes: torch.Tensor, cout: int, taps: int, tag: str = "conv_s2_x6p", tile_rows: int = 0,

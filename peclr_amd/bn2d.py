@@ -551,19 +551,22 @@ class _Conv3x3Gemm(torch.autograd.Function):
 
 _CONV_S2_X6 = os.environ.get("PECLR_CONV_S2_X6", "1") != "0"   # A/B switch: forward of the stride-2 convolutions in-tree
 _CONV_S2_WGRAD_X6 = os.environ.get("PECLR_CONV_S2_WGRAD_X6", "1") != "0"   # A/B switch: their weight gradients in-tree
+_CONV_S2_DGRAD_X6 = os.environ.get("PECLR_CONV_S2_DGRAD_X6", "1") != "0"   # A/B switch: the 3x3's input gradient in-tree (parity classes)
 
 
 class _ConvS2Gemm(torch.autograd.Function):
     """Stride-2 3x3 (padding 1) / 1x1 convolution of an NHWC fp32 tensor: forward on the six-product kernel
     (peclr_conv_s2_x6p_f32: the k-step's tap and the stride select the source pixel; BatchNorm statistics of the output
-    in the epilogue), weight gradient on peclr_gemm_x6t_f32 with stride 2, input gradient on MIOpen (the transposed
-    convolution is a scatter)."""
+    in the epilogue), weight gradient on peclr_gemm_x6t_f32 with stride 2.  Input gradient: 3x3 -- one dense implicit GEMM
+    per parity class of input pixels (peclr_conv3x3_s2_dgrad_x6p_f32); 1x1 shortcut -- kept compact for the block's
+    entry-gradient GEMM (`_compact_grad`) where that is its consumer, else MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, stats=None, compact=False):
+    def forward(ctx, x, weight, conv, stats=None, compact=False, link=None):
         ctx.save_for_backward(x, weight)
         ctx.conv = conv
         ctx.compact = compact
+        ctx.link = link
         planes = _x6_planes(conv)
         cout, taps = weight.shape[0], weight.shape[2] * weight.shape[3]
         shift = _stat_shift_for(stats[0], cout) if (stats and _BN_STATS_IN_GEMM) else None
@@ -595,9 +598,20 @@ class _ConvS2Gemm(torch.autograd.Function):
                 n, cout, ho, wo = gy.shape
                 dc = _capi.gemm_x6p(gy.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), _x6_planes(conv)[1], x.shape[1], tag="conv_s2_dgrad")
                 dx = _compact_grad(dc, x.shape)
+            elif (_CONV_S2_DGRAD_X6 and weight.shape[2] == 3 and x.shape[2] == 2 * gy.shape[2] and x.shape[3] == 2 * gy.shape[3]
+                  and x.shape[1] % 64 == 0 and gy.shape[1] % 16 == 0):
+                # 3x3: one dense implicit GEMM per parity class of input pixels (1, 2, 2, 4 taps); dx is the gradient arriving
+                # at the BatchNorm layer whose output x is: reduced in the epilogue
+                planes = _x6_planes(conv)
+                link = ctx.link
+                if link is not None and link[0].shape == x.shape and x.shape[1] % 32 == 0:
+                    dx, partial, ns = _capi.conv3x3_s2_dgrad_x6p(gy, planes[1], x.shape[1], bn_bwd=link[:5])
+                    _note_bn_bwd(dx, link, partial, ns)
+                else:
+                    dx = _capi.conv3x3_s2_dgrad_x6p(gy, planes[1], x.shape[1])
             else:
                 dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [2, 2], pad, [1, 1], False, [0, 0], 1, [True, False, False])[0]
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 # ---- gradients handed to a block's entry-gradient GEMM in another form than a dense tensor.  An autograd function may only
@@ -709,7 +723,8 @@ class Conv2d(nn.Conv2d):
             stats = [stats_for] if stats_for is not None else None
             compact = (_S2_DGRAD_COMPACT and self.kernel_size == (1, 1) and getattr(x, "_peclr_compact_ok", False)
                        and torch.is_grad_enabled() and x.requires_grad)
-            return _attach_stats(_ConvS2Gemm.apply(x, self.weight, self, stats, compact), stats)
+            link = _bn_link_of(x) if (torch.is_grad_enabled() and x.requires_grad and self.kernel_size == (3, 3)) else None
+            return _attach_stats(_ConvS2Gemm.apply(x, self.weight, self, stats, compact, link), stats)
         if (self.hip_gemm and _CONV3X3_X6 and _GEMM_X6P and getattr(self, "x6_group", None) is not None and self.kernel_size == (3, 3)
                 and self.stride == (1, 1)
                 and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x.dim() == 4

@@ -64,6 +64,13 @@ struct X6PArgs {
     // pixels; output pixel (oh, ow) reads input pixel (2 oh + dh, 2 ow + dw) -- the strided 3x3 of a layer's first block
     // (TAPS = 9) and its 1x1 downsample convolution (TAPS = 1, dh = dw = 0)
     int stride, Hin, Win;
+    // s2d = 1 (TAPS = 9): the INPUT gradient of the 3x3 / padding-1 / stride-2 convolution, one parity class of input pixels
+    // per blockIdx.y.  A = dY [images * H * W][lda = Cout] over the H x W OUTPUT grid, out = dX over 2H x 2W.  Input pixel
+    // (2 i + ph, 2 j + pw) receives filter row a only where ph + 1 - a is even: a = 1 from dY row i (ph = 0); a = 0 from
+    // row i + 1 and a = 2 from row i (ph = 1) -- likewise for columns: 1, 2, 2 or 4 taps per class instead of 9 with
+    // three quarters of them zero.  The M rows of a class are the (image, i, j) of the output grid; planes as for the
+    // stride-1 input gradient (K order (tap, Cout)).
+    int s2d;
     const float* zeros;                  // >= 64 bytes of zeros (source of the padding pixels)
     // optional: C is the gradient dY arriving at a BatchNorm2d(+ReLU) layer (this GEMM is the input gradient of the
     // convolution that consumed that layer's output).  The epilogue then performs the layer's backward REDUCTION on the tile
@@ -127,10 +134,15 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     const int row_block = 8 * (j / nct) + (int)(blockIdx.x % 8);      // all column tiles of a row block on one XCD
     if (row_block * TM >= g.M) return;
     const int m0 = row_block * TM + wave * RM, ct = j % nct, n0 = ct * PNL;
-    const int nk = g.K / PK;
+    // s2d: parity class of this workgroup (the four-tap class first: longest workgroups first)
+    const bool s2d = TAPS == 9 && g.s2d;
+    const int ph = s2d ? 1 - (int)(blockIdx.y >> 1) : 0, pw = s2d ? 1 - (int)(blockIdx.y & 1) : 0;
+    const int ntap = s2d ? (1 + ph) * (1 + pw) : TAPS;
+    const int nk = s2d ? ntap * (g.lda / PK) : g.K / PK;
+    const int nk_all = g.K / PK;                                      // k-steps of a column tile's packed chunks
     // packed chunk of this column tile (NTL = 2: the first or second half of a 128-column chunk's twelve pieces)
     const int piece0 = NTL == 4 ? 0 : (ct & 1) * 6;
-    const unsigned char* bsrc = static_cast<const unsigned char*>(g.Bp) + (size_t)(NTL == 4 ? ct : ct >> 1) * nk * CHUNK +
+    const unsigned char* bsrc = static_cast<const unsigned char*>(g.Bp) + (size_t)(NTL == 4 ? ct : ct >> 1) * nk_all * CHUNK +
                                 piece0 * 1024 + lane * 16;
 
     f32x16 acc[WM][NTL];
@@ -155,18 +167,44 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
             const int ih = g.stride * oh, iw = g.stride * ow;                 // centre pixel in the input image
             if (g.stride == 2) asrc[c] = g.A + ((size_t)(img * g.Hin + ih) * g.Win + iw) * g.lda + 4 * (lane & 3);
             if constexpr (TAPS == 9) {
+                if (s2d) {                                             // class tap u = ua (1 + pw) + ub reads dY (oh + da, ow + db)
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int dh = g.flip ? 1 - tap / 3 : tap / 3 - 1, dw = g.flip ? 1 - tap % 3 : tap % 3 - 1;
-                    if ((unsigned)(ih + dh) < (unsigned)g.Hin && (unsigned)(iw + dw) < (unsigned)g.Win) tapmask[c] |= 1u << tap;
+                    for (int u = 0; u < 4; ++u) {
+                        const int ua = u / (1 + pw), ub = u - ua * (1 + pw);
+                        const int da = ph && ua == 0, db = pw && ub == 0;
+                        if (u < ntap && oh + da < g.H && ow + db < g.W) tapmask[c] |= 1u << u;
+                    }
+                } else {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int dh = g.flip ? 1 - tap / 3 : tap / 3 - 1, dw = g.flip ? 1 - tap % 3 : tap % 3 - 1;
+                        if ((unsigned)(ih + dh) < (unsigned)g.Hin && (unsigned)(iw + dw) < (unsigned)g.Win) tapmask[c] |= 1u << tap;
+                    }
                 }
             }
         }
     }
     const float* const zsrc = TAPS == 9 ? g.zeros + 4 * (lane & 3) : nullptr;
-    const int kpt = TAPS == 9 ? g.lda / PK : 0;            // k-steps per tap
+    const int kpt = TAPS == 9 ? g.lda / PK : 1;            // k-steps per tap
+    // s2d: k-step t of the class = step `rem` of class tap u = filter tap (a, b), read from dY at (+da, +db)
+    auto class_tap = [&](int t, int& rem, int& ftap, int& da, int& db) {
+        const int u = t / kpt;
+        rem = t - u * kpt;
+        const int ua = u / (1 + pw), ub = u - ua * (1 + pw);
+        da = ph && ua == 0;
+        db = pw && ub == 0;
+        ftap = 3 * (ph ? 2 * ua : 1) + (pw ? 2 * ub : 1);
+    };
     auto issue_b = [&](int t) {                           // this wave's pieces (of 3 NTL) of chunk t -> buffer t % NB
-        const unsigned char* s = bsrc + (size_t)t * CHUNK;
+        int bt_step = t;
+        if constexpr (TAPS == 9) {
+            if (s2d) {
+                int rem, ftap, da, db;
+                class_tap(t, rem, ftap, da, db);
+                bt_step = ftap * kpt + rem;
+            }
+        }
+        const unsigned char* s = bsrc + (size_t)bt_step * CHUNK;
         const unsigned d = b_a + (t % NB) * CHUNK;
         if constexpr (NTL == 4) {
 #pragma unroll
@@ -181,10 +219,17 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         long off = (long)t * PK;                          // floats from the row's first channel
         int tap = 0;
         if constexpr (TAPS == 9) {
-            tap = t / kpt;
-            const int a = tap / 3, b = tap - 3 * a;
-            const int dh = g.flip ? 1 - a : a - 1, dw = g.flip ? 1 - b : b - 1;
-            off = (long)(dh * g.Win + dw) * g.lda + (t - tap * kpt) * PK;
+            if (s2d) {
+                int rem, ftap, da, db;
+                class_tap(t, rem, ftap, da, db);
+                tap = t / kpt;
+                off = (long)(da * g.W + db) * g.lda + rem * PK;
+            } else {
+                tap = t / kpt;
+                const int a = tap / 3, b = tap - 3 * a;
+                const int dh = g.flip ? 1 - a : a - 1, dw = g.flip ? 1 - b : b - 1;
+                off = (long)(dh * g.Win + dw) * g.lda + (t - tap * kpt) * PK;
+            }
         }
 #pragma unroll
         for (int c = 0; c < NRAW; ++c) {
@@ -312,6 +357,19 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     }
     const int er = lane >> 3, ec = (lane & 7) * 4;
     float* sl = reinterpret_cast<float*>(lds + 4 * (32 * XEPL * 4));              // [wave][2][128] (BatchNorm backward sums)
+    // output row of each of this lane's rows (s2d: row (image, i, j) of the class -> input pixel (2 i + ph, 2 j + pw))
+    size_t om[WM][4];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int m = m0 + a * 32 + er + 8 * jj;
+            om[a][jj] = m;
+            if (s2d && m < g.M) {
+                const int j2 = m % g.W, q = m / g.W, i2 = q % g.H, img = q / g.H;
+                om[a][jj] = ((size_t)(img * 2 * g.H + 2 * i2 + ph) * (2 * g.W) + 2 * j2 + pw);
+            }
+        }
 #pragma unroll
     for (int y = 0; y < NTL; ++y) {
         const int nt = n0 + y * 32;
@@ -349,8 +407,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                     }
                 }
                 if (g.bb_partial && m < g.M) {
-                    xv[jj] = *reinterpret_cast<const f32x4*>(g.bb_x + (size_t)m * g.N + nt + ec);
-                    mb[jj] = g.bb_mask ? g.bb_mask[(size_t)m * (g.N >> 5) + (nt >> 5)] >> ec : 0u;
+                    xv[jj] = *reinterpret_cast<const f32x4*>(g.bb_x + om[a][jj] * g.N + nt + ec);
+                    mb[jj] = g.bb_mask ? g.bb_mask[om[a][jj] * (g.N >> 5) + (nt >> 5)] >> ec : 0u;
                 }
             }
 #pragma unroll
@@ -361,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                 float4 c = *reinterpret_cast<const float4*>(wlds + (er + 8 * jj) * XEPL + ec);
                 c.x += dv[jj].x; c.y += dv[jj].y; c.z += dv[jj].z; c.w += dv[jj].w;
                 if (m < g.M) {
-                    f32x4* dst = reinterpret_cast<f32x4*>(g.out + (size_t)m * g.ldo + nt + ec);
+                    f32x4* dst = reinterpret_cast<f32x4*>(g.out + om[a][jj] * g.ldo + nt + ec);
                     const f32x4 tv = {c.x, c.y, c.z, c.w};
                     if (g.stream_out) __builtin_nontemporal_store(tv, dst);
                     else *dst = tv;
@@ -393,7 +451,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         if (col < PNL) {
             const float v = ((sl[(0 * 2 + which) * 128 + col] + sl[(1 * 2 + which) * 128 + col]) +
                              sl[(2 * 2 + which) * 128 + col]) + sl[(3 * 2 + which) * 128 + col];
-            g.bb_partial[((size_t)row_block * 2 + which) * g.N + n0 + col] = v;
+            // (s2d: the four classes' row blocks one after the other)
+            const size_t rb = (size_t)row_block + (s2d ? (size_t)blockIdx.y * ((g.M + TM - 1) / TM) : 0);
+            g.bb_partial[(rb * 2 + which) * g.N + n0 + col] = v;
         }
     }
 }
@@ -490,7 +550,7 @@ static void set_bb(X6PArgs& g, const peclr_bn_bwd_fuse* bb) {
 static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t stream) {
     const int nrb = (g.M + tile_rows - 1) / tile_rows;
     const bool narrow = g.N % PN != 0;                    // 64-column tiles (N a multiple of 64 only)
-    const dim3 grid(8 * ((nrb + 7) / 8) * (narrow ? g.N / 64 : g.N / PN));
+    const dim3 grid(8 * ((nrb + 7) / 8) * (narrow ? g.N / 64 : g.N / PN), taps == 9 && g.s2d ? 4 : 1);
 #define PECLR_LAUNCH(WM_, TAPS_)                                                                                      \
     do {                                                                                                              \
         if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, true, TAPS_, 2>), grid, dim3(256), 0, stream, g); \
@@ -503,6 +563,26 @@ static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t str
     }
 #undef PECLR_LAUNCH
     return launch_status();
+}
+
+extern "C" int peclr_conv3x3_s2_dgrad_x6p_f32(int NB, int Ho, int Wo, int Cout, int Cin, const float* dY, const void* Bp, float* dX,
+                                              int tile_rows, const float* zeros, const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
+    if (!dY || !Bp || !dX || !zeros) return PECLR_ERR_NULL;
+    if (bb && (!bb->x || !bb->mean || !bb->invstd || !bb->scale_shift || !bb->partial)) return PECLR_ERR_NULL;
+    if (NB <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % PK) return PECLR_ERR_SHAPE;
+    if ((long)NB * Ho * Wo * 4 > 0x7fffffffL) return PECLR_ERR_SHAPE;
+    if (!aligned16(dY) || !aligned16(Bp) || !aligned16(dX) || !aligned16(zeros)) return PECLR_ERR_ALIGN;
+    const int M = NB * Ho * Wo;                           // rows of one parity class
+    if (tile_rows == 0) tile_rows = peclr_gemm_x6p_tile_rows(M, Cin, 4 * Cout);
+    if (tile_rows != 128 && tile_rows != 256) return PECLR_ERR_UNSUPPORTED;
+    X6PArgs g;
+    g.A = dY; g.Bp = Bp; g.addend = nullptr; g.out = dX;
+    g.M = M; g.N = Cin; g.K = 9 * Cout; g.lda = Cout; g.ldo = Cin; g.ldd = Cin; g.add_h = g.add_w = 0; g.add_mask = nullptr;
+    g.stream_out = (size_t)M * 4 * Cin * sizeof(float) > ((size_t)64 << 20);
+    g.stat_shift = nullptr; g.stat_partial = nullptr;
+    g.H = Ho; g.W = Wo; g.flip = 1; g.zeros = zeros; g.stride = 1; g.Hin = Ho; g.Win = Wo; g.s2d = 1;
+    set_bb(g, bb);
+    return launch_x6p(g, tile_rows, 9, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int peclr_conv_s2_x6p_f32(int NB, int H, int W, int Cin, int Cout, int taps, const float* X, const void* Bp, float* Y,
@@ -520,7 +600,7 @@ extern "C" int peclr_conv_s2_x6p_f32(int NB, int H, int W, int Cin, int Cout, in
     g.M = M; g.N = Cout; g.K = taps * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout; g.add_h = g.add_w = 0; g.add_mask = nullptr;
     g.stream_out = (size_t)M * Cout * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
-    g.H = Ho; g.W = Wo; g.flip = 0; g.zeros = zeros; g.stride = 2; g.Hin = H; g.Win = W;
+    g.H = Ho; g.W = Wo; g.flip = 0; g.zeros = zeros; g.stride = 2; g.Hin = H; g.Win = W; g.s2d = 0;
     set_bb(g, nullptr);
     return launch_x6p(g, tile_rows, taps, static_cast<hipStream_t>(stream));
 }
@@ -542,7 +622,7 @@ extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, co
     g.M = M; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout; g.add_h = g.add_w = 0; g.add_mask = nullptr;
     g.stream_out = (size_t)M * Cout * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
-    g.H = H; g.W = W; g.flip = flip ? 1 : 0; g.zeros = zeros; g.stride = 1; g.Hin = H; g.Win = W;
+    g.H = H; g.W = W; g.flip = flip ? 1 : 0; g.zeros = zeros; g.stride = 1; g.Hin = H; g.Win = W; g.s2d = 0;
     set_bb(g, bb);
     return launch_x6p(g, tile_rows, 9, static_cast<hipStream_t>(stream));
 }
@@ -565,7 +645,7 @@ static int gemm_x6p_host(int M, int N, int K, const float* A, int lda, const voi
     g.add_h = add_h; g.add_w = add_w; g.add_mask = add_mask;
     g.stream_out = (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
-    g.H = g.W = 1; g.flip = 0; g.zeros = nullptr; g.stride = 1; g.Hin = g.Win = 1;
+    g.H = g.W = 1; g.flip = 0; g.zeros = nullptr; g.stride = 1; g.Hin = g.Win = 1; g.s2d = 0;
     set_bb(g, bb);
     return launch_x6p(g, tile_rows, 1, static_cast<hipStream_t>(stream));
 }

@@ -2109,6 +2109,45 @@ def test_gemm_x6p_masked_addend(capi, m, n, k):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("nb,cin,cout,ho,wo", [(3, 64, 64, 7, 7), (2, 128, 128, 5, 6), (16, 128, 128, 28, 28), (7, 256, 512, 14, 14), (1, 192, 48, 1, 3)])
+def test_conv3x3_stride_2_input_gradient_by_parity_classes(capi, nb, cin, cout, ho, wo):
+    """peclr_conv3x3_s2_dgrad_x6p_f32: the transposed 3x3 / stride-2 convolution as four dense implicit GEMMs, one per parity
+    class of input pixels (1, 2, 2 and 4 taps), against torch's float64 convolution_backward next to MIOpen's fp32 result;
+    with the BatchNorm backward reduction of the layer dX arrives at in the epilogue (sums over every input pixel, class
+    by class) against float64 sums."""
+    g = torch.Generator().manual_seed(cin + cout + ho)
+    x = torch.randn(nb, cin, 2 * ho, 2 * wo, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(nb, cout, ho, wo, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(DEV).contiguous(memory_format=torch.channels_last)
+    w4 = w.permute(0, 2, 3, 1)
+    pk = capi.X6Planes([(w4.reshape(cout * 9, cin), 9)]).pack()
+    args = (None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])
+    ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), *args)[0]
+    mi = torch.ops.aten.convolution_backward(gy, x, w, *args)[0]
+    scale = float(ref.abs().max())
+    for tile_rows in (128, 256):
+        dx = capi.conv3x3_s2_dgrad_x6p(gy, pk.planes[0], cin, tile_rows=tile_rows)
+        assert dx.shape == x.shape and dx.is_contiguous(memory_format=torch.channels_last)
+        e_new, e_mi = float((dx.double() - ref).abs().max()) / scale, float((mi.double() - ref).abs().max()) / scale
+        assert e_new <= max(4 * e_mi, 4e-6), (tile_rows, e_new, e_mi)
+    # + the backward reduction of a BatchNorm2d + ReLU layer whose input (pre-BN) is xb and whose output gradient is dX
+    if cin % 32 == 0:
+        xb = torch.randn(nb, cin, 2 * ho, 2 * wo, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        mean, invstd = xb.mean((0, 2, 3)), 1.0 / (xb.var((0, 2, 3), unbiased=False) + 1e-5).sqrt()
+        gamma, beta = torch.rand(cin, generator=g).to(DEV) + 0.5, torch.randn(cin, generator=g).to(DEV) * 0.2
+        ss = torch.stack([gamma * invstd, beta - mean * gamma * invstd]).contiguous()
+        save = torch.stack([mean, invstd]).contiguous()
+        dx2, partial, ns = capi.conv3x3_s2_dgrad_x6p(gy, pk.planes[0], cin, bn_bwd=(xb, save, ss, None, True))
+        assert torch.equal(dx2, capi.conv3x3_s2_dgrad_x6p(gy, pk.planes[0], cin))
+        on = (xb.double() * ss[0].double().view(1, -1, 1, 1) + ss[1].double().view(1, -1, 1, 1)) > 0
+        d = dx2.double() * on
+        xhat = (xb.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
+        want = torch.stack([d.sum((0, 2, 3)), (d * xhat).sum((0, 2, 3))])
+        got = partial.double().view(ns, 2, cin).sum(0)
+        bound = torch.stack([d.abs().sum((0, 2, 3)), (d * xhat).abs().sum((0, 2, 3))]) + 1e-30
+        assert float(((got - want).abs() / bound).max()) <= 1e-4      # (a ReLU decision within round-off of zero may differ: one element of ~5e4)
+
+
 @pytest.mark.parametrize("m,n,k,hw", [(2 * 12 * 12, 128, 64, 12), (5 * 6 * 10, 192, 48, (6, 10)), (3 * 28 * 28, 256, 512, 28)])
 def test_gemm_x6p_strided_addend(capi, m, n, k, hw):
     """peclr_gemm_x6p_s2add_f32: C = A . B_t^T + (addend_half at the even pixels): equal, bit for bit, to the dense-addend
@@ -2156,7 +2195,7 @@ def test_stride_2_convolution_forward_in_tree_matches_float64(cin, cout, k, hw, 
             _capi.EVENT_LOG = None
         res[mode] = (y.detach(), xx.grad.clone(), conv.weight.grad.clone())
     wgrad = "conv3x3_wgrad" if k == 3 else "conv1x1_wgrad"
-    assert tags[False] == [] and tags[True] == sorted(["conv_s2_fwd", "x6_pack", wgrad, "wgrad_slab_reduce"]), tags
+    assert tags[False] == [] and tags[True] == sorted(["conv_s2_fwd", "x6_pack", wgrad, "wgrad_slab_reduce"] + (["conv3x3_s2_dgrad"] if k == 3 else [])), tags
     assert res[True][0].shape == res[False][0].shape and res[True][0].is_contiguous(memory_format=torch.channels_last)
     sub = slice(0, min(n, 6))
     y_ref = torch.nn.functional.conv2d(x[sub].double(), conv.weight.detach().double(), stride=2, padding=k // 2)
@@ -2165,8 +2204,11 @@ def test_stride_2_convolution_forward_in_tree_matches_float64(cin, cout, k, hw, 
     e_old = float((res[False][0][sub].double() - y_ref).abs().max()) / scale
     assert e_new <= max(4 * e_old, 4e-6), (e_new, e_old)
     assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-5 * float(res[False][0].abs().max())
-    a, b = res[True][1], res[False][1]                                                # MIOpen either way (atomics: round-off apart)
-    assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+    dx_ref = torch.ops.aten.convolution_backward(gy[sub].double(), x[sub].double(), conv.weight.detach().double(), None, [2, 2], [k // 2] * 2,
+                                                 [1, 1], False, [0, 0], 1, [True, False, False])[0]
+    scale = float(dx_ref.abs().max())
+    e_new, e_old = (float((res[m][1][sub].double() - dx_ref).abs().max()) / scale for m in (True, False))
+    assert e_new <= max(4 * e_old, 4e-6), (e_new, e_old)             # (1x1 alone: MIOpen either way; 3x3: the parity-class GEMMs)
     dw_ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), conv.weight.detach().double(), None, [2, 2], [k // 2] * 2, [1, 1],
                                                  False, [0, 0], 1, [False, True, False])[1]
     scale = float(dw_ref.abs().max())
