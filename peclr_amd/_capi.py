@@ -144,6 +144,9 @@ def _stream():
 # pair recorded on the launch stream around a call times exactly that kernel.
 EVENT_LOG = None  # None = off; dict name -> list[(start, end)] when bench.py turns it on
 WEIGHTS_EPOCH = 0    # bumped by every fused optimiser launch (it updates the parameters through raw pointers)
+TAG_BOUND_SUFFIX = False   # bench.py: launches of the six-product GEMMs whose OWN roof is HBM (layer1 / layer2's 1x1 shapes: 4 B/elem
+#                            x (K + N) columns take longer at 8 TB/s than 2 K N flops at 417 TFLOP/s) log as "<tag>~hbm", so that a tag's
+#                            average is never a mix of MFMA-bound and HBM-bound launches priced against one roof
 LAUNCH_ORDER = None  # None = off; list of names in launch order (one entry per launch) while EVENT_LOG is on:
 #                      lets tools/pmc_mfma.py align a rocprofv3 dispatch table with the bench's kernel names
 
@@ -155,6 +158,8 @@ class _timed:
     __slots__ = ("name", "s", "e", "nbytes", "flops", "kernel")
 
     def __init__(self, name, nbytes=0, flops=0, kernel=None):
+        if TAG_BOUND_SUFFIX and flops and nbytes and kernel and kernel.startswith("gemm_x6") and nbytes / 8e12 > flops / 416.7e12:
+            name += "~hbm"
         self.name, self.nbytes, self.flops, self.kernel = name, nbytes, flops, kernel
 
     def __enter__(self):
