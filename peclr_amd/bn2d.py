@@ -549,6 +549,7 @@ class _Conv3x3Gemm(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
+_S2_TILE_ROWS = int(os.environ.get("PECLR_CONV_S2_TILE_ROWS", "0"))   # strided 3x3 kernels: 0 = the rounds-of-slots policy (256 forced: +6 / +17 us per launch, measured)
 _CONV_S2_X6 = os.environ.get("PECLR_CONV_S2_X6", "1") != "0"   # A/B switch: forward of the stride-2 convolutions in-tree
 _CONV_S2_WGRAD_X6 = os.environ.get("PECLR_CONV_S2_WGRAD_X6", "1") != "0"   # A/B switch: their weight gradients in-tree
 _CONV_S2_DGRAD_X6 = os.environ.get("PECLR_CONV_S2_DGRAD_X6", "1") != "0"   # A/B switch: the 3x3's input gradient in-tree (parity classes)
@@ -571,10 +572,10 @@ class _ConvS2Gemm(torch.autograd.Function):
         cout, taps = weight.shape[0], weight.shape[2] * weight.shape[3]
         shift = _stat_shift_for(stats[0], cout) if (stats and _BN_STATS_IN_GEMM) else None
         if shift is not None:
-            y, partial, ns = _capi.conv_s2_x6p(x, planes[0], cout, taps, tag="conv_s2_fwd", stat_shift=shift)
+            y, partial, ns = _capi.conv_s2_x6p(x, planes[0], cout, taps, tag="conv_s2_fwd", stat_shift=shift, tile_rows=_S2_TILE_ROWS if taps == 9 else 0)
             stats[:] = [partial, ns, shift, stats[0]]
             return y
-        return _capi.conv_s2_x6p(x, planes[0], cout, taps, tag="conv_s2_fwd")
+        return _capi.conv_s2_x6p(x, planes[0], cout, taps, tag="conv_s2_fwd", tile_rows=_S2_TILE_ROWS if taps == 9 else 0)
 
     @staticmethod
     def backward(ctx, gy):
@@ -605,10 +606,10 @@ class _ConvS2Gemm(torch.autograd.Function):
                 planes = _x6_planes(conv)
                 link = ctx.link
                 if link is not None and link[0].shape == x.shape and x.shape[1] % 32 == 0:
-                    dx, partial, ns = _capi.conv3x3_s2_dgrad_x6p(gy, planes[1], x.shape[1], bn_bwd=link[:5])
+                    dx, partial, ns = _capi.conv3x3_s2_dgrad_x6p(gy, planes[1], x.shape[1], bn_bwd=link[:5], tile_rows=_S2_TILE_ROWS)
                     _note_bn_bwd(dx, link, partial, ns)
                 else:
-                    dx = _capi.conv3x3_s2_dgrad_x6p(gy, planes[1], x.shape[1])
+                    dx = _capi.conv3x3_s2_dgrad_x6p(gy, planes[1], x.shape[1], tile_rows=_S2_TILE_ROWS)
             else:
                 dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [2, 2], pad, [1, 1], False, [0, 0], 1, [True, False, False])[0]
         return dx, dw, None, None, None, None
