@@ -162,8 +162,10 @@ int peclr_gemm_x6p_maskadd_f32(int M, int N, int K, const float* A, int lda, con
  * packed with `transposed` = 9 (B_t[ci][tap * Cout + co] = W[co][tap][ci]).  addend, tile_rows and the BatchNorm
  * statistics outputs as in peclr_gemm_x6p_f32.  Cin % 16 == 0, Cout % 128 == 0.                                      */
 int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* X, const void* Bp, float* Y,
-                          const float* addend, int flip, int tile_rows, const float* zeros, const float* stat_shift,
+                          const float* addend, int flip, int tile_rows, int variant, const float* zeros, const float* stat_shift,
                           float* stat_partial, const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
+/* (variant 0: every wave loads and splits its rows once per tap; 1: per 16-channel chunk the workgroup splits the pixels its
+ *  nine taps touch once into shared planes and the taps read their fragments at the tap's offset -- W <= 64, else as 0.)  */
 /* Weight gradients, second generation: C[M, taps * N] = sum_k A[k, M] . B[k shifted by the tap, N], the contraction over the
  * ROWS of two NHWC activations (A = dY [R, Cout], B = X [R, Cin]).  taps = 1: dW = dY^T X of a 1x1 convolution.  taps = 9:
  * the nine [Cout, Cin] products of a 3x3 / stride-1 / padding-1 convolution's weight gradient, X read at the pixel each

@@ -79,7 +79,7 @@ SIGNATURES = {
     "peclr_gemm_x6t_slabs": (c_int, [c_int, c_int, c_int, c_int]),
     "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "peclr_conv_s2_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
-    "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
@@ -518,6 +518,7 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
     return out if partial is None else (out, partial, ns)
 
 
+_CONV3X3_VARIANT = int(os.environ.get("PECLR_CONV3X3_HALO", "1"))   # A/B: 1 = one split per 16-channel chunk and workgroup (halo patch in LDS)
 _ZEROS = {}
 
 
@@ -529,7 +530,7 @@ def _zeros(device):
 
 
 def conv3x3_x6p(x: torch.Tensor, planes: torch.Tensor, cout: int, flip: bool = False, addend: Optional[torch.Tensor] = None,
-                tag: str = "conv3x3_x6p", tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None):
+                tag: str = "conv3x3_x6p", tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None, variant: Optional[int] = None):
     """3x3 / stride-1 / padding-1 convolution of an NHWC (channels_last) fp32 tensor x [N, Cin, H, W] as an implicit GEMM on
     the bf16 matrix cores at fp32 accuracy (peclr_conv3x3_x6p_f32); `planes` = X6Planes of W seen as [Cout, 9 * Cin]
     (flip=False) or, for the input gradient (flip=True, x = dY), of [Cout_w * 9, Cin_w] packed with transposed = 9.
@@ -552,7 +553,7 @@ def conv3x3_x6p(x: torch.Tensor, planes: torch.Tensor, cout: int, flip: bool = F
     with _timed(tag, 4 * (m * cin + (2 if addend is not None else 1) * m * cout + (m * cout if fuse is not None else 0)) + 54 * cin * cout,
                 18 * m * cin * cout, kernel="gemm_x6p_kernel (3x3)"):
         rc = lib().peclr_conv3x3_x6p_f32(nb, h, w, cin, cout, xp, _ptr(planes, torch.uint8), y.data_ptr(), ap, int(flip), tile_rows,
-                                         _zeros(x.device).data_ptr(), _ptr(stat_shift),
+                                         _CONV3X3_VARIANT if variant is None else int(variant), _zeros(x.device).data_ptr(), _ptr(stat_shift),
                                          partial.data_ptr() if stat_shift is not None else None,
                                          ctypes.byref(fuse) if fuse is not None else None, _stream())
     _check(rc, "peclr_conv3x3_x6p_f32")

@@ -105,7 +105,11 @@ __device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_offset)
 // ABL: ablation switches for tools/exp/x6p_ablate.hip (0 in the library): 1 no split / plane stores in the loop, 2 no raw-row
 // loads either, 4 no B DMA in the loop, 8 no MFMAs, 16 no barrier, 32 B fragments always from buffer 0 (bits combine)
 // NTL: 32-column MFMA tiles per wave (4 -> 128 output columns per workgroup; 2 -> 64, for 64-channel layers: half a packed chunk)
-template <int WM, int ABL = 0, bool AREG = true, bool ILV = true, int TAPS = 1, int NTL = 4>
+// HALO (TAPS = 9, stride 1): per 16-channel chunk the workgroup loads and splits the TM + 2 W + 2 pixels its nine taps touch
+// ONCE into shared planes [plane][k-half][pixel][8 k] and every tap reads its A fragments from there at the tap's pixel offset
+// (border rows from a 16-byte zero slot) -- instead of each wave loading and splitting its rows once per tap (nine times).
+// K order of the loop: (chunk, tap); the packed filter chunks are indexed tap * chunks + chunk as before.  W <= 62.
+template <int WM, int ABL = 0, bool AREG = true, bool ILV = true, int TAPS = 1, int NTL = 4, bool HALO = false>
 __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     constexpr int RM = 32 * WM;                          // rows per wave
     constexpr int TM = 4 * RM;                           // rows per workgroup
@@ -117,7 +121,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     constexpr int XEPL = 36;                             // floats per row of the epilogue's 32 x 32 transpose buffer
     constexpr int WAVE_PL = 3 * PLANE;
     constexpr int RAW0 = NB * CHUNK, PL0 = RAW0 + (AREG ? 0 : 4 * RM * 64);   // DMA targets first (LDS-DMA addresses < 64 KiB)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[PL0 + 4 * WAVE_PL];
+    constexpr int NPXM = TM + 2 * 62 + 2;                // HALO: pixels of the patch at most (W <= 62: six 16-byte loads per thread at TM = 256)
+    constexpr int PHALF = NPXM * 16, PPLANE = 2 * PHALF, PATCH = 3 * PPLANE;
+    constexpr int ZOFF = NB * CHUNK + PATCH;             // HALO: 16 bytes of zeros
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[HALO ? ZOFF + 64 : PL0 + 4 * WAVE_PL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kh = lane >> 5;
     typedef __attribute__((address_space(3))) unsigned char* lptr_t;
@@ -153,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][y][r] = 0.f;
 
+    if constexpr (!HALO) {
     // this lane's fp32 source: rows (lane >> 2) + 16 c of the wave's block, k-quad lane & 3 (rows past M re-read row M - 1)
     const float* asrc[NRAW];
     unsigned tapmask[NRAW];                               // TAPS = 9: bit tap = that tap's pixel lies inside the image
@@ -319,6 +327,132 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     PECLR_VMCNT(0);                                       // (B chunk 0; for nk > 1 also what was just issued)
     for (int t = 0; t + 1 < nk; ++t) kstep(t, std::true_type{});
     kstep(nk - 1, std::false_type{});
+    } else {
+        static_assert(!HALO || (TAPS == 9 && AREG && ABL == 0), "HALO is the 3x3 / stride-1 path");
+        constexpr int NLD = (NPXM * 4 + 255) / 256;      // 16-byte loads per thread and chunk
+        constexpr int NDMA = NTL == 4 ? 3 : 1;           // B DMA instructions per wave and k-step (at least)
+        unsigned char* const patch = lds + NB * CHUNK;
+        if (tid < 4) reinterpret_cast<unsigned*>(lds + ZOFF)[tid] = 0u;
+        const int W = g.W, npx = TM + 2 * W + 2;
+        const int wg_m0 = row_block * TM;
+        const int nkc = g.lda / PK;
+        // this lane's rows as fragment owner: pixel index inside the patch, and which taps lie inside the image
+        int fpix[WM];
+        unsigned fmask[WM];
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+            int row = m0 + a * 32 + i;
+            row = row < g.M ? row : g.M - 1;
+            const int ow = row % W, oh = (row / W) % g.H;
+            fpix[a] = wave * RM + a * 32 + i + W + 1;
+            fmask[a] = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dh = g.flip ? 1 - tap / 3 : tap / 3 - 1, dw = g.flip ? 1 - tap % 3 : tap % 3 - 1;
+                if ((unsigned)(oh + dh) < (unsigned)g.H && (unsigned)(ow + dw) < (unsigned)W) fmask[a] |= 1u << tap;
+            }
+        }
+        // patch loader: thread -> (pixel, k-quad) for idx = tid + 256 u; pixels past the patch re-read its last one
+        // (pixel tid / 4 + 64 u, k-quad tid & 3; addresses recomputed per chunk: registers are what this variant is short of)
+        const int px0 = tid >> 2, kq = tid & 3;
+        const int pd0 = (kq >> 1) * PHALF + px0 * 16 + (kq & 1) * 8;
+        const float* const pa = g.A + 4 * kq;
+        f32x4 pr[NLD];
+        auto load_patch = [&](int kc) {
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                int px = px0 + 64 * u;
+                px = px < npx ? px : npx - 1;
+                int r = wg_m0 - W - 1 + px;
+                r = r < 0 ? 0 : (r >= g.M ? g.M - 1 : r);
+                pr[u] = *reinterpret_cast<const f32x4*>(pa + (size_t)r * g.lda + kc * PK);
+            }
+        };
+        auto store_patch = [&]() {
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                unsigned h[2], m[2], l[2];
+                split3_pk(pr[u][0], pr[u][1], h[0], m[0], l[0]);
+                split3_pk(pr[u][2], pr[u][3], h[1], m[1], l[1]);
+                if (px0 + 64 * u < npx) {
+                    unsigned char* d = patch + pd0 + u * 1024;
+                    *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
+                    *reinterpret_cast<uint2*>(d + PPLANE) = make_uint2(m[0], m[1]);
+                    *reinterpret_cast<uint2*>(d + 2 * PPLANE) = make_uint2(l[0], l[1]);
+                }
+            }
+        };
+        auto issue_bh = [&](int s) {                      // step s = chunk * 9 + tap reads packed chunk tap * nkc + chunk
+            const int kc = s / 9, tap = s - 9 * kc;
+            const unsigned char* src = bsrc + (size_t)(tap * nkc + kc) * CHUNK;
+            const unsigned d = b_a + (s % NB) * CHUNK;
+            if constexpr (NTL == 4) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dma16(src + (3 * wave_s + q) * 1024, d + (3 * wave_s + q) * 1024);
+            } else {
+                dma16(src + wave_s * 1024, d + wave_s * 1024);
+                if (wave_s < 2) dma16(src + (4 + wave_s) * 1024, d + (4 + wave_s) * 1024);
+            }
+        };
+        const int nsteps = 9 * nkc;
+        load_patch(0);
+        asm volatile("" ::: "memory");
+        issue_bh(0);
+        issue_bh(1);
+        store_patch();
+        PECLR_VMCNT(0);
+        for (int kc = 0; kc < nkc; ++kc) {
+            for (int j = 0; j < 9; ++j) {
+                const int s = kc * 9 + j;
+                // B chunk s has landed: issued after it are chunk s + 1 (and, at j == 1, the next patch's rows)
+                if (j == 1 && kc + 1 < nkc) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA + NLD) : "memory");
+                else if (s + 1 == nsteps) PECLR_VMCNT(0);        // (nothing was issued after the last chunk)
+                else if (s > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const int ja = j / 3, jb = j - 3 * ja;
+                const int dh = g.flip ? 1 - ja : ja - 1, dw = g.flip ? 1 - jb : jb - 1;
+                const int shift = (dh * W + dw) * 16;
+                uint4 af[WM][3];
+#pragma unroll
+                for (int a = 0; a < WM; ++a) {
+                    const bool in = (fmask[a] >> j) & 1u;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const int off = in ? NB * CHUNK + p * PPLANE + kh * PHALF + fpix[a] * 16 + shift : ZOFF;
+                        af[a][p] = *reinterpret_cast<const uint4*>(lds + off);
+                    }
+                }
+                const unsigned char* bt = lds + (s % NB) * CHUNK + lane * 16;
+#pragma unroll
+                for (int half = 0; half < NTL / 2; ++half) {
+                    uint4 bf[2][3];
+#pragma unroll
+                    for (int y = 0; y < 2; ++y)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) bf[y][p] = *reinterpret_cast<const uint4*>(bt + ((2 * half + y) * 3 + p) * 1024);
+#define PECLR_X6(P, Q)                                                                        \
+    _Pragma("unroll") for (int y = 0; y < 2; ++y) _Pragma("unroll") for (int a = 0; a < WM; ++a) \
+        acc[a][2 * half + y] = mma(af[a][P], bf[y][Q], acc[a][2 * half + y]);
+                    PECLR_X6(2, 0) PECLR_X6(0, 2) PECLR_X6(1, 1) PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)
+#undef PECLR_X6
+                    if (half == 0) {
+                        if (j == 0 && kc + 1 < nkc) { load_patch(kc + 1); asm volatile("" ::: "memory"); }
+                        if (j == 3 && kc + 1 < nkc) {     // the next patch's rows are in (hipcc places its own wait here, long after the issue)
+#pragma unroll
+                            for (int u = 0; u < NLD; ++u) asm volatile("" :: "v"(pr[u][0]), "v"(pr[u][3]));
+                        }
+                        if (s + 2 < nsteps) issue_bh(s + 2);
+                    }
+                }
+            }
+            if (kc + 1 < nkc) {
+                __builtin_amdgcn_s_barrier();             // every wave has read this chunk's patch
+                asm volatile("" ::: "memory");
+                store_patch();
+            }
+        }
+    }
 
     // epilogue: wave-private 32 x 32 transposes through LDS (the B buffers, once every wave is done with them), 16 bytes per lane
     __syncthreads();
@@ -358,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     const int er = lane >> 3, ec = (lane & 7) * 4;
     float* sl = reinterpret_cast<float*>(lds + 4 * (32 * XEPL * 4));              // [wave][2][128] (BatchNorm backward sums)
     // output row of each of this lane's rows (s2d: row (image, i, j) of the class -> input pixel (2 i + ph, 2 j + pw))
-    size_t om[WM][4];
+    int om[WM][4];
 #pragma unroll
     for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -367,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
             om[a][jj] = m;
             if (s2d && m < g.M) {
                 const int j2 = m % g.W, q = m / g.W, i2 = q % g.H, img = q / g.H;
-                om[a][jj] = ((size_t)(img * 2 * g.H + 2 * i2 + ph) * (2 * g.W) + 2 * j2 + pw);
+                om[a][jj] = (img * 2 * g.H + 2 * i2 + ph) * (2 * g.W) + 2 * j2 + pw;
             }
         }
 #pragma unroll
@@ -407,8 +541,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                     }
                 }
                 if (g.bb_partial && m < g.M) {
-                    xv[jj] = *reinterpret_cast<const f32x4*>(g.bb_x + om[a][jj] * g.N + nt + ec);
-                    mb[jj] = g.bb_mask ? g.bb_mask[om[a][jj] * (g.N >> 5) + (nt >> 5)] >> ec : 0u;
+                    xv[jj] = *reinterpret_cast<const f32x4*>(g.bb_x + (size_t)om[a][jj] * g.N + nt + ec);
+                    mb[jj] = g.bb_mask ? g.bb_mask[(size_t)om[a][jj] * (g.N >> 5) + (nt >> 5)] >> ec : 0u;
                 }
             }
 #pragma unroll
@@ -419,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                 float4 c = *reinterpret_cast<const float4*>(wlds + (er + 8 * jj) * XEPL + ec);
                 c.x += dv[jj].x; c.y += dv[jj].y; c.z += dv[jj].z; c.w += dv[jj].w;
                 if (m < g.M) {
-                    f32x4* dst = reinterpret_cast<f32x4*>(g.out + om[a][jj] * g.ldo + nt + ec);
+                    f32x4* dst = reinterpret_cast<f32x4*>(g.out + (size_t)om[a][jj] * g.ldo + nt + ec);
                     const f32x4 tv = {c.x, c.y, c.z, c.w};
                     if (g.stream_out) __builtin_nontemporal_store(tv, dst);
                     else *dst = tv;
@@ -547,7 +681,7 @@ static void set_bb(X6PArgs& g, const peclr_bn_bwd_fuse* bb) {
     g.bb_partial = bb ? bb->partial : nullptr;
 }
 
-static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t stream) {
+static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t stream, bool halo = false) {
     const int nrb = (g.M + tile_rows - 1) / tile_rows;
     const bool narrow = g.N % PN != 0;                    // 64-column tiles (N a multiple of 64 only)
     const dim3 grid(8 * ((nrb + 7) / 8) * (narrow ? g.N / 64 : g.N / PN), taps == 9 && g.s2d ? 4 : 1);
@@ -556,7 +690,15 @@ static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t str
         if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, true, TAPS_, 2>), grid, dim3(256), 0, stream, g); \
         else hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, true, TAPS_, 4>), grid, dim3(256), 0, stream, g);       \
     } while (0)
-    if (taps == 9) {
+    if (taps == 9 && halo) {
+        if (tile_rows == 256) {
+            if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<2, 0, true, true, 9, 2, true>), grid, dim3(256), 0, stream, g);
+            else hipLaunchKernelGGL((gemm_x6p_kernel<2, 0, true, true, 9, 4, true>), grid, dim3(256), 0, stream, g);
+        } else {
+            if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<1, 0, true, true, 9, 2, true>), grid, dim3(256), 0, stream, g);
+            else hipLaunchKernelGGL((gemm_x6p_kernel<1, 0, true, true, 9, 4, true>), grid, dim3(256), 0, stream, g);
+        }
+    } else if (taps == 9) {
         if (tile_rows == 256) PECLR_LAUNCH(2, 9); else PECLR_LAUNCH(1, 9);
     } else {
         if (tile_rows == 256) PECLR_LAUNCH(2, 1); else PECLR_LAUNCH(1, 1);
@@ -606,10 +748,11 @@ extern "C" int peclr_conv_s2_x6p_f32(int NB, int H, int W, int Cin, int Cout, in
 }
 
 extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* X, const void* Bp, float* Y,
-                                     const float* addend, int flip, int tile_rows, const float* zeros,
+                                     const float* addend, int flip, int tile_rows, int variant, const float* zeros,
                                      const float* stat_shift, float* stat_partial, const peclr_bn_bwd_fuse* bb,
                                      peclr_stream_t stream) {
     if (!X || !Bp || !Y || !zeros || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
+    if (variant != 0 && variant != 1) return PECLR_ERR_UNSUPPORTED;
     if (bb && (stat_partial || !bb->x || !bb->mean || !bb->invstd || !bb->scale_shift || !bb->partial || Cout % 32)) return PECLR_ERR_NULL;
     if (NB <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cout % 64 || Cin % PK) return PECLR_ERR_SHAPE;
     if ((long)NB * H * W > 0x7FFFFFFFL / 2) return PECLR_ERR_SHAPE;
@@ -624,7 +767,7 @@ extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, co
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = H; g.W = W; g.flip = flip ? 1 : 0; g.zeros = zeros; g.stride = 1; g.Hin = H; g.Win = W; g.s2d = 0;
     set_bb(g, bb);
-    return launch_x6p(g, tile_rows, 9, static_cast<hipStream_t>(stream));
+    return launch_x6p(g, tile_rows, 9, static_cast<hipStream_t>(stream), variant == 1 && W <= 62 && Cin >= 2 * PK);
 }
 
 static int gemm_x6p_host(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc, int add_h, int add_w,

@@ -2109,6 +2109,37 @@ def test_gemm_x6p_masked_addend(capi, m, n, k):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("nb,cin,cout,h,w", [(3, 64, 64, 7, 7), (2, 128, 128, 5, 6), (9, 64, 128, 28, 28), (4, 256, 256, 14, 14), (1, 32, 64, 62, 62),
+                                            (1, 64, 64, 64, 64), (37, 128, 64, 7, 9), (2, 48, 192, 11, 3)])
+@pytest.mark.parametrize("flip", [False, True])
+def test_conv3x3_halo_patch_variant_matches_float64_and_the_per_tap_variant(capi, nb, cin, cout, h, w, flip):
+    """peclr_conv3x3_x6p_f32, variant 1 (per 16-channel chunk the workgroup splits the pixels its nine taps touch once into
+    shared planes; K order (chunk, tap)) against torch's float64 convolution and next to variant 0 (every wave splits its
+    rows once per tap; K order (tap, chunk)): the same six products per term, summed in another order.  Both tile heights,
+    forward and flipped (input-gradient) filters, image borders inside a tile, ragged last tiles, W = 64 (falls back to 0)."""
+    g = torch.Generator().manual_seed(cin + cout + h + w)
+    x = torch.randn(nb, cin, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(DEV).contiguous(memory_format=torch.channels_last)
+    w4 = wt.permute(0, 2, 3, 1)
+    if flip:    # input gradient of a convolution with `cout` inputs and `cin` outputs: dX = conv_transpose(dY = x)
+        wt_t = (torch.randn(cin, cout, 3, 3, generator=g) * 0.05).to(DEV).contiguous(memory_format=torch.channels_last)
+        planes = capi.X6Planes([(wt_t.permute(0, 2, 3, 1).reshape(cin * 9, cout), 9)]).pack().planes[0]
+        ref = torch.nn.functional.conv_transpose2d(x.double(), wt_t.double(), padding=1)
+    else:
+        planes = capi.X6Planes([(w4.reshape(cout, 9 * cin), False)]).pack().planes[0]
+        ref = torch.nn.functional.conv2d(x.double(), wt.double(), padding=1)
+    scale = float(ref.abs().max())
+    for tile_rows in (128, 256):
+        y0 = capi.conv3x3_x6p(x, planes, cout, flip=flip, tile_rows=tile_rows, variant=0)
+        y1 = capi.conv3x3_x6p(x, planes, cout, flip=flip, tile_rows=tile_rows, variant=1)
+        e0, e1 = float((y0.double() - ref).abs().max()) / scale, float((y1.double() - ref).abs().max()) / scale
+        assert e1 <= max(1.5 * e0, 4e-6), (tile_rows, e1, e0)
+        assert float((y1 - y0).abs().max()) <= 1e-5 * scale
+        if w > 62:
+            assert torch.equal(y0, y1)                    # too wide for the patch: variant 1 runs variant 0
+        assert torch.equal(capi.conv3x3_x6p(x, planes, cout, flip=flip, tile_rows=tile_rows, variant=1), y1)
+
+
 @pytest.mark.parametrize("nb,cin,cout,ho,wo", [(3, 64, 64, 7, 7), (2, 128, 128, 5, 6), (16, 128, 128, 28, 28), (7, 256, 512, 14, 14), (1, 192, 48, 1, 3)])
 def test_conv3x3_stride_2_input_gradient_by_parity_classes(capi, nb, cin, cout, ho, wo):
     """peclr_conv3x3_s2_dgrad_x6p_f32: the transposed 3x3 / stride-2 convolution as four dense implicit GEMMs, one per parity
