@@ -400,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         issue_bh(0);
         issue_bh(1);
         store_patch();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the plane stores are in the LDS before the (raw) barrier lets other waves read
         PECLR_VMCNT(0);
         for (int kc = 0; kc < nkc; ++kc) {
             for (int j = 0; j < 9; ++j) {
@@ -450,6 +451,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                 __builtin_amdgcn_s_barrier();             // every wave has read this chunk's patch
                 asm volatile("" ::: "memory");
                 store_patch();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (published by the barrier at the top of the next step)
             }
         }
     }

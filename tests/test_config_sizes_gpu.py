@@ -100,9 +100,12 @@ def test_c2_graph_replay_loss_matches_oracle():
         torch.cuda.synchronize()
         d = step_check.step_deltas(model, batch)             # eager forward, no_grad
     torch.cuda.current_stream().wait_stream(side)
-    # batch statistics do not depend on the running statistics, the weights did not move: every replay is
-    # the same forward; MIOpen's forward convolutions are deterministic
-    assert max(losses) - min(losses) <= 1e-6
+    # The weights did not move and every forward kernel is deterministic, so every replay is the same forward -- up to the
+    # centring of the BatchNorm statistics: the GEMM epilogues sum (y - running_mean) and its square, exact in the shift but
+    # not in fp32 rounding, and the running mean moves with every replay.  That is worth a few ulp of the loss (4.8e-7 at
+    # 5.54): measured 0-3 ulp between replays, the same sequence in every run (no race: test_conv3x3_kernels_repeat_
+    # themselves_bit_for_bit and the x6p bit-equality tests hold the kernels to identical bits on identical inputs).
+    assert max(losses) - min(losses) <= 2.5e-6
     assert abs(losses[-1] - d["loss_oracle"]) <= 1e-4 and d["loss_delta_vs_oracle"] <= 1e-4
 
 

@@ -2140,6 +2140,27 @@ def test_conv3x3_halo_patch_variant_matches_float64_and_the_per_tap_variant(capi
         assert torch.equal(capi.conv3x3_x6p(x, planes, cout, flip=flip, tile_rows=tile_rows, variant=1), y1)
 
 
+@pytest.mark.parametrize("nb,c,hw", [(256, 64, 56), (256, 128, 28), (256, 256, 14), (256, 512, 7)])
+def test_conv3x3_kernels_repeat_themselves_bit_for_bit(capi, nb, c, hw):
+    """Race detector for the shared-memory protocols of the 3x3 kernels (filter chunks published by hand-counted vmcnt waits
+    and raw barriers, the halo patch written by all waves and read by all): the same launch forty times at ResNet-50's full
+    shapes must give the same bits every time, forward and flipped, both variants, and the strided parity-class kernel."""
+    g = torch.Generator().manual_seed(c + hw)
+    x = torch.randn(nb, c, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(DEV).contiguous(memory_format=torch.channels_last)
+    w4 = w.permute(0, 2, 3, 1)
+    pk = capi.X6Planes([(w4.reshape(c, 9 * c), False), (w4.reshape(c * 9, c), 9)]).pack()
+    for variant in (1, 0):
+        for flip in (False, True):
+            first = capi.conv3x3_x6p(x, pk.planes[int(flip)], c, flip=flip, variant=variant)
+            for _ in range(20 if variant else 6):
+                assert torch.equal(capi.conv3x3_x6p(x, pk.planes[int(flip)], c, flip=flip, variant=variant), first), (variant, flip)
+    gy = x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last)
+    first = capi.conv3x3_s2_dgrad_x6p(gy, pk.planes[1], c)
+    for _ in range(6):
+        assert torch.equal(capi.conv3x3_s2_dgrad_x6p(gy, pk.planes[1], c), first)
+
+
 @pytest.mark.parametrize("nb,cin,cout,ho,wo", [(3, 64, 64, 7, 7), (2, 128, 128, 5, 6), (16, 128, 128, 28, 28), (7, 256, 512, 14, 14), (1, 192, 48, 1, 3)])
 def test_conv3x3_stride_2_input_gradient_by_parity_classes(capi, nb, cin, cout, ho, wo):
     """peclr_conv3x3_s2_dgrad_x6p_f32: the transposed 3x3 / stride-2 convolution as four dense implicit GEMMs, one per parity
