@@ -651,7 +651,7 @@ def main():
                                   "one hipGraph replay per step (whole step captured)" if use_graph else
                                   "eager launches" + (f" ({graph_note})" if graph_note else "")),
                        "graph_fallback": graph_note,   # None unless --graph auto had to fall back to eager launches
-                       # fp32 runs: the GEMM-shaped backbone work (1x1 convolutions from K = 128 on and 3x3 stride-1 convolutions: forward,
+                       # fp32 runs: the GEMM-shaped backbone work (the 1x1 and 3x3 convolutions of the residual blocks: forward,
                        # input gradient, weight gradient; the fused entry gradient) runs on the bf16 matrix cores at fp32 ACCURACY: every fp32 operand is split
                        # exactly into three bf16 numbers and six of the nine partial products are accumulated in fp32
                        # (peclr_gemm_x6_f32; error vs float64 <= the v_mfma_f32 kernel's, tests/test_hip_parity.py)
@@ -670,9 +670,9 @@ def main():
             "roofline": roof,
             "kernels": kernels,
             "backbone": {"note": "whole encoder, 3x forward conv FLOPs over the step time, against the v_mfma_f32 / bf16 MFMA peak; fp32: "
-                                 "the stride-1 1x1 (layers 2-4) and 3x3 (layers 1-4) convolutions run on the in-tree six-product "
-                                 "kernels (config.fp32_gemm), the 7x7 stem, the strided convolutions and layer1's 1x1 on "
-                                 "PyTorch-ROCm/MIOpen",
+                                 "every 1x1 and 3x3 convolution of the residual blocks (stride 1 and 2; forward, input gradient, weight "
+                                 "gradient) runs on the in-tree six-product kernels (config.fp32_gemm), only the 7x7 stem on "
+                                 "PyTorch-ROCm/MIOpen; 16-bit runs: all convolutions on MIOpen",
                          "flops_per_step_per_gpu": step_flops, "achieved": round(ach_tf, 2), "peak": peak_tf,
                          "unit": "TFLOP/s", "frac": round(ach_tf / peak_tf, 4)},
             "hand_written_us_per_step": round(sum(k["avg_us"] * k["launches"] / table_steps
