@@ -120,7 +120,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     constexpr int PLANE = 2 * HALF;
     constexpr int XEPL = 36;                             // floats per row of the epilogue's 32 x 32 transpose buffer
     constexpr int WAVE_PL = 3 * PLANE;
-    constexpr int RAW0 = NB * CHUNK, PL0 = RAW0 + (AREG ? 0 : 4 * RM * 64);   // DMA targets first (LDS-DMA addresses < 64 KiB)
+    // bytes of one filter buffer: a 64-column workgroup lands only its six 1 KiB pieces of a chunk (18 instead of 36 KiB of
+    // buffers: with its 120 VGPRs a fourth workgroup per CU); the halo variant keeps the 12 KiB stride (its patch sets the count)
+    constexpr int CHL = HALO ? CHUNK : CHUNK * NTL / 4;
+    constexpr int RAW0 = (NB * CHL < 5 * 32 * 36 * 4 && !HALO) ? 5 * 32 * 36 * 4 : NB * CHL;   // (the epilogue's transposes + sums live here: 22.5 KiB)
+    constexpr int PL0 = RAW0 + (AREG ? 0 : 4 * RM * 64);   // DMA targets first (LDS-DMA addresses < 64 KiB)
     constexpr int NPXM = TM + 2 * 62 + 2;                // HALO: pixels of the patch at most (W <= 62: six 16-byte loads per thread at TM = 256)
     constexpr int PHALF = NPXM * 16, PPLANE = 2 * PHALF, PATCH = 3 * PPLANE;
     constexpr int ZOFF = NB * CHUNK + PATCH;             // HALO: 16 bytes of zeros
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
             }
         }
         const unsigned char* s = bsrc + (size_t)bt_step * CHUNK;
-        const unsigned d = b_a + (t % NB) * CHUNK;
+        const unsigned d = b_a + (t % NB) * CHL;
         if constexpr (NTL == 4) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) dma16(s + (3 * wave_s + q) * 1024, d + (3 * wave_s + q) * 1024);
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         for (int a = 0; a < WM; ++a)
 #pragma unroll
             for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const uint4*>(planes + p * PLANE + foff + a * 512);
-        const unsigned char* bt = lds + ((ABL & 32) ? 0 : (t % NB)) * CHUNK + lane * 16;
+        const unsigned char* bt = lds + ((ABL & 32) ? 0 : (t % NB)) * CHL + lane * 16;
 #pragma unroll
         for (int half = 0; half < NTL / 2; ++half) {
             uint4 bf[2][3];
