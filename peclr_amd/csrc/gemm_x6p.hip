@@ -689,10 +689,10 @@ static void set_bb(X6PArgs& g, const peclr_bn_bwd_fuse* bb) {
 
 static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t stream, bool halo = false) {
     const int nrb = (g.M + tile_rows - 1) / tile_rows;
-    // 64-column tiles (N a multiple of 64 only) -- and for the entry-gradient GEMMs with K <= 128 (layer1 / layer2: HBM-bound,
+    // 64-column tiles (N a multiple of 64 only) -- and for the entry-gradient GEMMs with K <= 256 (layers 1-3: HBM-bound,
     // their time is the epilogue's addend / BatchNorm-x loads and stores): 37 KiB of LDS and 120 VGPRs put four workgroups on a
     // CU instead of three (420 -> 394 us per launch in the step; the plain 1x1 products of the same shapes lose 5 %: not them)
-    const bool narrow = g.N % PN != 0 || (taps == 1 && g.addend != nullptr && g.K <= 128 && g.stride == 1);
+    const bool narrow = g.N % PN != 0 || (taps == 1 && g.addend != nullptr && g.K <= 256 && g.stride == 1);
     const dim3 grid(8 * ((nrb + 7) / 8) * (narrow ? g.N / 64 : g.N / PN), taps == 9 && g.s2d ? 4 : 1);
 #define PECLR_LAUNCH(WM_, TAPS_)                                                                                      \
     do {                                                                                                              \
