@@ -121,13 +121,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     constexpr int XEPL = 36;                             // floats per row of the epilogue's 32 x 32 transpose buffer
     constexpr int WAVE_PL = 3 * PLANE;
     // bytes of one filter buffer: a 64-column workgroup lands only its six 1 KiB pieces of a chunk (18 instead of 36 KiB of
-    // buffers: with its 120 VGPRs a fourth workgroup per CU); the halo variant keeps the 12 KiB stride (its patch sets the count)
-    constexpr int CHL = HALO ? CHUNK : CHUNK * NTL / 4;
-    constexpr int RAW0 = (NB * CHL < 5 * 32 * 36 * 4 && !HALO) ? 5 * 32 * 36 * 4 : NB * CHL;   // (the epilogue's transposes + sums live here: 22.5 KiB)
+    // buffers: with its 120 VGPRs a fourth workgroup per CU; the halo variant's 128-row tile: a third)
+    constexpr int CHL = CHUNK * NTL / 4;
+    constexpr int RAW0 = NB * CHL < 5 * 32 * 36 * 4 ? 5 * 32 * 36 * 4 : NB * CHL;   // (the epilogue's transposes + sums live here: 22.5 KiB)
     constexpr int PL0 = RAW0 + (AREG ? 0 : 4 * RM * 64);   // DMA targets first (LDS-DMA addresses < 64 KiB)
     constexpr int NPXM = TM + 2 * 62 + 2;                // HALO: pixels of the patch at most (W <= 62: six 16-byte loads per thread at TM = 256)
     constexpr int PHALF = NPXM * 16, PPLANE = 2 * PHALF, PATCH = 3 * PPLANE;
-    constexpr int ZOFF = NB * CHUNK + PATCH;             // HALO: 16 bytes of zeros
+    constexpr int ZOFF = RAW0 + PATCH;                   // HALO: 16 bytes of zeros
     __shared__ __attribute__((aligned(1024))) unsigned char lds[HALO ? ZOFF + 64 : PL0 + 4 * WAVE_PL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kh = lane >> 5;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         static_assert(!HALO || (TAPS == 9 && AREG && ABL == 0), "HALO is the 3x3 / stride-1 path");
         constexpr int NLD = (NPXM * 4 + 255) / 256;      // 16-byte loads per thread and chunk
         constexpr int NDMA = NTL == 4 ? 3 : 1;           // B DMA instructions per wave and k-step (at least)
-        unsigned char* const patch = lds + NB * CHUNK;
+        unsigned char* const patch = lds + RAW0;
         if (tid < 4) reinterpret_cast<unsigned*>(lds + ZOFF)[tid] = 0u;
         const int W = g.W, npx = TM + 2 * W + 2;
         const int wg_m0 = row_block * TM;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         auto issue_bh = [&](int s) {                      // step s = chunk * 9 + tap reads packed chunk tap * nkc + chunk
             const int kc = s / 9, tap = s - 9 * kc;
             const unsigned char* src = bsrc + (size_t)(tap * nkc + kc) * CHUNK;
-            const unsigned d = b_a + (s % NB) * CHUNK;
+            const unsigned d = b_a + (s % NB) * CHL;
             if constexpr (NTL == 4) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) dma16(src + (3 * wave_s + q) * 1024, d + (3 * wave_s + q) * 1024);
@@ -424,11 +424,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                     const bool in = (fmask[a] >> j) & 1u;
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
-                        const int off = in ? NB * CHUNK + p * PPLANE + kh * PHALF + fpix[a] * 16 + shift : ZOFF;
+                        const int off = in ? RAW0 + p * PPLANE + kh * PHALF + fpix[a] * 16 + shift : ZOFF;
                         af[a][p] = *reinterpret_cast<const uint4*>(lds + off);
                     }
                 }
-                const unsigned char* bt = lds + (s % NB) * CHUNK + lane * 16;
+                const unsigned char* bt = lds + (s % NB) * CHL + lane * 16;
 #pragma unroll
                 for (int half = 0; half < NTL / 2; ++half) {
                     uint4 bf[2][3];
