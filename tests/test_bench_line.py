@@ -1,0 +1,89 @@
+"""bench.py's output contract, without a GPU: the LAST stdout line is a compact object the driver can parse (round 3's
+23.5 KB line was recorded as `parsed: null`), and `python bench.py --gpus N` starts its own ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+CONTRACT = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config"}
+
+
+def recorded_full_line():
+    """A full record as round 3's bench printed it (committed profile: 60-odd kernel tags, long cpu_baseline text)."""
+    with open(os.path.join(ROOT, "profiles", "r03d_bench_n1.json")) as f:
+        return json.load(f)
+
+
+def test_compact_line_is_small_and_carries_the_judged_keys():
+    full = recorded_full_line()
+    assert len(json.dumps(full)) > 20000                      # the record that did not parse
+    line = bench.compact_line(full)
+    assert "\n" not in line and len(line) < bench.COMPACT_LIMIT < 6000
+    out = json.loads(line)
+    assert CONTRACT <= set(out) and "kernels" not in out
+    assert {"roofline", "backbone", "cpu_baseline", "parity", "fp32_gemm_check", "loss_delta_vs_oracle", "sim_max_abs_delta"} <= set(out)
+    assert out["value"] == full["value"] and out["ms_per_step"] == full["ms_per_step"] and out["dtype"] == "fp32"
+    assert out["config"]["workload"] == full["config"]["workload"]
+    roof = out["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_us", "algorithmic_bytes", "traffic"):
+        assert k in roof, k
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3)
+    cb = out["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port"
+
+
+def test_compact_line_stays_small_with_long_free_text_and_a_dist_record():
+    full = recorded_full_line()
+    full["config"]["launch"] = "x" * 3000
+    full["cpu_baseline"]["sample"] = "y" * 5000
+    full["n_gpus"] = 8
+    full["dist"] = {"backend": "nccl", "rccl_version": "2.26.6", "ranks_seen": 8, "devices": list(range(8)),
+                    "grad_buckets": [{"params": 40, "bytes": 1 << 25}] * 4, "launcher": "bench.py (self-spawned ranks)",
+                    "collective_bytes_per_step": {"all_reduce_total": 98_000_000}, "note": "z" * 2000}
+    line = bench.compact_line(full)
+    assert len(line) < bench.COMPACT_LIMIT
+    out = json.loads(line)
+    assert out["dist"]["ranks_seen"] == 8 and out["dist"]["grad_buckets"] == 4
+
+
+def test_emit_prints_details_first_and_the_compact_line_last(capsys, tmp_path, monkeypatch):
+    monkeypatch.setenv("PECLR_BENCH_DETAILS", str(tmp_path / "d.json"))
+    bench.emit(recorded_full_line())
+    lines = capsys.readouterr().out.splitlines()
+    assert len(lines) == 2 and lines[0].startswith("BENCH_DETAILS {") and lines[1].startswith("{")
+    assert "kernels" in json.loads(lines[0][len("BENCH_DETAILS "):]) and len(lines[1]) < bench.COMPACT_LIMIT
+    assert "kernels" in json.load(open(tmp_path / "d.json"))
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_2_without_a_launcher_spawns_its_own_ranks():
+    """The literal command form the driver uses (`python bench.py --gpus N ...`, no WORLD_SIZE in the environment):
+    both ranks come up, form the group (gloo here: no GPU) and see each other."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-dist"],
+                       env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["ok"] and r["ranks_seen"] == 2 and r["world_size"] == 2 and "self-spawned" in r["launcher"]
+
+
+@pytest.mark.timeout(300)
+def test_bench_without_a_gpu_fails_loudly_on_every_spawned_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert p.returncode != 0 and "needs an MI355X" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
