@@ -57,6 +57,10 @@ typedef void* peclr_stream_t; /* hipStream_t */
 
 int peclr_version(void);
 const char* peclr_error_string(int code);
+/* Identity of the hipGraph capture `stream` is in (*id_out = 0: not capturing).  Plumbing for the host side, which packs
+ * the six-product GEMMs' weight planes once per optimiser step AND once per capture (no reference counterpart: the
+ * reference launches eagerly, peclr_training.py:96). */
+int peclr_stream_capture_id(void* stream, unsigned long long* id_out);
 
 /* ---- K1 / K2-GEMM and their backward GEMMs -------------------------------------------
  * Replaces nn.Linear forward/backward of the projection head (simclr_model.py:22-26,29-33).

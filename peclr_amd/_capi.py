@@ -27,6 +27,7 @@ _P = c_void_p
 SIGNATURES = {
     "peclr_version": (c_int, []),
     "peclr_error_string": (c_char_p, [c_int]),
+    "peclr_stream_capture_id": (c_int, [_P, _P]),
     "peclr_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P]),
     "peclr_gemm_add_f32": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
     "peclr_gemm_add_bf16": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
@@ -138,6 +139,15 @@ def _ptr(t: Optional[torch.Tensor], dtype=torch.float32, what: str = "tensor"):
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def capture_id() -> int:
+    """Identity of the hipGraph capture the current stream is in; 0 when it is not capturing."""
+    if not torch.cuda.is_current_stream_capturing():
+        return 0
+    out = ctypes.c_ulonglong(0)
+    _check(lib().peclr_stream_capture_id(_stream(), ctypes.addressof(out)), "peclr_stream_capture_id")
+    return int(out.value) or 1
 
 
 # ---- optional per-kernel HIP-event timing (bench.py): one entry point = one launch, so an event

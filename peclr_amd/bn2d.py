@@ -89,12 +89,14 @@ class X6PackGroup:
     input-gradient GEMMs.  A member convolution asks `planes(conv)` right before it launches; the group re-packs
     everything when that convolution's weight changed since the last pack (in-place update: `_version`; fused optimiser
     step, which writes through raw pointers: `_capi.WEIGHTS_EPOCH`; new storage: `data_ptr`).  While a hipGraph is
-    being captured the first member always packs, so that every replay re-splits the weights it is about to use."""
+    being captured, the FIRST `planes()` call of that capture (whichever member makes it, whatever the stamps say) packs:
+    the host-side stamps describe the moment of recording, a replay must re-split the weights it is about to use."""
 
     def __init__(self, convs):
         self.convs = [c for c in convs if self.member(c)]
         self._x6 = None
         self._ptrs = None
+        self._capture = 0           # identity of the hipGraph capture that already holds a pack launch
         self._stamp = [None] * len(self.convs)
         for i, c in enumerate(self.convs):   # (position kept on the module: a deep copy of the model keeps group and members consistent)
             c.x6_group, c.x6_index = self, i
@@ -138,8 +140,10 @@ class X6PackGroup:
         if at >= len(self.convs) or self.convs[at] is not conv:
             raise _capi.PeclrHipError("X6PackGroup: convolution is not a member of its group (call enable_hip_batchnorm again)")
         stale = self._stamp[at] != self._key(conv)
-        if not stale and at == 0 and torch.cuda.is_current_stream_capturing():
-            stale = True
+        cap = _capi.capture_id()
+        if cap != self._capture:          # a new capture (or back to eager launches): this capture has no pack launch yet
+            stale = stale or cap != 0
+            self._capture = cap
         if stale:
             self.pack()
         return self._x6.planes[2 * at], self._x6.planes[2 * at + 1]
@@ -190,8 +194,11 @@ class _BN2dAct(torch.autograd.Function):
         dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         pre = None
         ent = _BN_BWD_STATS.pop(dy.data_ptr(), None) if ctx.token is not None else None
-        if ent is not None and ent[0] is ctx.token:          # the GEMM that produced dy reduced it against x already
-            pre = ent[1:]
+        # the GEMM that produced dy reduced it against x already -- valid only for the tensor that GEMM wrote, untouched:
+        # a second consumer of this layer's output makes autograd add its gradient INTO that buffer (in place: the
+        # version counter moves), and the sums would miss that contribution
+        if ent is not None and ent[0] is ctx.token and ent[3] == dy._version:
+            pre = ent[1:3]
         lazy = ctx.lazy_res and has_res and ctx.needs_input_grad[3] and _LAZY_RESIDUAL_GRAD and not torch.is_anomaly_enabled()
         dx, dgamma, dbeta, dres = _capi.bn2d_bwd(dy, x, y, mask, save, ss, training, relu,
                                                  has_res and ctx.needs_input_grad[3] and not lazy, sync_group=ctx.sync_group, pre=pre)
@@ -687,7 +694,20 @@ def _bn_link_of(x: Tensor):
 
 
 def _note_bn_bwd(dx: Tensor, link, partial, ns):
-    _BN_BWD_STATS[dx.data_ptr()] = (link[5], partial, ns)
+    _BN_BWD_STATS[dx.data_ptr()] = (link[5], partial, ns, dx._version)
+
+
+def end_backward(strict: bool = False) -> int:
+    """After every backward pass (the Trainer calls it): drop what the side channels still hold -- a BatchNorm reduction
+    whose gradient tensor was merged into another consumer's buffer and never arrived under its own address, a lazy
+    payload whose NaN view nobody took -- so that nothing pins device memory or meets a recycled address later.  Returns
+    the number of entries dropped; strict=True raises instead (tests: the in-tree ResNets leave none behind)."""
+    n = len(_BN_BWD_STATS) + len(_COMPACT)
+    _BN_BWD_STATS.clear()
+    _COMPACT.clear()
+    if n and strict:
+        raise _capi.PeclrHipError(f"{n} gradient hand-overs were never consumed")
+    return n
 
 
 def _attach_stats(y: Tensor, stats):
@@ -703,9 +723,14 @@ class Conv2d(nn.Conv2d):
 
     hip_gemm = False   # enable_hip_batchnorm: fp32 1x1 / stride-1 convolutions as GEMMs on the bf16 matrix cores
 
-    def forward(self, x: Tensor, stats_for=None) -> Tensor:
+    def forward(self, x: Tensor, stats_for=None, sole_consumer: bool = False) -> Tensor:
         """stats_for: the BatchNorm2d that consumes the output -- when this convolution runs as an in-tree GEMM its
-        epilogue sums that layer's training statistics (one pass over the activation less)."""
+        epilogue sums that layer's training statistics (one pass over the activation less).
+        sole_consumer: the caller guarantees that NOTHING else reads `x` (bn -> conv inside a residual block): only then
+        is this convolution's input gradient THE gradient arriving at the BatchNorm layer that produced x, and only then
+        may the input-gradient GEMM perform that layer's backward reduction in its epilogue.  A block input (x also feeds
+        the shortcut) is not: BasicBlock.conv1 passes False."""
+        bn_link = _bn_link_of if sole_consumer else (lambda t: None)
         if (self.hip_gemm and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")
                 and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1
                 and self.bias is None and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
@@ -716,7 +741,7 @@ class Conv2d(nn.Conv2d):
                          and self.weight.requires_grad)
             if use_fwd or use_bwd or use_wgrad:
                 stats = [stats_for] if (stats_for is not None and use_fwd) else None
-                return _attach_stats(_Conv1x1Gemm.apply(x, self.weight, self, use_fwd, use_bwd, stats, _bn_link_of(x) if use_bwd else None), stats)
+                return _attach_stats(_Conv1x1Gemm.apply(x, self.weight, self, use_fwd, use_bwd, stats, bn_link(x) if use_bwd else None), stats)
         if (self.hip_gemm and _CONV_S2_X6 and _GEMM_X6P and getattr(self, "x6_group", None) is not None and self.stride == (2, 2)
                 and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x.dim() == 4
                 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
@@ -724,14 +749,14 @@ class Conv2d(nn.Conv2d):
             stats = [stats_for] if stats_for is not None else None
             compact = (_S2_DGRAD_COMPACT and self.kernel_size == (1, 1) and getattr(x, "_peclr_compact_ok", False)
                        and torch.is_grad_enabled() and x.requires_grad)
-            link = _bn_link_of(x) if (torch.is_grad_enabled() and x.requires_grad and self.kernel_size == (3, 3)) else None
+            link = bn_link(x) if (torch.is_grad_enabled() and x.requires_grad and self.kernel_size == (3, 3)) else None
             return _attach_stats(_ConvS2Gemm.apply(x, self.weight, self, stats, compact, link), stats)
         if (self.hip_gemm and _CONV3X3_X6 and _GEMM_X6P and getattr(self, "x6_group", None) is not None and self.kernel_size == (3, 3)
                 and self.stride == (1, 1)
                 and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x.dim() == 4
                 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[0] * x.shape[2] * x.shape[3] >= 8192):
             stats = [stats_for] if stats_for is not None else None
-            return _attach_stats(_Conv3x3Gemm.apply(x, self.weight, self, stats, _bn_link_of(x)), stats)
+            return _attach_stats(_Conv3x3Gemm.apply(x, self.weight, self, stats, bn_link(x)), stats)
         if (_overlap_stream() is not None and x.is_cuda and torch.is_grad_enabled() and self.bias is None
                 and self.groups == 1 and self.dilation == (1, 1) and isinstance(self.padding, tuple)
                 and x.is_contiguous(memory_format=torch.channels_last) and self.weight.requires_grad):
@@ -851,7 +876,7 @@ def fork_conv1x1(conv: nn.Conv2d, x: Tensor, stats_for=None):
         if flags and flags[0]:
             identity._peclr_compact_ok = True     # a 1x1 / stride-2 shortcut may hand its input gradient over compact
         return _attach_stats(out, stats), identity
-    return (conv(x, stats_for=stats_for) if isinstance(conv, Conv2d) else conv(x)), x
+    return (conv(x, stats_for=stats_for) if isinstance(conv, Conv2d) else conv(x)), x     # (x has two consumers: no link)
 
 
 class FusedBatchNormAct2d(nn.BatchNorm2d):

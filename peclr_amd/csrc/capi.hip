@@ -16,3 +16,16 @@ extern "C" const char* peclr_error_string(int code) {
     if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
     return "unknown error";
 }
+
+// Identity of the hipGraph capture the stream is in (0 = not capturing).  The host side packs the per-step weight planes
+// once per CAPTURE: a replayed graph must re-split the weights it is about to use whatever the host-side stamps said
+// when it was recorded.
+extern "C" int peclr_stream_capture_id(void* stream, unsigned long long* id_out) {
+    if (!id_out) return PECLR_ERR_NULL;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    hipError_t e = hipStreamGetCaptureInfo(static_cast<hipStream_t>(stream), &st, &id);
+    if (e != hipSuccess) return static_cast<int>(e);
+    *id_out = (st == hipStreamCaptureStatusActive) ? (id ? id : 1ull) : 0ull;
+    return PECLR_OK;
+}

@@ -29,9 +29,10 @@ def conv1x1(cin, cout, stride=1):
     return Conv2d(cin, cout, 1, stride=stride, bias=False)
 
 
-def _conv(conv, x, bn):
-    """conv(x), telling an in-tree Conv2d which BatchNorm consumes the result."""
-    return conv(x, stats_for=bn) if isinstance(conv, Conv2d) else conv(x)
+def _conv(conv, x, bn, sole_consumer=False):
+    """conv(x), telling an in-tree Conv2d which BatchNorm consumes the result and whether it is the ONLY reader of x
+    (then its input-gradient GEMM may also perform the backward reduction of the BatchNorm that produced x)."""
+    return conv(x, stats_for=bn, sole_consumer=sole_consumer) if isinstance(conv, Conv2d) else conv(x)
 
 
 def _bn(bn, x, residual=None, relu=False):
@@ -65,8 +66,9 @@ class BasicBlock(nn.Module):
 
     def _run(self, x: Tensor) -> Tensor:
         identity = x if self.downsample is None else self.downsample(x)
-        out = _bn(self.bn1, _conv(self.conv1, x, self.bn1), relu=True)
-        return _bn(self.bn2, _conv(self.conv2, out, self.bn2), identity, relu=True)
+        # x feeds conv1 AND the shortcut: conv1's input gradient is only one of the two terms of x's gradient
+        out = _bn(self.bn1, _conv(self.conv1, x, self.bn1, sole_consumer=False), relu=True)
+        return _bn(self.bn2, _conv(self.conv2, out, self.bn2, sole_consumer=True), identity, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -101,8 +103,8 @@ class Bottleneck(nn.Module):
             else:
                 identity = ds(identity)
         out = _bn(self.bn1, out, relu=True)
-        out = _bn(self.bn2, _conv(self.conv2, out, self.bn2), relu=True)
-        return _bn(self.bn3, _conv(self.conv3, out, self.bn3), identity, relu=True)
+        out = _bn(self.bn2, _conv(self.conv2, out, self.bn2, sole_consumer=True), relu=True)
+        return _bn(self.bn3, _conv(self.conv3, out, self.bn3, sole_consumer=True), identity, relu=True)
 
 
 class ResNet(nn.Module):

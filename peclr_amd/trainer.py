@@ -244,11 +244,13 @@ class Trainer:
         return {key: v.detach() for key, v in out.items()}
 
     def _join_wgrad(self):
-        """After a backward pass: the current stream waits for the side stream's weight gradients."""
-        if self.overlap_wgrad:
-            from . import bn2d as _bn2d
+        """After a backward pass: the current stream waits for the side stream's weight gradients, and the gradient
+        hand-over side channels of the fused backbone are emptied (bn2d.end_backward)."""
+        from . import bn2d as _bn2d
 
+        if self.overlap_wgrad:
             _bn2d.wgrad_join(self.reducer._hook if self.reducer is not None else None)
+        _bn2d.end_backward()
 
     def _no_fp16_graphs(self):
         if self.precision == "fp16" and not self._device_scaler():
