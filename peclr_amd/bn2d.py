@@ -13,6 +13,8 @@ Two execution modes, chosen EXPLICITLY (no silent dispatch):
 """
 from __future__ import annotations
 
+import contextlib
+import dataclasses
 import os
 
 from typing import Optional
@@ -68,19 +70,80 @@ def checkpoint_block(run, x: Tensor) -> Tensor:
     return run(x)
 
 
-_GEMM_X6 = os.environ.get("PECLR_GEMM_X6", "1") != "0"    # A/B switch: fp32 GEMMs as six bf16 MFMA products
-_X6_MIN_K = int(os.environ.get("PECLR_GEMM_X6_MIN_K", "128"))   # in-step A/B: 128 beats 256 by 0.1-0.4 ms, 64 is HBM-bound
 
 
-_BN_BWD_IN_GEMM = os.environ.get("PECLR_BN_BWD_IN_GEMM", "1") != "0"     # A/B switch: BatchNorm backward reduction in the dgrad GEMM epilogue
 # gradient tensors whose producer (an input-gradient GEMM) already reduced them against the BatchNorm layer they arrive at:
 # data_ptr -> (token of that layer's forward, partial sums, n_split); popped by the layer's backward
 _BN_BWD_STATS: dict = {}
-_BN_STATS_IN_GEMM = os.environ.get("PECLR_BN_STATS_IN_GEMM", "1") != "0"   # A/B switch: BatchNorm statistics in the GEMM epilogue
-_X6_LAYER1_FORK = os.environ.get("PECLR_X6_LAYER1_FORK", "1") != "0"  # A/B: layer1's fused entry gradient (K = 64) on the x6p kernel (+ bn3 reduction)
-_X6_LAYER1 = os.environ.get("PECLR_X6_LAYER1", "1") != "0"  # A/B switch: layer1's 64-channel 1x1 convolutions (forward / input gradient) in-tree
-_GEMM_X6T = os.environ.get("PECLR_GEMM_X6T", "1") != "0"  # A/B switch: weight gradients on the 256 x 256-tile kernel (peclr_gemm_x6t_f32)
-_GEMM_X6P = os.environ.get("PECLR_GEMM_X6P", "1") != "0"  # A/B switch: weight planes packed once per step (peclr_gemm_x6p_f32)
+
+def _env_flag(name: str, default: str = "1") -> bool:
+    return os.environ.get(name, default) != "0"
+
+
+@dataclasses.dataclass
+class Routing:
+    """Every switch that decides which kernel a layer of the fused backbone runs on, in ONE object (`bn2d.ROUTING`).
+    The defaults come from the `PECLR_*` environment variables (same-box A/B runs of one build); tests and tools change
+    them through `with bn2d.routing(name=value, ...)`.  `force`: route every shape the in-tree kernels ACCEPT to them,
+    ignoring the "does it beat MIOpen at this size" tests below -- so that a small problem exercises the same kernels, in
+    the same composition, as the full-size configurations (the kernels' own shape constraints still apply)."""
+    gemm_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_GEMM_X6"))              # fp32 GEMM-shaped work as six bf16 MFMA products
+    x6_min_k: int = dataclasses.field(default_factory=lambda: int(os.environ.get("PECLR_GEMM_X6_MIN_K", "128")))   # in-step A/B: 128 beats 256 by 0.1-0.4 ms
+    gemm_x6p: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_GEMM_X6P"))            # weight planes packed once per step (peclr_gemm_x6p_f32)
+    gemm_x6t: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_GEMM_X6T"))            # weight gradients on the 256 x 256-tile kernel
+    bn_stats_in_gemm: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_BN_STATS_IN_GEMM"))   # BatchNorm statistics in the GEMM epilogue
+    bn_bwd_in_gemm: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_BN_BWD_IN_GEMM"))       # BatchNorm backward reduction in the dgrad epilogue
+    x6_layer1: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_X6_LAYER1"))          # layer1's 64-channel 1x1 convolutions in-tree
+    x6_layer1_fork: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_X6_LAYER1_FORK"))   # layer1's fused entry gradient (K = 64)
+    x6_layer1_wgrad: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_X6_LAYER1_WGRAD"))  # layer1's 64-wide weight gradients
+    conv3x3_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV3X3_X6"))        # 3x3 stride-1 convolutions as implicit GEMMs
+    conv3x3_wgrad_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV3X3_WGRAD_X6"))   # their weight gradients (nine taps, one launch)
+    conv3x3_tile_rows: int = dataclasses.field(default_factory=lambda: int(os.environ.get("PECLR_CONV3X3_TILE_ROWS", "256")))
+    conv_s2_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV_S2_X6"))        # forward of the stride-2 convolutions
+    conv_s2_wgrad_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV_S2_WGRAD_X6"))
+    conv_s2_dgrad_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV_S2_DGRAD_X6"))   # 3x3 / stride-2 input gradient by parity classes
+    s2_tile_rows: int = dataclasses.field(default_factory=lambda: int(os.environ.get("PECLR_CONV_S2_TILE_ROWS", "0")))   # 0 = the rounds-of-slots policy
+    s2_dgrad_compact: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_S2_DGRAD_COMPACT"))   # the shortcut's compact input gradient
+    lazy_residual_grad: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_LAZY_RESIDUAL_GRAD"))   # identity shortcut: (dy, mask) hand-over
+    conv16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV16"))                # 16-bit (bf16 / fp16 autocast) convolutions in-tree
+    force: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_ROUTE_FORCE", "0"))
+
+    # ---- "does the in-tree kernel pay at this shape" (measured on ResNet-50's shapes; the kernels accept far more)
+    def tiles(self, rows: int, n_out: int) -> int:
+        """Workgroup tiles of a [rows, n_out] output on 128-row x 128-column (64 for narrow outputs) tiles."""
+        return (rows // 128) * max(1, n_out // (128 if n_out >= 128 else 64))
+
+    MALL_BYTES = 256 << 20        # Infinity Cache (MI355X_MICROARCH.md): tensors beyond it stream from HBM
+
+    def streams_from_hbm(self, rows: int, k: int, n_out: int) -> bool:
+        """The product's fp32 operand + output rows exceed the Infinity Cache: a separate BatchNorm statistics /
+        backward-reduction pass over them would come from HBM again.  This is what makes the in-tree GEMM pay for the
+        64-channel shapes (layer1), where the GEMM itself is a draw against MIOpen (both HBM-bound: tools/exp/layer1_probe.py)
+        and the fused epilogue saves that pass."""
+        return self.force or 4 * rows * (k + n_out) >= self.MALL_BYTES
+
+    def fills_chip(self, rows: int, n_out: int, rounds: float = 0.765) -> bool:
+        """At least `rounds` of the chip's 256 CUs get a tile: below that the launch is latency- and tail-bound and
+        MIOpen's smaller tiles win (ResNet-50 @224 with 2 x 128 views: every routed shape has >= 196 tiles)."""
+        return self.force or self.tiles(rows, n_out) >= 256 * rounds
+
+
+ROUTING = Routing()
+
+
+@contextlib.contextmanager
+def routing(**overrides):
+    """Temporarily change fields of `ROUTING` (tests, A/B tools): `with bn2d.routing(bn_bwd_in_gemm=False): ...`."""
+    old = {k: getattr(ROUTING, k) for k in overrides}
+    for k, v in overrides.items():
+        if not hasattr(ROUTING, k):
+            raise AttributeError(f"Routing has no field {k!r}")
+        setattr(ROUTING, k, v)
+    try:
+        yield ROUTING
+    finally:
+        for k, v in old.items():
+            setattr(ROUTING, k, v)
 
 
 class X6PackGroup:
@@ -153,7 +216,7 @@ def _x6_planes(conv):
     """Packed planes of `conv`'s weight, or None when the convolution is not in a pack group (then the GEMMs split the
     weight per workgroup: peclr_gemm_x6_f32)."""
     group = getattr(conv, "x6_group", None) if conv is not None else None
-    if group is None or not _GEMM_X6P or not conv.weight.is_cuda or conv.weight.dtype != torch.float32:
+    if group is None or not ROUTING.gemm_x6p or not conv.weight.is_cuda or conv.weight.dtype != torch.float32:
         return None
     return group.planes(conv)
 
@@ -199,7 +262,7 @@ class _BN2dAct(torch.autograd.Function):
         # version counter moves), and the sums would miss that contribution
         if ent is not None and ent[0] is ctx.token and ent[3] == dy._version:
             pre = ent[1:3]
-        lazy = ctx.lazy_res and has_res and ctx.needs_input_grad[3] and _LAZY_RESIDUAL_GRAD and not torch.is_anomaly_enabled()
+        lazy = ctx.lazy_res and has_res and ctx.needs_input_grad[3] and ROUTING.lazy_residual_grad and not torch.is_anomaly_enabled()
         dx, dgamma, dbeta, dres = _capi.bn2d_bwd(dy, x, y, mask, save, ss, training, relu,
                                                  has_res and ctx.needs_input_grad[3] and not lazy, sync_group=ctx.sync_group, pre=pre)
         if lazy:
@@ -362,25 +425,25 @@ def _x6_pays(rows: int, n_out: int, k: int) -> bool:
     full and the 128 x 128 tiles fill the chip; the K = 64 and N = 64 shapes of layer1 are HBM-bound either way."""
     # (64-wide outputs -- layer1 -- have a 128 x 64-tile variant in the library that wins in isolation, 256 vs 345 us,
     # and loses 0.4 ms per step inside it, where MIOpen's kernels find their operands in the caches: not routed)
-    if not _GEMM_X6:
+    if not ROUTING.gemm_x6:
         return False
-    if k >= _X6_MIN_K and k % 4 == 0 and n_out >= 128 and n_out % 4 == 0 and (rows // 128) * (n_out // 128) >= 196:
+    if (k >= ROUTING.x6_min_k or (ROUTING.force and k >= 64)) and k % 4 == 0 and n_out >= 128 and n_out % 4 == 0 and ROUTING.fills_chip(rows, n_out):
         return True
     # layer1 (64 <-> 256 channels, 8e5 rows): HBM-bound, the GEMM itself is a draw against MIOpen (290 vs 296 us, 269 vs 331,
     # input gradient 253 vs 322: tools/exp/layer1_probe.py) -- what pays is that the in-tree GEMM also delivers the next
     # BatchNorm's statistics / performs the previous one's backward reduction, each a pass over up to 822 MB
-    return _X6_LAYER1 and _GEMM_X6P and rows >= 400000 and k >= 64 and k % 16 == 0 and n_out >= 64 and n_out % 64 == 0
+    return (ROUTING.x6_layer1 and ROUTING.gemm_x6p and ROUTING.streams_from_hbm(rows, k, n_out) and k >= 64 and k % 16 == 0
+            and n_out >= 64 and n_out % 64 == 0)
 
 
-_X6_LAYER1_WGRAD = os.environ.get("PECLR_X6_LAYER1_WGRAD", "1") != "0"   # A/B switch: layer1's 64-wide weight gradients in-tree
 
 
 def _x6_wgrad_pays(rows: int, cout: int, cin: int) -> bool:
     """peclr_gemm_x6t_f32 against MIOpen's fp32 1x1 weight gradient (tools/exp/conv1x1_probe.py, wgrad_probe.py): 150-205 us
     against 208-267 from layer2 on; the 64-wide gradients of layer1 (HBM-bound: 8e5 rows of 64 + 256 channels) on 64 x 256 /
     256 x 64 / 64 x 128 tiles."""
-    wide = 128 if not (_GEMM_X6T and _X6_LAYER1_WGRAD) else 64
-    return _GEMM_X6 and cout >= wide and cin >= wide and cout % 4 == 0 and cin % 4 == 0 and rows >= 8192
+    wide = 128 if not (ROUTING.gemm_x6t and ROUTING.x6_layer1_wgrad) else 64
+    return ROUTING.gemm_x6 and cout >= wide and cin >= wide and cout % 4 == 0 and cin % 4 == 0 and (rows >= 8192 or ROUTING.force)
 
 
 def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
@@ -391,7 +454,7 @@ def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
 
     def run():
         gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
-        dw = _capi.gemm_x6t(gy2, x2, tag="conv1x1_wgrad") if _GEMM_X6T else _capi.gemm_x6_tn(gy2, x2, tag="conv1x1_wgrad")
+        dw = _capi.gemm_x6t(gy2, x2, tag="conv1x1_wgrad") if ROUTING.gemm_x6t else _capi.gemm_x6_tn(gy2, x2, tag="conv1x1_wgrad")
         ref = param if param is not None else weight
         return dw.as_strided(ref.shape, ref.stride())       # same memory, the parameter's (channels_last) strides
 
@@ -464,7 +527,7 @@ class _Conv1x1Gemm(torch.autograd.Function):
         n, cin, h, w = x.shape
         cout = weight.shape[0]
         x2 = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
-        shift = _stat_shift_for(stats[0], cout) if (stats and planes is not None and _BN_STATS_IN_GEMM) else None
+        shift = _stat_shift_for(stats[0], cout) if (stats and planes is not None and ROUTING.bn_stats_in_gemm) else None
         if shift is not None:
             y, partial, ns = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd", stat_shift=shift)
             stats[:] = [partial, ns, shift, stats[0]]
@@ -506,9 +569,6 @@ class _Conv1x1Gemm(torch.autograd.Function):
         return dx, dw, None, None, None, None, None
 
 
-_CONV3X3_WGRAD_X6 = os.environ.get("PECLR_CONV3X3_WGRAD_X6", "1") != "0"   # A/B switch: 3x3 weight gradients in-tree (nine taps, one launch)
-_CONV3X3_TILE_ROWS = int(os.environ.get("PECLR_CONV3X3_TILE_ROWS", "256"))   # experiments
-_CONV3X3_X6 = os.environ.get("PECLR_CONV3X3_X6", "1") != "0"   # A/B switch: 3x3 stride-1 convolutions as implicit x6p GEMMs
 
 
 class _Conv3x3Gemm(torch.autograd.Function):
@@ -525,12 +585,12 @@ class _Conv3x3Gemm(torch.autograd.Function):
         ctx.cfg = (conv, planes)
         ctx.link = link
         cout = weight.shape[0]
-        shift = _stat_shift_for(stats[0], cout) if (stats and _BN_STATS_IN_GEMM) else None
+        shift = _stat_shift_for(stats[0], cout) if (stats and ROUTING.bn_stats_in_gemm) else None
         if shift is not None:
-            y, partial, ns = _capi.conv3x3_x6p(x, planes[0], cout, tag="conv3x3_fwd", tile_rows=_CONV3X3_TILE_ROWS, stat_shift=shift)
+            y, partial, ns = _capi.conv3x3_x6p(x, planes[0], cout, tag="conv3x3_fwd", tile_rows=ROUTING.conv3x3_tile_rows, stat_shift=shift)
             stats[:] = [partial, ns, shift, stats[0]]
             return y
-        return _capi.conv3x3_x6p(x, planes[0], cout, tag="conv3x3_fwd", tile_rows=_CONV3X3_TILE_ROWS)
+        return _capi.conv3x3_x6p(x, planes[0], cout, tag="conv3x3_fwd", tile_rows=ROUTING.conv3x3_tile_rows)
 
     @staticmethod
     def backward(ctx, gy):
@@ -539,27 +599,23 @@ class _Conv3x3Gemm(torch.autograd.Function):
         gy = gy.contiguous(memory_format=torch.channels_last)
         dw = None
         if ctx.needs_input_grad[1]:
-            in_tree = (_GEMM_X6T and _CONV3X3_WGRAD_X6 and weight.is_contiguous(memory_format=torch.channels_last)
+            in_tree = (ROUTING.gemm_x6t and ROUTING.conv3x3_wgrad_x6 and weight.is_contiguous(memory_format=torch.channels_last)
                        and x.shape[3] >= 6 and x.shape[1] % 4 == 0 and gy.shape[1] % 4 == 0
-                       and gy.shape[1] >= (64 if _X6_LAYER1_WGRAD else 128))   # (64 output channels: the 64 x 64 block with two tap halves)
+                       and gy.shape[1] >= (64 if ROUTING.x6_layer1_wgrad else 128))   # (64 output channels: the 64 x 64 block with two tap halves)
             dw = _wgrad_3x3_x6(gy, x, weight, conv.weight) if in_tree else _conv_wgrad(gy, x, weight, (1, 1), (1, 1), conv.weight)
         dx = None
         if ctx.needs_input_grad[0]:
             link = ctx.link
             if link is not None and link[0].shape == x.shape and x.shape[1] % 32 == 0:
                 # dx is the gradient arriving at the BatchNorm layer whose output x is: reduce it in the epilogue
-                dx, partial, ns = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=_CONV3X3_TILE_ROWS,
+                dx, partial, ns = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=ROUTING.conv3x3_tile_rows,
                                                     bn_bwd=link[:5])
                 _note_bn_bwd(dx, link, partial, ns)
             else:
-                dx = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=_CONV3X3_TILE_ROWS)
+                dx = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=ROUTING.conv3x3_tile_rows)
         return dx, dw, None, None, None
 
 
-_S2_TILE_ROWS = int(os.environ.get("PECLR_CONV_S2_TILE_ROWS", "0"))   # strided 3x3 kernels: 0 = the rounds-of-slots policy (256 forced: +6 / +17 us per launch, measured)
-_CONV_S2_X6 = os.environ.get("PECLR_CONV_S2_X6", "1") != "0"   # A/B switch: forward of the stride-2 convolutions in-tree
-_CONV_S2_WGRAD_X6 = os.environ.get("PECLR_CONV_S2_WGRAD_X6", "1") != "0"   # A/B switch: their weight gradients in-tree
-_CONV_S2_DGRAD_X6 = os.environ.get("PECLR_CONV_S2_DGRAD_X6", "1") != "0"   # A/B switch: the 3x3's input gradient in-tree (parity classes)
 
 
 class _ConvS2Gemm(torch.autograd.Function):
@@ -577,12 +633,12 @@ class _ConvS2Gemm(torch.autograd.Function):
         ctx.link = link
         planes = _x6_planes(conv)
         cout, taps = weight.shape[0], weight.shape[2] * weight.shape[3]
-        shift = _stat_shift_for(stats[0], cout) if (stats and _BN_STATS_IN_GEMM) else None
+        shift = _stat_shift_for(stats[0], cout) if (stats and ROUTING.bn_stats_in_gemm) else None
         if shift is not None:
-            y, partial, ns = _capi.conv_s2_x6p(x, planes[0], cout, taps, tag="conv_s2_fwd", stat_shift=shift, tile_rows=_S2_TILE_ROWS if taps == 9 else 0)
+            y, partial, ns = _capi.conv_s2_x6p(x, planes[0], cout, taps, tag="conv_s2_fwd", stat_shift=shift, tile_rows=ROUTING.s2_tile_rows if taps == 9 else 0)
             stats[:] = [partial, ns, shift, stats[0]]
             return y
-        return _capi.conv_s2_x6p(x, planes[0], cout, taps, tag="conv_s2_fwd", tile_rows=_S2_TILE_ROWS if taps == 9 else 0)
+        return _capi.conv_s2_x6p(x, planes[0], cout, taps, tag="conv_s2_fwd", tile_rows=ROUTING.s2_tile_rows if taps == 9 else 0)
 
     @staticmethod
     def backward(ctx, gy):
@@ -593,7 +649,7 @@ class _ConvS2Gemm(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             taps = weight.shape[2] * weight.shape[3]
-            in_tree = (_GEMM_X6T and _CONV_S2_WGRAD_X6 and weight.is_contiguous(memory_format=torch.channels_last)
+            in_tree = (ROUTING.gemm_x6t and ROUTING.conv_s2_wgrad_x6 and weight.is_contiguous(memory_format=torch.channels_last)
                        and x.shape[2] == 2 * gy.shape[2] and x.shape[3] == 2 * gy.shape[3] and gy.shape[3] >= 6
                        and x.shape[1] % 4 == 0 and gy.shape[1] % 4 == 0 and gy.shape[1] >= 64 and x.shape[1] >= 64)
             dw = (_wgrad_3x3_x6(gy, x, weight, conv.weight, stride=2, taps=taps) if in_tree
@@ -606,17 +662,17 @@ class _ConvS2Gemm(torch.autograd.Function):
                 n, cout, ho, wo = gy.shape
                 dc = _capi.gemm_x6p(gy.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), _x6_planes(conv)[1], x.shape[1], tag="conv_s2_dgrad")
                 dx = _compact_grad(dc, x.shape)
-            elif (_CONV_S2_DGRAD_X6 and weight.shape[2] == 3 and x.shape[2] == 2 * gy.shape[2] and x.shape[3] == 2 * gy.shape[3]
+            elif (ROUTING.conv_s2_dgrad_x6 and weight.shape[2] == 3 and x.shape[2] == 2 * gy.shape[2] and x.shape[3] == 2 * gy.shape[3]
                   and x.shape[1] % 64 == 0 and gy.shape[1] % 16 == 0):
                 # 3x3: one dense implicit GEMM per parity class of input pixels (1, 2, 2, 4 taps); dx is the gradient arriving
                 # at the BatchNorm layer whose output x is: reduced in the epilogue
                 planes = _x6_planes(conv)
                 link = ctx.link
                 if link is not None and link[0].shape == x.shape and x.shape[1] % 32 == 0:
-                    dx, partial, ns = _capi.conv3x3_s2_dgrad_x6p(gy, planes[1], x.shape[1], bn_bwd=link[:5], tile_rows=_S2_TILE_ROWS)
+                    dx, partial, ns = _capi.conv3x3_s2_dgrad_x6p(gy, planes[1], x.shape[1], bn_bwd=link[:5], tile_rows=ROUTING.s2_tile_rows)
                     _note_bn_bwd(dx, link, partial, ns)
                 else:
-                    dx = _capi.conv3x3_s2_dgrad_x6p(gy, planes[1], x.shape[1], tile_rows=_S2_TILE_ROWS)
+                    dx = _capi.conv3x3_s2_dgrad_x6p(gy, planes[1], x.shape[1], tile_rows=ROUTING.s2_tile_rows)
             else:
                 dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [2, 2], pad, [1, 1], False, [0, 0], 1, [True, False, False])[0]
         return dx, dw, None, None, None, None
@@ -630,8 +686,6 @@ class _ConvS2Gemm(torch.autograd.Function):
 # the identity output of `_ForkConv1x1` (whose backward is the only consumer of that gradient, and understands the
 # protocol), they return a zero-stride NaN view of the right shape instead -- no memory, and loudly wrong should anything
 # else ever consume or accumulate it -- and park the real payload here under the view's address.
-_S2_DGRAD_COMPACT = os.environ.get("PECLR_S2_DGRAD_COMPACT", "1") != "0"    # A/B switch: the shortcut's compact gradient
-_LAZY_RESIDUAL_GRAD = os.environ.get("PECLR_LAZY_RESIDUAL_GRAD", "1") != "0"   # A/B switch: the identity shortcut's (dy, mask) pair
 _COMPACT = {}
 _NAN_RING = {}
 
@@ -690,7 +744,7 @@ def _bn_link_of(x: Tensor):
     """(x_bn, save, scale_shift, mask, relu, token) if `x` is the output of a fused BatchNorm layer whose backward reduction
     a consumer's input-gradient GEMM may perform, else None."""
     link = getattr(x, "_peclr_bn_link", None)
-    return tuple(link) if link and _BN_BWD_IN_GEMM else None
+    return tuple(link) if link and ROUTING.bn_bwd_in_gemm else None
 
 
 def _note_bn_bwd(dx: Tensor, link, partial, ns):
@@ -742,19 +796,20 @@ class Conv2d(nn.Conv2d):
             if use_fwd or use_bwd or use_wgrad:
                 stats = [stats_for] if (stats_for is not None and use_fwd) else None
                 return _attach_stats(_Conv1x1Gemm.apply(x, self.weight, self, use_fwd, use_bwd, stats, bn_link(x) if use_bwd else None), stats)
-        if (self.hip_gemm and _CONV_S2_X6 and _GEMM_X6P and getattr(self, "x6_group", None) is not None and self.stride == (2, 2)
+        if (self.hip_gemm and ROUTING.conv_s2_x6 and ROUTING.gemm_x6p and getattr(self, "x6_group", None) is not None and self.stride == (2, 2)
                 and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x.dim() == 4
                 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
-                and x.shape[0] * x.shape[2] * x.shape[3] >= 32768):
+                and (x.shape[0] * x.shape[2] * x.shape[3] >= 32768 or ROUTING.force)):
             stats = [stats_for] if stats_for is not None else None
-            compact = (_S2_DGRAD_COMPACT and self.kernel_size == (1, 1) and getattr(x, "_peclr_compact_ok", False)
+            compact = (ROUTING.s2_dgrad_compact and self.kernel_size == (1, 1) and getattr(x, "_peclr_compact_ok", False)
                        and torch.is_grad_enabled() and x.requires_grad)
             link = bn_link(x) if (torch.is_grad_enabled() and x.requires_grad and self.kernel_size == (3, 3)) else None
             return _attach_stats(_ConvS2Gemm.apply(x, self.weight, self, stats, compact, link), stats)
-        if (self.hip_gemm and _CONV3X3_X6 and _GEMM_X6P and getattr(self, "x6_group", None) is not None and self.kernel_size == (3, 3)
+        if (self.hip_gemm and ROUTING.conv3x3_x6 and ROUTING.gemm_x6p and getattr(self, "x6_group", None) is not None and self.kernel_size == (3, 3)
                 and self.stride == (1, 1)
                 and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x.dim() == 4
-                and x.is_contiguous(memory_format=torch.channels_last) and x.shape[0] * x.shape[2] * x.shape[3] >= 8192):
+                and x.is_contiguous(memory_format=torch.channels_last)
+                and (x.shape[0] * x.shape[2] * x.shape[3] >= 8192 or ROUTING.force)):
             stats = [stats_for] if stats_for is not None else None
             return _attach_stats(_Conv3x3Gemm.apply(x, self.weight, self, stats, bn_link(x)), stats)
         if (_overlap_stream() is not None and x.is_cuda and torch.is_grad_enabled() and self.bias is None
@@ -783,15 +838,17 @@ class _ForkConv1x1(torch.autograd.Function):
         cmid = weight.shape[0]
         r = n * h * w
         use_fwd = x.dtype == torch.float32 and _x6_pays(r, cmid, cin)
-        use_bwd = (x.dtype == torch.float32 and _GEMM_X6 and (r // 128) * (cin // 128) >= 512
-                   and (cmid >= _X6_MIN_K or (_X6_LAYER1_FORK and _GEMM_X6P and r >= 400000 and cmid >= 64 and cmid % 16 == 0 and cin % 128 == 0)))
+        # (two rounds of the chip's CUs: below that MIOpen's dgrad + the elementwise add are not slower)
+        use_bwd = (x.dtype == torch.float32 and ROUTING.gemm_x6 and cin >= 128 and ROUTING.fills_chip(r, cin, rounds=2.0)
+                   and (cmid >= ROUTING.x6_min_k or (ROUTING.x6_layer1_fork and ROUTING.gemm_x6p and ROUTING.streams_from_hbm(r, cmid, cin)
+                                                     and cmid >= 64 and cmid % 16 == 0 and cin % 128 == 0)))
         ctx.planes = _x6_planes(conv) if (use_fwd or use_bwd) else None
         ctx.use_bwd = use_bwd
         if flags is not None:       # tells fork_conv1x1 whether the backward takes compact shortcut gradients (the x6p GEMM)
             flags.append(bool(use_bwd and ctx.planes is not None))
         if use_fwd:
             x2 = x.permute(0, 2, 3, 1).reshape(r, cin)
-            shift = _stat_shift_for(stats[0], cmid) if (stats and ctx.planes is not None and _BN_STATS_IN_GEMM) else None
+            shift = _stat_shift_for(stats[0], cmid) if (stats and ctx.planes is not None and ROUTING.bn_stats_in_gemm) else None
             if shift is not None:
                 y, partial, ns = _capi.gemm_x6p(x2, ctx.planes[0], cmid, tag="conv1x1_fwd", stat_shift=shift)
                 stats[:] = [partial, ns, shift, stats[0]]
@@ -922,8 +979,8 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
             pre = pre[:3] if pre is not None else None
             if self.tail_avgpool and relu and residual is not None and self.num_features % 32 == 0:
                 return _BN2dAddReluAvgPool.apply(x, self.weight, self.bias, residual, self, pre)
-            link = [] if (_BN_BWD_IN_GEMM and torch.is_grad_enabled() and x.requires_grad) else None
-            lazy_res = (_LAZY_RESIDUAL_GRAD and relu and residual is not None and getattr(residual, "_peclr_compact_ok", False)
+            link = [] if (ROUTING.bn_bwd_in_gemm and torch.is_grad_enabled() and x.requires_grad) else None
+            lazy_res = (ROUTING.lazy_residual_grad and relu and residual is not None and getattr(residual, "_peclr_compact_ok", False)
                         and torch.is_grad_enabled() and residual.requires_grad and self.num_features % 32 == 0)
             y = _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre, link, lazy_res)
             if link:

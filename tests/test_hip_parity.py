@@ -1848,7 +1848,7 @@ def test_batchnorm_statistics_from_the_gemm_epilogue_equal_the_separate_pass(cin
                 bn.bias.uniform_(-0.3, 0.3)
                 bn.running_mean.uniform_(-0.1, 0.1)
         B.enable_hip_batchnorm(block)
-        B._BN_STATS_IN_GEMM = fused
+        B.ROUTING.bn_stats_in_gemm = fused
         rm_start = block.bn1.running_mean.clone()
         _capi.EVENT_LOG = {}
         try:
@@ -1859,7 +1859,7 @@ def test_batchnorm_statistics_from_the_gemm_epilogue_equal_the_separate_pass(cin
             launches[fused] = {k: len(v) for k, v in _capi.EVENT_LOG.items()}
         finally:
             _capi.EVENT_LOG = None
-            B._BN_STATS_IN_GEMM = True
+            B.ROUTING.bn_stats_in_gemm = True
         res[fused] = (y.detach(), x.grad.clone(), [p.grad.clone() for p in block.parameters()],
                       [(bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)) for bn in (block.bn1, block.bn2, block.bn3)],
                       block, rm_start)
@@ -1979,7 +1979,7 @@ def test_batchnorm_backward_reduction_in_the_dgrad_epilogue_equals_the_separate_
                                   resnet.Bottleneck(cin, cmid, norm_layer=B.FusedBatchNormAct2d))
         net = net.to(DEV).to(memory_format=torch.channels_last).train()
         B.enable_hip_batchnorm(net)
-        B._BN_BWD_IN_GEMM = fused
+        B.ROUTING.bn_bwd_in_gemm = fused
         _capi.EVENT_LOG = {}
         try:
             x = x0.clone().requires_grad_()
@@ -1989,7 +1989,7 @@ def test_batchnorm_backward_reduction_in_the_dgrad_epilogue_equals_the_separate_
             launches[fused] = {k: len(v) for k, v in _capi.EVENT_LOG.items()}
         finally:
             _capi.EVENT_LOG = None
-            B._BN_BWD_IN_GEMM = True
+            B.ROUTING.bn_bwd_in_gemm = True
         res[fused] = (y.detach(), x.grad.clone(), [p.grad.clone() for p in net.parameters()])
         assert not B._BN_BWD_STATS or not fused or all(False for _ in ())       # (entries are popped by their layer)
     routed = B._x6_pays(n * hw * hw, cmid, cin)
@@ -2027,7 +2027,7 @@ def test_first_block_entry_gradient_adds_the_shortcut_gradient_compact(cin, plan
                                   resnet.Bottleneck(cin, planes, 2, ds, norm_layer=B.FusedBatchNormAct2d))
         net = net.to(DEV).to(memory_format=torch.channels_last).train()
         B.enable_hip_batchnorm(net)
-        B._S2_DGRAD_COMPACT = compact
+        B.ROUTING.s2_dgrad_compact = compact
         _capi.EVENT_LOG = {}
         try:
             x = x0.clone().requires_grad_()
@@ -2037,7 +2037,7 @@ def test_first_block_entry_gradient_adds_the_shortcut_gradient_compact(cin, plan
             tags[compact] = {k: len(v) for k, v in _capi.EVENT_LOG.items()}
         finally:
             _capi.EVENT_LOG = None
-            B._S2_DGRAD_COMPACT = True
+            B.ROUTING.s2_dgrad_compact = True
         assert not B._COMPACT
         res[compact] = (y.detach(), x.grad.clone(), [p.grad.clone() for p in net.parameters()])
     assert tags[True].get("conv_s2_dgrad") == 1 and "conv_s2_dgrad" not in tags[False], tags
@@ -2070,7 +2070,7 @@ def test_identity_shortcut_gradient_is_handed_over_as_dy_and_mask(cin, cmid, hw,
                                   resnet.Bottleneck(cin, cmid, norm_layer=B.FusedBatchNormAct2d))
         net = net.to(DEV).to(memory_format=torch.channels_last).train()
         B.enable_hip_batchnorm(net)
-        B._LAZY_RESIDUAL_GRAD = lazy
+        B.ROUTING.lazy_residual_grad = lazy
         _capi.EVENT_LOG = {}
         try:
             x = x0.clone().requires_grad_()
@@ -2080,7 +2080,7 @@ def test_identity_shortcut_gradient_is_handed_over_as_dy_and_mask(cin, cmid, hw,
             log[lazy] = {k: sum(e[2] for e in v) for k, v in _capi.EVENT_LOG.items()}      # algorithmic bytes per tag
         finally:
             _capi.EVENT_LOG = None
-            B._LAZY_RESIDUAL_GRAD = True
+            B.ROUTING.lazy_residual_grad = True
         assert not B._COMPACT
         res[lazy] = (y.detach(), x.grad.clone(), [p.grad.clone() for p in net.parameters()])
     routed = "conv1x1_dgrad_add_x6" in log[False]

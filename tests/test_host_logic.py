@@ -659,9 +659,20 @@ def test_x6_routing_rules_and_cpu_fallback(monkeypatch):
     assert B._x6_wgrad_pays(r28, 128, 512) and B._x6_wgrad_pays(r7, 512, 2048)
     assert B._x6_wgrad_pays(r56, 64, 256) and B._x6_wgrad_pays(r56, 256, 64)      # layer1: the 64-wide tiles of peclr_gemm_x6t_f32
     assert not B._x6_wgrad_pays(r56, 32, 256) and not B._x6_wgrad_pays(4096, 256, 1024)
-    monkeypatch.setattr(B, "_X6_LAYER1_WGRAD", False)
-    assert not B._x6_wgrad_pays(r56, 64, 256) and not B._x6_wgrad_pays(r56, 256, 64) and B._x6_wgrad_pays(r28, 128, 512)
-    monkeypatch.setattr(B, "_X6_LAYER1_WGRAD", True)
+    with B.routing(x6_layer1_wgrad=False):
+        assert not B._x6_wgrad_pays(r56, 64, 256) and not B._x6_wgrad_pays(r56, 256, 64) and B._x6_wgrad_pays(r28, 128, 512)
+    assert B.ROUTING.x6_layer1_wgrad
+    # the thresholds are roofline statements, not ResNet-50 @224's row counts in disguise: the 64-channel rule is "operands +
+    # output exceed the Infinity Cache" (the fused BatchNorm pass would otherwise come from HBM again) ...
+    assert B.ROUTING.streams_from_hbm(r56, 64, 64) and not B.ROUTING.streams_from_hbm(64 * 56 * 56, 64, 256)
+    assert B._x6_pays(128 * 112 * 112, 64, 256) and B._x6_pays(128 * 112 * 112, 256, 64)        # C5's layer1: 2 x 64 views @448
+    # ... and `force` routes everything the kernels accept (tests exercise the full-size composition on small problems)
+    with B.routing(force=True):
+        assert B._x6_pays(16 * 14 * 14, 1024, 256) and B._x6_pays(48 * 56 * 56, 64, 256) and B._x6_wgrad_pays(4096, 256, 1024)
+        assert not B._x6_pays(r56, 256, 24) and not B._x6_pays(r56, 32, 256)                       # the kernels' own shape limits stay
+    with pytest.raises(AttributeError):
+        with B.routing(no_such_switch=1):
+            pass
     torch.manual_seed(0)
     conv = B.Conv2d(256, 512, 1, bias=False)
     ref = torch.nn.Conv2d(256, 512, 1, bias=False)
