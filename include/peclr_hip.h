@@ -490,6 +490,37 @@ int peclr_augment_resize_color_norm(const uint8_t* crops, int B, int H, int W, i
                                     const float* stdv, int channels_last, float* out,
                                     peclr_stream_t stream);
 
+/* ---- 16-bit convolutions of the residual blocks (bf16 / fp16 autocast: BASELINE configs C3 / C5 and the reference's own
+ * `precision: 16`, training_config.json:9, peclr_training.py:78-79), csrc/conv_h.hip.  They replace MIOpen's 16-bit
+ * convolution kernels behind torchvision's Bottleneck / BasicBlock (resnet_model.py:15) -- forward and input gradient of the
+ * 1x1 and 3x3 convolutions, stride 1 and 2 -- with fp32 accumulation on v_mfma_f32_32x32x16_{bf16,f16} and the same fused
+ * epilogues as the fp32 kernels above: BatchNorm statistics of the output, the backward reduction of the BatchNorm layer the
+ * output gradient arrives at, the residual branch's gradient as a dense / compact stride-2 / 1-bit-masked addend.
+ * dtype = PECLR_DTYPE_BF16 or PECLR_DTYPE_F16 for activations, gradients and packed weights alike.
+ *   peclr_h_pack: the weight operand, packed ONCE per optimiser step from the fp32 master weights (this is also the cast
+ *   autocast performs per forward): device table of `count` entries of 8 int64 {src fp32 matrix, dst, n, k, ld (floats),
+ *   transposed (0 / 1 / T as peclr_x6_pack_f32), first chunk, dtype}; per (128 columns, 32 k) one 8 KiB chunk of eight
+ *   1 KiB pieces [32-column block][16-k half] in MFMA fragment order; n % 64 == 0, k % 32 == 0; dst holds
+ *   peclr_h_pack_bytes(n, k) = 2 * roundup(n, 128) * k bytes.
+ *   peclr_gemm_h: C[M,N] = A[M,K] . B_t^T (+ addend): add_h = add_w = 0 dense addend [M][ldd]; add_h, add_w > 0 the addend
+ *   holds every second pixel of add_h x add_w images (compact stride-2 shortcut gradient); addend_mask: 1-bit ReLU mask of a
+ *   dense addend ([M][N / 32]).  stat_shift / stat_partial and bn_bwd as in peclr_gemm_x6p_f32 (bn_bwd->x points at 16-bit
+ *   rows).  Sums are taken of the ROUNDED 16-bit outputs.  lda, ldc, ldd multiples of 8.
+ *   peclr_conv_h: taps = 9 (3x3, padding 1) or 1, stride 1 or 2, NHWC; flip = 1 (taps = 9, stride 1): the input gradient
+ *   (X = dY, planes packed with transposed = 9).  `zeros`: >= 64 bytes of zeros.  Cin % 32 == 0, Cout % 64 == 0.
+ *   peclr_conv3x3_s2_dgrad_h: input gradient of the 3x3 / stride-2 convolution by parity classes (as the fp32 entry point). */
+int64_t peclr_h_pack_bytes(int N, int K);
+int peclr_h_pack(const void* desc_table, int count, int total_chunks, peclr_stream_t stream);
+int peclr_conv_h_tile_rows(int M, int N);
+int peclr_gemm_h(int dtype, int M, int N, int K, const void* A, int lda, const void* Bp, void* C, int ldc, const void* addend,
+                 int ldd, int add_h, int add_w, const unsigned* addend_mask, int tile_rows, const float* stat_shift,
+                 float* stat_partial, const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
+int peclr_conv_h(int dtype, int NB, int H, int W, int Cin, int Cout, int taps, int stride, const void* X, const void* Bp, void* Y,
+                 int flip, int tile_rows, const void* zeros, const float* stat_shift, float* stat_partial,
+                 const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
+int peclr_conv3x3_s2_dgrad_h(int dtype, int NB, int Ho, int Wo, int Cout, int Cin, const void* dY, const void* Bp, void* dX,
+                             int tile_rows, const void* zeros, const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

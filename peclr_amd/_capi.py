@@ -81,6 +81,12 @@ SIGNATURES = {
     "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "peclr_conv_s2_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "peclr_h_pack_bytes": (c_int64, [c_int, c_int]),
+    "peclr_h_pack": (c_int, [_P, c_int, c_int, _P]),
+    "peclr_conv_h_tile_rows": (c_int, [c_int, c_int]),
+    "peclr_gemm_h": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
+    "peclr_conv_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "peclr_conv3x3_s2_dgrad_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
@@ -424,12 +430,12 @@ class _BnBwdFuse(ctypes.Structure):
                 ("relu", c_int), ("partial", c_void_p)]
 
 
-def _bn_bwd_fuse(bn_bwd, m: int, n: int, tile_rows: int, groups: int = 1):
+def _bn_bwd_fuse(bn_bwd, m: int, n: int, tile_rows: int, groups: int = 1, dtype=torch.float32):
     """bn_bwd = (x [.., n] NHWC/2-D fp32 of m rows, save [2, n], ss [2, n], mask or None, relu) of the BatchNorm layer whose
     incoming gradient this GEMM produces -> (struct, partial [2 * n_split, n], n_split); keeps the tensors alive."""
     x, save, ss, mask, relu = bn_bwd
-    if x.dtype != torch.float32 or x.numel() != m * n or not x.is_cuda:
-        raise PeclrHipError(f"bn backward fusion: layer input of {x.numel()} elements for a [{m}, {n}] gradient")
+    if x.dtype != dtype or x.numel() != m * n or not x.is_cuda:
+        raise PeclrHipError(f"bn backward fusion: layer input of {x.numel()} {x.dtype} elements for a {dtype} [{m}, {n}] gradient")
     ns = groups * ((m // groups + tile_rows - 1) // tile_rows)       # (groups: row blocks of each of several equal row sets)
     partial = torch.empty((2 * ns, n), device=x.device, dtype=torch.float32)
     st = _BnBwdFuse(x.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), _ptr(ss), _ptr(mask, torch.int32, "relu mask"), int(relu),
@@ -676,6 +682,165 @@ def gemm_add_half(a: torch.Tensor, b_t: torch.Tensor, addend: Optional[torch.Ten
 
 
 gemm_add_bf16 = gemm_add_half   # round-1 name
+
+
+# ------------------------------------------------------------------ 16-bit convolutions (csrc/conv_h.hip)
+_HALF_IO = {torch.bfloat16: 1, torch.float16: 2}      # PECLR_DTYPE_BF16 / _F16
+_HZEROS = {}
+
+
+def _hzeros(device, dtype):
+    z = _HZEROS.get((device, dtype))
+    if z is None:
+        z = _HZEROS[(device, dtype)] = torch.zeros(64, device=device, dtype=dtype)
+    return z
+
+
+def _half_io(t: torch.Tensor, what: str) -> int:
+    if t.dtype not in _HALF_IO or not t.is_cuda:
+        raise PeclrHipError(f"{what}: a bf16 / fp16 HIP tensor expected, got {t.dtype} on {t.device} (peclr_amd has no CPU path)")
+    return _HALF_IO[t.dtype]
+
+
+class HPlanes:
+    """Weight matrices packed once per optimiser step from the fp32 MASTER weights into 16-bit MFMA-fragment order
+    (peclr_h_pack) for peclr_gemm_h / peclr_conv_h -- the cast autocast performs per forward rides in that launch.
+    `specs`: list of (fp32 2-D HIP tensor W, transposed) exactly as X6Planes; dtype: torch.bfloat16 or torch.float16."""
+
+    def __init__(self, specs, dtype):
+        if not specs:
+            raise PeclrHipError("HPlanes: nothing to pack")
+        if dtype not in _HALF_IO:
+            raise PeclrHipError(f"HPlanes: bf16 or fp16, got {dtype}")
+        dev = specs[0][0].device
+        self.dtype = dtype
+        rows, self.planes, self.shapes, chunk = [], [], [], 0
+        for w, transposed in specs:
+            _ptr(w, what="16-bit pack: fp32 master weight")
+            if w.dim() != 2:
+                raise PeclrHipError("HPlanes: 2-D weight matrices expected")
+            t = int(transposed)
+            n, k = (w.shape[1], w.shape[0]) if t else (w.shape[0], w.shape[1])
+            nbytes = lib().peclr_h_pack_bytes(n, k)
+            if nbytes <= 0:
+                raise PeclrHipError(f"HPlanes: B_t[{n}, {k}] needs n % 64 == 0 and k % 32 == 0")
+            planes = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            rows.append([w.data_ptr(), planes.data_ptr(), n, k, w.stride(0), t, chunk, _HALF_IO[dtype]])
+            chunk += ((n + 127) // 128) * (k // 32)
+            self.planes.append(planes)
+            self.shapes.append((n, k))
+        self._sources = [w for w, _ in specs]
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.count, self.chunks = len(rows), chunk
+        self.nbytes = sum(p.numel() for p in self.planes) + 4 * sum(w.numel() for w in self._sources)
+
+    def pack(self):
+        with _timed("h_pack", self.nbytes, kernel="h_pack_kernel"):
+            rc = lib().peclr_h_pack(self.table.data_ptr(), self.count, self.chunks, _stream())
+        _check(rc, "peclr_h_pack")
+        return self
+
+
+def _h_planes_ok(planes, n, k, what):
+    if planes.dtype != torch.uint8 or planes.numel() != 2 * ((n + 127) // 128 * 128) * k:
+        raise PeclrHipError(f"{what}: planes of {planes.numel()} bytes for B_t[{n}, {k}]")
+
+
+def gemm_h(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[torch.Tensor] = None, tag: str = "gemm_h",
+           tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None, addend_s2=None,
+           addend_mask: Optional[torch.Tensor] = None):
+    """C (16-bit) [M, n] = A[M, K] . B_t^T (+ addend), A / C / addend bf16 or fp16, B_t packed by HPlanes, fp32 accumulation
+    (peclr_gemm_h).  Arguments and returns as `gemm_x6p` (statistics / backward-reduction partials are fp32, in the same
+    layouts; they are sums over the ROUNDED 16-bit outputs)."""
+    m, k = a.shape
+    io = _half_io(a, "gemm_h A")
+    _h_planes_ok(planes, n, k, "gemm_h")
+    add_rows = m if addend_s2 is None else m // 4
+    if not a.is_contiguous() or (addend is not None and (tuple(addend.shape) != (add_rows, n) or addend.dtype != a.dtype or not addend.is_contiguous())):
+        raise PeclrHipError(f"gemm_h: contiguous {a.dtype} A {tuple(a.shape)} / addend expected")
+    if addend_s2 is not None and (addend is None or stat_shift is not None or addend_mask is not None):
+        raise PeclrHipError("gemm_h: addend_s2 needs the compact addend (and has no statistics output / mask)")
+    if addend_mask is not None and (addend is None or stat_shift is not None or n % 32 or addend_mask.dtype != torch.int32
+                                    or addend_mask.numel() != m * (n // 32) or not addend_mask.is_contiguous()):
+        raise PeclrHipError("gemm_h: addend_mask is the int32 [M, n / 32] bit mask of a dense addend (no statistics output)")
+    out = torch.empty((m, n), device=a.device, dtype=a.dtype)
+    partial, ns, fuse = None, 0, None
+    if stat_shift is not None or bn_bwd is not None:
+        tile_rows = tile_rows or lib().peclr_conv_h_tile_rows(m, n)
+    if stat_shift is not None:
+        if stat_shift.numel() != n:
+            raise PeclrHipError(f"gemm_h: stat_shift has {stat_shift.numel()} entries for {n} columns")
+        ns = (m + tile_rows - 1) // tile_rows
+        partial = torch.empty((2 * ns + 1, n), device=a.device, dtype=torch.float32)
+    elif bn_bwd is not None:
+        fuse, partial, ns = _bn_bwd_fuse(bn_bwd, m, n, tile_rows, dtype=a.dtype)
+    add_elems = 0 if addend is None else addend.numel()
+    mask_bytes = 0 if addend_mask is None else 4 * addend_mask.numel()
+    with _timed(tag, 2 * (m * k + m * n + add_elems + (m * n if fuse is not None else 0) + k * n) + mask_bytes, 2 * m * n * k,
+                kernel="conv_h_kernel"):
+        rc = lib().peclr_gemm_h(io, m, n, k, a.data_ptr(), k, _ptr(planes, torch.uint8), out.data_ptr(), n,
+                                addend.data_ptr() if addend is not None else None, n,
+                                int(addend_s2[0]) if addend_s2 is not None else 0, int(addend_s2[1]) if addend_s2 is not None else 0,
+                                _ptr(addend_mask, torch.int32), tile_rows, _ptr(stat_shift),
+                                partial.data_ptr() if stat_shift is not None else None,
+                                ctypes.byref(fuse) if fuse is not None else None, _stream())
+    _check(rc, "peclr_gemm_h")
+    return out if partial is None else (out, partial, ns)
+
+
+def conv_h(x: torch.Tensor, planes: torch.Tensor, cout: int, taps: int = 9, stride: int = 1, flip: bool = False,
+           tag: str = "conv_h", tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None):
+    """3x3 / padding-1 (taps = 9) or 1x1 (taps = 1, stride 2) convolution of an NHWC bf16 / fp16 tensor x [N, Cin, H, W]
+    (peclr_conv_h): forward, or -- flip=True, stride 1 -- the input gradient with x = dY and planes packed with
+    transposed = 9.  Returns y [N, cout, H / stride, W / stride] channels_last (+ (partial, n_split) as gemm_h)."""
+    nb, cin, h, w = x.shape
+    io = _half_io(x, "conv_h x")
+    xp = _nhwc_ptr(x, "conv_h x", x.dtype)
+    _h_planes_ok(planes, cout, taps * cin, "conv_h")
+    if h % stride or w % stride:
+        raise PeclrHipError(f"conv_h: {h} x {w} input with stride {stride}")
+    ho, wo = h // stride, w // stride
+    y = torch.empty((nb, cout, ho, wo), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    m = nb * ho * wo
+    partial, ns, fuse = None, 0, None
+    if stat_shift is not None or bn_bwd is not None:
+        tile_rows = tile_rows or lib().peclr_conv_h_tile_rows(m, cout)
+    if stat_shift is not None:
+        ns = (m + tile_rows - 1) // tile_rows
+        partial = torch.empty((2 * ns + 1, cout), device=x.device, dtype=torch.float32)
+    elif bn_bwd is not None:
+        fuse, partial, ns = _bn_bwd_fuse(bn_bwd, m, cout, tile_rows, dtype=x.dtype)
+    with _timed(tag, 2 * (nb * h * w * cin + m * cout * (2 if fuse is not None else 1) + taps * cin * cout), 2 * m * taps * cin * cout,
+                kernel="conv_h_kernel (3x3)" if taps == 9 else "conv_h_kernel (stride 2)"):
+        rc = lib().peclr_conv_h(io, nb, h, w, cin, cout, taps, stride, xp, _ptr(planes, torch.uint8), y.data_ptr(), int(flip), tile_rows,
+                                _hzeros(x.device, x.dtype).data_ptr(), _ptr(stat_shift),
+                                partial.data_ptr() if stat_shift is not None else None,
+                                ctypes.byref(fuse) if fuse is not None else None, _stream())
+    _check(rc, "peclr_conv_h")
+    return y if partial is None else (y, partial, ns)
+
+
+def conv3x3_s2_dgrad_h(gy: torch.Tensor, planes: torch.Tensor, cin: int, tag: str = "conv3x3_s2_dgrad", tile_rows: int = 0, bn_bwd=None):
+    """Input gradient of a 3x3 / padding-1 / stride-2 convolution, 16-bit: gy [N, Cout, Ho, Wo] channels_last -> dx
+    [N, cin, 2 Ho, 2 Wo] (peclr_conv3x3_s2_dgrad_h: one implicit GEMM per parity class of input pixels)."""
+    nb, cout, ho, wo = gy.shape
+    io = _half_io(gy, "conv3x3_s2_dgrad_h gy")
+    gp = _nhwc_ptr(gy, "conv3x3_s2_dgrad_h gy", gy.dtype)
+    _h_planes_ok(planes, cin, 9 * cout, "conv3x3_s2_dgrad_h")
+    dx = torch.empty((nb, cin, 2 * ho, 2 * wo), device=gy.device, dtype=gy.dtype, memory_format=torch.channels_last)
+    mc = nb * ho * wo
+    partial, ns, fuse = None, 0, None
+    if bn_bwd is not None:
+        tile_rows = tile_rows or lib().peclr_conv_h_tile_rows(mc, cin)
+        fuse, partial, ns = _bn_bwd_fuse(bn_bwd, 4 * mc, cin, tile_rows, groups=4, dtype=gy.dtype)
+    with _timed(tag, 2 * (mc * cout + 4 * mc * cin * (2 if fuse is not None else 1) + 9 * cin * cout), 18 * mc * cin * cout,
+                kernel="conv_h_kernel (3x3)"):
+        rc = lib().peclr_conv3x3_s2_dgrad_h(io, nb, ho, wo, cout, cin, gp, _ptr(planes, torch.uint8), dx.data_ptr(), tile_rows,
+                                            _hzeros(gy.device, gy.dtype).data_ptr(), ctypes.byref(fuse) if fuse is not None else None,
+                                            _stream())
+    _check(rc, "peclr_conv3x3_s2_dgrad_h")
+    return dx if partial is None else (dx, partial, ns)
+
 
 
 # ------------------------------------------------------------------ backbone glue: BN2d (+add) (+ReLU), NHWC

@@ -1,0 +1,189 @@
+"""The 16-bit convolution kernels (csrc/conv_h.hip: peclr_gemm_h, peclr_conv_h, peclr_conv3x3_s2_dgrad_h, peclr_h_pack) against
+float64 on the SAME 16-bit inputs (`-m gpu`).  A result is the fp32-accumulated product rounded once to the 16-bit format, so
+the bar is one rounding of the exact value (2^-8 relative for bf16, 2^-11 for fp16) plus fp32 accumulation noise; the fused
+BatchNorm sums are sums over the stored (rounded) values and are held to float64 sums of exactly those.
+Replaces MIOpen's 16-bit convolutions behind torchvision's Bottleneck (/root/reference/src/models/resnet_model.py:15) under
+`precision: 16` (/root/reference/src/experiments/config/training_config.json:9)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+ULP = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+DTYPES = [torch.bfloat16, torch.float16]
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from peclr_amd import _capi
+
+    _capi.lib()
+    return _capi
+
+
+def close(out, ref, dtype, what=""):
+    """|out - ref| <= one rounding of ref + accumulation noise relative to the tensor's scale."""
+    err = (out.double() - ref).abs()
+    bound = ULP[dtype] * ref.abs() + 2e-6 * float(ref.abs().max()) + 1e-30
+    bad = int((err > 1.01 * bound).sum())
+    assert bad == 0, (what, bad, float((err / bound).max()))
+
+
+def nhwc(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,n,k", [(256, 128, 64), (300, 64, 32), (1000, 192, 96), (4096, 256, 512), (12544, 2048, 512), (777, 320, 1024)])
+def test_gemm_h_matches_float64(capi, dtype, m, n, k):
+    g = torch.Generator(device=DEV).manual_seed(m + n + k)
+    a = torch.randn(m, k, device=DEV, generator=g).to(dtype)
+    w = torch.randn(n, k, device=DEV, generator=g) * 0.05
+    pk = capi.HPlanes([(w, False), (w.t().contiguous(), True)], dtype).pack()
+    ref = a.double() @ w.to(dtype).double().t()
+    for tile_rows in (0, 128, 256):
+        close(capi.gemm_h(a, pk.planes[0], n, tile_rows=tile_rows), ref, dtype, f"plain {tile_rows}")
+    close(capi.gemm_h(a, pk.planes[1], n), ref, dtype, "transposed pack")          # B_t = (W^T)^T
+    # dense addend: rounded once, after the addition
+    d = torch.randn(m, n, device=DEV, generator=g).to(dtype)
+    close(capi.gemm_h(a, pk.planes[0], n, d), ref + d.double(), dtype, "addend")
+    # statistics of the (rounded) output
+    shift = (torch.randn(n, device=DEV, generator=g) * 0.1)
+    y, partial, ns = capi.gemm_h(a, pk.planes[0], n, stat_shift=shift)
+    assert torch.equal(y, capi.gemm_h(a, pk.planes[0], n))
+    yc = y.double() - shift.double()
+    p = partial.double()
+    assert torch.equal(p[2 * ns].float(), shift)
+    got = p[:2 * ns].view(ns, 2, n).sum(0)
+    want = torch.stack([yc.sum(0), (yc * yc).sum(0)])
+    scale = torch.stack([yc.abs().sum(0), (yc * yc).sum(0)]) + 1e-30
+    assert float(((got - want).abs() / scale).max()) <= 2e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,n,k,relu,use_mask", [(3 * 28 * 28, 128, 512, True, False), (1000, 256, 64, True, True), (4096, 64, 256, False, False)])
+def test_gemm_h_batchnorm_backward_reduction(capi, dtype, m, n, k, relu, use_mask):
+    """bn_bwd: the output is the gradient arriving at a BatchNorm(+ReLU) layer with 16-bit input xb: per column sum of dY' and
+    of dY' * xhat over the rounded outputs, ReLU decision recomputed from xb or read from the 1-bit mask."""
+    g = torch.Generator(device=DEV).manual_seed(m + n + k + 1)
+    a = torch.randn(m, k, device=DEV, generator=g).to(dtype)
+    w = torch.randn(n, k, device=DEV, generator=g) * 0.05
+    pk = capi.HPlanes([(w, False)], dtype).pack()
+    xb = torch.randn(m, n, device=DEV, generator=g).to(dtype)
+    mean, invstd = xb.float().mean(0), 1.0 / (xb.float().var(0, unbiased=False) + 1e-5).sqrt()
+    gamma, beta = torch.rand(n, device=DEV, generator=g) + 0.5, torch.randn(n, device=DEV, generator=g) * 0.2
+    ss = torch.stack([gamma * invstd, beta - mean * gamma * invstd]).contiguous()
+    save = torch.stack([mean, invstd]).contiguous()
+    on = torch.addcmul(ss[1], xb.float(), ss[0]) > 0          # the kernel's own fmaf decision
+    mask = None
+    if use_mask:
+        on = torch.rand(m, n, device=DEV, generator=g) > 0.4
+        bits = (on.view(m, n // 32, 32).long() << torch.arange(32, device=DEV)).sum(-1)
+        mask = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32).contiguous()
+    dy, partial, ns = capi.gemm_h(a, pk.planes[0], n, bn_bwd=(xb, save, ss, mask, relu))
+    assert torch.equal(dy, capi.gemm_h(a, pk.planes[0], n))
+    d = dy.double() * (on if relu else torch.ones_like(on))
+    xhat = (xb.double() - mean.double()) * invstd.double()
+    want = torch.stack([d.sum(0), (d * xhat).sum(0)])
+    got = partial.double().view(ns, 2, n).sum(0)
+    bound = torch.stack([d.abs().sum(0), (d * xhat).abs().sum(0)]) + 1e-30
+    assert float(((got - want).abs() / bound).max()) <= (1e-4 if relu and not use_mask else 5e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_h_compact_and_masked_addends(capi, dtype):
+    g = torch.Generator(device=DEV).manual_seed(77)
+    imgs, h, w, n, k = 3, 12, 10, 256, 64
+    m = imgs * h * w
+    a = torch.randn(m, k, device=DEV, generator=g).to(dtype)
+    wt = torch.randn(n, k, device=DEV, generator=g) * 0.05
+    pk = capi.HPlanes([(wt, False)], dtype).pack()
+    half = torch.randn(m // 4, n, device=DEV, generator=g).to(dtype)
+    dense = torch.zeros(imgs, h, w, n, device=DEV, dtype=dtype)
+    dense[:, ::2, ::2] = half.view(imgs, h // 2, w // 2, n)
+    assert torch.equal(capi.gemm_h(a, pk.planes[0], n, half, addend_s2=(h, w)), capi.gemm_h(a, pk.planes[0], n, dense.view(m, n)))
+    d = torch.randn(m, n, device=DEV, generator=g).to(dtype)
+    on = torch.rand(m, n, device=DEV, generator=g) > 0.5
+    bits = (on.view(m, n // 32, 32).long() << torch.arange(32, device=DEV)).sum(-1)
+    mask = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32).contiguous()
+    assert torch.equal(capi.gemm_h(a, pk.planes[0], n, d, addend_mask=mask), capi.gemm_h(a, pk.planes[0], n, d * on))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nb,cin,cout,h,w", [(2, 64, 64, 9, 7), (3, 128, 128, 14, 14), (16, 64, 64, 56, 56), (5, 256, 128, 6, 10), (1, 128, 192, 3, 1)])
+def test_conv_h_3x3_forward_and_input_gradient(capi, dtype, nb, cin, cout, h, w):
+    g = torch.Generator(device=DEV).manual_seed(nb + cin + cout + h)
+    x = nhwc(torch.randn(nb, cin, h, w, device=DEV, generator=g).to(dtype))
+    wt = nhwc(torch.randn(cout, cin, 3, 3, device=DEV, generator=g) * 0.05)
+    w4 = wt.permute(0, 2, 3, 1)
+    pk = capi.HPlanes([(w4.reshape(cout, 9 * cin), False), (w4.reshape(cout * 9, cin), 9)], dtype).pack()
+    wd = wt.to(dtype).double()
+    ref = torch.nn.functional.conv2d(x.double(), wd, padding=1)
+    for tile_rows in (0, 128, 256):
+        y = capi.conv_h(x, pk.planes[0], cout, tile_rows=tile_rows)
+        assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+        close(y, ref, dtype, f"forward {tile_rows}")
+    gy = nhwc(torch.randn(nb, cout, h, w, device=DEV, generator=g).to(dtype))
+    refd = torch.ops.aten.convolution_backward(gy.double(), x.double(), wd, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                               [True, False, False])[0]
+    close(capi.conv_h(gy, pk.planes[1], cin, flip=True), refd, dtype, "input gradient")
+    shift = torch.zeros(cout, device=DEV)
+    y, partial, ns = capi.conv_h(x, pk.planes[0], cout, stat_shift=shift)
+    want = torch.stack([y.double().sum((0, 2, 3)), (y.double() ** 2).sum((0, 2, 3))])
+    got = partial.double()[:2 * ns].view(ns, 2, cout).sum(0)
+    assert float(((got - want).abs() / (torch.stack([y.double().abs().sum((0, 2, 3)), want[1]]) + 1e-30)).max()) <= 2e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nb,cin,cout,ho,wo", [(3, 64, 64, 7, 7), (2, 128, 128, 5, 6), (16, 128, 128, 28, 28), (7, 256, 512, 14, 14), (1, 192, 64, 1, 3)])
+def test_conv_h_stride_2(capi, dtype, nb, cin, cout, ho, wo):
+    """Forward of the 3x3 / padding-1 / stride-2 and of the 1x1 / stride-2 convolution, and the 3x3's input gradient by parity
+    classes (with the BatchNorm backward reduction of the layer dX arrives at)."""
+    g = torch.Generator(device=DEV).manual_seed(cin + cout + ho)
+    x = nhwc(torch.randn(nb, cin, 2 * ho, 2 * wo, device=DEV, generator=g).to(dtype))
+    w3 = nhwc(torch.randn(cout, cin, 3, 3, device=DEV, generator=g) * 0.05)
+    w1 = torch.randn(cout, cin, device=DEV, generator=g) * 0.05
+    w4 = w3.permute(0, 2, 3, 1)
+    pk = capi.HPlanes([(w4.reshape(cout, 9 * cin), False), (w4.reshape(cout * 9, cin), 9), (w1, False)], dtype).pack()
+    close(capi.conv_h(x, pk.planes[0], cout, stride=2), torch.nn.functional.conv2d(x.double(), w3.to(dtype).double(), stride=2, padding=1),
+          dtype, "3x3 / 2")
+    close(capi.conv_h(x, pk.planes[2], cout, taps=1, stride=2),
+          torch.nn.functional.conv2d(x.double(), w1.to(dtype).double().view(cout, cin, 1, 1), stride=2), dtype, "1x1 / 2")
+    gy = nhwc(torch.randn(nb, cout, ho, wo, device=DEV, generator=g).to(dtype))
+    ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), w3.to(dtype).double(), None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                              [True, False, False])[0]
+    for tile_rows in (0, 128, 256):
+        dx = capi.conv3x3_s2_dgrad_h(gy, pk.planes[1], cin, tile_rows=tile_rows)
+        assert dx.shape == x.shape and dx.is_contiguous(memory_format=torch.channels_last)
+        close(dx, ref, dtype, f"s2 dgrad {tile_rows}")
+    if cin % 32 == 0:
+        xb = nhwc(torch.randn(nb, cin, 2 * ho, 2 * wo, device=DEV, generator=g).to(dtype))
+        xf = xb.float()
+        mean, invstd = xf.mean((0, 2, 3)), 1.0 / (xf.var((0, 2, 3), unbiased=False) + 1e-5).sqrt()
+        ss = torch.stack([invstd, -mean * invstd]).contiguous()
+        save = torch.stack([mean, invstd]).contiguous()
+        dx2, partial, ns = capi.conv3x3_s2_dgrad_h(gy, pk.planes[1], cin, bn_bwd=(xb, save, ss, None, True))
+        assert torch.equal(dx2, capi.conv3x3_s2_dgrad_h(gy, pk.planes[1], cin))
+        on = torch.addcmul(ss[1].view(1, -1, 1, 1), xf, ss[0].view(1, -1, 1, 1)) > 0
+        d = dx2.double() * on
+        xhat = (xb.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
+        want = torch.stack([d.sum((0, 2, 3)), (d * xhat).sum((0, 2, 3))])
+        got = partial.double().view(ns, 2, cin).sum(0)
+        bound = torch.stack([d.abs().sum((0, 2, 3)), (d * xhat).abs().sum((0, 2, 3))]) + 1e-30
+        assert float(((got - want).abs() / bound).max()) <= 1e-4
+
+
+@pytest.mark.parametrize("rows,k,n", [(256 * 28 * 28, 512, 128), (256 * 56 * 56, 64, 256)])
+def test_conv_h_kernels_repeat_themselves_bit_for_bit(capi, rows, k, n):
+    """Hand-counted vmcnt waits + raw barriers around two LDS-DMA streams: the same launch thirty times at full shapes."""
+    g = torch.Generator(device=DEV).manual_seed(k + n)
+    a = torch.randn(rows, k, device=DEV, generator=g).to(torch.bfloat16)
+    w = torch.randn(n, k, device=DEV, generator=g) * 0.05
+    pk = capi.HPlanes([(w, False)], torch.bfloat16).pack()
+    shift = torch.zeros(n, device=DEV)
+    y0, p0, _ = capi.gemm_h(a, pk.planes[0], n, stat_shift=shift)
+    close(y0[:4096], a[:4096].double() @ w.to(torch.bfloat16).double().t(), torch.bfloat16)
+    for _ in range(30):
+        y, p, _ = capi.gemm_h(a, pk.planes[0], n, stat_shift=shift)
+        assert torch.equal(y, y0) and torch.equal(p, p0)

@@ -45,16 +45,34 @@ def _rel(a, b):
     return float((a.double() - b).norm() / (b.norm() + 1e-30))
 
 
-def _check(got, want, bars, what):
+def _errors(got, want):
     (y, dx, gp, bufs), (yr, dxr, gpr, bufr) = got, want
-    worst = {"y": float((y.double() - yr).abs().max() / yr.abs().max()), "dx": _rel(dx, dxr),
-             "grad": max(_rel(gp[n], gpr[n]) for n in gpr), "stat": max(float((bufs[n].double() - bufr[n]).abs().max() /
-                                                                              (bufr[n].abs().max() + 1e-30)) for n in bufr)}
-    worst["grad_at"] = max(gpr, key=lambda n: _rel(gp[n], gpr[n]))
     assert set(gp) == set(gpr)
-    for k, bar in bars.items():
-        assert worst[k] <= bar, (what, worst)
-    return worst
+    e = {"y": float((y.double() - yr).abs().max() / yr.abs().max()), "dx": _rel(dx, dxr),
+         "grad": max(_rel(gp[n], gpr[n]) for n in gpr),
+         "stat": max(float((bufs[n].double() - bufr[n]).abs().max() / (bufr[n].abs().max() + 1e-30)) for n in bufr)}
+    e["grad_at"] = max(gpr, key=lambda n: _rel(gp[n], gpr[n]))
+    return e
+
+
+def _check(got, want, stock, floors, what):
+    """In-tree fp32 against float64, CALIBRATED by stock fp32 ops (MIOpen + ATen) against the same float64 run: train-mode
+    BatchNorm over few rows amplifies fp32 round-off (and a ReLU decision within round-off of zero flips a whole gradient
+    element) by an amount that depends on depth and batch, so the bar is 4 x what the stock fp32 path shows on the same
+    data, with a floor.  A dropped term -- a shortcut gradient missing from a reduction, a parity class, stale weight
+    planes -- is O(0.1 ... 1) and two to three orders above either."""
+    mine, theirs = _errors(got, want), _errors(stock, want)
+    for k, floor in floors.items():
+        assert mine[k] <= max(4 * theirs[k], floor), (what, k, mine, theirs)
+    return mine, theirs
+
+
+def _f32_stock_copy(net):
+    from peclr_amd import bn2d as B
+
+    ref = copy.deepcopy(net)
+    B.enable_hip_batchnorm(ref, False)
+    return ref
 
 
 def test_basicblock_input_with_two_consumers_gets_the_whole_batchnorm_reduction():
@@ -71,7 +89,7 @@ def test_basicblock_input_with_two_consumers_gets_the_whole_batchnorm_reduction(
                               resnet.BasicBlock(64, 64, norm_layer=B.FusedBatchNormAct2d),
                               resnet.BasicBlock(64, 128, 2, ds, norm_layer=B.FusedBatchNormAct2d))
     net = net.to(DEV).to(memory_format=torch.channels_last).train()
-    ref = _f64_copy(net)
+    ref, stock = _f64_copy(net), _f32_stock_copy(net)
     B.enable_hip_batchnorm(net)
     g = torch.Generator().manual_seed(3)
     x = _nhwc(torch.randn(32, 64, 32, 32, generator=g) * 0.7 + 0.3)
@@ -88,7 +106,7 @@ def test_basicblock_input_with_two_consumers_gets_the_whole_batchnorm_reduction(
     assert tags.get("conv3x3_dgrad", 0) >= 4 and tags.get("conv3x3_fwd", 0) >= 5, tags     # the in-tree kernels did run
     assert B.end_backward() == 0 or True
     want = _run(ref, x.double(), gy.double())
-    _check(got, want, {"y": 2e-5, "dx": 1e-4, "grad": 2e-4, "stat": 1e-5}, "BasicBlock x 3")
+    print(_check(got, want, _run(stock, x, gy), {"y": 2e-5, "dx": 1e-4, "grad": 2e-4, "stat": 1e-5}, "BasicBlock x 3"))
 
 
 @pytest.mark.parametrize("arch,n,size", [("resnet50", 8, 224), ("resnet18", 16, 128)])
@@ -106,7 +124,7 @@ def test_whole_network_in_tree_equals_float64_stock(arch, n, size):
     net = get_wrapper_model(Config({"resnet_size": arch[len("resnet"):]}), False).to(DEV).to(memory_format=torch.channels_last).train()
     for p in net.final_layer.parameters():          # never receives a gradient (resnet_model.py:27-29)
         p.requires_grad_(False)
-    ref = _f64_copy(net)
+    ref, stock = _f64_copy(net), _f32_stock_copy(net)
     B.enable_hip_batchnorm(net)
     g = torch.Generator().manual_seed(size)
     x = _nhwc(torch.randn(n, 3, size, size, generator=g))
@@ -129,8 +147,8 @@ def test_whole_network_in_tree_equals_float64_stock(arch, n, size):
     want = _run(ref, x.double(), gy.double())
     # fp32 round-off through 53 (20) train-mode BatchNorm layers over few rows; a dropped term (shortcut gradient, one parity
     # class, a stale reduction) is O(0.1 - 1) in the gradients of the layers below it
-    worst = _check(got, want, {"y": 5e-5, "dx": 2e-3, "grad": 2e-3, "stat": 1e-5}, arch)
-    print(f"{arch}: {worst}")
+    worst = _check(got, want, _run(stock, x, gy), {"y": 2e-5, "dx": 2e-4, "grad": 2e-4, "stat": 1e-5}, arch)
+    print(f"{arch}: in-tree {worst[0]} | stock fp32 {worst[1]}")
 
 
 def test_c5_layer1_shape_w112_routes_in_tree_and_matches_float64():
@@ -144,7 +162,7 @@ def test_c5_layer1_shape_w112_routes_in_tree_and_matches_float64():
     net = torch.nn.Sequential(resnet.Bottleneck(256, 64, norm_layer=B.FusedBatchNormAct2d),
                               resnet.Bottleneck(256, 64, norm_layer=B.FusedBatchNormAct2d))
     net = net.to(DEV).to(memory_format=torch.channels_last).train()
-    ref = _f64_copy(net)
+    ref, stock = _f64_copy(net), _f32_stock_copy(net)
     B.enable_hip_batchnorm(net)
     g = torch.Generator().manual_seed(112)
     x = _nhwc(torch.randn(6, 256, 112, 112, generator=g) * 0.7 + 0.3)
@@ -158,7 +176,7 @@ def test_c5_layer1_shape_w112_routes_in_tree_and_matches_float64():
         _capi.EVENT_LOG = None
     assert {"conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "conv1x1_dgrad_add_x6"} <= tags, tags
     want = _run(ref, x.double(), gy.double())
-    _check(got, want, {"y": 2e-5, "dx": 1e-4, "grad": 2e-4, "stat": 1e-5}, "Bottleneck x 2 @112")
+    print(_check(got, want, _run(stock, x, gy), {"y": 2e-5, "dx": 1e-4, "grad": 2e-4, "stat": 1e-5}, "Bottleneck x 2 @112"))
 
 
 def test_graph_captured_after_a_pass_without_optimiser_step_repacks_the_weight_planes():
@@ -216,10 +234,12 @@ def test_graph_captured_after_a_pass_without_optimiser_step_repacks_the_weight_p
         gw_replay = [p.grad.clone() for p in net.parameters()]
         y_eager = step().detach().clone()
         torch.cuda.synchronize()
-    # (BatchNorm running statistics moved once more between the two: they do not enter the train-mode outputs)
-    assert torch.equal(y_replay, y_eager) and torch.equal(dx_replay, x.grad)
+    # (the running means moved once more between the two passes; they are the centre the GEMM epilogues subtract before
+    # summing the statistics, so the two passes round differently in the last bits -- stale planes would be off by 25 %)
+    close = lambda a, b: float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7   # noqa: E731
+    assert close(y_replay, y_eager) and close(dx_replay, x.grad)
     for a, p in zip(gw_replay, net.parameters()):
-        assert torch.equal(a, p.grad)
+        assert close(a, p.grad)
 
 
 @pytest.mark.parametrize("rows,k,n", [(256 * 28 * 28, 512, 128), (256 * 14 * 14, 256, 1024), (256 * 56 * 56, 64, 256),
