@@ -106,6 +106,7 @@ class Routing:
     s2_dgrad_compact: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_S2_DGRAD_COMPACT"))   # the shortcut's compact input gradient
     lazy_residual_grad: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_LAZY_RESIDUAL_GRAD"))   # identity shortcut: (dy, mask) hand-over
     conv16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV16"))                # 16-bit (bf16 / fp16 autocast) convolutions in-tree
+    wgrad16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD16"))              # ... and their weight gradients
     force: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_ROUTE_FORCE", "0"))
 
     # ---- "does the in-tree kernel pay at this shape" (measured on ResNet-50's shapes; the kernels accept far more)
@@ -157,10 +158,10 @@ class X6PackGroup:
 
     def __init__(self, convs):
         self.convs = [c for c in convs if self.member(c)]
-        self._x6 = None
-        self._ptrs = None
-        self._capture = 0           # identity of the hipGraph capture that already holds a pack launch
-        self._stamp = [None] * len(self.convs)
+        # one plane set per operand format: None = the three bf16 planes of the fp32 six-product kernels (peclr_x6_pack_f32);
+        # torch.bfloat16 / torch.float16 = the single 16-bit plane of the autocast kernels (peclr_h_pack), packed from the same
+        # fp32 master weights.  Each: [planes object, parameter addresses, stamps, capture that already holds a pack launch]
+        self._sets = {}
         for i, c in enumerate(self.convs):   # (position kept on the module: a deep copy of the model keeps group and members consistent)
             c.x6_group, c.x6_index = self, i
 
@@ -177,39 +178,45 @@ class X6PackGroup:
     def _key(self, conv):
         return (conv.weight.data_ptr(), conv.weight._version, _capi.WEIGHTS_EPOCH)
 
-    def pack(self):
-        ptrs = [c.weight.data_ptr() for c in self.convs]
-        if self._x6 is None or ptrs != self._ptrs:
-            specs = []
-            for c in self.convs:
-                if c.kernel_size == (3, 3):
-                    # [Cout][3][3][Cin] as it lies in (channels_last) memory: forward B_t = [Cout, 9 Cin]; input gradient
-                    # B_t[ci][tap * Cout + co] = W[co][tap][ci]
-                    w4 = c.weight.detach().permute(0, 2, 3, 1)
-                    if not w4.is_contiguous():
-                        raise _capi.PeclrHipError("X6PackGroup: 3x3 weights must be channels_last (NHWC encoder)")
-                    specs += [(w4.reshape(c.out_channels, 9 * c.in_channels), False), (w4.reshape(c.out_channels * 9, c.in_channels), 9)]
-                else:
-                    w2 = c.weight.detach().reshape(c.out_channels, c.in_channels)
-                    specs += [(w2, False), (w2, True)]
-            self._x6 = _capi.X6Planes(specs)
-            self._ptrs = ptrs
-        self._x6.pack()
-        self._stamp = [self._key(c) for c in self.convs]
+    def _specs(self):
+        specs = []
+        for c in self.convs:
+            if c.kernel_size == (3, 3):
+                # [Cout][3][3][Cin] as it lies in (channels_last) memory: forward B_t = [Cout, 9 Cin]; input gradient
+                # B_t[ci][tap * Cout + co] = W[co][tap][ci]
+                w4 = c.weight.detach().permute(0, 2, 3, 1)
+                if not w4.is_contiguous():
+                    raise _capi.PeclrHipError("X6PackGroup: 3x3 weights must be channels_last (NHWC encoder)")
+                specs += [(w4.reshape(c.out_channels, 9 * c.in_channels), False), (w4.reshape(c.out_channels * 9, c.in_channels), 9)]
+            else:
+                w2 = c.weight.detach().reshape(c.out_channels, c.in_channels)
+                specs += [(w2, False), (w2, True)]
+        return specs
 
-    def planes(self, conv):
-        """(forward planes of W [Cout, Cin], input-gradient planes of W^T), fresh."""
+    def pack(self, dtype=None):
+        st = self._sets.setdefault(dtype, [None, None, [None] * len(self.convs), 0])
+        ptrs = [c.weight.data_ptr() for c in self.convs]
+        if st[0] is None or ptrs != st[1]:
+            st[0] = _capi.X6Planes(self._specs()) if dtype is None else _capi.HPlanes(self._specs(), dtype)
+            st[1] = ptrs
+        st[0].pack()
+        st[2] = [self._key(c) for c in self.convs]
+
+    def planes(self, conv, dtype=None):
+        """(forward planes of W [Cout, Cin], input-gradient planes of W^T), fresh; dtype None: the fp32 kernels' three-plane
+        format, torch.bfloat16 / torch.float16: the 16-bit kernels' format."""
         at = conv.x6_index
         if at >= len(self.convs) or self.convs[at] is not conv:
             raise _capi.PeclrHipError("X6PackGroup: convolution is not a member of its group (call enable_hip_batchnorm again)")
-        stale = self._stamp[at] != self._key(conv)
+        st = self._sets.setdefault(dtype, [None, None, [None] * len(self.convs), 0])
+        stale = st[2][at] != self._key(conv)
         cap = _capi.capture_id()
-        if cap != self._capture:          # a new capture (or back to eager launches): this capture has no pack launch yet
+        if cap != st[3]:          # a new capture (or back to eager launches): this capture has no pack launch yet
             stale = stale or cap != 0
-            self._capture = cap
+            st[3] = cap
         if stale:
-            self.pack()
-        return self._x6.planes[2 * at], self._x6.planes[2 * at + 1]
+            self.pack(dtype)
+        return st[0].planes[2 * at], st[0].planes[2 * at + 1]
 
 
 def _x6_planes(conv):
@@ -219,6 +226,17 @@ def _x6_planes(conv):
     if group is None or not ROUTING.gemm_x6p or not conv.weight.is_cuda or conv.weight.dtype != torch.float32:
         return None
     return group.planes(conv)
+
+
+_HALF = (torch.bfloat16, torch.float16)
+
+
+def _h_ok(conv, x: Tensor) -> bool:
+    """Does `conv` run on the in-tree 16-bit kernels for input `x`?  bf16 / fp16 NHWC activations under the matching autocast,
+    fp32 master weights in a pack group (peclr_h_pack packs them once per step: autocast's per-forward cast is gone)."""
+    return (ROUTING.conv16 and x.is_cuda and x.dtype in _HALF and x.dim() == 4 and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") == x.dtype and getattr(conv, "x6_group", None) is not None
+            and conv.weight.is_cuda and conv.weight.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last))
 
 
 class _BN2dAct(torch.autograd.Function):
@@ -242,8 +260,8 @@ class _BN2dAct(torch.autograd.Function):
         ctx.token = None
         # the residual's gradient is relu'(y) * dy: when its only consumer is the block's entry-gradient GEMM (which then
         # reads dy and the 1-bit mask itself), it is handed over as that pair instead of being written out
-        ctx.lazy_res = bool(lazy_res and mask is not None and x.dtype == torch.float32)
-        if link is not None and x.dtype == torch.float32 and (keep is None or mask is not None):
+        ctx.lazy_res = bool(lazy_res and mask is not None and (x.dtype == torch.float32 or ROUTING.conv16))
+        if link is not None and (x.dtype == torch.float32 or ROUTING.conv16) and (keep is None or mask is not None):
             ctx.token = object()
             link[:] = [x, save, ss, mask, relu, ctx.token]
         return y
@@ -266,7 +284,7 @@ class _BN2dAct(torch.autograd.Function):
         dx, dgamma, dbeta, dres = _capi.bn2d_bwd(dy, x, y, mask, save, ss, training, relu,
                                                  has_res and ctx.needs_input_grad[3] and not lazy, sync_group=ctx.sync_group, pre=pre)
         if lazy:
-            dres = _lazy_grad(("mask", dy, mask), x.shape, x.device)
+            dres = _lazy_grad(("mask", dy, mask), x.shape, x.device, x.dtype)
         elif has_res and dres is None and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dgamma, dbeta, dres, None, None, None, None, None
@@ -690,10 +708,10 @@ _COMPACT = {}
 _NAN_RING = {}
 
 
-def _lazy_grad(payload, shape, device) -> Tensor:
-    ring = _NAN_RING.get(device)
+def _lazy_grad(payload, shape, device, dtype=torch.float32) -> Tensor:
+    ring = _NAN_RING.get((device, dtype))        # (autograd casts a gradient of another dtype: that would materialise the view)
     if ring is None:
-        ring = _NAN_RING[device] = [torch.full((64,), float("nan"), device=device, dtype=torch.float32), 0]
+        ring = _NAN_RING[(device, dtype)] = [torch.full((64,), float("nan"), device=device, dtype=dtype), 0]
     buf, at = ring
     ring[1] = (at + 1) % 64
     sentinel = buf[at:at + 1].view(1, 1, 1, 1).expand(shape)
@@ -702,7 +720,7 @@ def _lazy_grad(payload, shape, device) -> Tensor:
 
 
 def _compact_grad(dc: Tensor, shape) -> Tensor:
-    return _lazy_grad(("s2", dc), shape, dc.device)
+    return _lazy_grad(("s2", dc), shape, dc.device, dc.dtype)
 
 
 def _take_lazy(g: Tensor):
@@ -771,6 +789,98 @@ def _attach_stats(y: Tensor, stats):
     return y
 
 
+def _wgrad_h(gy: Tensor, x: Tensor, conv, stride: int):
+    """d(weight) (fp32, the parameter's layout) of a 16-bit convolution.  In-tree (peclr_wgrad_h: fixed-order slabs, fp32
+    out straight into the master weight's layout) where the kernel takes the shape, else MIOpen's 16-bit weight gradient
+    (+ its cast to fp32)."""
+    w = conv.weight
+    taps = w.shape[2] * w.shape[3]
+    fn = getattr(_capi, "wgrad_h", None)
+    if (fn is not None and ROUTING.wgrad16 and w.is_contiguous(memory_format=torch.channels_last)
+            and _capi.wgrad_h_ok(gy, x, taps, stride)):
+        def run():
+            dw = fn(gy, x, taps, stride)                  # [Cout, taps * Cin] fp32
+            if taps == 9:
+                return dw.view(w.shape[0], 3, 3, w.shape[1]).permute(0, 3, 1, 2)    # = a channels_last [Cout, Cin, 3, 3] tensor
+            return dw.as_strided(w.shape, w.stride())
+        st = _overlap_stream()
+        if st is None:
+            return run()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            g = run()
+        _WgradOverlap.parked.append((w, g, (gy, x)))
+        return None
+    return _conv_wgrad(gy, x, w, conv.stride, conv.padding, w)
+
+
+class _ConvH(torch.autograd.Function):
+    """A residual block's convolution on 16-bit (bf16 / fp16 autocast) NHWC activations, in-tree (csrc/conv_h.hip): 1x1 or
+    3x3 / padding 1, stride 1 or 2 -- forward with the consuming BatchNorm's statistics in the epilogue, input gradient with
+    the producing BatchNorm's backward reduction in the epilogue, both from weight planes packed once per step out of the
+    fp32 master weights.  Same hand-over protocols as the fp32 classes above (`stats`, `link`, compact shortcut gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, conv, stats=None, link=None, compact=False):
+        ctx.save_for_backward(x)
+        ctx.conv, ctx.link, ctx.compact = conv, link, compact
+        planes = conv.x6_group.planes(conv, x.dtype)
+        ctx.planes = planes
+        cout, taps, stride = conv.out_channels, conv.kernel_size[0] * conv.kernel_size[1], conv.stride[0]
+        shift = _stat_shift_for(stats[0], cout) if (stats and ROUTING.bn_stats_in_gemm) else None
+        n, cin, h, w = x.shape
+        if taps == 1 and stride == 1:
+            x2 = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
+            if shift is not None:
+                y, partial, ns = _capi.gemm_h(x2, planes[0], cout, tag="conv1x1_fwd", stat_shift=shift)
+                stats[:] = [partial, ns, shift, stats[0]]
+            else:
+                y = _capi.gemm_h(x2, planes[0], cout, tag="conv1x1_fwd")
+            return y.view(n, h, w, cout).permute(0, 3, 1, 2)
+        tag = "conv3x3_fwd" if stride == 1 else "conv_s2_fwd"
+        if shift is not None:
+            y, partial, ns = _capi.conv_h(x, planes[0], cout, taps=taps, stride=stride, tag=tag, stat_shift=shift)
+            stats[:] = [partial, ns, shift, stats[0]]
+            return y
+        return _capi.conv_h(x, planes[0], cout, taps=taps, stride=stride, tag=tag)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        conv, planes, link = ctx.conv, ctx.planes, ctx.link
+        gy = gy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        n, cin, h, w = x.shape
+        cout, taps, stride = conv.out_channels, conv.kernel_size[0] * conv.kernel_size[1], conv.stride[0]
+        dw = _wgrad_h(gy, x, conv, stride) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            fuse = link[:5] if (link is not None and link[0].shape == x.shape and link[0].dtype == x.dtype and cin % 32 == 0) else None
+            if taps == 1 and stride == 1:
+                gy2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout)
+                out = _capi.gemm_h(gy2, planes[1], cin, tag="conv1x1_dgrad", bn_bwd=fuse)
+            elif taps == 9 and stride == 1:
+                out = _capi.conv_h(gy, planes[1], cin, flip=True, tag="conv3x3_dgrad", bn_bwd=fuse)
+            elif taps == 9:
+                out = _capi.conv3x3_s2_dgrad_h(gy, planes[1], cin, bn_bwd=fuse)
+            elif ctx.compact and not torch.is_anomaly_enabled():
+                # 1x1 / stride-2 shortcut: dY . W over the OUTPUT pixels only; the block's entry-gradient GEMM adds it at the even pixels
+                ho, wo = gy.shape[2:]
+                dc = _capi.gemm_h(gy.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), planes[1], cin, tag="conv_s2_dgrad")
+                return _compact_grad(dc, x.shape), dw, None, None, None, None
+            else:
+                w16 = conv.weight.detach().to(x.dtype)
+                return (torch.ops.aten.convolution_backward(gy, x, w16, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0],
+                        dw, None, None, None, None)
+            if fuse is not None:
+                dx, partial, ns = out
+                _note_bn_bwd(dx, link, partial, ns)
+            else:
+                dx = out
+            if taps == 1:
+                dx = dx.view(n, h, w, cin).permute(0, 3, 1, 2)
+        return dx, dw, None, None, None, None
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d (same parameters / state_dict) that routes through `_Conv2dSplitBackward` while the side-stream
     weight gradients are enabled and the input is a channels_last HIP tensor; the stock op otherwise."""
@@ -785,6 +895,12 @@ class Conv2d(nn.Conv2d):
         may the input-gradient GEMM perform that layer's backward reduction in its epilogue.  A block input (x also feeds
         the shortcut) is not: BasicBlock.conv1 passes False."""
         bn_link = _bn_link_of if sole_consumer else (lambda t: None)
+        if self.hip_gemm and _h_ok(self, x) and (x.shape[2] % self.stride[0] == 0 and x.shape[3] % self.stride[1] == 0):
+            stats = [stats_for] if stats_for is not None else None
+            grad = torch.is_grad_enabled() and x.requires_grad
+            compact = (ROUTING.s2_dgrad_compact and self.kernel_size == (1, 1) and self.stride == (2, 2)
+                       and getattr(x, "_peclr_compact_ok", False) and grad)
+            return _attach_stats(_ConvH.apply(x, self.weight, self, stats, bn_link(x) if grad else None, compact), stats)
         if (self.hip_gemm and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")
                 and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1
                 and self.bias is None and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
@@ -914,6 +1030,55 @@ class _ForkConv1x1(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+class _ForkConvH(torch.autograd.Function):
+    """Bottleneck entry on 16-bit activations, in-tree: (x, W) -> (conv1x1(x, W), x); forward with bn1's statistics, backward
+    dY . W + the shortcut's gradient (dense, compact stride-2 or (dy, mask)) as ONE GEMM with the previous block's bn3
+    backward reduction in its epilogue (peclr_gemm_h)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, conv, stats=None, link=None):
+        ctx.save_for_backward(x)
+        ctx.conv, ctx.link = conv, link
+        planes = ctx.planes = conv.x6_group.planes(conv, x.dtype)
+        n, cin, h, w = x.shape
+        cmid = conv.out_channels
+        x2 = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
+        shift = _stat_shift_for(stats[0], cmid) if (stats and ROUTING.bn_stats_in_gemm) else None
+        if shift is not None:
+            y, partial, ns = _capi.gemm_h(x2, planes[0], cmid, tag="conv1x1_fwd", stat_shift=shift)
+            stats[:] = [partial, ns, shift, stats[0]]
+        else:
+            y = _capi.gemm_h(x2, planes[0], cmid, tag="conv1x1_fwd")
+        return y.view(n, h, w, cmid).permute(0, 3, 1, 2), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, gid):
+        (x,) = ctx.saved_tensors
+        conv, planes, link = ctx.conv, ctx.planes, ctx.link
+        n, cin, h, w = x.shape
+        cmid = conv.out_channels
+        r = n * h * w
+        gy = gy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        dw = _wgrad_h(gy, x, conv, 1) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            a = gy.permute(0, 2, 3, 1).reshape(r, cmid)
+            lazy = _take_lazy(gid)
+            if lazy is None:
+                kw = dict(addend=gid.to(x.dtype).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(r, cin))
+            elif lazy[0] == "s2":
+                kw = dict(addend=lazy[1], addend_s2=(h, w))
+            else:
+                kw = dict(addend=lazy[1].contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(r, cin), addend_mask=lazy[2])
+            if link is not None and link[0].shape == x.shape and link[0].dtype == x.dtype and cin % 32 == 0:
+                out, partial, ns = _capi.gemm_h(a, planes[1], cin, tag="conv1x1_dgrad_add", bn_bwd=link[:5], **kw)
+                _note_bn_bwd(out, link, partial, ns)
+            else:
+                out = _capi.gemm_h(a, planes[1], cin, tag="conv1x1_dgrad_add", **kw)
+            dx = out.view(n, h, w, cin).permute(0, 3, 1, 2)
+        return dx, dw, None, None, None
+
+
 def fork_conv1x1(conv: nn.Conv2d, x: Tensor, stats_for=None):
     """`(conv(x), x)` with the fused input gradient when `conv.hip_fork` is set (enable_hip_batchnorm does
     it for the bottlenecks' first 1x1 convolution) and the activations are channels_last on a HIP device,
@@ -926,6 +1091,11 @@ def fork_conv1x1(conv: nn.Conv2d, x: Tensor, stats_for=None):
           and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and x.requires_grad
           and x.is_contiguous(memory_format=torch.channels_last)
           and conv.weight.shape[0] % 8 == 0 and conv.weight.shape[1] % 8 == 0)
+    if ok and _h_ok(conv, x):
+        stats = [stats_for] if stats_for is not None else None
+        out, identity = _ForkConvH.apply(x, conv.weight, conv, stats, _bn_link_of(x))
+        identity._peclr_compact_ok = True         # its backward takes the shortcut's gradient compact / as (dy, mask)
+        return _attach_stats(out, stats), identity
     if ok:
         stats = [stats_for] if stats_for is not None else None
         flags = []

@@ -18,6 +18,8 @@
 // These GEMMs are bound by HBM and by operand traffic from L2, not by the matrix cores (26 GFLOP per 1x1 product is 10 us
 // at the bf16 peak; its 130 - 510 MB are 20 - 80 us at the achievable 6.3 TB/s): three stages of 24 KiB in flight per
 // workgroup, two workgroups per CU, 256-row tiles so that A is re-read from L2 once per 128 output columns only.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.hpp"
@@ -88,8 +90,11 @@ __device__ __forceinline__ void hdma16(const void* src, unsigned lds_byte_offset
 
 // WM: 32-row MFMA tiles per wave (2 -> 256-row workgroup tile, 1 -> 128); NTL: 32-column tiles per wave (4 -> 128 output
 // columns per workgroup, 2 -> 64); TAPS = 9: 3x3 / padding 1 as an implicit GEMM, K ordered (tap, channel)
-template <typename H, int WM, int TAPS, int NTL>
-__global__ __launch_bounds__(256, 2) void conv_h_kernel(HArgs g) {
+// EP: epilogue features compiled in (registers are allotted for the largest path of an instantiation, and these launches live
+// on workgroups per CU): bit 0 = an addend (dense / compact stride-2 / 1-bit-masked), bit 1 = the BatchNorm backward reduction
+template <typename H, int WM, int TAPS, int NTL, int EP>
+__global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_kernel(HArgs g) {
+    constexpr bool ADD = (EP & 1) != 0, BBF = (EP & 2) != 0;
     constexpr int RM = 32 * WM, TM = 4 * RM;
     constexpr int NA = RM / 16;                          // A DMA instructions per wave and k-step (16 rows x 64 B each)
     constexpr int NBD = NTL == 4 ? 2 : 1;                // B DMA instructions per wave and k-step
@@ -102,7 +107,8 @@ __global__ __launch_bounds__(256, 2) void conv_h_kernel(HArgs g) {
     constexpr int OPS = B0 + NSB * BSZ;
     static_assert(OPS <= 65536, "LDS-DMA targets below 64 KiB");
     constexpr int XE = 68;                               // floats per row of the epilogue's 32 x 64 transpose buffer
-    constexpr int EPI = 4 * 32 * XE * 4 + 4 * 2 * 128 * 4;
+    constexpr int CST = 4 * 32 * XE * 4 + 4 * 2 * 128 * 4;      // BB: [4][128] per-column constants of the BatchNorm layer
+    constexpr int EPI = CST + (BBF ? 4 * 128 * 4 : 0);
     __shared__ __attribute__((aligned(1024))) unsigned char lds[OPS > EPI ? OPS : EPI];   // (the epilogue re-uses the stages)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kh = lane >> 5;
@@ -222,11 +228,32 @@ __global__ __launch_bounds__(256, 2) void conv_h_kernel(HArgs g) {
     issue_a(0);
     issue_b(0);
     if (nk > 1) issue_a(1);
+    // per-column constants of the epilogue, requested behind the first stages (their latency hides behind the main loop): the
+    // statistics' shift of this lane's columns; the BatchNorm backward's mean / invstd / scale / shift of column tid (to LDS
+    // after the loop).  Always NE load instructions, whatever the launch asks for, so that the DMA waits below stay exact
+    // (without statistics they read the first floats of the packed weights)
+    constexpr int NE = NTL + (BBF ? 4 : 0);
+    float kshift[NTL];
+    {
+        const float* sp = g.stat_partial ? g.stat_shift + n0 : reinterpret_cast<const float*>(g.Bp);
+#pragma unroll
+        for (int y = 0; y < NTL; ++y) kshift[y] = sp[y * 32 + i];
+    }
+    float bcst[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BBF) {
+        const int c = n0 + (tid < PNL ? tid : PNL - 1);
+        bcst[0] = g.bb_mean[c]; bcst[1] = g.bb_invstd[c]; bcst[2] = g.bb_ss[c]; bcst[3] = g.bb_ss[g.N + c];
+    }
     // fragment (tile a, k-extent kk) of this lane: row a * 32 + i, chunk 2 kk + kh, at slot chunk ^ ((row >> 2) & 3)
     const int arow = wave * RM + i;
     const int asw = (i >> 2) & 3;
     for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NA) : "memory");
+        // A(t), B(t) have landed: younger than them are at most the NA row DMAs of A(t + 1) -- and, in step 0, the NE
+        // constant loads issued behind the first stages
+        if (t == 0) {
+            if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NA + NE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NE) : "memory");
+        } else if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // publishes A(t), B(t); every wave is done reading step t - 1
         asm volatile("" ::: "memory");
@@ -258,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv_h_kernel(HArgs g) {
         for (int y = 0; y < NTL; ++y)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                if (!g.addend) {                          // (with an addend the rounding happens after the addition, below)
+                if (!ADD || !g.addend) {                  // (with an addend the rounding happens after the addition, below)
                     const unsigned p = H::pack2(acc[a][y][r], acc[a][y][r + 1]);
                     acc[a][y][r] = H::up(p & 0xFFFFu);
                     acc[a][y][r + 1] = H::up(p >> 16);
@@ -266,16 +293,17 @@ __global__ __launch_bounds__(256, 2) void conv_h_kernel(HArgs g) {
             }
     float* sl = reinterpret_cast<float*>(lds + 4 * 32 * XE * 4);      // [wave][2][128] column sums
     if (g.stat_partial) {
+        const bool full = row_block * TM + TM <= g.M;     // (uniform: whole tile inside the matrix)
 #pragma unroll
         for (int y = 0; y < NTL; ++y) {
-            const float k0 = g.stat_shift[n0 + y * 32 + i];
+            const float k0 = kshift[y];
             float sum = 0.f, sq = 0.f;
 #pragma unroll
             for (int a = 0; a < WM; ++a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float d = acc[a][y][r] - k0;
-                    if (m0 + a * 32 + mfma32_row(r, kh) < g.M) { sum += d; sq = fmaf(d, d, sq); }
+                    if (full || m0 + a * 32 + mfma32_row(r, kh) < g.M) { sum += d; sq = fmaf(d, d, sq); }
                 }
             sum += __shfl_xor(sum, 32, 64);
             sq += __shfl_xor(sq, 32, 64);
@@ -290,7 +318,16 @@ __global__ __launch_bounds__(256, 2) void conv_h_kernel(HArgs g) {
                 g.stat_partial[((size_t)row_block * 2 + which) * g.N + n0 + col] = v;
                 if (row_block == 0 && which == 0)
                     g.stat_partial[(size_t)((g.M + TM - 1) / TM) * 2 * g.N + n0 + col] = g.stat_shift[n0 + col];
+
             }
+        }
+        __syncthreads();
+    }
+    float* cst = reinterpret_cast<float*>(lds + CST);                 // [mean | invstd | scale | shift][128]
+    if (BBF && g.bb_partial) {
+        if (tid < PNL) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cst[q * 128 + tid] = bcst[q];
         }
         __syncthreads();
     }
@@ -317,13 +354,14 @@ __global__ __launch_bounds__(256, 2) void conv_h_kernel(HArgs g) {
         float sb[8], sg[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) sb[q] = sg[q] = 0.f;
-        if (g.bb_partial) {
+        if (BBF && g.bb_partial) {
 #pragma unroll
             for (int q = 0; q < 8; q += 4) {
-                *reinterpret_cast<f32x4*>(bmean + q) = *reinterpret_cast<const f32x4*>(g.bb_mean + nt + ec + q);
-                *reinterpret_cast<f32x4*>(binv + q) = *reinterpret_cast<const f32x4*>(g.bb_invstd + nt + ec + q);
-                *reinterpret_cast<f32x4*>(bsc + q) = *reinterpret_cast<const f32x4*>(g.bb_ss + nt + ec + q);
-                *reinterpret_cast<f32x4*>(bsh + q) = *reinterpret_cast<const f32x4*>(g.bb_ss + g.N + nt + ec + q);
+                const int cc = yp * 64 + ec + q;
+                *reinterpret_cast<f32x4*>(bmean + q) = *reinterpret_cast<const f32x4*>(cst + cc);
+                *reinterpret_cast<f32x4*>(binv + q) = *reinterpret_cast<const f32x4*>(cst + 128 + cc);
+                *reinterpret_cast<f32x4*>(bsc + q) = *reinterpret_cast<const f32x4*>(cst + 256 + cc);
+                *reinterpret_cast<f32x4*>(bsh + q) = *reinterpret_cast<const f32x4*>(cst + 384 + cc);
             }
         }
 #pragma unroll
@@ -336,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_h_kernel(HArgs g) {
                 const int m = mt + er + 8 * jj;
                 dv[jj] = make_uint4(0u, 0u, 0u, 0u);
                 ab[jj] = 0u;
-                if (g.addend && m < g.M) {
+                if (ADD && g.addend && m < g.M) {
                     size_t arow = m;
                     bool has = true;
                     if (g.add_h) {
@@ -349,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void conv_h_kernel(HArgs g) {
                         ab[jj] = g.add_mask ? (g.add_mask[(size_t)m * (g.N >> 5) + ((nt + ec) >> 5)] >> (ec & 31)) & 0xFFu : 0xFFu;
                     }
                 }
-                if (g.bb_partial && m < g.M) {
+                if (BBF && g.bb_partial && m < g.M) {
                     xv[jj] = *reinterpret_cast<const uint4*>(g.bb_x + (size_t)om[a][jj] * g.N + nt + ec);
                     mb[jj] = g.bb_mask ? (g.bb_mask[(size_t)om[a][jj] * (g.N >> 5) + ((nt + ec) >> 5)] >> (ec & 31)) & 0xFFu : 0u;
                 }
@@ -368,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv_h_kernel(HArgs g) {
                 unsigned ow[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (g.addend) {
+                    if (ADD && g.addend) {
                         c[2 * q] += (ab[jj] >> (2 * q)) & 1u ? H::up(dw[q] & 0xFFFFu) : 0.f;
                         c[2 * q + 1] += (ab[jj] >> (2 * q + 1)) & 1u ? H::up(dw[q] >> 16) : 0.f;
                     }
@@ -376,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void conv_h_kernel(HArgs g) {
                 }
                 if (m < g.M) {
                     *reinterpret_cast<uint4*>(g.out + (size_t)om[a][jj] * g.ldo + nt + ec) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-                    if (g.bb_partial) {
+                    if (BBF && g.bb_partial) {
                         const unsigned xw[4] = {xv[jj].x, xv[jj].y, xv[jj].z, xv[jj].w};
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
@@ -392,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void conv_h_kernel(HArgs g) {
                 }
             }
         }
-        if (g.bb_partial) {                               // lanes with equal (lane & 7) hold the same eight columns
+        if (BBF && g.bb_partial) {                        // lanes with equal (lane & 7) hold the same eight columns
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
 #pragma unroll
@@ -401,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv_h_kernel(HArgs g) {
             }
         }
     }
-    if (g.bb_partial) {
+    if (BBF && g.bb_partial) {
         __syncthreads();
         const int which = tid >> 7, col = tid & 127;
         if (col < PNL) {
@@ -461,12 +499,11 @@ __global__ __launch_bounds__(256) void h_pack_kernel(const HPackDesc* descs, int
 }
 
 int pick_rows(int M, int N) {
-    // 128-row tiles run three workgroups per CU (768 slots), 256-row tiles two (512 slots) at half the tiles and half the W
-    // traffic: fewer (rounds of slots) x (rows per tile) wins, 256 on a tie (as peclr_gemm_x6p_tile_rows)
-    const long nct = N % HN ? N / 64 : N / HN;
-    const long t128 = (long)((M + 127) / 128) * nct, t256 = (long)((M + 255) / 256) * nct;
-    const long c128 = ((t128 + 767) / 768) * 128, c256 = ((t256 + 511) / 512) * 256;
-    return c128 < c256 ? 128 : 256;
+    // These launches stream: what counts is workgroups per CU (each one's load -> multiply -> store phases are serial), and
+    // 128-row tiles run four per CU (<= 128 VGPRs, 40 KiB of LDS) where 256-row tiles run two.  Probe at ResNet-50's shapes
+    // (tools/exp/conv_h_probe.py): 128 rows win everywhere but one shape (K = 1024 -> N = 256: 40.6 vs 44.5 us).
+    (void)M; (void)N;
+    return 128;
 }
 
 void set_bb(HArgs& g, const peclr_bn_bwd_fuse* bb) {
@@ -476,25 +513,42 @@ void set_bb(HArgs& g, const peclr_bn_bwd_fuse* bb) {
     g.bb_mask = bb ? bb->relu_mask : nullptr; g.bb_relu = bb ? bb->relu : 0; g.bb_partial = bb ? bb->partial : nullptr;
 }
 
-template <typename H>
+template <typename H, int EP>
 int launch_h(const HArgs& g, int tile_rows, int taps, hipStream_t stream) {
     const int nrb = (g.M + tile_rows - 1) / tile_rows;
-    const bool narrow = g.N % HN != 0;
+    static const int force_narrow = getenv("PECLR_CONV_H_NARROW") ? atoi(getenv("PECLR_CONV_H_NARROW")) : 0;   // experiments
+    // the fused entry gradient (addend + BatchNorm reduction: three streams in the epilogue) runs best on 64-column tiles at
+    // four workgroups per CU (probe: 392 -> 315, 218 -> 178, 111 -> 93, 77 -> 68 us at layers 1 - 4)
+    const bool narrow = g.N % HN != 0 || force_narrow == 1 || (EP == 3 && force_narrow != 2);
     const dim3 grid(8 * ((nrb + 7) / 8) * (narrow ? g.N / 64 : g.N / HN), taps == 9 && g.s2d ? 4 : 1);
-#define PECLR_LAUNCH(WM_, TAPS_)                                                                                \
-    do {                                                                                                        \
-        if (narrow) hipLaunchKernelGGL((conv_h_kernel<H, WM_, TAPS_, 2>), grid, dim3(256), 0, stream, g);       \
-        else hipLaunchKernelGGL((conv_h_kernel<H, WM_, TAPS_, 4>), grid, dim3(256), 0, stream, g);              \
+#define PECLR_LAUNCH(WM_, TAPS_)                                                                                    \
+    do {                                                                                                            \
+        if (narrow) hipLaunchKernelGGL((conv_h_kernel<H, WM_, TAPS_, 2, EP>), grid, dim3(256), 0, stream, g);       \
+        else hipLaunchKernelGGL((conv_h_kernel<H, WM_, TAPS_, 4, EP>), grid, dim3(256), 0, stream, g);              \
     } while (0)
-    if (taps == 9) { if (tile_rows == 256) PECLR_LAUNCH(2, 9); else PECLR_LAUNCH(1, 9); }
-    else { if (tile_rows == 256) PECLR_LAUNCH(2, 1); else PECLR_LAUNCH(1, 1); }
+    if constexpr ((EP & 1) == 0) {                        // (an addend only exists for the 1x1 products)
+        if (taps == 9) { if (tile_rows == 256) PECLR_LAUNCH(2, 9); else PECLR_LAUNCH(1, 9); return launch_status(); }
+    }
+    if (taps == 9) return PECLR_ERR_UNSUPPORTED;
+    if (tile_rows == 256) PECLR_LAUNCH(2, 1); else PECLR_LAUNCH(1, 1);
 #undef PECLR_LAUNCH
     return launch_status();
 }
 
+template <typename H>
+int launch_ep(const HArgs& g, int tile_rows, int taps, hipStream_t stream) {
+    const int ep = (g.addend ? 1 : 0) | (g.bb_partial ? 2 : 0);
+    switch (ep) {
+        case 0: return launch_h<H, 0>(g, tile_rows, taps, stream);
+        case 1: return launch_h<H, 1>(g, tile_rows, taps, stream);
+        case 2: return launch_h<H, 2>(g, tile_rows, taps, stream);
+        default: return launch_h<H, 3>(g, tile_rows, taps, stream);
+    }
+}
+
 int dispatch(int dtype, const HArgs& g, int tile_rows, int taps, hipStream_t stream) {
-    if (dtype == PECLR_DTYPE_BF16) return launch_h<BF16>(g, tile_rows, taps, stream);
-    if (dtype == PECLR_DTYPE_F16) return launch_h<F16>(g, tile_rows, taps, stream);
+    if (dtype == PECLR_DTYPE_BF16) return launch_ep<BF16>(g, tile_rows, taps, stream);
+    if (dtype == PECLR_DTYPE_F16) return launch_ep<F16>(g, tile_rows, taps, stream);
     return PECLR_ERR_UNSUPPORTED;
 }
 

@@ -187,3 +187,61 @@ def test_conv_h_kernels_repeat_themselves_bit_for_bit(capi, rows, k, n):
     for _ in range(30):
         y, p, _ = capi.gemm_h(a, pk.planes[0], n, stat_shift=shift)
         assert torch.equal(y, y0) and torch.equal(p, p0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("arch,n,size", [("resnet50", 8, 224), ("resnet18", 8, 128)])
+def test_whole_network_under_autocast_runs_in_tree_and_tracks_float64(dtype, arch, n, size):
+    """The whole encoder under 16-bit autocast with the in-tree convolutions (forward, input gradients, fused entry gradient,
+    statistics / backward reductions in the epilogues, compact + masked shortcut gradients) against the same weights on stock
+    ops in float64, next to stock autocast (MIOpen's 16-bit kernels + the stock BatchNorm ops): the in-tree arm may not be
+    further from float64 than 1.5 x the stock 16-bit arm (+ a floor) -- a dropped term would be O(1)."""
+    import copy
+
+    from peclr_amd import _capi
+    from peclr_amd import bn2d as B
+    from peclr_amd.config import Config
+    from peclr_amd.encoder import get_wrapper_model
+
+    torch.manual_seed(5)
+    net = get_wrapper_model(Config({"resnet_size": arch[len("resnet"):]}), False).to(DEV).to(memory_format=torch.channels_last).train()
+    for p in net.final_layer.parameters():
+        p.requires_grad_(False)
+    ref, stock = copy.deepcopy(net), copy.deepcopy(net)
+    for m in (ref, stock):
+        B.enable_hip_batchnorm(m, False)
+    ref = ref.double()
+    B.enable_hip_batchnorm(net)
+    g = torch.Generator().manual_seed(size)
+    x = nhwc(torch.randn(n, 3, size, size, generator=g).to(DEV))
+    din = 2048 if arch == "resnet50" else 512
+    gy = (torch.randn(n, din, generator=g) / din).to(DEV)
+
+    def run(model, inp, cast):
+        inp = inp.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=dtype, enabled=cast):
+            y = model(inp)
+        y.backward(gy.to(y.dtype))
+        torch.cuda.synchronize()
+        return y.detach().double(), inp.grad.double(), {k: p.grad.double() for k, p in model.named_parameters() if p.grad is not None}
+
+    _capi.EVENT_LOG = {}
+    try:
+        with B.routing(force=True):
+            got = run(net, x, True)
+            left = B.end_backward()
+        tags = {k.split("~")[0]: [e[4] for e in v] for k, v in _capi.EVENT_LOG.items()}
+    finally:
+        _capi.EVENT_LOG = None
+    assert left == 0
+    for t in ("conv1x1_fwd", "conv1x1_dgrad", "conv1x1_dgrad_add", "conv3x3_fwd", "conv3x3_dgrad") if arch == "resnet50" else ("conv3x3_fwd", "conv3x3_dgrad"):
+        assert t in tags and all(k and k.startswith("conv_h_kernel") for k in tags[t]), (t, tags.get(t))
+    assert "h_pack" in tags
+    want, base = run(ref, x.double(), False), run(stock, x, True)
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))   # noqa: E731
+    mine = {"y": rel(got[0], want[0]), "dx": rel(got[1], want[1]), "grad": max(rel(got[2][k], want[2][k]) for k in want[2])}
+    theirs = {"y": rel(base[0], want[0]), "dx": rel(base[1], want[1]), "grad": max(rel(base[2][k], want[2][k]) for k in want[2])}
+    print(f"{arch} {dtype}: in-tree {mine} | stock autocast {theirs}")
+    assert set(got[2]) == set(want[2])
+    for k in mine:
+        assert mine[k] <= 1.5 * theirs[k] + 4 * ULP[dtype], (k, mine, theirs)
