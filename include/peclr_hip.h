@@ -520,6 +520,16 @@ int peclr_conv_h(int dtype, int NB, int H, int W, int Cin, int Cout, int taps, i
                  const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
 int peclr_conv3x3_s2_dgrad_h(int dtype, int NB, int Ho, int Wo, int Cout, int Cin, const void* dY, const void* Bp, void* dX,
                              int tile_rows, const void* zeros, const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
+/* Weight gradient of a 16-bit 1x1 convolution (csrc/wgrad_h.hip): dW[Cout][Cin] (fp32) = dY^T X over the rows of two NHWC
+ * activations -- A = dY [K][lda] (M = Cout), B = X [K][ldb] (N = Cin); stride = 2 (the 1x1 / stride-2 shortcut): A's K rows are
+ * the Ho x Wo output pixels, B holds the 2 Ho x 2 Wo input pixels.  Both operands go global -> LDS by LDS-DMA as they lie in
+ * memory and are transposed by the LDS read (ds_read_b64_tr_b16).  K is split over peclr_wgrad_h_slabs(M, N, K) workgroup rows,
+ * each writing one fp32 slab [M][N]; peclr_slab_reduce_f32 adds them in a fixed order (deterministic; fp32 gradient of the fp32
+ * master weight).  Replaces MIOpen's 16-bit weight gradients (zero-fill + atomic split-K + cast) under resnet_model.py:15.
+ * M, N multiples of 32, lda / ldb multiples of 8; `zeros`: >= 64 bytes of zeros. */
+int peclr_wgrad_h_slabs(int M, int N, int K);
+int peclr_wgrad_h(int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* slabs, int n_slabs,
+                  int stride, int Ho, int Wo, const void* zeros, peclr_stream_t stream);
 
 #ifdef __cplusplus
 }

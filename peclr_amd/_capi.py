@@ -87,6 +87,8 @@ SIGNATURES = {
     "peclr_gemm_h": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
     "peclr_conv_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_conv3x3_s2_dgrad_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
+    "peclr_wgrad_h_slabs": (c_int, [c_int, c_int, c_int]),
+    "peclr_wgrad_h": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_lars_adam_update_f32": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int,
@@ -818,6 +820,35 @@ def conv_h(x: torch.Tensor, planes: torch.Tensor, cout: int, taps: int = 9, stri
                                 ctypes.byref(fuse) if fuse is not None else None, _stream())
     _check(rc, "peclr_conv_h")
     return y if partial is None else (y, partial, ns)
+
+
+def wgrad_h_ok(gy: torch.Tensor, x: torch.Tensor, taps: int, stride: int) -> bool:
+    """Does peclr_wgrad_h take this weight gradient?  (1x1 convolutions, stride 1 or 2, channel counts multiples of 32.)"""
+    cout, cin = gy.shape[1], x.shape[1]
+    return (taps == 1 and stride in (1, 2) and cout % 32 == 0 and cin % 32 == 0 and gy.dtype in _HALF_IO and x.dtype == gy.dtype
+            and gy.shape[0] * gy.shape[2] * gy.shape[3] >= 32
+            and (stride == 1 or (x.shape[2] == 2 * gy.shape[2] and x.shape[3] == 2 * gy.shape[3])))
+
+
+def wgrad_h(gy: torch.Tensor, x: torch.Tensor, taps: int = 1, stride: int = 1, tag: str = "conv1x1_wgrad") -> torch.Tensor:
+    """dW [Cout, Cin] (fp32) of a 1x1 convolution from 16-bit NHWC activations gy [N, Cout, Ho, Wo], x [N, Cin, H, W]
+    (peclr_wgrad_h + peclr_slab_reduce_f32: fixed-order split-K, deterministic)."""
+    if not wgrad_h_ok(gy, x, taps, stride):
+        raise PeclrHipError(f"wgrad_h: unsupported problem gy {tuple(gy.shape)} x {tuple(x.shape)} taps {taps} stride {stride}")
+    io = _half_io(gy, "wgrad_h gy")
+    nb, cout, ho, wo = gy.shape
+    cin = x.shape[1]
+    gp, xp = _nhwc_ptr(gy, "wgrad_h gy", gy.dtype), _nhwc_ptr(x, "wgrad_h x", gy.dtype)
+    k = nb * ho * wo
+    ns = lib().peclr_wgrad_h_slabs(cout, cin, k)
+    if ns < 1:
+        raise PeclrHipError(f"wgrad_h: unsupported shape M={cout} N={cin} K={k}")
+    slabs = torch.empty((ns, cout, cin), device=gy.device, dtype=torch.float32)
+    with _timed(tag, 2 * k * (cout + cin) + 4 * ns * cout * cin, 2 * cout * cin * k, kernel="wgrad_h_kernel"):
+        rc = lib().peclr_wgrad_h(io, cout, cin, k, gp, cout, xp, cin, slabs.data_ptr(), ns, stride, ho, wo,
+                                 _hzeros(gy.device, gy.dtype).data_ptr(), _stream())
+    _check(rc, "peclr_wgrad_h")
+    return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
 
 
 def conv3x3_s2_dgrad_h(gy: torch.Tensor, planes: torch.Tensor, cin: int, tag: str = "conv3x3_s2_dgrad", tile_rows: int = 0, bn_bwd=None):

@@ -1,0 +1,230 @@
+// Weight gradients of the 16-bit (bf16 / fp16 autocast) 1x1 convolutions:  dW[Cout][Cin] (fp32) = sum over pixels r of
+// dY[r][co] * X[r][ci]  -- the contraction runs over the ROWS of two NHWC activations (channels contiguous), so both MFMA
+// operands have to be transposed on their way into the matrix cores.  gfx950 does that in the LDS read:
+//   * both operands stream global -> LDS by LDS-DMA exactly as they lie in memory (16 pixels x 64 bytes per
+//     `global_load_lds_dwordx4`, four lanes per pixel), into the image [32-channel block][pixel][64 B];
+//   * `ds_read_b64_tr_b16` hands lane l of a 16-lane group the elements src[(l >> 2) + 4 j][l & 3], j = 0..3, of the 8-byte
+//     words its sixteen lanes address: with source lane r pointing at pixel k0 + (r >> 2), channels 4 (r & 3) .. + 3, lane
+//     l receives channel l of pixels k0 .. k0 + 3 -- two such reads are the 8-k fragment of v_mfma_f32_32x32x16 (4 consecutive
+//     pixels of a 32-channel block are 256 contiguous bytes: all 64 banks once, conflict-free at any pixel offset);
+// no VGPR staging, no VALU transposes, no ds_write.  fp32 accumulators go to one fp32 slab per K split
+// (peclr_slab_reduce_f32 adds the slabs in a fixed order: deterministic, and the result is the fp32 gradient of the fp32
+// master weight -- MIOpen's 16-bit weight gradients need a zero-fill, atomics and a cast back).
+// These products are HBM-bound (layer1: 800 k pixels x 320 channels in, 64 KiB out): what counts is bytes in flight --
+// two stages of 16 - 20 KiB per workgroup (32 - 40 KiB of LDS), four workgroups per CU (three stages at two to three
+// workgroups per CU measured the same or slower: tools/exp/wgrad_h_probe.py).
+#include "common.hpp"
+
+namespace peclr {
+namespace {
+
+typedef uint16_t h16_t;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int WK = 32;                   // pixels per k-step
+
+struct WArgs {
+    const h16_t* A;                      // dY [K rows][lda], M = Cout channels
+    const h16_t* B;                      // X  [K (or 4 K for stride 2) rows][ldb], N = Cin channels
+    float* slabs;                        // [n_slabs][M][ldc]
+    int M, N, K, lda, ldb, ldc;
+    int kchunk;                          // rows per slab (multiple of WK)
+    int stride, Ho, Wo;                  // stride 2: A's rows are the Ho x Wo output pixels, B's row of output pixel (img, oh, ow)
+                                         // is input pixel (img, 2 oh, 2 ow) of the 2 Ho x 2 Wo image
+    const h16_t* zeros;                  // >= 64 bytes of zeros (rows past K)
+};
+
+__device__ __forceinline__ void wdma16(const void* src, unsigned lds_byte_offset) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(src), "s"(lds_byte_offset) : "memory", "m0");
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x16 wmma(const uint4& a, const uint4& b, f32x16 acc) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+// 8 consecutive k (pixels) of one channel per lane out of the pixel-major image: two transposing reads
+__device__ __forceinline__ uint4 tr_frag(const unsigned char* base) {
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + 4 * 64));     // pixels + 4
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+
+// MB, NB: 32-channel blocks of dY / X per workgroup (MB * NB = 16: every wave a 64 x 64 output block = 2 x 2 MFMA tiles)
+#ifndef PECLR_WGRAD_H_STAGES
+#define PECLR_WGRAD_H_STAGES 2
+#endif
+template <bool F16, int MB, int NB, bool S2>
+__global__ __launch_bounds__(256, 4) void wgrad_h_kernel(WArgs g) {
+    static_assert(MB * NB == 16, "four waves of 64 x 64");
+    constexpr int NS = PECLR_WGRAD_H_STAGES;             // stages (2: 32 - 40 KiB of LDS, four workgroups per CU)
+    constexpr int ASZ = MB * 2048, BSZ = NB * 2048;      // bytes per stage: [block][32 pixels][64 B]
+    constexpr int STAGE = ASZ + BSZ;
+    constexpr int NPA = MB * 2 / 4, NPB = NB * 2 / 4;    // DMA pieces (16 pixels x 64 B of one block) per wave and step
+    constexpr int ND = NPA + NPB;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    typedef __attribute__((address_space(3))) unsigned char* lptr_t;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(lptr_t)lds);
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+
+    const int ntn = (g.N + 32 * NB - 1) / (32 * NB);
+    const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+    const int m0 = tm * 32 * MB, n0 = tn * 32 * NB;
+    const int k_begin = blockIdx.y * g.kchunk;
+    const int k_end = min(g.K, k_begin + g.kchunk);
+    const int nk = (k_end - k_begin + WK - 1) / WK;
+
+    // wave -> its 64 x 64 block of the MB*32 x NB*32 tile: blocks of two 32-channel rows / columns
+    constexpr int WN = NB / 2;                           // waves along N
+    const int wm = wave / WN, wn = wave % WN;            // (MB / 2) x (NB / 2) waves
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // DMA roles: piece q of a stage = (operand, block, 16-pixel half); this wave issues pieces wave_s, wave_s + 4, ...
+    // lane l of a piece: pixel (l >> 2) of the half, 16-byte chunk (l & 3) = channels 8 (l & 3) .. + 7 of the block
+    const int lpix = lane >> 2, lch = 8 * (lane & 3);
+    auto issue = [&](int t) {
+        const unsigned st = lds0 + (t % NS) * STAGE;
+        const int kbase = k_begin + t * WK;
+#pragma unroll
+        for (int q = 0; q < ND; ++q) {
+            const int piece = wave_s + 4 * q;             // 0 .. 2 (MB + NB) - 1
+            const bool isb = piece >= 2 * MB;
+            const int pb = isb ? piece - 2 * MB : piece;
+            const int blk = pb >> 1, half = pb & 1;
+            const int k = kbase + half * 16 + lpix;
+            const h16_t* src;
+            if (!isb) {
+                int ch = m0 + blk * 32;
+                ch = ch < g.M ? ch : g.M - 32;            // (blocks past the matrix re-read the last one; masked at the store)
+                src = g.A + (size_t)k * g.lda + ch + lch;
+            } else {
+                int ch = n0 + blk * 32;
+                ch = ch < g.N ? ch : g.N - 32;
+                size_t row = k;
+                if constexpr (S2) {
+                    const int ow = k % g.Wo, q2 = k / g.Wo, oh = q2 % g.Ho, img = q2 / g.Ho;
+                    row = ((size_t)img * 2 * g.Ho + 2 * oh) * (2 * g.Wo) + 2 * ow;
+                }
+                src = g.B + row * g.ldb + ch + lch;
+            }
+            if (k >= k_end) src = g.zeros + lch;
+            wdma16(src, st + (isb ? ASZ : 0) + blk * 2048 + half * 1024);
+        }
+    };
+
+    for (int t = 0; t < NS - 1 && t < nk; ++t) issue(t);
+    // transposing fragment reads: source-lane role of this lane inside its 16-lane group: pixel (ll >> 2), channels 4 (ll & 3)..;
+    // group gq = lane >> 4: channels 16 (gq & 1) .., pixels 8 (gq >> 1) ..
+    const int ll = lane & 15, gq = lane >> 4;
+    const int foff = (8 * (gq >> 1) + (ll >> 2)) * 64 + (16 * (gq & 1) + 4 * (ll & 3)) * 2;
+    for (int t = 0; t < nk; ++t) {
+        // stage t has landed: younger than it are the stages t + 1 .. t + NS - 2 (those that exist)
+        if (NS > 2 && t + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * ND) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NS - 1 < nk) issue(t + NS - 1);
+        const unsigned char* sa = lds + (t % NS) * STAGE + (2 * wm) * 2048 + foff;
+        const unsigned char* sb = lds + (t % NS) * STAGE + ASZ + (2 * wn) * 2048 + foff;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = tr_frag(sa + a * 2048 + kk * 16 * 64);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = tr_frag(sb + b * 2048 + kk * 16 * 64);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = wmma<F16>(af[a], bf[b], acc[a][b]);
+        }
+    }
+
+    // accumulators -> this K split's slab: lane holds column (lane & 31) of 16 rows per tile: 128-byte row segments
+    float* slab = g.slabs + (size_t)blockIdx.y * g.M * g.ldc;
+    const int i = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int mb = m0 + (2 * wm + a) * 32, nb = n0 + (2 * wn + b) * 32;
+            if (mb < g.M && nb < g.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[(size_t)(mb + mfma32_row(r, kh)) * g.ldc + nb + i] = acc[a][b][r];
+            }
+        }
+}
+
+struct WTile { int mb, nb; };
+WTile pick_tile(int M, int N) {
+    if (M >= 256 && N <= 64) return {8, 2};
+    if (N >= 256 && M <= 64) return {2, 8};
+    if (M <= 64) return {2, 8};
+    if (N <= 64) return {8, 2};
+    return {4, 4};
+}
+
+}  // namespace
+}  // namespace peclr
+
+using namespace peclr;
+
+extern "C" int peclr_wgrad_h_slabs(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || M % 32 || N % 32) return 0;
+    const WTile t = pick_tile(M, N);
+    const long tiles = (long)((M + 32 * t.mb - 1) / (32 * t.mb)) * ((N + 32 * t.nb - 1) / (32 * t.nb));
+    long s = (1024 + tiles - 1) / tiles;                 // four workgroups per CU
+    const long max_s = (K + 8 * WK - 1) / (8 * WK);      // at least eight k-steps per slab
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    const int kchunk = (int)(((K + s - 1) / s + WK - 1) / WK * WK);
+    return (K + kchunk - 1) / kchunk;
+}
+
+// dW slabs of a 1x1 convolution from 16-bit activations: A = dY [K][lda] (M = Cout), B = X [K][ldb] (N = Cin) -- stride 2: X
+// holds the 2 Ho x 2 Wo input pixels and dY's rows are the Ho x Wo output pixels.  slabs: [n_slabs][M][N] fp32.
+extern "C" int peclr_wgrad_h(int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* slabs, int n_slabs,
+                             int stride, int Ho, int Wo, const void* zeros, peclr_stream_t stream) {
+    if (!A || !B || !slabs || !zeros) return PECLR_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0 || n_slabs < 1 || (stride != 1 && stride != 2)) return PECLR_ERR_SHAPE;
+    if (M % 32 || N % 32 || lda % 8 || ldb % 8 || lda < M || ldb < N) return PECLR_ERR_SHAPE;
+    if (stride == 2 && (Ho <= 0 || Wo <= 0 || K % (Ho * Wo))) return PECLR_ERR_SHAPE;
+    if (!aligned16(A) || !aligned16(B) || !aligned16(slabs) || !aligned16(zeros)) return PECLR_ERR_ALIGN;
+    if (n_slabs != peclr_wgrad_h_slabs(M, N, K)) return PECLR_ERR_WORKSPACE;
+    if (dtype != PECLR_DTYPE_BF16 && dtype != PECLR_DTYPE_F16) return PECLR_ERR_UNSUPPORTED;
+    WArgs g;
+    g.A = static_cast<const h16_t*>(A); g.B = static_cast<const h16_t*>(B); g.slabs = slabs;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = N;
+    g.kchunk = ((K + n_slabs - 1) / n_slabs + WK - 1) / WK * WK;
+    g.stride = stride; g.Ho = Ho > 0 ? Ho : 1; g.Wo = Wo > 0 ? Wo : 1; g.zeros = static_cast<const h16_t*>(zeros);
+    const WTile t = pick_tile(M, N);
+    const dim3 grid(((M + 32 * t.mb - 1) / (32 * t.mb)) * ((N + 32 * t.nb - 1) / (32 * t.nb)), n_slabs);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool f16 = dtype == PECLR_DTYPE_F16;
+#define PECLR_LAUNCH(MB_, NB_)                                                                                      \
+    do {                                                                                                            \
+        if (f16) { if (stride == 2) hipLaunchKernelGGL((wgrad_h_kernel<true, MB_, NB_, true>), grid, dim3(256), 0, s, g); \
+                   else hipLaunchKernelGGL((wgrad_h_kernel<true, MB_, NB_, false>), grid, dim3(256), 0, s, g); }     \
+        else { if (stride == 2) hipLaunchKernelGGL((wgrad_h_kernel<false, MB_, NB_, true>), grid, dim3(256), 0, s, g); \
+               else hipLaunchKernelGGL((wgrad_h_kernel<false, MB_, NB_, false>), grid, dim3(256), 0, s, g); }        \
+    } while (0)
+    if (t.mb == 8) PECLR_LAUNCH(8, 2);
+    else if (t.mb == 2) PECLR_LAUNCH(2, 8);
+    else PECLR_LAUNCH(4, 4);
+#undef PECLR_LAUNCH
+    return launch_status();
+}

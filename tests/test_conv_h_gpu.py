@@ -245,3 +245,24 @@ def test_whole_network_under_autocast_runs_in_tree_and_tracks_float64(dtype, arc
     assert set(got[2]) == set(want[2])
     for k in mine:
         assert mine[k] <= 1.5 * theirs[k] + 4 * ULP[dtype], (k, mine, theirs)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nb,cout,cin,h,w,stride", [(2, 64, 64, 9, 7, 1), (3, 256, 64, 14, 14, 1), (4, 64, 256, 16, 12, 1), (5, 128, 512, 10, 10, 1),
+                                                    (16, 512, 128, 28, 28, 1), (2, 96, 160, 5, 4, 1), (3, 512, 256, 14, 14, 2), (2, 2048, 1024, 6, 8, 2),
+                                                    (64, 1024, 256, 14, 14, 1)])
+def test_wgrad_h_matches_float64(capi, dtype, nb, cout, cin, h, w, stride):
+    """peclr_wgrad_h: dW = dY^T X from 16-bit activations (LDS-DMA + transposing LDS reads), fp32 slabs summed in a fixed order,
+    against float64 on the same 16-bit inputs: fp32-accumulation accuracy, and bit-identical when repeated."""
+    g = torch.Generator(device=DEV).manual_seed(nb + cout + cin + h)
+    x = nhwc(torch.randn(nb, cin, h * stride, w * stride, device=DEV, generator=g).to(dtype))
+    gy = nhwc(torch.randn(nb, cout, h, w, device=DEV, generator=g).to(dtype))
+    assert capi.wgrad_h_ok(gy, x, 1, stride)
+    dw = capi.wgrad_h(gy, x, 1, stride)
+    assert dw.shape == (cout, cin) and dw.dtype == torch.float32
+    xs = x[:, :, ::stride, ::stride]
+    ref = torch.einsum("nohw,nihw->oi", gy.double(), xs.double())
+    scale = float(ref.abs().max())
+    assert float((dw.double() - ref).abs().max()) <= 3e-6 * scale * max(1.0, (nb * h * w / 4096) ** 0.5), float((dw.double() - ref).abs().max()) / scale
+    for _ in range(5):
+        assert torch.equal(capi.wgrad_h(gy, x, 1, stride), dw)
