@@ -520,6 +520,15 @@ int peclr_conv_h(int dtype, int NB, int H, int W, int Cin, int Cout, int taps, i
                  const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
 int peclr_conv3x3_s2_dgrad_h(int dtype, int NB, int Ho, int Wo, int Cout, int Cin, const void* dY, const void* Bp, void* dX,
                              int tile_rows, const void* zeros, const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
+/* fp32 weight gradient of the 3x3 / padding-1 / stride-1 convolutions, third generation (csrc/wgrad_x6r.hip): the same six-product
+ * arithmetic as peclr_gemm_x6t_f32 with taps = 9 (fp32 accuracy on the bf16 matrix cores, fixed-order slabs), but every element
+ * of dY and X is split ONCE per workgroup: the bf16 planes lie pixel-major in LDS, X in a ring that each k-step advances, and
+ * ds_read_b64_tr_b16 builds the nine taps' fragments at their slot offsets over a padded linear pixel space (see
+ * peclr_wgrad3_h).  dY [images, H, W, M = Cout], X [images, H, W, N = Cin] fp32 NHWC; M, N multiples of 64, W <= 62; slabs
+ * [peclr_wgrad3_x6r_slabs(...)][M][9 N].  Replaces MIOpen's fp32 3x3 weight gradient behind resnet_model.py:15. */
+int peclr_wgrad3_x6r_slabs(int M, int N, int images, int H, int W);
+int peclr_wgrad3_x6r_f32(int M, int N, int images, int H, int W, const float* dY, const float* X, float* slabs, int n_slabs,
+                         peclr_stream_t stream);
 /* Weight gradient of a 16-bit 1x1 convolution (csrc/wgrad_h.hip): dW[Cout][Cin] (fp32) = dY^T X over the rows of two NHWC
  * activations -- A = dY [K][lda] (M = Cout), B = X [K][ldb] (N = Cin); stride = 2 (the 1x1 / stride-2 shortcut): A's K rows are
  * the Ho x Wo output pixels, B holds the 2 Ho x 2 Wo input pixels.  Both operands go global -> LDS by LDS-DMA as they lie in
@@ -527,6 +536,14 @@ int peclr_conv3x3_s2_dgrad_h(int dtype, int NB, int Ho, int Wo, int Cout, int Ci
  * each writing one fp32 slab [M][N]; peclr_slab_reduce_f32 adds them in a fixed order (deterministic; fp32 gradient of the fp32
  * master weight).  Replaces MIOpen's 16-bit weight gradients (zero-fill + atomic split-K + cast) under resnet_model.py:15.
  * M, N multiples of 32, lda / ldb multiples of 8; `zeros`: >= 64 bytes of zeros. */
+/* ... and of the 16-bit 3x3 / padding-1 / stride-1 convolutions: dW[Cout][3][3][Cin] (the storage of a channels_last weight) from
+ * dY [images, H, W, M = Cout] and X [images, H, W, N = Cin].  The contraction runs over a PADDED linear pixel space (one shared
+ * zero column per row, one shared zero row per image, applied by the addresses the LDS-DMAs fetch), in which tap (a, b) is a
+ * uniform shift: X goes through a ring in LDS once and serves all nine taps by transposing reads at the taps' offsets.
+ * M, N multiples of 64, W <= 62; slabs [peclr_wgrad3_h_slabs(...)][M][9 N] fp32, summed by peclr_slab_reduce_f32. */
+int peclr_wgrad3_h_slabs(int M, int N, int images, int H, int W);
+int peclr_wgrad3_h(int dtype, int M, int N, int images, int H, int W, const void* A, const void* B, float* slabs, int n_slabs,
+                   const void* zeros, peclr_stream_t stream);
 int peclr_wgrad_h_slabs(int M, int N, int K);
 int peclr_wgrad_h(int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* slabs, int n_slabs,
                   int stride, int Ho, int Wo, const void* zeros, peclr_stream_t stream);

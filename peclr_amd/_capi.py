@@ -87,6 +87,10 @@ SIGNATURES = {
     "peclr_gemm_h": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
     "peclr_conv_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_conv3x3_s2_dgrad_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
+    "peclr_wgrad3_x6r_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "peclr_wgrad3_x6r_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P]),
+    "peclr_wgrad3_h_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "peclr_wgrad3_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "peclr_wgrad_h_slabs": (c_int, [c_int, c_int, c_int]),
     "peclr_wgrad_h": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
@@ -662,6 +666,40 @@ def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, stride: i
     return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
 
 
+def wgrad3_x6r_pays(gy: torch.Tensor, x: torch.Tensor) -> bool:
+    """Is the ring kernel the faster one?  Measured at ResNet-50's shapes (tools/exp/wgrad3_probe.py, 2 x 128 views @224): 64
+    channels at 56 x 56: 425 us against the nine-splits kernel's 527; 128 / 256 / 512 channels: 384 / 405 / 461 against 360 / 360 /
+    344 -- there the padded pixel space (+ 7 ... 31 % MFMA work) and the exposed LDS round trips of its one workgroup per CU
+    cost more than the eight saved splits bring."""
+    return wgrad3_x6r_ok(gy, x) and gy.shape[1] <= 64
+
+
+def wgrad3_x6r_ok(gy: torch.Tensor, x: torch.Tensor) -> bool:
+    """Does peclr_wgrad3_x6r_f32 take this 3x3 / stride-1 weight gradient?"""
+    return (gy.dtype == torch.float32 and x.dtype == torch.float32 and x.shape[2:] == gy.shape[2:] and x.shape[3] <= 62
+            and gy.shape[1] % 64 == 0 and x.shape[1] % 64 == 0 and gy.shape[0] * gy.shape[2] * gy.shape[3] >= 1024)
+
+
+def wgrad3_x6r(gy: torch.Tensor, x: torch.Tensor, tag: str = "conv3x3_wgrad") -> torch.Tensor:
+    """dW [Cout, 9 * Cin] (fp32; = the [Cout][3][3][Cin] storage of a channels_last weight) of a 3x3 / padding-1 / stride-1
+    convolution from fp32 NHWC gy [N, Cout, H, W], x [N, Cin, H, W]: every element split once, nine taps by transposing LDS
+    reads of a ring (peclr_wgrad3_x6r_f32 + peclr_slab_reduce_f32: deterministic)."""
+    if not wgrad3_x6r_ok(gy, x):
+        raise PeclrHipError(f"wgrad3_x6r: unsupported problem gy {tuple(gy.shape)} x {tuple(x.shape)}")
+    nb, cout, h, w = gy.shape
+    cin = x.shape[1]
+    gp, xp = _nhwc_ptr(gy, "wgrad3_x6r gy", torch.float32), _nhwc_ptr(x, "wgrad3_x6r x", torch.float32)
+    ns = lib().peclr_wgrad3_x6r_slabs(cout, cin, nb, h, w)
+    if ns < 1:
+        raise PeclrHipError(f"wgrad3_x6r: unsupported shape M={cout} N={cin} {nb} x {h} x {w}")
+    slabs = torch.empty((ns, cout, 9 * cin), device=gy.device, dtype=torch.float32)
+    k = nb * h * w
+    with _timed(tag, 4 * (k * cout + k * cin + ns * cout * 9 * cin), 18 * cout * cin * k, kernel="gemm_x6t_kernel"):
+        rc = lib().peclr_wgrad3_x6r_f32(cout, cin, nb, h, w, gp, xp, slabs.data_ptr(), ns, _stream())
+    _check(rc, "peclr_wgrad3_x6r_f32")
+    return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
+
+
 def gemm_add_half(a: torch.Tensor, b_t: torch.Tensor, addend: Optional[torch.Tensor], tag: str = "gemm_add") -> torch.Tensor:
     """C (16-bit) = A[M,K] . B_t[N,K]^T + addend, row-major contiguous 2-D HIP tensors that are ALL bf16 or ALL
     fp16, fp32 accumulate (peclr_gemm_add_bf16 / peclr_gemm_add_f16)."""
@@ -825,20 +863,34 @@ def conv_h(x: torch.Tensor, planes: torch.Tensor, cout: int, taps: int = 9, stri
 def wgrad_h_ok(gy: torch.Tensor, x: torch.Tensor, taps: int, stride: int) -> bool:
     """Does peclr_wgrad_h take this weight gradient?  (1x1 convolutions, stride 1 or 2, channel counts multiples of 32.)"""
     cout, cin = gy.shape[1], x.shape[1]
+    if taps == 9:       # 3x3 / padding 1 / stride 1 (peclr_wgrad3_h)
+        return (stride == 1 and cout % 64 == 0 and cin % 64 == 0 and gy.dtype in _HALF_IO and x.dtype == gy.dtype
+                and x.shape[2:] == gy.shape[2:] and x.shape[3] <= 62 and gy.shape[0] * gy.shape[2] * gy.shape[3] >= 512)
     return (taps == 1 and stride in (1, 2) and cout % 32 == 0 and cin % 32 == 0 and gy.dtype in _HALF_IO and x.dtype == gy.dtype
             and gy.shape[0] * gy.shape[2] * gy.shape[3] >= 32
             and (stride == 1 or (x.shape[2] == 2 * gy.shape[2] and x.shape[3] == 2 * gy.shape[3])))
 
 
 def wgrad_h(gy: torch.Tensor, x: torch.Tensor, taps: int = 1, stride: int = 1, tag: str = "conv1x1_wgrad") -> torch.Tensor:
-    """dW [Cout, Cin] (fp32) of a 1x1 convolution from 16-bit NHWC activations gy [N, Cout, Ho, Wo], x [N, Cin, H, W]
-    (peclr_wgrad_h + peclr_slab_reduce_f32: fixed-order split-K, deterministic)."""
+    """dW [Cout, taps * Cin] (fp32) of a 1x1 (taps = 1, stride 1 / 2) or 3x3 / padding-1 / stride-1 (taps = 9) convolution from
+    16-bit NHWC activations gy [N, Cout, Ho, Wo], x [N, Cin, H, W] (peclr_wgrad_h / peclr_wgrad3_h + peclr_slab_reduce_f32:
+    fixed-order split-K, deterministic)."""
     if not wgrad_h_ok(gy, x, taps, stride):
         raise PeclrHipError(f"wgrad_h: unsupported problem gy {tuple(gy.shape)} x {tuple(x.shape)} taps {taps} stride {stride}")
     io = _half_io(gy, "wgrad_h gy")
     nb, cout, ho, wo = gy.shape
     cin = x.shape[1]
     gp, xp = _nhwc_ptr(gy, "wgrad_h gy", gy.dtype), _nhwc_ptr(x, "wgrad_h x", gy.dtype)
+    if taps == 9:
+        ns = lib().peclr_wgrad3_h_slabs(cout, cin, nb, ho, wo)
+        if ns < 1:
+            raise PeclrHipError(f"wgrad_h: unsupported 3x3 shape M={cout} N={cin} {nb} x {ho} x {wo}")
+        slabs = torch.empty((ns, cout, 9 * cin), device=gy.device, dtype=torch.float32)
+        with _timed("conv3x3_wgrad" if tag == "conv1x1_wgrad" else tag, 2 * nb * ho * wo * (cout + cin) + 4 * ns * cout * 9 * cin,
+                    18 * cout * cin * nb * ho * wo, kernel="wgrad3_h_kernel"):
+            rc = lib().peclr_wgrad3_h(io, cout, cin, nb, ho, wo, gp, xp, slabs.data_ptr(), ns, _hzeros(gy.device, gy.dtype).data_ptr(), _stream())
+        _check(rc, "peclr_wgrad3_h")
+        return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
     k = nb * ho * wo
     ns = lib().peclr_wgrad_h_slabs(cout, cin, k)
     if ns < 1:

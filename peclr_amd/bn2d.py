@@ -31,6 +31,7 @@ from . import _capi
 # move their running statistics a second time (`_RECOMPUTING`); batch statistics are recomputed and are
 # identical (the kernels are deterministic).
 _RECOMPUTING = False
+_FIRST_RUN = False      # inside the no-grad first run of a checkpointed block (its BatchNorm layers note the statistics' shift)
 
 
 class _CheckpointedBlock(torch.autograd.Function):
@@ -43,8 +44,14 @@ class _CheckpointedBlock(torch.autograd.Function):
         ctx.run = run
         ctx.autocast = (torch.is_autocast_enabled(x.device.type), torch.get_autocast_dtype(x.device.type))
         ctx.save_for_backward(x)
-        with torch.no_grad():
-            return run(x)
+        global _FIRST_RUN
+        was = _FIRST_RUN
+        _FIRST_RUN = True
+        try:
+            with torch.no_grad():
+                return run(x)
+        finally:
+            _FIRST_RUN = was
 
     @staticmethod
     def backward(ctx, dy):
@@ -106,6 +113,7 @@ class Routing:
     s2_dgrad_compact: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_S2_DGRAD_COMPACT"))   # the shortcut's compact input gradient
     lazy_residual_grad: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_LAZY_RESIDUAL_GRAD"))   # identity shortcut: (dy, mask) hand-over
     conv16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV16"))                # 16-bit (bf16 / fp16 autocast) convolutions in-tree
+    wgrad3_ring: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD3_RING"))      # fp32 3x3 weight gradient: one split per element (LDS ring + transposing reads)
     wgrad16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD16"))              # ... and their weight gradients
     force: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_ROUTE_FORCE", "0"))
 
@@ -497,6 +505,14 @@ def _stat_shift_for(bn, cout: int):
         return None
     if _RECOMPUTING and bn.sync_group is not None and getattr(bn, "_sync_shift", None) is not None:
         return bn._sync_shift
+    # activation checkpointing: the re-run centres its sums where the first run did (the running mean has moved in between),
+    # so that it reproduces the first run's statistics bit for bit -- 16-bit activations amplify a last-bit difference in a
+    # scale into whole-ulp differences a few layers on
+    if _FIRST_RUN:
+        bn._ckpt_shift = bn.running_mean.detach().clone()
+        return bn._ckpt_shift
+    if _RECOMPUTING and getattr(bn, "_ckpt_shift", None) is not None:
+        return bn._ckpt_shift
     return bn.running_mean
 
 
@@ -509,6 +525,9 @@ def _wgrad_3x3_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, stride: int
     cout, ho, wo = gy.shape[1:]
 
     def run():
+        if taps == 9 and stride == 1 and ROUTING.wgrad3_ring and (_capi.wgrad3_x6r_pays(gy, x) or (ROUTING.force and _capi.wgrad3_x6r_ok(gy, x))):
+            # every element split once, the nine taps by transposing reads of an LDS ring (peclr_wgrad3_x6r_f32)
+            return _capi.wgrad3_x6r(gy, x).view(cout, 3, 3, cin).permute(0, 3, 1, 2)
         gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
         dw = _capi.gemm_x6t(gy2, x2, taps=taps, hw=(ho, wo), stride=stride, tag="conv3x3_wgrad" if taps == 9 else "conv1x1_wgrad")
         if taps == 9:

@@ -228,3 +228,160 @@ extern "C" int peclr_wgrad_h(int dtype, int M, int N, int K, const void* A, int 
 #undef PECLR_LAUNCH
     return launch_status();
 }
+
+// ---- 3x3 / padding-1 / stride-1 weight gradient, 16-bit:  dW[co][tap][ci] = sum over output pixels r of dY[r][co] * X[r + tap][ci].
+//
+// The contraction runs over a PADDED linear pixel space: every image becomes (H + 1) x (W + 1) slots -- one zero column in
+// front of each row (it is also the zero column behind the previous row) and one zero row in front of each image (also the
+// zero row behind the previous image) -- so that tap (a, b) of dY's slot p is X's slot p + (a - 1)(W + 1) + (b - 1) for EVERY
+// p, borders included: taps that leave the image land on zero slots, dY's own zero slots contribute nothing, and the loop
+// needs no per-(pixel, tap) masks (4 - 30 % more MFMA work, on a product that is bound by LDS fragment reads).  Both
+// operands are written into LDS by LDS-DMA with the padding applied by the ADDRESS each lane fetches (pad slots read a zero
+// line): dY as k-step tiles, X into a RING of slots that every k-step advances by 32 -- each X element is fetched once and
+// serves all nine taps through transposing reads (ds_read_b64_tr_b16) at the taps' slot offsets.
+// Workgroup: 64 output x 64 input channels x 9 taps; wave = 32 x 32 x 9 (nine accumulators).
+namespace peclr {
+namespace {
+
+struct W3Args {
+    const h16_t* A;                      // dY [images * H * W][lda]
+    const h16_t* B;                      // X  [images * H * W][ldb]
+    float* slabs;                        // [n_slabs][M][9 * N]
+    int M, N, lda, ldb;
+    int H, W, images;
+    int P;                               // padded slots: images * (H + 1) * (W + 1)
+    int pchunk;                          // padded slots per slab (multiple of 32)
+    const h16_t* zeros;
+};
+
+// RINGP: slots of the X ring (power of two >= 2 * roundup(W + 2, 32) + 96: the k-step's 32 slots, lead and lag of the taps, and
+// the group in flight; 256 slots = 32 KiB serve W <= 62, i.e. every 3x3 of ResNet at 224 x 224 -- wider rows stay on MIOpen:
+// a 512-slot ring would leave the 64 KiB an LDS-DMA can address)
+template <bool F16, int RINGP>
+__global__ __launch_bounds__(256, 2) void wgrad3_h_kernel(W3Args g) {
+    constexpr int NSA = 3;                               // dY stages (two k-steps of run-ahead)
+    constexpr int ASZ = 2 * 2048;                        // [2 blocks][32 slots][64 B]
+    constexpr int R0 = NSA * ASZ;                        // ring: [2 blocks][RINGP slots][64 B]
+    constexpr int RB = RINGP * 64;
+    static_assert(R0 + 2 * RB <= 65536, "LDS-DMA targets below 64 KiB");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[R0 + 2 * RB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    typedef __attribute__((address_space(3))) unsigned char* lptr_t;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(lptr_t)lds);
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int W1 = g.W + 1, HW1 = (g.H + 1) * W1;
+    const int L = (g.W + 2 + 31) / 32 * 32;              // lead / lag of the ring around the current k-step, in slots
+    const int ntn = g.N / 64;
+    const int m0 = (int)(blockIdx.x / ntn) * 64, n0 = (int)(blockIdx.x % ntn) * 64;
+    const int p_begin = blockIdx.y * g.pchunk;
+    const int p_end = min(g.P, p_begin + g.pchunk);
+    const int nk = (p_end - p_begin + 31) / 32;
+    const int mblk = wave >> 1, nblk = wave & 1;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // DMA: this wave moves piece (block = wave >> 1, 16-slot half = wave & 1) of every 32-slot group; lane = slot (lane >> 2) of
+    // the half, channels 8 (lane & 3) .. + 7 of the block.  A padded slot p is real pixel (img, hh - 1, ww - 1) iff hh, ww >= 1.
+    const int dblk = wave_s >> 1, dhalf = wave_s & 1;
+    const int lch = 8 * (lane & 3);
+    auto src_of = [&](const h16_t* base, int ld, int ch0, int p, bool live) -> const h16_t* {
+        const int img = p / HW1, rem = p - img * HW1, hh = rem / W1, ww = rem - hh * W1;
+        const bool real = live && p >= 0 && img < g.images && hh >= 1 && ww >= 1;
+        const size_t row = ((size_t)img * g.H + (hh - 1)) * g.W + (ww - 1);
+        return real ? base + row * ld + ch0 + lch : g.zeros + lch;
+    };
+    auto issue_a = [&](int t) {                           // dY slots [p_begin + 32 t, + 32) -> stage t % NSA
+        const int p = p_begin + 32 * t + 16 * dhalf + (lane >> 2);
+        wdma16(src_of(g.A, g.lda, m0 + 32 * dblk, p, p < p_end), lds0 + (t % NSA) * ASZ + dblk * 2048 + dhalf * 1024);
+    };
+    auto issue_x = [&](int u) {                           // ring group u: X slots [p_begin - L + 32 u, + 32)
+        const int p = p_begin - L + 32 * u + 16 * dhalf + (lane >> 2);
+        const unsigned slot0 = (unsigned)(32 * u + 16 * dhalf) & (RINGP - 1);
+        wdma16(src_of(g.B, g.ldb, n0 + 32 * dblk, p, true), lds0 + R0 + dblk * RB + slot0 * 64);
+    };
+    // k-step t reads ring groups t .. t + 2 L / 32 (slots [32 t, 32 t + 32 + 2 L) relative to p_begin - L); groups are issued two
+    // steps ahead of their first use
+    const int G0 = 2 * L / 32 + 1;                        // groups the first step needs
+    // order of issue: what step 0 needs -- dY(0), ring groups 0 .. G0 - 1 -- first, then what step 1 adds: ring group G0, dY(1)
+    issue_a(0);
+    for (int u = 0; u < G0; ++u) issue_x(u);
+    if (nk > 1) { issue_x(G0); issue_a(1); }
+    const int ll = lane & 15, gq = lane >> 4;
+    const int fpix = 8 * (gq >> 1) + (ll >> 2);           // slot of this source lane inside a 16-slot k-extent (+ 4 for the second read)
+    const int fch = (16 * (gq & 1) + 4 * (ll & 3)) * 2;
+    for (int t = 0; t < nk; ++t) {
+        // landed: dY(t) and ring groups <= t + G0 - 1; younger than those: dY(t + 1) [1 DMA] and ring group t + G0 [1 DMA]
+        if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < nk) issue_x(t + G0 + 1);              // (the ring slot group it overwrites was last read in step t - 1 at the latest)
+        if (t + 2 < nk) issue_a(t + 2);
+        const unsigned char* sa = lds + (t % NSA) * ASZ + mblk * 2048 + fch;
+        const unsigned char* sx = lds + R0 + nblk * RB + fch;
+        const int xbase = 32 * t + L + fpix;              // ring slot (before the wrap) of this lane's first pixel at shift 0
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const uint4 af = tr_frag(sa + (kk * 16 + fpix) * 64);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int shift = (tap / 3 - 1) * W1 + (tap % 3 - 1);
+                typedef __attribute__((address_space(3))) s16x4* lp;
+                const unsigned s0 = (unsigned)(xbase + kk * 16 + shift) & (RINGP - 1), s1 = (unsigned)(xbase + kk * 16 + shift + 4) & (RINGP - 1);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(sx + s0 * 64));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(sx + s1 * 64));
+                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                acc[tap] = wmma<F16>(af, make_uint4(l2.x, l2.y, h2.x, h2.y), acc[tap]);
+            }
+        }
+    }
+    float* slab = g.slabs + (size_t)blockIdx.y * g.M * 9 * g.N;
+    const int i = lane & 31, kh = lane >> 5;
+    const int mb = m0 + 32 * mblk, nb = n0 + 32 * nblk;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(size_t)(mb + mfma32_row(r, kh)) * (9 * g.N) + tap * g.N + nb + i] = acc[tap][r];
+}
+
+}  // namespace
+}  // namespace peclr
+
+extern "C" int peclr_wgrad3_h_slabs(int M, int N, int images, int H, int W) {
+    if (M <= 0 || N <= 0 || images <= 0 || H <= 0 || W <= 0 || M % 64 || N % 64 || W > 62) return 0;
+    const long P = (long)images * (H + 1) * (W + 1);
+    const long tiles = (long)(M / 64) * (N / 64);
+    long s = (512 + tiles - 1) / tiles;                  // two workgroups per CU
+    const long max_s = (P + 16 * 32 - 1) / (16 * 32);    // at least sixteen k-steps per slab (the ring warm-up is 3 - 9 groups)
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    const long pchunk = ((P + s - 1) / s + 31) / 32 * 32;
+    return (int)((P + pchunk - 1) / pchunk);
+}
+
+// dW slabs [n_slabs][Cout][9 * Cin] of a 3x3 / padding-1 / stride-1 convolution from 16-bit NHWC activations dY [images, H, W,
+// Cout], X [images, H, W, Cin].
+extern "C" int peclr_wgrad3_h(int dtype, int M, int N, int images, int H, int W, const void* A, const void* B, float* slabs,
+                              int n_slabs, const void* zeros, peclr_stream_t stream) {
+    if (!A || !B || !slabs || !zeros) return PECLR_ERR_NULL;
+    if (M <= 0 || N <= 0 || images <= 0 || H <= 0 || W <= 0 || M % 64 || N % 64 || W > 62) return PECLR_ERR_SHAPE;
+    if ((long)images * (H + 1) * (W + 1) > 0x7fffffffL / 2) return PECLR_ERR_SHAPE;
+    if (!aligned16(A) || !aligned16(B) || !aligned16(slabs) || !aligned16(zeros)) return PECLR_ERR_ALIGN;
+    if (n_slabs != peclr_wgrad3_h_slabs(M, N, images, H, W)) return PECLR_ERR_WORKSPACE;
+    if (dtype != PECLR_DTYPE_BF16 && dtype != PECLR_DTYPE_F16) return PECLR_ERR_UNSUPPORTED;
+    W3Args g;
+    g.A = static_cast<const h16_t*>(A); g.B = static_cast<const h16_t*>(B); g.slabs = slabs;
+    g.M = M; g.N = N; g.lda = M; g.ldb = N; g.H = H; g.W = W; g.images = images;
+    g.P = images * (H + 1) * (W + 1);
+    g.pchunk = ((g.P + n_slabs - 1) / n_slabs + 31) / 32 * 32;
+    g.zeros = static_cast<const h16_t*>(zeros);
+    const dim3 grid((M / 64) * (N / 64), n_slabs);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == PECLR_DTYPE_F16) hipLaunchKernelGGL((wgrad3_h_kernel<true, 256>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((wgrad3_h_kernel<false, 256>), grid, dim3(256), 0, s, g);
+    return launch_status();
+}

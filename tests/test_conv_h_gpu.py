@@ -266,3 +266,85 @@ def test_wgrad_h_matches_float64(capi, dtype, nb, cout, cin, h, w, stride):
     assert float((dw.double() - ref).abs().max()) <= 3e-6 * scale * max(1.0, (nb * h * w / 4096) ** 0.5), float((dw.double() - ref).abs().max()) / scale
     for _ in range(5):
         assert torch.equal(capi.wgrad_h(gy, x, 1, stride), dw)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nb,cout,cin,h,w", [(9, 64, 64, 9, 7), (3, 128, 64, 14, 14), (4, 64, 128, 16, 12), (16, 128, 128, 28, 28),
+                                             (1, 64, 64, 30, 62), (7, 256, 256, 14, 14), (32, 512, 512, 7, 7), (2, 64, 64, 56, 56)])
+def test_wgrad3_h_matches_float64(capi, dtype, nb, cout, cin, h, w):
+    """peclr_wgrad3_h: the 3x3 / padding-1 weight gradient from 16-bit activations over the padded linear pixel space (zero
+    columns / rows applied by the DMA addresses, X through an LDS ring, nine taps by transposing reads at their offsets) against
+    float64 on the same inputs, every tap incl. the image borders; bit-identical when repeated."""
+    g = torch.Generator(device=DEV).manual_seed(nb + cout + cin + h + w)
+    x = nhwc(torch.randn(nb, cin, h, w, device=DEV, generator=g).to(dtype))
+    gy = nhwc(torch.randn(nb, cout, h, w, device=DEV, generator=g).to(dtype))
+    assert capi.wgrad_h_ok(gy, x, 9, 1)
+    dw = capi.wgrad_h(gy, x, 9, 1)
+    assert dw.shape == (cout, 9 * cin) and dw.dtype == torch.float32
+    wz = torch.zeros(cout, cin, 3, 3, device=DEV, dtype=torch.float64)
+    ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), wz, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                              [False, True, False])[1]                     # [Cout, Cin, 3, 3]
+    got = dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2).double()
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max()) / scale
+    assert err <= 3e-6 * max(1.0, (nb * h * w / 4096) ** 0.5), err
+    for _ in range(4):
+        assert torch.equal(capi.wgrad_h(gy, x, 9, 1), dw)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,planes,hw,n,stride", [(256, 64, 56, 16, 1), (256, 128, 28, 32, 2), (1024, 256, 14, 64, 1)])
+def test_bottleneck_chain_under_autocast_tracks_float64(dtype, cin, planes, hw, n, stride):
+    """Three chained bottlenecks (the middle one optionally a layer's first block: stride 2 + 1x1 shortcut) under 16-bit
+    autocast on the in-tree kernels -- fused entry gradient with (dY, mask) / compact shortcut addends, BatchNorm statistics and
+    backward reductions in the epilogues, in-tree weight gradients -- against float64 stock ops, calibrated by stock autocast
+    (MIOpen + stock BatchNorm) on the same data.  Thousands of rows per channel: 16-bit noise averages out, so both arms sit at
+    ~1e-2 and a dropped or doubled term (O(0.3 - 1)) stands out."""
+    import copy
+
+    from peclr_amd import _capi
+    from peclr_amd import bn2d as B
+    from peclr_amd import resnet
+
+    torch.manual_seed(3)
+    cout = 4 * planes
+    ds = torch.nn.Sequential(resnet.conv1x1(cin, cout, stride), B.FusedBatchNormAct2d(cout)) if (stride != 1 or cin != cout) else None
+    net = torch.nn.Sequential(resnet.Bottleneck(cin, cin // 4, norm_layer=B.FusedBatchNormAct2d),
+                              resnet.Bottleneck(cin, planes, stride, ds, norm_layer=B.FusedBatchNormAct2d),
+                              resnet.Bottleneck(cout, planes, norm_layer=B.FusedBatchNormAct2d))
+    net = net.to(DEV).to(memory_format=torch.channels_last).train()
+    ref, stock = copy.deepcopy(net), copy.deepcopy(net)
+    for m in (ref, stock):
+        B.enable_hip_batchnorm(m, False)
+    ref = ref.double()
+    B.enable_hip_batchnorm(net)
+    g = torch.Generator().manual_seed(cin + hw)
+    x = nhwc((torch.randn(n, cin, hw, hw, generator=g) * 0.7 + 0.3).to(DEV).to(dtype).float())     # (exactly representable)
+    gy = nhwc(torch.randn(n, cout, hw // stride, hw // stride, generator=g).to(DEV))
+
+    def run(model, inp, cast):
+        inp = inp.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=dtype, enabled=cast):
+            y = model(inp)
+        y.backward(gy.to(y.dtype))
+        torch.cuda.synchronize()
+        return y.detach().double(), inp.grad.double(), {k: p.grad.double() for k, p in model.named_parameters()}
+
+    _capi.EVENT_LOG = {}
+    try:
+        with B.routing(force=True):
+            got = run(net, x.to(dtype), True)       # (inside the encoder the stem hands the blocks 16-bit activations)
+            assert B.end_backward() == 0
+        tags = {k.split("~")[0]: {e[4] for e in v} for k, v in _capi.EVENT_LOG.items()}
+    finally:
+        _capi.EVENT_LOG = None
+    assert tags["conv1x1_dgrad_add"] == {"conv_h_kernel"} and tags["conv1x1_wgrad"] == {"wgrad_h_kernel"}, tags
+    want, base = run(ref, x.double(), False), run(stock, x.to(dtype), True)
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))   # noqa: E731
+    worst = {}
+    for name, (mine, theirs) in {"y": (rel(got[0], want[0]), rel(base[0], want[0])), "dx": (rel(got[1], want[1]), rel(base[1], want[1])),
+                                 **{k: (rel(got[2][k], want[2][k]), rel(base[2][k], want[2][k])) for k in want[2]}}.items():
+        worst[name] = (mine, theirs)
+        assert mine <= 2.0 * theirs + 8 * ULP[dtype], (name, mine, theirs)
+    top = sorted(worst.items(), key=lambda kv: -kv[1][0])[:4]
+    print(f"[{cin}->{planes} @{hw} s{stride} {dtype}] worst (in-tree, stock) vs float64: {top}")

@@ -1419,7 +1419,11 @@ def test_activation_checkpointing_on_the_fused_glue(precision):
     # samples do not bound that noise well, so the bf16 arm is a sanity bar (exactness is established in fp32 and,
     # bit for bit, on CPU: test_activation_checkpointing_is_exact_and_moves_running_stats_once)
     assert abs(l1 - l0) / abs(l0) <= max(4 * loss_noise, 2e-5 if precision == "fp32" else 2e-2), (l0, l1, l2)
-    assert len(g0) == len(g1) and dev(g0, g1) <= max(4 * grad_noise, 1e-3), (dev(g0, g1), grad_noise)
+    # (bf16 since round 4: every convolution is in-tree and deterministic, so grad_noise is ~1e-5 -- but the two arms are not the
+    # same arithmetic: the plain run reduces each block's last BatchNorm backward in the NEXT block's entry-gradient GEMM, the
+    # checkpointed one in a pass of its own: sums in another order, a last-bit difference in dgamma, whole-ulp flips of 16-bit
+    # activations behind it, amplified through 50 layers: 1.7e-2 observed, 2.5e-4 per block pair in tools/exp/h_fuse_ab.py)
+    assert len(g0) == len(g1) and dev(g0, g1) <= max(4 * grad_noise, 1e-3 if precision == "fp32" else 5e-2), (dev(g0, g1), grad_noise)
     for k in b0:
         # moved once (a second update would shift them by ~10 % of the batch statistic); the two runs' forward
         # convolutions agree to ~1e-6, not bit for bit
