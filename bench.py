@@ -184,7 +184,8 @@ def kernel_table(event_log, m_rows, m_global, din, hid, n_params):
         if ran:
             entry["kernel"] = ran[0] if len(ran) == 1 else ran
         x6 = any(k.startswith("gemm_x6") for k in ran) if ran else name in X6_TAGS
-        peak_tf = MFMA_BF16_PEAK_TF / 6.0 if x6 else MFMA_F32_PEAK_TF
+        h16 = bool(ran) and all(k.startswith(("conv_h", "wgrad_h", "wgrad3_h")) for k in ran)     # 16-bit operands: the dense bf16 / fp16 MFMA peak
+        peak_tf = MFMA_BF16_PEAK_TF if h16 else MFMA_BF16_PEAK_TF / 6.0 if x6 else MFMA_F32_PEAK_TF
         if bound is None:
             bound = entry["bound"] = "mfma" if flops / (peak_tf * 1e12) > nbytes / (HBM_PEAK_GBS * 1e9) else "hbm"
         if bound == "hbm":
@@ -822,6 +823,11 @@ def main():
                        # input gradient, weight gradient; the fused entry gradient) runs on the bf16 matrix cores at fp32 ACCURACY: every fp32 operand is split
                        # exactly into three bf16 numbers and six of the nine partial products are accumulated in fp32
                        # (peclr_gemm_x6_f32; error vs float64 <= the v_mfma_f32 kernel's, tests/test_hip_parity.py)
+                       # 16-bit runs: which kernels carry the residual blocks' convolutions
+                       "conv16": (None if args.dtype == "fp32" else
+                                  "in-tree (conv_h / wgrad_h: LDS-DMA operands, fp32 accumulate, fused BatchNorm epilogues, weights packed "
+                                  "from the fp32 masters); MIOpen: 7x7 stem, 3x3 / stride-2 weight gradients"
+                                  if (fused_bn and os.environ.get("PECLR_CONV16", "1") != "0") else "MIOpen"),
                        "fp32_gemm": (("exact 3-way bf16 split, 6 MFMA products, fp32 accumulate (fp32 accuracy)"
                                       if os.environ.get("PECLR_GEMM_X6", "1") != "0" else "v_mfma_f32 / MIOpen fp32")
                                      if args.dtype == "fp32" else None),

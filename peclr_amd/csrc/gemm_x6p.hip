@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     constexpr int NPXM = TM + 2 * 62 + 2;                // HALO: pixels of the patch at most (W <= 62: six 16-byte loads per thread at TM = 256)
     constexpr int PHALF = NPXM * 16, PPLANE = 2 * PHALF, PATCH = 3 * PPLANE;
     constexpr int ZOFF = RAW0 + PATCH;                   // HALO: 16 bytes of zeros
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[HALO ? ZOFF + 64 : PL0 + 4 * WAVE_PL];
+    // + 2.5 KiB at the end: the epilogue's per-column constants ([shift | mean | invstd | scale | shift'][128] floats), fetched
+    // BEFORE the main loop -- in the epilogue each of the four column tiles used to wait a full memory round trip for them
+    constexpr int CST0 = HALO ? ZOFF + 64 : PL0 + 4 * WAVE_PL;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[CST0 + 5 * 128 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kh = lane >> 5;
     typedef __attribute__((address_space(3))) unsigned char* lptr_t;
@@ -164,6 +167,15 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][y][r] = 0.f;
 
+    float* const cst = reinterpret_cast<float*>(lds + CST0);
+    {
+        constexpr int PNL0 = 32 * NTL;
+        const int c = (int)(blockIdx.x / 8 % ((g.N + PNL0 - 1) / PNL0)) * PNL0 + (tid < PNL0 ? tid : PNL0 - 1);
+        float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f, k4 = 0.f;
+        if (g.stat_partial) k0 = g.stat_shift[c];
+        if (g.bb_partial) { k1 = g.bb_mean[c]; k2 = g.bb_invstd[c]; k3 = g.bb_ss[c]; k4 = g.bb_ss[g.N + c]; }
+        if (tid < PNL0) { cst[tid] = k0; cst[128 + tid] = k1; cst[256 + tid] = k2; cst[384 + tid] = k3; cst[512 + tid] = k4; }
+    }
     if constexpr (!HALO) {
     // this lane's fp32 source: rows (lane >> 2) + 16 c of the wave's block, k-quad lane & 3 (rows past M re-read row M - 1)
     const float* asrc[NRAW];
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         float* sl = reinterpret_cast<float*>(lds + 4 * (32 * XEPL * 4));          // [wave][2][128]
 #pragma unroll
         for (int y = 0; y < NTL; ++y) {
-            const float k0 = g.stat_shift[n0 + y * 32 + i];
+            const float k0 = cst[y * 32 + i];
             float sum = 0.f, sq = 0.f;
 #pragma unroll
             for (int a = 0; a < WM; ++a)
@@ -516,10 +528,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         f32x4 bmean, binv, bsc, bsh;
         float sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
         if (g.bb_partial) {
-            bmean = *reinterpret_cast<const f32x4*>(g.bb_mean + nt + ec);
-            binv = *reinterpret_cast<const f32x4*>(g.bb_invstd + nt + ec);
-            bsc = *reinterpret_cast<const f32x4*>(g.bb_ss + nt + ec);
-            bsh = *reinterpret_cast<const f32x4*>(g.bb_ss + g.N + nt + ec);
+            bmean = *reinterpret_cast<const f32x4*>(cst + 128 + y * 32 + ec);
+            binv = *reinterpret_cast<const f32x4*>(cst + 256 + y * 32 + ec);
+            bsc = *reinterpret_cast<const f32x4*>(cst + 384 + y * 32 + ec);
+            bsh = *reinterpret_cast<const f32x4*>(cst + 512 + y * 32 + ec);
         }
 #pragma unroll
         for (int a = 0; a < WM; ++a) {

@@ -32,9 +32,13 @@ import sys
 EXPECT = {
     "gemm_k1_fwd": "gemm_f32_", "gemm_k2_fwd": "gemm_f32_", "gemm_dw1": "gemm_f32_",
     "gemm_dw2": "gemm_f32_", "gemm_da": "gemm_f32_", "gemm_dh": "gemm_f32_",
-    "conv1x1_dgrad_add": "gemm_", "conv1x1_dgrad_add_x6": "gemm_x6", "conv1x1_fwd": "gemm_x6", "conv1x1_dgrad": "gemm_x6",
-    "conv1x1_wgrad": "gemm_x6", "conv3x3_fwd": "gemm_x6p", "conv3x3_dgrad": "gemm_x6p", "conv3x3_wgrad": "gemm_x6w", "gemm_x6p": "gemm_x6p",
-    "gemm_x6t": "gemm_x6t", "conv3x3_x6p": "gemm_x6p", "conv_s2_fwd": "gemm_x6p", "conv_s2_dgrad": "gemm_x6p", "conv3x3_s2_dgrad": "gemm_x6p", "conv_s2_x6p": "gemm_x6p", "wgrad_slab_reduce": "slab_reduce", "x6_pack": "x6_pack_kernel", "bn_relu_fwd": "bn_relu_fwd_kernel", "bn_relu_bwd": "bn_relu_bwd_kernel",
+    # (convolution tags: the fp32 six-product kernels, or -- 16-bit runs -- conv_h / wgrad_h kernels)
+    "conv1x1_dgrad_add": ("gemm_", "conv_h_kernel"), "conv1x1_dgrad_add_x6": "gemm_x6", "conv1x1_fwd": ("gemm_x6", "conv_h_kernel"),
+    "conv1x1_dgrad": ("gemm_x6", "conv_h_kernel"), "conv1x1_wgrad": ("gemm_x6", "wgrad_h_kernel"), "conv3x3_fwd": ("gemm_x6p", "conv_h_kernel"),
+    "conv3x3_dgrad": ("gemm_x6p", "conv_h_kernel"), "conv3x3_wgrad": ("gemm_x6w", "wgrad3_h_kernel", "wgrad_x6r_kernel"), "gemm_x6p": "gemm_x6p",
+    "gemm_x6t": "gemm_x6t", "conv3x3_x6p": "gemm_x6p", "conv_s2_fwd": ("gemm_x6p", "conv_h_kernel"), "conv_s2_dgrad": ("gemm_x6p", "conv_h_kernel"),
+    "conv3x3_s2_dgrad": ("gemm_x6p", "conv_h_kernel"), "conv_s2_x6p": "gemm_x6p", "wgrad_slab_reduce": "slab_reduce", "x6_pack": "x6_pack_kernel",
+    "h_pack": "h_pack_kernel", "bn_relu_fwd": "bn_relu_fwd_kernel", "bn_relu_bwd": "bn_relu_bwd_kernel",
     "align_fwd": "align_fwd_kernel", "align_bwd": "align_bwd_kernel", "ntxent_fwd": "ntxent_kernel<false>",
     "ntxent_bwd": "ntxent_kernel<true>", "ntxent_finalize": "ntxent_finalize_kernel", "slab_reduce": "slab_reduce",
     "lars_sumsq": "sumsq_kernel", "lars_adam_update": "lars_adam_kernel", "bn2d_stats": "bn2d_stats_kernel",
@@ -70,7 +74,7 @@ def align(db, order):
     # launches of ours may follow it, e.g. the FLOP counter's eval-mode forward in bench.py)
     for off in range(len(ours) - len(order) + 1):
         lo = len(ours) - len(order) - off
-        if all(w is None or w in d[1] for w, d in zip(wants, ours[lo:lo + len(order)])):
+        if all(w is None or (any(x in d[1] for x in w) if isinstance(w, tuple) else w in d[1]) for w, d in zip(wants, ours[lo:lo + len(order)])):
             tail = ours[lo:lo + len(order)]
             break
     else:

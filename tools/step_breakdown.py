@@ -18,10 +18,12 @@ CATS = OrderedDict([
     ("MIOpen / CK convolution weight gradient", lambda n: ("igemm_wrw" in n or "conv_bwd_weight" in n or "ConvBwdWeight" in n
                                                           or "kernel_batched_gemm_xdl" in n)),   # CK's wrw-as-batched-GEMM solver
     ("MIOpen zero-fill / cast for split-K weight gradients", lambda n: "SubTensorOp" in n or "fillBufferAligned" in n),
+    ("hand-written: 16-bit convolutions (conv_h: forward, input gradient, fused entry gradient; wgrad_h / wgrad3_h: weight gradients; h_pack)",
+     lambda n: "peclr" in n and any(k in n for k in ("conv_h_kernel", "wgrad_h_kernel", "wgrad3_h_kernel", "h_pack_kernel"))),
     ("hand-written: BatchNorm2d glue (bn2d_*)", lambda n: "peclr" in n and "bn2d_" in n),
     ("hand-written: fused dgrad + residual GEMM (128x128)", lambda n: "peclr" in n and "gemm_f32_nn128" in n),
     ("hand-written: 3x3 convolutions on the bf16 matrix cores (forward, input gradient: gemm_x6p <.., 9>; weight gradient: gemm_x6w)",
-     lambda n: "peclr" in n and ("gemm_x6w" in n or ("gemm_x6p_kernel" in n and ", 9, " in n))),
+     lambda n: "peclr" in n and ("gemm_x6w" in n or "wgrad_x6r" in n or ("gemm_x6p_kernel" in n and ", 9, " in n))),
     ("hand-written: fp32 GEMMs on the bf16 matrix cores (1x1 convolutions, fused dgrad, weight gradients)", lambda n: "peclr" in n and "gemm_x6" in n),
     ("hand-written: head GEMMs / bf16 GEMM", lambda n: "peclr" in n and "gemm_" in n),
     ("hand-written: BN1d+ReLU, align, NT-Xent", lambda n: "peclr" in n and any(k in n for k in ("bn_relu", "align_", "ntxent", "slab_reduce"))),
@@ -42,7 +44,7 @@ def main():
     wants = [EXPECT.get(name.split("::")[-1]) for name in order]
     for off in range(len(ours) - len(order) + 1):
         lo = len(ours) - len(order) - off
-        if all(w is None or w in d[1] for w, d in zip(wants, ours[lo:lo + len(order)])):
+        if all(w is None or (any(x in d[1] for x in w) if isinstance(w, tuple) else w in d[1]) for w, d in zip(wants, ours[lo:lo + len(order)])):
             first, last = ours[lo][0], ours[lo + len(order) - 1][0]
             break
     else:
