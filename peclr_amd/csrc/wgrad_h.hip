@@ -13,6 +13,8 @@
 // These products are HBM-bound (layer1: 800 k pixels x 320 channels in, 64 KiB out): what counts is bytes in flight --
 // two stages of 16 - 20 KiB per workgroup (32 - 40 KiB of LDS), four workgroups per CU (three stages at two to three
 // workgroups per CU measured the same or slower: tools/exp/wgrad_h_probe.py).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace peclr {
@@ -187,7 +189,8 @@ extern "C" int peclr_wgrad_h_slabs(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || M % 32 || N % 32) return 0;
     const WTile t = pick_tile(M, N);
     const long tiles = (long)((M + 32 * t.mb - 1) / (32 * t.mb)) * ((N + 32 * t.nb - 1) / (32 * t.nb));
-    long s = (1024 + tiles - 1) / tiles;                 // four workgroups per CU
+    static const long target = getenv("PECLR_WGRAD_H_WGS") ? atol(getenv("PECLR_WGRAD_H_WGS")) : 512;   // workgroups per launch (probe: 512 beats 1024 by 15 - 25 % -- half the slab traffic -- and 256 by 5 - 40 %)
+    long s = (target + tiles - 1) / tiles;
     const long max_s = (K + 8 * WK - 1) / (8 * WK);      // at least eight k-steps per slab
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
