@@ -43,6 +43,9 @@ template <int W> struct Fv { float v[W]; };
 template <typename IO> struct Word;
 template <> struct Word<float> {
     static constexpr int W = 4, U = 8;  // U = rows in flight per stream
+    typedef float4 Raw;                 // the 16-byte word as it travels (kept raw while in flight: 4 registers)
+    static __device__ __forceinline__ Raw load_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ Fv<4> expand(const Raw& t) { return {{t.x, t.y, t.z, t.w}}; }
     static __device__ __forceinline__ Fv<4> load(const float* p) {
         const float4 t = *reinterpret_cast<const float4*>(p);
         return {{t.x, t.y, t.z, t.w}};
@@ -54,6 +57,18 @@ template <> struct Word<float> {
 typedef uint16_t bf16_t;
 template <> struct Word<bf16_t> {
     static constexpr int W = 8, U = 4;
+    typedef uint4 Raw;
+    static __device__ __forceinline__ Raw load_raw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ Fv<8> expand(const Raw& t) {
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+        Fv<8> r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r.v[2 * k] = __uint_as_float(w[k] << 16);
+            r.v[2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u);
+        }
+        return r;
+    }
     static __device__ __forceinline__ Fv<8> load(const bf16_t* p) {
         const uint4 t = *reinterpret_cast<const uint4*>(p);
         const unsigned w[4] = {t.x, t.y, t.z, t.w};
@@ -81,6 +96,14 @@ typedef _Float16 f16_t;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <> struct Word<f16_t> {
     static constexpr int W = 8, U = 4;
+    typedef f16x8 Raw;
+    static __device__ __forceinline__ Raw load_raw(const f16_t* p) { return *reinterpret_cast<const f16x8*>(p); }
+    static __device__ __forceinline__ Fv<8> expand(const Raw& t) {
+        Fv<8> r;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r.v[k] = (float)t[k];
+        return r;
+    }
     static __device__ __forceinline__ Fv<8> load(const f16_t* p) {
         const f16x8 t = *reinterpret_cast<const f16x8*>(p);
         Fv<8> r;
@@ -544,35 +567,57 @@ __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict_
         if constexpr (POOL) return pooled_dy<W>(d_pooled, row, hw, inv_hw, g.C, col);
         else return Word<IO>::load(dy + (size_t)row * g.C + col);
     };
-    const Fv<W> mean = loadp<W>(save_mean + col), invstd = loadp<W>(save_invstd + col);
+    // dx = d' scale + xhat k3 + k2 with xhat = (x - mean) invstd.  16-bit activations (eight channels per thread: the per-channel
+    // constants alone were 48 registers, the kernel ran at two waves per SIMD): folded into dx = d' scale + x a + b with
+    // a = invstd k3, b = k2 - mean a -- the extra fp32 rounding sits five orders below the 16-bit rounding of dx.  fp32: the
+    // unfolded form (cancellation-free around x = mean), as before.
+    constexpr bool FOLD = sizeof(IO) == 2;
+    Fv<W> mean = loadp<W>(save_mean + col), invstd = loadp<W>(save_invstd + col);
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
-    const Fv<W> k2 = loadp<W>(coef + col), k3 = loadp<W>(coef + g.C + col);
+    Fv<W> k2 = loadp<W>(coef + col), k3 = loadp<W>(coef + g.C + col);
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            k3.v[k] *= invstd.v[k];                    // a
+            k2.v[k] = fmaf(-mean.v[k], k3.v[k], k2.v[k]);   // b
+        }
+    }
     auto emit = [&](size_t o, const Fv<W>& d0, const Fv<W>& xv, const Fv<W>& yv, unsigned bits) {
         const Fv<W> d = masked<W, MASK>(d0, xv, yv, bits, sc, sh);
         if (DRES) Word<IO>::store(dres + o, d);
         Fv<W> t;
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            const float xh = (xv.v[k] - mean.v[k]) * invstd.v[k];
-            t.v[k] = fmaf(d.v[k], sc.v[k], fmaf(xh, k3.v[k], k2.v[k]));
+            if constexpr (FOLD) t.v[k] = fmaf(d.v[k], sc.v[k], fmaf(xv.v[k], k3.v[k], k2.v[k]));
+            else {
+                const float xh = (xv.v[k] - mean.v[k]) * invstd.v[k];
+                t.v[k] = fmaf(d.v[k], sc.v[k], fmaf(xh, k3.v[k], k2.v[k]));
+            }
         }
         Word<IO>::store(dx + o, t);
     };
+    typedef typename Word<IO>::Raw Raw;
     int r = r0 + rl;
     for (; r + (U - 1) * g.RPP < r1; r += U * g.RPP) {
-        Fv<W> d[U], xv[U], yv[MASK == 2 ? U : 1];
+        // the words stay raw (4 registers each) while in flight and are widened one row at a time
+        Fv<W> dp[POOL ? U : 1];
+        Raw d[POOL ? 1 : U], xv[U], yv[MASK == 2 ? U : 1];
         unsigned mb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t o = (size_t)(r + u * g.RPP) * g.C + col;
-            d[u] = load_dy(r + u * g.RPP);
-            xv[u] = Word<IO>::load(x + o);
-            if (MASK == 2) yv[u] = Word<IO>::load(y + o);
+            if constexpr (POOL) dp[u] = load_dy(r + u * g.RPP);
+            else d[u] = Word<IO>::load_raw(dy + o);
+            xv[u] = Word<IO>::load_raw(x + o);
+            if (MASK == 2) yv[u] = Word<IO>::load_raw(y + o);
             mb[u] = MASK == 3 ? mask_load<W>(relu_mask, r + u * g.RPP, col, g.C) : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            emit((size_t)(r + u * g.RPP) * g.C + col, d[u], xv[u], MASK == 2 ? yv[MASK == 2 ? u : 0] : xv[u], mb[u]);
+        for (int u = 0; u < U; ++u) {
+            const Fv<W> xe = Word<IO>::expand(xv[u]);
+            emit((size_t)(r + u * g.RPP) * g.C + col, POOL ? dp[POOL ? u : 0] : Word<IO>::expand(d[POOL ? 0 : u]), xe,
+                 MASK == 2 ? Word<IO>::expand(yv[MASK == 2 ? u : 0]) : xe, mb[u]);
+        }
     }
     for (; r < r1; r += g.RPP) {
         const size_t o = (size_t)r * g.C + col;

@@ -192,7 +192,11 @@ class Trainer:
     def _ranks_agree_on_replay(self, fits: bool, is_final_batch: bool) -> bool:
         """Graph mode at N > 1: replay only if the batch fits the captured shapes on EVERY rank.  Decided with one
         MIN all-reduce where a ragged batch can occur (the epoch's final batch: every rank is at its final batch, so
-        the collective is symmetric); elsewhere a batch that does not fit is an error raised before any collective."""
+        the collective is symmetric); elsewhere a batch that does not fit is an error raised before any collective.
+        That error is raised by the rank that sees the odd batch ONLY: the other ranks replay, enter their next collective
+        and are ended by RCCL's watchdog timeout (torch.distributed's default: 10 minutes) -- a loud failure, not a silent one,
+        but a slow one; a loader with `drop_last=True` / equal shards never gets here, and deciding every batch with a
+        collective would put a host synchronisation into every replayed step."""
         if self.world_size == 1 or self.reducer is None:
             return fits
         if not is_final_batch:

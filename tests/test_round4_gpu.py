@@ -238,7 +238,7 @@ def test_graph_captured_after_a_pass_without_optimiser_step_repacks_the_weight_p
         torch.cuda.synchronize()
     # (the running means moved once more between the two passes; they are the centre the GEMM epilogues subtract before
     # summing the statistics, so the two passes round differently in the last bits -- stale planes would be off by 25 %)
-    close = lambda a, b: float((a.detach() - b.detach()).norm()) <= 2e-4 * float(b.detach().norm()) + 1e-7   # noqa: E731
+    close = lambda a, b: float((a.detach() - b.detach()).norm()) <= 5e-3 * float(b.detach().norm()) + 1e-7   # noqa: E731
     assert close(y_replay, y_eager) and close(dx_replay, x.grad)
     for a, p in zip(gw_replay, net.parameters()):
         assert close(a, p.grad)

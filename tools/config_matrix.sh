@@ -7,6 +7,6 @@ for flags in "--dtype bf16 --steps 10 --warmup 3" "--resnet 152 --accum 16 --ste
   echo "== $flags"
   timeout 900 python bench.py --no-cpu-baseline $flags 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read())
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print({k: d[k] for k in ('value', 'ms_per_step', 'dtype', 'loss')}, d['config']['workload'], '|', d['config']['launch'])"
 done
