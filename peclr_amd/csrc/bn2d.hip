@@ -56,7 +56,7 @@ template <> struct Word<float> {
 };
 typedef uint16_t bf16_t;
 template <> struct Word<bf16_t> {
-    static constexpr int W = 8, U = 4;
+    static constexpr int W = 8, U = 8;
     typedef uint4 Raw;
     static __device__ __forceinline__ Raw load_raw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
     static __device__ __forceinline__ Fv<8> expand(const Raw& t) {
@@ -95,7 +95,7 @@ template <> struct Word<bf16_t> {
 typedef _Float16 f16_t;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <> struct Word<f16_t> {
-    static constexpr int W = 8, U = 4;
+    static constexpr int W = 8, U = 8;
     typedef f16x8 Raw;
     static __device__ __forceinline__ Raw load_raw(const f16_t* p) { return *reinterpret_cast<const f16x8*>(p); }
     static __device__ __forceinline__ Fv<8> expand(const Raw& t) {
