@@ -532,6 +532,7 @@ def try_graph_child():
     details = [ln for ln in p.stdout.splitlines() if ln.startswith("BENCH_DETAILS ")]
     if p.returncode == 0 and lines:
         return "\n".join(details[-1:] + lines[-1:]), None
+    sys.stderr.write("# graph child failed; the end of its stderr:\n" + "\n".join(p.stderr.splitlines()[-12:]) + "\n")
     return None, f"graph child exited with {p.returncode}"
 
 
