@@ -508,10 +508,17 @@ int peclr_augment_resize_color_norm(const uint8_t* crops, int B, int H, int W, i
  *   rows).  Sums are taken of the ROUNDED 16-bit outputs.  lda, ldc, ldd multiples of 8.
  *   peclr_conv_h: taps = 9 (3x3, padding 1) or 1, stride 1 or 2, NHWC; flip = 1 (taps = 9, stride 1): the input gradient
  *   (X = dY, planes packed with transposed = 9).  `zeros`: >= 64 bytes of zeros.  Cin % 32 == 0, Cout % 64 == 0.
+ *   tile_rows: 128 or 256 output rows per workgroup, 0 = the library's choice.  3x3 / stride 1 with rows of <= 62 pixels:
+ *   PECLR_CONV_H_RING (and the choice of 0) runs the ring form -- a workgroup owns 256 consecutive pixels of the PADDED space
+ *   NB x (H + 1) x (W + 1) (one shared zero row / column per image, as peclr_wgrad3_h) and fetches the 256 + 2 (W + 2) input
+ *   pixels its nine taps read once per 32-channel chunk instead of once per tap.  peclr_conv_h_row_blocks: the rows the
+ *   partial-sum tables (stat_partial: 2 * rows + 1, bn_bwd->partial: 2 * rows) of such a launch have (0: unsupported).
  *   peclr_conv3x3_s2_dgrad_h: input gradient of the 3x3 / stride-2 convolution by parity classes (as the fp32 entry point). */
+#define PECLR_CONV_H_RING 1
 int64_t peclr_h_pack_bytes(int N, int K);
 int peclr_h_pack(const void* desc_table, int count, int total_chunks, peclr_stream_t stream);
 int peclr_conv_h_tile_rows(int M, int N);
+int peclr_conv_h_row_blocks(int NB, int H, int W, int Cout, int taps, int stride, int tile_rows);
 int peclr_gemm_h(int dtype, int M, int N, int K, const void* A, int lda, const void* Bp, void* C, int ldc, const void* addend,
                  int ldd, int add_h, int add_w, const unsigned* addend_mask, int tile_rows, const float* stat_shift,
                  float* stat_partial, const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);

@@ -84,6 +84,7 @@ SIGNATURES = {
     "peclr_h_pack_bytes": (c_int64, [c_int, c_int]),
     "peclr_h_pack": (c_int, [_P, c_int, c_int, _P]),
     "peclr_conv_h_tile_rows": (c_int, [c_int, c_int]),
+    "peclr_conv_h_row_blocks": (c_int, [c_int] * 7),
     "peclr_gemm_h": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
     "peclr_conv_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_conv3x3_s2_dgrad_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
@@ -436,13 +437,13 @@ class _BnBwdFuse(ctypes.Structure):
                 ("relu", c_int), ("partial", c_void_p)]
 
 
-def _bn_bwd_fuse(bn_bwd, m: int, n: int, tile_rows: int, groups: int = 1, dtype=torch.float32):
+def _bn_bwd_fuse(bn_bwd, m: int, n: int, tile_rows: int, groups: int = 1, dtype=torch.float32, row_blocks: int = 0):
     """bn_bwd = (x [.., n] NHWC/2-D fp32 of m rows, save [2, n], ss [2, n], mask or None, relu) of the BatchNorm layer whose
     incoming gradient this GEMM produces -> (struct, partial [2 * n_split, n], n_split); keeps the tensors alive."""
     x, save, ss, mask, relu = bn_bwd
     if x.dtype != dtype or x.numel() != m * n or not x.is_cuda:
         raise PeclrHipError(f"bn backward fusion: layer input of {x.numel()} {x.dtype} elements for a {dtype} [{m}, {n}] gradient")
-    ns = groups * ((m // groups + tile_rows - 1) // tile_rows)       # (groups: row blocks of each of several equal row sets)
+    ns = row_blocks or groups * ((m // groups + tile_rows - 1) // tile_rows)       # (groups: row blocks of each of several equal row sets)
     partial = torch.empty((2 * ns, n), device=x.device, dtype=torch.float32)
     st = _BnBwdFuse(x.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), _ptr(ss), _ptr(mask, torch.int32, "relu mask"), int(relu),
                     partial.data_ptr())
@@ -844,12 +845,13 @@ def conv_h(x: torch.Tensor, planes: torch.Tensor, cout: int, taps: int = 9, stri
     m = nb * ho * wo
     partial, ns, fuse = None, 0, None
     if stat_shift is not None or bn_bwd is not None:
-        tile_rows = tile_rows or lib().peclr_conv_h_tile_rows(m, cout)
+        ns = lib().peclr_conv_h_row_blocks(nb, h, w, cout, taps, stride, tile_rows)     # (tile_rows 0: the library's choice)
+        if ns <= 0:
+            raise PeclrHipError(f"conv_h: no launch for tile_rows = {tile_rows} at {h} x {w}, taps {taps}, stride {stride}")
     if stat_shift is not None:
-        ns = (m + tile_rows - 1) // tile_rows
         partial = torch.empty((2 * ns + 1, cout), device=x.device, dtype=torch.float32)
     elif bn_bwd is not None:
-        fuse, partial, ns = _bn_bwd_fuse(bn_bwd, m, cout, tile_rows, dtype=x.dtype)
+        fuse, partial, ns = _bn_bwd_fuse(bn_bwd, m, cout, tile_rows, dtype=x.dtype, row_blocks=ns)
     with _timed(tag, 2 * (nb * h * w * cin + m * cout * (2 if fuse is not None else 1) + taps * cin * cout), 2 * m * taps * cin * cout,
                 kernel="conv_h_kernel (3x3)" if taps == 9 else "conv_h_kernel (stride 2)"):
         rc = lib().peclr_conv_h(io, nb, h, w, cin, cout, taps, stride, xp, _ptr(planes, torch.uint8), y.data_ptr(), int(flip), tile_rows,

@@ -70,6 +70,7 @@ struct HArgs {
     int H, W, flip;                      // TAPS = 9: rows are the pixels of H x W images; flip = the input gradient's filter
     int stride, Hin, Win;                // stride = 2 (forward): rows are OUTPUT pixels of an Hin x Win input
     int s2d;                             // TAPS = 9: input gradient of the stride-2 3x3, one parity class per blockIdx.y
+    int Mp;                              // RING: pixels of the padded space, images x (H + 1) x (W + 1)
     const h16_t* zeros;                  // >= 64 bytes of zeros (padding pixels)
     // optional: C is the gradient arriving at a BatchNorm2d(+ReLU) layer -> its backward reduction in the epilogue
     const h16_t* bb_x;
@@ -88,21 +89,42 @@ __device__ __forceinline__ void hdma16(const void* src, unsigned lds_byte_offset
                  :: "v"(src), "s"(lds_byte_offset) : "memory", "m0");
 }
 
+// ... the same with a wave-uniform 64-bit base (scalar registers) + a 32-bit lane offset + an immediate: no vector arithmetic
+// per request.  The instruction's immediate offset is added to the global address AND to the LDS address (M0 + offset +
+// lane * 16): piece k of a contiguous run is (same base, same M0, offset k * 1024)
+template <int IMM>
+__device__ __forceinline__ void hdma16s(const void* sbase, unsigned lane_off, unsigned lds_byte_offset) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 :: "v"(lane_off), "s"(sbase), "s"(lds_byte_offset), "n"(IMM) : "memory", "m0");
+}
+
 // WM: 32-row MFMA tiles per wave (2 -> 256-row workgroup tile, 1 -> 128); NTL: 32-column tiles per wave (4 -> 128 output
 // columns per workgroup, 2 -> 64); TAPS = 9: 3x3 / padding 1 as an implicit GEMM, K ordered (tap, channel)
 // EP: epilogue features compiled in (registers are allotted for the largest path of an instantiation, and these launches live
 // on workgroups per CU): bit 0 = an addend (dense / compact stride-2 / 1-bit-masked), bit 1 = the BatchNorm backward reduction
-template <typename H, int WM, int TAPS, int NTL, int EP>
+// RING > 0 (3x3, stride 1, 256-row tiles): the rows of a tile are RING-free consecutive pixels of the PADDED space -- images of
+// (H + 1) x (W + 1) pixels whose last row and column are zeros, so that the tap (dh, dw) of pixel p is pixel p + dh (W + 1) + dw
+// for every p (the zero column is the right neighbour of a row and the left neighbour of the next, the zero row the bottom of
+// an image and the top of the next).  Per 32-channel chunk the workgroup fetches the 256 + 2 (W + 2) pixels its nine taps read
+// ONCE (RING = rows of that stage: 320 or 384, W <= 62) and the nine products take their A fragments from shifted rows of it;
+// only the W chunks (8 KiB) arrive per step.  Without it every tap fetches its own 256 x 64 B rows: nine times the LDS fill,
+// in half-line pieces -- the 3x3 launches ran at 0.19 - 0.26 of the matrix cores (93 - 127 us at every layer of ResNet-50).
+// Outputs at padding positions are not stored and not counted in the fused sums (7 % / 13 % / 23 % more rows at 28 / 14 / 7).
+template <typename H, int WM, int TAPS, int NTL, int EP, int RING = 0>
 __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_kernel(HArgs g) {
+    static_assert(RING == 0 || (WM == 2 && TAPS == 9 && RING % 64 == 0), "ring stages: 3x3 on 256-row tiles");
     constexpr bool ADD = (EP & 1) != 0, BBF = (EP & 2) != 0;
     constexpr int RM = 32 * WM, TM = 4 * RM;
-    constexpr int NA = RM / 16;                          // A DMA instructions per wave and k-step (16 rows x 64 B each)
+    constexpr int NA = RING ? RING / 64 : RM / 16;       // A DMA instructions per wave and k-step / ring stage (16 rows x 64 B each)
     constexpr int NBD = NTL == 4 ? 2 : 1;                // B DMA instructions per wave and k-step
     // LDS-DMA targets must lie below 64 KiB (M0 carries a 16-bit LDS address): three stages of A rows (two k-steps of
-    // run-ahead: they come from HBM) and two of W (one step of run-ahead: L2) are 3 x 16 + 2 x 8 = 64 KiB at 256-row tiles
-    constexpr int NSA = 3, NSB = 2;
-    constexpr int ASZ = TM * 64;                         // bytes of activation rows per stage
+    // run-ahead: they come from HBM) and two of W (one step of run-ahead: L2) are 3 x 16 + 2 x 8 = 64 KiB at 256-row tiles.
+    // RING: two stages of RING rows (a chunk lasts nine steps) and as many W stages as fit, at most four
     constexpr int BSZ = NTL * 2048;                      // bytes of W per stage
+    constexpr int NSA = RING ? 2 : 3;
+    constexpr int ASZ = RING ? RING * 64 : TM * 64;      // bytes of activation rows per stage
+    constexpr int NSB = !RING ? 2 : ((65536 - NSA * ASZ) / BSZ < 4 ? (65536 - NSA * ASZ) / BSZ : 4);
+    static_assert(NSB >= 2, "two W stages at least");
     constexpr int B0 = NSA * ASZ;
     constexpr int OPS = B0 + NSB * BSZ;
     static_assert(OPS <= 65536, "LDS-DMA targets below 64 KiB");
@@ -120,7 +142,13 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
     const int nct = (g.N + PNL - 1) / PNL;
     const int j = blockIdx.x / 8;
     const int row_block = 8 * (j / nct) + (int)(blockIdx.x % 8);      // all column tiles of a row block on one XCD
-    if (row_block * TM >= g.M) return;
+    const int Wp = g.W + 1, Hp = g.H + 1;                             // (RING) the padded image
+    if (row_block * TM >= (RING ? g.Mp : g.M)) return;
+    auto ring_row = [&](int p) -> int {                               // padded pixel -> row of the NHWC tensor, -1: a zero
+        if (p < 0 || p >= g.Mp) return -1;
+        const int w = p % Wp, q = p / Wp, h = q % Hp, img = q / Hp;
+        return w < g.W && h < g.H ? (img * g.H + h) * g.W + w : -1;
+    };
     const int m0 = row_block * TM + wave * RM, ct = j % nct, n0 = ct * PNL;
     const bool s2d = TAPS == 9 && g.s2d;
     const int ph = s2d ? 1 - (int)(blockIdx.y >> 1) : 0, pw = s2d ? 1 - (int)(blockIdx.y & 1) : 0;
@@ -146,6 +174,12 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
     unsigned tapmask[NA];
 #pragma unroll
     for (int c = 0; c < NA; ++c) {
+        if constexpr (RING != 0) {                        // stage row r = pixel P0 - (W + 2) + r of the padded space
+            const int real = ring_row(row_block * TM - (Wp + 1) + 16 * (wave * NA + c) + (lane >> 2));
+            asrc[c] = real >= 0 ? g.A + (size_t)real * g.lda + 8 * achunk : nullptr;
+            tapmask[c] = 0;
+            continue;
+        }
         int row = m0 + 16 * c + (lane >> 2);
         row = row < g.M ? row : g.M - 1;
         asrc[c] = g.A + (size_t)row * g.lda + 8 * achunk;
@@ -181,7 +215,7 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
         db = pw && ub == 0;
         ftap = 3 * (ph ? 2 * ua : 1) + (pw ? 2 * ub : 1);
     };
-    auto issue_b = [&](int t) {                           // this wave's pieces of W chunk t -> W stage t % NSB
+    auto issue_b = [&](int t, int step) {                 // this wave's pieces of W chunk t -> W stage step % NSB
         int bt_step = t;
         if constexpr (TAPS == 9) {
             if (s2d) {
@@ -191,13 +225,18 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
             }
         }
         const unsigned char* s = bsrc + (size_t)bt_step * HCHUNK;
-        const unsigned d = lds0 + B0 + (t % NSB) * BSZ;
+        const unsigned d = lds0 + B0 + (step % NSB) * BSZ;
         if constexpr (NTL == 4) {
             hdma16(s + (2 * wave_s) * 1024, d + (2 * wave_s) * 1024);
             hdma16(s + (2 * wave_s + 1) * 1024, d + (2 * wave_s + 1) * 1024);
         } else {
             hdma16(s + wave_s * 1024, d + wave_s * 1024);
         }
+    };
+    auto issue_ring = [&](int chunk) {                    // RING: this wave's rows of the 32-channel chunk -> stage chunk & 1
+        const unsigned st = lds0 + (chunk & 1) * ASZ;
+#pragma unroll
+        for (int c = 0; c < NA; ++c) hdma16(asrc[c] ? asrc[c] + chunk * HK : zsrc, st + 16 * (wave_s * NA + c) * 64);
     };
     auto issue_a = [&](int t) {                           // this wave's rows of step t -> activation stage t % NSA
         const unsigned st = lds0 + (t % NSA) * ASZ;
@@ -225,9 +264,15 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
 
     // order of issue: A(0), B(0), A(1) | step t: B(t + 1), A(t + 2).  The counter retires in order, so at the top of step t
     // "at most the NA row DMAs of A(t + 1) still in flight" means A(t) and B(t) have landed.
-    issue_a(0);
-    issue_b(0);
-    if (nk > 1) issue_a(1);
+    if constexpr (RING != 0) {                            // RING: stage 0, then W chunks 0 .. NSB - 2 (step s = chunk * 9 + tap
+        issue_ring(0);                                    // reads W chunk tap * kpt + chunk)
+#pragma unroll
+        for (int q = 0; q < NSB - 1; ++q) issue_b(q < nk ? (q % 9) * kpt + q / 9 : 0, q);
+    } else {
+        issue_a(0);
+        issue_b(0, 0);
+        if (nk > 1) issue_a(1);
+    }
     // per-column constants of the epilogue, requested behind the first stages (their latency hides behind the main loop): the
     // statistics' shift of this lane's columns; the BatchNorm backward's mean / invstd / scale / shift of column tid (to LDS
     // after the loop).  Always NE load instructions, whatever the launch asks for, so that the DMA waits below stay exact
@@ -247,6 +292,85 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
     // fragment (tile a, k-extent kk) of this lane: row a * 32 + i, chunk 2 kk + kh, at slot chunk ^ ((row >> 2) & 3)
     const int arow = wave * RM + i;
     const int asw = (i >> 2) & 3;
+    if constexpr (RING != 0) {
+        // The loop is written for its instruction count: a wave shares its SIMD with at most one other (64 KiB of LDS per
+        // workgroup), and what it issues besides the 16 products of a step is not hidden (measured: 1 300 clocks per step with
+        // the address arithmetic in the loop, 865 for the same requests / reads / products without it).  So the nine taps are
+        // unrolled (their fragment offsets are nine registers computed once), the W requests take a scalar base + the lane's
+        // 16 bytes, and every fragment read is base + immediate.
+        // In-order counter: younger than W chunk s at the top of step s are the W chunks of steps s + 1 .. s + NSB - 2, the
+        // next ring stage if it was requested after them (at tap 0, behind that step's W request: taps 1 .. NSB - 1), and in
+        // step 0 the NE constants.  The last NSB - 2 steps simply wait for everything.
+        constexpr int N0 = (NSB - 2) * NBD;
+        unsigned aoff[9];                                  // byte offset of this lane's fragment (a = 0, kk = 0) in a stage, per tap
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ta = tap / 3, tb = tap - 3 * ta;
+            const int dh = g.flip ? 1 - ta : ta - 1, dw = g.flip ? 1 - tb : tb - 1;
+            const int r = arow + (Wp + 1) + dh * Wp + dw;  // (a = 1: + 32 rows = + 2048 bytes, same slot permutation; kk = 1: ^ 32)
+            aoff[tap] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+        }
+        // W chunk of (chunk, tap) = tap * kpt + chunk; this wave's pieces of it start at wbase + that * HCHUNK
+        const unsigned char* wbase = static_cast<const unsigned char*>(g.Bp) + (size_t)(NTL == 4 ? ct : ct >> 1) * nk_all * HCHUNK +
+                                     ((NTL == 4 ? 0 : (ct & 1) * 4) + (NTL == 4 ? 2 : 1) * wave_s) * 1024;
+        const unsigned wlds = lds0 + B0 + (NTL == 4 ? 2 : 1) * wave_s * 1024;
+        const unsigned lane16 = lane * 16;
+        const unsigned tap_stride = (unsigned)kpt * HCHUNK;
+        int bst = 0;                                       // W stage of the current step (= step % NSB)
+        auto request_w = [&](int chunk, int tap, int stage) {
+            const unsigned char* src = wbase + (size_t)((unsigned)tap * tap_stride) + (size_t)chunk * HCHUNK;
+            const unsigned d = wlds + stage * BSZ;
+            hdma16s<0>(src, lane16, d);
+            if constexpr (NTL == 4) hdma16s<1024>(src, lane16, d);      // (the immediate moves BOTH addresses)
+        };
+        auto step = [&](auto tapc, int chunk) {
+            constexpr int tap = decltype(tapc)::value;
+            const bool last_chunk = chunk + 1 == kpt;
+            if (tap + NSB - 1 > 9 && last_chunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (tap == 0 && chunk == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N0 + NE) : "memory");
+            else if (tap >= 1 && tap <= NSB - 1 && !last_chunk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N0 + NA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N0) : "memory");
+            __builtin_amdgcn_s_barrier();                 // publishes W chunk s (and the stage); every wave is done with step s - 1
+            asm volatile("" ::: "memory");
+            const unsigned char* sa = lds + (chunk & 1) * ASZ + aoff[tap];
+            const unsigned char* sb = lds + B0 + bst * BSZ + lane16;
+            uint4 af[2][WM], bf[2][NTL];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const unsigned char* sak = kk ? lds + (((unsigned)(sa - lds)) ^ 32u) : sa;
+#pragma unroll
+                for (int a = 0; a < WM; ++a) af[kk][a] = *reinterpret_cast<const uint4*>(sak + a * 2048);
+#pragma unroll
+                for (int y = 0; y < NTL; ++y) bf[kk][y] = *reinterpret_cast<const uint4*>(sb + (2 * y + kk) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int y = 0; y < NTL; ++y)
+#pragma unroll
+                    for (int a = 0; a < WM; ++a) acc[a][y] = H::mma(af[kk][a], bf[kk][y], acc[a][y]);
+                if (kk == 0) {
+                    // the next requests go out while the matrix cores work through the first half's products: W chunk
+                    // s + NSB - 1 into the buffer step s - 1 read, and at tap 0 the next ring stage into the one chunk - 1 read
+                    constexpr int t2 = (tap + NSB - 1) % 9, dc = (tap + NSB - 1) / 9;
+                    int st2 = bst + NSB - 1;
+                    st2 = st2 >= NSB ? st2 - NSB : st2;
+                    if (chunk + dc < kpt) request_w(chunk + dc, t2, st2);
+                    if (tap == 0 && !last_chunk) issue_ring(chunk + 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);            // (the products stay in their step)
+            bst = bst + 1 == NSB ? 0 : bst + 1;
+        };
+        for (int chunk = 0; chunk < kpt; ++chunk) {
+            step(std::integral_constant<int, 0>{}, chunk); step(std::integral_constant<int, 1>{}, chunk);
+            step(std::integral_constant<int, 2>{}, chunk); step(std::integral_constant<int, 3>{}, chunk);
+            step(std::integral_constant<int, 4>{}, chunk); step(std::integral_constant<int, 5>{}, chunk);
+            step(std::integral_constant<int, 6>{}, chunk); step(std::integral_constant<int, 7>{}, chunk);
+            step(std::integral_constant<int, 8>{}, chunk);
+        }
+    } else
     for (int t = 0; t < nk; ++t) {
         // A(t), B(t) have landed: younger than them are at most the NA row DMAs of A(t + 1) -- and, in step 0, the NE
         // constant loads issued behind the first stages
@@ -257,7 +381,7 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // publishes A(t), B(t); every wave is done reading step t - 1
         asm volatile("" ::: "memory");
-        if (t + 1 < nk) issue_b(t + 1);                   // into the W buffer step t - 1 read
+        if (t + 1 < nk) issue_b(t + 1, t + 1);            // into the W buffer step t - 1 read
         if (t + 2 < nk) issue_a(t + 2);                   // into the row buffer step t - 1 read
         const unsigned char* sa = lds + (t % NSA) * ASZ;
         const unsigned char* sb = lds + B0 + (t % NSB) * BSZ + lane * 16;
@@ -293,7 +417,9 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
             }
     float* sl = reinterpret_cast<float*>(lds + 4 * 32 * XE * 4);      // [wave][2][128] column sums
     if (g.stat_partial) {
-        const bool full = row_block * TM + TM <= g.M;     // (uniform: whole tile inside the matrix)
+        const bool full = !RING && row_block * TM + TM <= g.M;     // (uniform: whole tile inside the matrix)
+        unsigned long long ring_ok = 0;                   // RING: bit r = row r of this wave's 64 is a pixel (not padding)
+        if constexpr (RING != 0) ring_ok = __ballot(ring_row(m0 + lane) >= 0);
 #pragma unroll
         for (int y = 0; y < NTL; ++y) {
             const float k0 = kshift[y];
@@ -303,7 +429,8 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float d = acc[a][y][r] - k0;
-                    if (full || m0 + a * 32 + mfma32_row(r, kh) < g.M) { sum += d; sq = fmaf(d, d, sq); }
+                    const bool in = RING ? (ring_ok >> (a * 32 + mfma32_row(r, kh))) & 1ull : m0 + a * 32 + mfma32_row(r, kh) < g.M;
+                    if (full || in) { sum += d; sq = fmaf(d, d, sq); }
                 }
             sum += __shfl_xor(sum, 32, 64);
             sq += __shfl_xor(sq, 32, 64);
@@ -317,7 +444,7 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
                                  sl[(2 * 2 + which) * 128 + col]) + sl[(3 * 2 + which) * 128 + col];
                 g.stat_partial[((size_t)row_block * 2 + which) * g.N + n0 + col] = v;
                 if (row_block == 0 && which == 0)
-                    g.stat_partial[(size_t)((g.M + TM - 1) / TM) * 2 * g.N + n0 + col] = g.stat_shift[n0 + col];
+                    g.stat_partial[(size_t)(((RING ? g.Mp : g.M) + TM - 1) / TM) * 2 * g.N + n0 + col] = g.stat_shift[n0 + col];
 
             }
         }
@@ -341,7 +468,8 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int m = m0 + a * 32 + er + 8 * jj;
-            om[a][jj] = m;
+            om[a][jj] = m < g.M || RING ? m : -1;         // (-1: no such row)
+            if constexpr (RING != 0) om[a][jj] = ring_row(m);
             if (s2d && m < g.M) {
                 const int j2 = m % g.W, q = m / g.W, i2 = q % g.H, img = q / g.H;
                 om[a][jj] = (img * 2 * g.H + 2 * i2 + ph) * (2 * g.W) + 2 * j2 + pw;
@@ -374,7 +502,7 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
                 const int m = mt + er + 8 * jj;
                 dv[jj] = make_uint4(0u, 0u, 0u, 0u);
                 ab[jj] = 0u;
-                if (ADD && g.addend && m < g.M) {
+                if (ADD && g.addend && om[a][jj] >= 0) {
                     size_t arow = m;
                     bool has = true;
                     if (g.add_h) {
@@ -387,7 +515,7 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
                         ab[jj] = g.add_mask ? (g.add_mask[(size_t)m * (g.N >> 5) + ((nt + ec) >> 5)] >> (ec & 31)) & 0xFFu : 0xFFu;
                     }
                 }
-                if (BBF && g.bb_partial && m < g.M) {
+                if (BBF && g.bb_partial && om[a][jj] >= 0) {
                     xv[jj] = *reinterpret_cast<const uint4*>(g.bb_x + (size_t)om[a][jj] * g.N + nt + ec);
                     mb[jj] = g.bb_mask ? (g.bb_mask[(size_t)om[a][jj] * (g.N >> 5) + ((nt + ec) >> 5)] >> (ec & 31)) & 0xFFu : 0u;
                 }
@@ -412,7 +540,7 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
                     }
                     ow[q] = H::pack2(c[2 * q], c[2 * q + 1]);
                 }
-                if (m < g.M) {
+                if (om[a][jj] >= 0) {
                     *reinterpret_cast<uint4*>(g.out + (size_t)om[a][jj] * g.ldo + nt + ec) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
                     if (BBF && g.bb_partial) {
                         const unsigned xw[4] = {xv[jj].x, xv[jj].y, xv[jj].z, xv[jj].w};
@@ -445,7 +573,7 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
         if (col < PNL) {
             const float v = ((sl[(0 * 2 + which) * 128 + col] + sl[(1 * 2 + which) * 128 + col]) +
                              sl[(2 * 2 + which) * 128 + col]) + sl[(3 * 2 + which) * 128 + col];
-            const size_t rb = (size_t)row_block + (s2d ? (size_t)blockIdx.y * ((g.M + TM - 1) / TM) : 0);
+            const size_t rb = (size_t)row_block + (s2d ? (size_t)blockIdx.y * ((g.M + TM - 1) / TM) : 0);   // (RING: row blocks of the padded space)
             g.bb_partial[(rb * 2 + which) * g.N + n0 + col] = v;
         }
     }
@@ -513,8 +641,34 @@ void set_bb(HArgs& g, const peclr_bn_bwd_fuse* bb) {
     g.bb_mask = bb ? bb->relu_mask : nullptr; g.bb_relu = bb ? bb->relu : 0; g.bb_partial = bb ? bb->partial : nullptr;
 }
 
+// rows of the ring stage a 3x3 / stride-1 launch over W-pixel rows needs (0: not eligible -- rows wider than 62 pixels, or
+// switched off: PECLR_CONV3_RING=0 for A/B runs)
+int ring_rows(int taps, int stride, int s2d, int W) {
+    static const int on = getenv("PECLR_CONV3_RING") ? atoi(getenv("PECLR_CONV3_RING")) : 1;
+    if (!on || taps != 9 || stride != 1 || s2d || W > 62) return 0;
+    return 256 + 2 * (W + 2) <= 320 ? 320 : 384;
+}
+
 template <typename H, int EP>
 int launch_h(const HArgs& g, int tile_rows, int taps, hipStream_t stream) {
+    if constexpr ((EP & 1) == 0) {
+        if (tile_rows == PECLR_CONV_H_RING) {
+            const int rr = ring_rows(taps, g.stride, g.s2d, g.W);
+            if (!rr) return PECLR_ERR_UNSUPPORTED;
+            const int nrb = (g.Mp + 255) / 256;
+            const bool narrow = g.N % HN != 0;
+            const dim3 grid(8 * ((nrb + 7) / 8) * (narrow ? g.N / 64 : g.N / HN));
+            if (rr == 320) {
+                if (narrow) hipLaunchKernelGGL((conv_h_kernel<H, 2, 9, 2, EP, 320>), grid, dim3(256), 0, stream, g);
+                else hipLaunchKernelGGL((conv_h_kernel<H, 2, 9, 4, EP, 320>), grid, dim3(256), 0, stream, g);
+            } else {
+                if (narrow) hipLaunchKernelGGL((conv_h_kernel<H, 2, 9, 2, EP, 384>), grid, dim3(256), 0, stream, g);
+                else hipLaunchKernelGGL((conv_h_kernel<H, 2, 9, 4, EP, 384>), grid, dim3(256), 0, stream, g);
+            }
+            return launch_status();
+        }
+    }
+    if (tile_rows == PECLR_CONV_H_RING) return PECLR_ERR_UNSUPPORTED;
     const int nrb = (g.M + tile_rows - 1) / tile_rows;
     static const int force_narrow = getenv("PECLR_CONV_H_NARROW") ? atoi(getenv("PECLR_CONV_H_NARROW")) : 0;   // experiments
     // the fused entry gradient (addend + BatchNorm reduction: three streams in the epilogue) runs best on 64-column tiles at
@@ -575,6 +729,20 @@ extern "C" int peclr_conv_h_tile_rows(int M, int N) {
     return pick_rows(M, N);
 }
 
+// Rows of the partial-sum tables (BatchNorm statistics / backward reduction) a peclr_conv_h launch with this tile_rows argument
+// writes: row blocks of the output pixels, or -- ring launches (tile_rows 0 picks them where they apply, PECLR_CONV_H_RING asks
+// for them) -- 256-pixel blocks of the padded space NB x (H + 1) x (W + 1).  0: unsupported arguments.
+extern "C" int peclr_conv_h_row_blocks(int NB, int H, int W, int Cout, int taps, int stride, int tile_rows) {
+    if (NB <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (stride != 1 && stride != 2) || H % stride || W % stride) return 0;
+    const int Ho = H / stride, Wo = W / stride;
+    const long M = (long)NB * Ho * Wo;
+    const int rr = ring_rows(taps, stride, 0, Wo);
+    if (tile_rows == 0) tile_rows = rr ? PECLR_CONV_H_RING : pick_rows((int)M, Cout);
+    if (tile_rows == PECLR_CONV_H_RING) return rr ? (int)(((long)NB * (Ho + 1) * (Wo + 1) + 255) / 256) : 0;
+    if (tile_rows != 128 && tile_rows != 256) return 0;
+    return (int)((M + tile_rows - 1) / tile_rows);
+}
+
 // 1x1 / stride-1 product with the optional epilogues: dense addend (add_h = 0), compact stride-2 addend (add_h, add_w > 0),
 // 1-bit mask on the dense addend, BatchNorm statistics of the output, BatchNorm backward reduction.
 extern "C" int peclr_gemm_h(int dtype, int M, int N, int K, const void* A, int lda, const void* Bp, void* C, int ldc,
@@ -593,7 +761,7 @@ extern "C" int peclr_gemm_h(int dtype, int M, int N, int K, const void* A, int l
     g.A = static_cast<const h16_t*>(A); g.Bp = Bp; g.addend = static_cast<const h16_t*>(addend); g.out = static_cast<h16_t*>(C);
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldc; g.ldd = ldd; g.add_h = add_h; g.add_w = add_w; g.add_mask = addend_mask;
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
-    g.H = g.W = 1; g.flip = 0; g.zeros = nullptr; g.stride = 1; g.Hin = g.Win = 1; g.s2d = 0;
+    g.H = g.W = 1; g.flip = 0; g.zeros = nullptr; g.stride = 1; g.Hin = g.Win = 1; g.s2d = 0; g.Mp = 0;
     set_bb(g, bb);
     return dispatch(dtype, g, tile_rows, 1, static_cast<hipStream_t>(stream));
 }
@@ -611,9 +779,12 @@ extern "C" int peclr_conv_h(int dtype, int NB, int H, int W, int Cin, int Cout, 
     if ((long)NB * H * W > 0x7FFFFFFFL / 2) return PECLR_ERR_SHAPE;
     if (!aligned16(X) || !aligned16(Bp) || !aligned16(Y) || !aligned16(zeros)) return PECLR_ERR_ALIGN;
     const int Ho = H / stride, Wo = W / stride, M = NB * Ho * Wo;
-    if (tile_rows == 0) tile_rows = pick_rows(M, Cout);
-    if (tile_rows != 128 && tile_rows != 256) return PECLR_ERR_UNSUPPORTED;
+    if (tile_rows == 0) tile_rows = ring_rows(taps, stride, 0, Wo) ? PECLR_CONV_H_RING : pick_rows(M, Cout);
+    if (tile_rows != 128 && tile_rows != 256 && tile_rows != PECLR_CONV_H_RING) return PECLR_ERR_UNSUPPORTED;
+    if (tile_rows == PECLR_CONV_H_RING && ((long)NB * (H + 1) * (W + 1) > 0x7FFFFFFFL / 2 || !ring_rows(taps, stride, 0, Wo)))
+        return PECLR_ERR_UNSUPPORTED;
     HArgs g;
+    g.Mp = NB * (Ho + 1) * (Wo + 1);
     g.A = static_cast<const h16_t*>(X); g.Bp = Bp; g.addend = nullptr; g.out = static_cast<h16_t*>(Y);
     g.M = M; g.N = Cout; g.K = taps * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout; g.add_h = g.add_w = 0; g.add_mask = nullptr;
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
@@ -637,7 +808,7 @@ extern "C" int peclr_conv3x3_s2_dgrad_h(int dtype, int NB, int Ho, int Wo, int C
     g.A = static_cast<const h16_t*>(dY); g.Bp = Bp; g.addend = nullptr; g.out = static_cast<h16_t*>(dX);
     g.M = M; g.N = Cin; g.K = 9 * Cout; g.lda = Cout; g.ldo = Cin; g.ldd = Cin; g.add_h = g.add_w = 0; g.add_mask = nullptr;
     g.stat_shift = nullptr; g.stat_partial = nullptr;
-    g.H = Ho; g.W = Wo; g.flip = 1; g.zeros = static_cast<const h16_t*>(zeros); g.stride = 1; g.Hin = Ho; g.Win = Wo; g.s2d = 1;
+    g.H = Ho; g.W = Wo; g.flip = 1; g.zeros = static_cast<const h16_t*>(zeros); g.stride = 1; g.Hin = Ho; g.Win = Wo; g.s2d = 1; g.Mp = 0;
     set_bb(g, bb);
     return dispatch(dtype, g, tile_rows, 9, static_cast<hipStream_t>(stream));
 }

@@ -120,7 +120,7 @@ def test_conv_h_3x3_forward_and_input_gradient(capi, dtype, nb, cin, cout, h, w)
     pk = capi.HPlanes([(w4.reshape(cout, 9 * cin), False), (w4.reshape(cout * 9, cin), 9)], dtype).pack()
     wd = wt.to(dtype).double()
     ref = torch.nn.functional.conv2d(x.double(), wd, padding=1)
-    for tile_rows in (0, 128, 256):
+    for tile_rows in (0, 128, 256):                                   # (0: the ring form where rows have <= 62 pixels)
         y = capi.conv_h(x, pk.planes[0], cout, tile_rows=tile_rows)
         assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
         close(y, ref, dtype, f"forward {tile_rows}")
@@ -133,6 +133,69 @@ def test_conv_h_3x3_forward_and_input_gradient(capi, dtype, nb, cin, cout, h, w)
     want = torch.stack([y.double().sum((0, 2, 3)), (y.double() ** 2).sum((0, 2, 3))])
     got = partial.double()[:2 * ns].view(ns, 2, cout).sum(0)
     assert float(((got - want).abs() / (torch.stack([y.double().abs().sum((0, 2, 3)), want[1]]) + 1e-30)).max()) <= 2e-6
+
+
+RING = 1          # PECLR_CONV_H_RING
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nb,cin,cout,h,w", [(2, 64, 64, 9, 7), (16, 128, 128, 28, 28), (6, 64, 64, 56, 56), (3, 256, 256, 14, 14), (33, 512, 512, 7, 7),
+                                             (1, 64, 128, 5, 62), (2, 128, 64, 1, 1), (1, 64, 192, 2, 40)])
+def test_conv_h_3x3_ring_form(capi, dtype, nb, cin, cout, h, w):
+    """3x3 / stride 1 over the padded pixel space (tile_rows = PECLR_CONV_H_RING): forward with the fused statistics, input gradient
+    with the fused BatchNorm backward reduction, against float64; padding positions are neither stored nor counted;
+    bit-identical from launch to launch."""
+    g = torch.Generator(device=DEV).manual_seed(nb + cin + cout + h + w)
+    x = nhwc(torch.randn(nb, cin, h, w, device=DEV, generator=g).to(dtype))
+    wt = nhwc(torch.randn(cout, cin, 3, 3, device=DEV, generator=g) * 0.05)
+    w4 = wt.permute(0, 2, 3, 1)
+    pk = capi.HPlanes([(w4.reshape(cout, 9 * cin), False), (w4.reshape(cout * 9, cin), 9)], dtype).pack()
+    wd = wt.to(dtype).double()
+    ref = torch.nn.functional.conv2d(x.double(), wd, padding=1)
+    shift = (torch.randn(cout, device=DEV, generator=g) * 0.1).contiguous()
+    y, partial, ns = capi.conv_h(x, pk.planes[0], cout, stat_shift=shift, tile_rows=RING)
+    assert ns == (nb * (h + 1) * (w + 1) + 255) // 256 == capi.lib().peclr_conv_h_row_blocks(nb, h, w, cout, 9, 1, RING)
+    close(y, ref, dtype, "ring forward")
+    d = y.double() - shift.double().view(1, -1, 1, 1)
+    want = torch.stack([d.sum((0, 2, 3)), (d ** 2).sum((0, 2, 3))])
+    got = partial.double()[:2 * ns].view(ns, 2, cout).sum(0)
+    assert float(((got - want).abs() / (torch.stack([d.abs().sum((0, 2, 3)), want[1]]) + 1e-30)).max()) <= 2e-6
+    assert torch.equal(partial[2 * ns], shift)
+    y2, partial2, _ = capi.conv_h(x, pk.planes[0], cout, stat_shift=shift, tile_rows=RING)
+    assert torch.equal(y, y2) and torch.equal(partial, partial2)
+    # input gradient arriving at a BatchNorm + ReLU layer whose 16-bit input is xb
+    gy = nhwc(torch.randn(nb, cout, h, w, device=DEV, generator=g).to(dtype))
+    refd = torch.ops.aten.convolution_backward(gy.double(), x.double(), wd, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                               [True, False, False])[0]
+    xb = nhwc(torch.randn(nb, cin, h, w, device=DEV, generator=g).to(dtype))
+    xf = xb.float().permute(0, 2, 3, 1).reshape(-1, cin)
+    mean, invstd = xf.mean(0), 1.0 / (xf.var(0, unbiased=False) + 1e-5).sqrt()
+    gamma, beta = torch.rand(cin, device=DEV, generator=g) + 0.5, torch.randn(cin, device=DEV, generator=g) * 0.2
+    ss = torch.stack([gamma * invstd, beta - mean * gamma * invstd]).contiguous()
+    save = torch.stack([mean, invstd]).contiguous()
+    dx, bpart, bns = capi.conv_h(gy, pk.planes[1], cin, flip=True, bn_bwd=(xb, save, ss, None, True), tile_rows=RING)
+    close(dx, refd, dtype, "ring input gradient")
+    assert torch.equal(dx, capi.conv_h(gy, pk.planes[1], cin, flip=True, tile_rows=RING))
+    on = torch.addcmul(ss[1], xf, ss[0]) > 0
+    dd = dx.double().permute(0, 2, 3, 1).reshape(-1, cin) * on
+    xhat = (xf.double() - mean.double()) * invstd.double()
+    want = torch.stack([dd.sum(0), (dd * xhat).sum(0)])
+    got = bpart.double().view(bns, 2, cin).sum(0)
+    bound = torch.stack([dd.abs().sum(0), (dd * xhat).abs().sum(0)]) + 1e-30
+    assert float(((got - want).abs() / bound).max()) <= 1e-4
+
+
+def test_conv_h_ring_form_is_refused_for_rows_wider_than_62_pixels(capi):
+    x = nhwc(torch.randn(1, 64, 3, 63, device=DEV).to(torch.bfloat16))
+    wt = torch.randn(64, 9 * 64, device=DEV) * 0.05
+    pk = capi.HPlanes([(wt, False)], torch.bfloat16).pack()
+    assert capi.lib().peclr_conv_h_row_blocks(1, 3, 63, 64, 9, 1, RING) == 0
+    assert capi.lib().peclr_conv_h_row_blocks(1, 3, 63, 64, 9, 1, 0) == 2          # 189 pixels, 128-row tiles
+    with pytest.raises(capi.PeclrHipError):
+        capi.conv_h(x, pk.planes[0], 64, tile_rows=RING)
+    y = capi.conv_h(x, pk.planes[0], 64)                                            # (the library's choice: per-tap form)
+    ref = torch.nn.functional.conv2d(x.double(), wt.view(64, 3, 3, 64).permute(0, 3, 1, 2).to(torch.bfloat16).double(), padding=1)
+    close(y, ref, torch.bfloat16, "wide rows")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
