@@ -102,6 +102,13 @@ __device__ __forceinline__ void hdma16s(const void* sbase, unsigned lane_off, un
 // columns per workgroup, 2 -> 64); TAPS = 9: 3x3 / padding 1 as an implicit GEMM, K ordered (tap, channel)
 // EP: epilogue features compiled in (registers are allotted for the largest path of an instantiation, and these launches live
 // on workgroups per CU): bit 0 = an addend (dense / compact stride-2 / 1-bit-masked), bit 1 = the BatchNorm backward reduction
+#ifdef PECLR_CONV_H_TIMING                                 // experiment builds only (tools/exp/ab): shader clocks per kernel phase
+__device__ unsigned long long conv_h_timing[8];
+#define PECLR_PHASE(k) do { if (threadIdx.x == 0 && blockIdx.x == 8) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&conv_h_timing[k], now_ - tphase); tphase = now_; } } while (0)
+#else
+#define PECLR_PHASE(k) do { } while (0)
+#endif
+
 // RING > 0 (3x3, stride 1, 256-row tiles): the rows of a tile are RING-free consecutive pixels of the PADDED space -- images of
 // (H + 1) x (W + 1) pixels whose last row and column are zeros, so that the tap (dh, dw) of pixel p is pixel p + dh (W + 1) + dw
 // for every p (the zero column is the right neighbour of a row and the left neighbour of the next, the zero row the bottom of
@@ -134,6 +141,9 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
     __shared__ __attribute__((aligned(1024))) unsigned char lds[OPS > EPI ? OPS : EPI];   // (the epilogue re-uses the stages)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kh = lane >> 5;
+#ifdef PECLR_CONV_H_TIMING
+    unsigned long long tphase = __builtin_readcyclecounter();
+#endif
     typedef __attribute__((address_space(3))) unsigned char* lptr_t;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(lptr_t)lds);
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
@@ -264,6 +274,7 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
 
     // order of issue: A(0), B(0), A(1) | step t: B(t + 1), A(t + 2).  The counter retires in order, so at the top of step t
     // "at most the NA row DMAs of A(t + 1) still in flight" means A(t) and B(t) have landed.
+    PECLR_PHASE(0);
     if constexpr (RING != 0) {                            // RING: stage 0, then W chunks 0 .. NSB - 2 (step s = chunk * 9 + tap
         issue_ring(0);                                    // reads W chunk tap * kpt + chunk)
 #pragma unroll
@@ -402,6 +413,7 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
 
     // ---- epilogue.  The stored value is the accumulator rounded to the 16-bit format; the fused BatchNorm sums are taken of
     // those rounded values (what a separate pass over the stored tensor would read).
+    PECLR_PHASE(1);                                       // (0: set-up + first requests, 1: main loop, 2: statistics, 3: stores)
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < WM; ++a)
@@ -450,6 +462,7 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
         }
         __syncthreads();
     }
+    PECLR_PHASE(2);
     float* cst = reinterpret_cast<float*>(lds + CST);                 // [mean | invstd | scale | shift][128]
     if (BBF && g.bb_partial) {
         if (tid < PNL) {
@@ -577,6 +590,7 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
             g.bb_partial[(rb * 2 + which) * g.N + n0 + col] = v;
         }
     }
+    PECLR_PHASE(3);
 }
 
 // ---- weight packing: W[N][K] fp32 master weights (or their transpose) -> fragment-ordered 16-bit chunks.  One workgroup per
@@ -710,6 +724,14 @@ int dispatch(int dtype, const HArgs& g, int tile_rows, int taps, hipStream_t str
 }  // namespace peclr
 
 using namespace peclr;
+
+#ifdef PECLR_CONV_H_TIMING
+extern "C" int peclr_debug_conv_h_timing(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(conv_h_timing), sizeof(conv_h_timing));
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(conv_h_timing), z, sizeof(z)); }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int64_t peclr_h_pack_bytes(int N, int K) {
     if (N <= 0 || K <= 0 || N % 64 || K % HK) return 0;
