@@ -94,7 +94,9 @@ __device__ __forceinline__ void hdma16(const void* src, unsigned lds_byte_offset
 // lane * 16): piece k of a contiguous run is (same base, same M0, offset k * 1024)
 template <int IMM>
 __device__ __forceinline__ void hdma16s(const void* sbase, unsigned lane_off, unsigned lds_byte_offset) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+    // (s_nop 4: the base may come straight from scalar arithmetic -- a vector memory instruction reading a scalar register the
+    // scalar unit has just written needs five wait states, and the compiler does not see into this string)
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
                  :: "v"(lane_off), "s"(sbase), "s"(lds_byte_offset), "n"(IMM) : "memory", "m0");
 }
 
