@@ -143,13 +143,19 @@ template <int W> __device__ __forceinline__ Fv<W> zero() {
 // (blockIdx.x = column block) and RPP = 256/CGB rows per pass; blockIdx.y = row slice.
 struct Geo {
     int R, C, CGB, RPP, rows_per_block;
+    int rev;   // row slices are taken back to front: the workgroups dispatched first own the LAST rows -- the ones the GEMM that
+               // produced the tensor wrote last and the 256 MB memory-side cache still holds (a 411 MB tensor read back to front
+               // right after it was written front to back: 4.6 instead of 3.4 TB/s, tools/exp/mall_order.hip), and the GEMM
+               // that consumes this kernel's output (front to back) starts on the rows written last.  Results do not change:
+               // slices keep their logical index.
 };
+__device__ __forceinline__ int slice_y(const Geo& g) { return g.rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y; }
 template <int W>
 __device__ __forceinline__ void thread_geo(const Geo& g, int& col, int& r_begin, int& r_end, int& rl) {
     const int cgl = threadIdx.x % g.CGB;
     rl = threadIdx.x / g.CGB;
     col = (blockIdx.x * g.CGB + cgl) * W;
-    r_begin = blockIdx.y * g.rows_per_block;
+    r_begin = slice_y(g) * g.rows_per_block;
     r_end = min(g.R, r_begin + g.rows_per_block);
 }
 
@@ -202,10 +208,10 @@ __global__ __launch_bounds__(T) void bn2d_stats_kernel(const IO* __restrict__ x,
     s = lane_reduce<W>(s, red, g, rl);
     q = lane_reduce<W>(q, red, g, rl);
     if (rl == 0) {
-        float* o = partial + (size_t)blockIdx.y * 2 * g.C;
+        float* o = partial + (size_t)slice_y(g) * 2 * g.C;
         storep<W>(o + col, s);
         storep<W>(o + g.C + col, q);
-        if (blockIdx.y == 0) storep<W>(partial + (size_t)n_split * 2 * g.C + col, k0);
+        if (slice_y(g) == 0) storep<W>(partial + (size_t)n_split * 2 * g.C + col, k0);
     }
 }
 
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(T) void bn2d_apply_avgpool_kernel(const IO* __restr
     if (rl == 0) {
 #pragma unroll
         for (int k = 0; k < W; ++k) sum.v[k] *= inv_hw;
-        storep<W>(pooled + (size_t)blockIdx.y * g.C + col, sum);
+        storep<W>(pooled + (size_t)slice_y(g) * g.C + col, sum);
     }
 }
 
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(T) void bn2d_bwd_reduce_kernel(const IO* __restrict
     sb = lane_reduce<W>(sb, red, g, rl);
     sg = lane_reduce<W>(sg, red, g, rl);
     if (rl == 0) {
-        float* o = partial + (size_t)blockIdx.y * 2 * g.C;
+        float* o = partial + (size_t)slice_y(g) * 2 * g.C;
         storep<W>(o + col, sb);
         storep<W>(o + g.C + col, sg);
     }
@@ -639,6 +645,7 @@ __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict_
 // Tap code = 3*dh + dw of the FIRST maximum in row-major window order (strict >), torch's rule.
 struct PoolGeo {
     int N, H, Wd, C, PH, PW, CW, PPB;  // CW = C / W column groups, PPB = 256 / CW pixels per block pass
+    int rev;                           // walk the tensor back to front (as Geo::rev: these tensors are 411 - 1 644 MB)
 };
 // Workgroups are handed to the 8 XCDs round-robin and every XCD has its own L2.  The 3x3/2 windows of
 // neighbouring pixels overlap, so the pixels of ONE image should meet in ONE L2: hardware block b works on
@@ -650,8 +657,9 @@ constexpr int kXcd = 8;
 struct XcdSlot {
     int n, run;
 };
-__device__ __forceinline__ XcdSlot xcd_slot(int runs_per_image) {
-    const int j = blockIdx.x / kXcd;
+__device__ __forceinline__ XcdSlot xcd_slot(int runs_per_image, int rev) {
+    int j = blockIdx.x / kXcd;
+    if (rev) j = (int)(gridDim.x / kXcd) - 1 - j;        // (same XCD, the image groups and runs in reverse order)
     return {kXcd * (j / runs_per_image) + (int)(blockIdx.x % kXcd), j % runs_per_image};
 }
 
@@ -665,7 +673,7 @@ __global__ __launch_bounds__(T) void bn2d_pool_apply_kernel(const IO* __restrict
     const int cg = threadIdx.x % g.CW, pl = threadIdx.x / g.CW, col = cg * W;
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
     const int per_image = g.PH * g.PW, span = g.PPB * kPoolIter;
-    const XcdSlot slot = xcd_slot((per_image + span - 1) / span);
+    const XcdSlot slot = xcd_slot((per_image + span - 1) / span, g.rev);
     if (slot.n >= g.N) return;
     const int n = slot.n;
     for (int it = 0; it < kPoolIter; ++it) {
@@ -720,7 +728,8 @@ __global__ __launch_bounds__(T) void bn2d_pool_bwd_reduce_kernel(const IO* __res
     // streaming reduction over the pooled grid.  gridDim.x blocks, contiguous chunks, 4 loads in flight.
     const long long P = (long long)g.N * g.PH * g.PW;
     const long long chunk = ((P + gridDim.x - 1) / gridDim.x + g.PPB - 1) / g.PPB * g.PPB;
-    const long long p_begin = (long long)blockIdx.x * chunk, p_end = p_begin + chunk < P ? p_begin + chunk : P;
+    const long long lb = g.rev ? (long long)gridDim.x - 1 - blockIdx.x : (long long)blockIdx.x;       // logical block (slot of its sums)
+    const long long p_begin = lb * chunk, p_end = p_begin + chunk < P ? p_begin + chunk : P;
     auto acc = [&](const Fv<W>& gy, const Fv<W>& xv) {
 #pragma unroll
         for (int k = 0; k < W; ++k) {
@@ -751,8 +760,8 @@ __global__ __launch_bounds__(T) void bn2d_pool_bwd_reduce_kernel(const IO* __res
         for (int l = 0; l < g.PPB; ++l)
 #pragma unroll
             for (int k = 0; k < W; ++k) ts.v[k] += red[k * T + l * g.CW + cg], tq.v[k] += red[(W + k) * T + l * g.CW + cg];
-        storep<W>(partial + (size_t)blockIdx.x * 2 * g.C + col, ts);      // slot order is irrelevant to the
-        storep<W>(partial + (size_t)blockIdx.x * 2 * g.C + g.C + col, tq);  // fixed-order combine that follows
+        storep<W>(partial + (size_t)lb * 2 * g.C + col, ts);      // slot order is irrelevant to the
+        storep<W>(partial + (size_t)lb * 2 * g.C + g.C + col, tq);  // fixed-order combine that follows
     }
 }
 
@@ -769,7 +778,7 @@ __global__ __launch_bounds__(T) void bn2d_pool_bwd_apply_kernel(const IO* __rest
     const Fv<W> mean = loadp<W>(save_mean + col), inv = loadp<W>(save_invstd + col);
     const Fv<W> c0 = loadp<W>(coef + col), c1 = loadp<W>(coef + g.C + col);
     const int per_image = g.H * g.Wd, span = g.PPB * 2 * kPoolIter;
-    const XcdSlot slot = xcd_slot((per_image + span - 1) / span);
+    const XcdSlot slot = xcd_slot((per_image + span - 1) / span, g.rev);
     if (slot.n >= g.N) return;
     const int n = slot.n;
     for (int it = 0; it < 2 * kPoolIter; ++it) {
@@ -837,7 +846,8 @@ inline bool make_plan(int R, int C, int W, int U, int want_split, Plan& p) {
         rows = ((R + split - 1) / split + rpp - 1) / rpp * rpp;
         split = (R + rows - 1) / rows;
     }
-    p.g = {R, C, cgb, rpp, rows};
+    static const int rev = getenv("PECLR_BN_REVERSE") ? atoi(getenv("PECLR_BN_REVERSE")) != 0 : 1;     // (0: A/B runs)
+    p.g = {R, C, cgb, rpp, rows, rev};
     p.grid = dim3(ncb, split);
     p.n_split = split;
     return true;
@@ -1028,7 +1038,8 @@ bool pool_geo(int io_dtype, int N, int H, int W_, int C, peclr::PoolGeo& g) {
     if (!w || N <= 0 || H <= 0 || W_ <= 0 || C <= 0 || C % w) return false;
     const int cw = C / w;
     if (cw > T || T % cw) return false;
-    g = {N, H, W_, C, (H - 1) / 2 + 1, (W_ - 1) / 2 + 1, cw, T / cw};
+    static const int rev = getenv("PECLR_BN_REVERSE") ? atoi(getenv("PECLR_BN_REVERSE")) == 1 : 1;    // (2: the residual blocks' kernels only)
+    g = {N, H, W_, C, (H - 1) / 2 + 1, (W_ - 1) / 2 + 1, cw, T / cw, rev};
     return true;
 }
 // grid = 8 * ceil(N / 8) * runs-per-image (see xcd_slot); cap > 0 bounds the total (the reduce's partials)
