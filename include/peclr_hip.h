@@ -551,6 +551,13 @@ int peclr_wgrad3_x6r_f32(int M, int N, int images, int H, int W, const float* dY
 int peclr_wgrad3_h_slabs(int M, int N, int images, int H, int W);
 int peclr_wgrad3_h(int dtype, int M, int N, int images, int H, int W, const void* A, const void* B, float* slabs, int n_slabs,
                    const void* zeros, peclr_stream_t stream);
+/* ... and of the 3x3 / padding-1 / STRIDE-2 convolutions (the first block of layers 2 - 4): dY [images, Ho, Wo, M], X [images, 2 Ho,
+ * 2 Wo, N].  X splits into four parity planes X_pq[i][j] = X[2 i + p][2 j + q]; tap row a reads plane p = (a != 1) at row shift
+ * -1 (a = 0) or 0, columns alike: the same padded space and ring as peclr_wgrad3_h, four workgroups per (tile, slab) -- one per
+ * plane, 4 / 2 / 2 / 1 taps -- writing disjoint tap columns of the slab.  n_slabs = peclr_wgrad3_h_slabs(M, N, images, Ho, Wo);
+ * Wo <= 62.  Replaces MIOpen's last 16-bit weight gradients of the residual blocks (resnet_model.py:15). */
+int peclr_wgrad3_s2_h(int dtype, int M, int N, int images, int Ho, int Wo, const void* dY, const void* X, float* slabs,
+                      int n_slabs, const void* zeros, peclr_stream_t stream);
 int peclr_wgrad_h_slabs(int M, int N, int K);
 int peclr_wgrad_h(int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* slabs, int n_slabs,
                   int stride, int Ho, int Wo, const void* zeros, peclr_stream_t stream);

@@ -92,6 +92,7 @@ SIGNATURES = {
     "peclr_wgrad3_x6r_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P]),
     "peclr_wgrad3_h_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "peclr_wgrad3_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
+    "peclr_wgrad3_s2_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "peclr_wgrad_h_slabs": (c_int, [c_int, c_int, c_int]),
     "peclr_wgrad_h": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
@@ -865,18 +866,19 @@ def conv_h(x: torch.Tensor, planes: torch.Tensor, cout: int, taps: int = 9, stri
 def wgrad_h_ok(gy: torch.Tensor, x: torch.Tensor, taps: int, stride: int) -> bool:
     """Does peclr_wgrad_h take this weight gradient?  (1x1 convolutions, stride 1 or 2, channel counts multiples of 32.)"""
     cout, cin = gy.shape[1], x.shape[1]
-    if taps == 9:       # 3x3 / padding 1 / stride 1 (peclr_wgrad3_h)
-        return (stride == 1 and cout % 64 == 0 and cin % 64 == 0 and gy.dtype in _HALF_IO and x.dtype == gy.dtype
-                and x.shape[2:] == gy.shape[2:] and x.shape[3] <= 62 and gy.shape[0] * gy.shape[2] * gy.shape[3] >= 512)
+    if taps == 9:       # 3x3 / padding 1, stride 1 (peclr_wgrad3_h) or 2 (peclr_wgrad3_s2_h)
+        return (stride in (1, 2) and cout % 64 == 0 and cin % 64 == 0 and gy.dtype in _HALF_IO and x.dtype == gy.dtype
+                and x.shape[2] == stride * gy.shape[2] and x.shape[3] == stride * gy.shape[3] and gy.shape[3] <= 62
+                and gy.shape[0] * gy.shape[2] * gy.shape[3] >= 512)
     return (taps == 1 and stride in (1, 2) and cout % 32 == 0 and cin % 32 == 0 and gy.dtype in _HALF_IO and x.dtype == gy.dtype
             and gy.shape[0] * gy.shape[2] * gy.shape[3] >= 32
             and (stride == 1 or (x.shape[2] == 2 * gy.shape[2] and x.shape[3] == 2 * gy.shape[3])))
 
 
 def wgrad_h(gy: torch.Tensor, x: torch.Tensor, taps: int = 1, stride: int = 1, tag: str = "conv1x1_wgrad") -> torch.Tensor:
-    """dW [Cout, taps * Cin] (fp32) of a 1x1 (taps = 1, stride 1 / 2) or 3x3 / padding-1 / stride-1 (taps = 9) convolution from
-    16-bit NHWC activations gy [N, Cout, Ho, Wo], x [N, Cin, H, W] (peclr_wgrad_h / peclr_wgrad3_h + peclr_slab_reduce_f32:
-    fixed-order split-K, deterministic)."""
+    """dW [Cout, taps * Cin] (fp32) of a 1x1 (taps = 1) or 3x3 / padding-1 (taps = 9) convolution, stride 1 or 2, from 16-bit NHWC
+    activations gy [N, Cout, Ho, Wo], x [N, Cin, H, W] (peclr_wgrad_h / peclr_wgrad3_h / peclr_wgrad3_s2_h +
+    peclr_slab_reduce_f32: fixed-order split-K, deterministic)."""
     if not wgrad_h_ok(gy, x, taps, stride):
         raise PeclrHipError(f"wgrad_h: unsupported problem gy {tuple(gy.shape)} x {tuple(x.shape)} taps {taps} stride {stride}")
     io = _half_io(gy, "wgrad_h gy")
@@ -890,8 +892,9 @@ def wgrad_h(gy: torch.Tensor, x: torch.Tensor, taps: int = 1, stride: int = 1, t
         slabs = torch.empty((ns, cout, 9 * cin), device=gy.device, dtype=torch.float32)
         with _timed("conv3x3_wgrad" if tag == "conv1x1_wgrad" else tag, 2 * nb * ho * wo * (cout + cin) + 4 * ns * cout * 9 * cin,
                     18 * cout * cin * nb * ho * wo, kernel="wgrad3_h_kernel"):
-            rc = lib().peclr_wgrad3_h(io, cout, cin, nb, ho, wo, gp, xp, slabs.data_ptr(), ns, _hzeros(gy.device, gy.dtype).data_ptr(), _stream())
-        _check(rc, "peclr_wgrad3_h")
+            entry = lib().peclr_wgrad3_h if stride == 1 else lib().peclr_wgrad3_s2_h
+            rc = entry(io, cout, cin, nb, ho, wo, gp, xp, slabs.data_ptr(), ns, _hzeros(gy.device, gy.dtype).data_ptr(), _stream())
+        _check(rc, "peclr_wgrad3_h" if stride == 1 else "peclr_wgrad3_s2_h")
         return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
     k = nb * ho * wo
     ns = lib().peclr_wgrad_h_slabs(cout, cin, k)

@@ -115,6 +115,7 @@ class Routing:
     conv16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV16"))                # 16-bit (bf16 / fp16 autocast) convolutions in-tree
     wgrad3_ring: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD3_RING"))      # fp32 3x3 weight gradient: one split per element (LDS ring + transposing reads)
     wgrad16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD16"))              # ... and their weight gradients
+    wgrad16_s2: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD16_S2", "0"))   # ... the three 3x3 / stride-2 ones too (in-tree 171 - 196 us vs MIOpen 137 - 150: off)
     force: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_ROUTE_FORCE", "0"))
 
     # ---- "does the in-tree kernel pay at this shape" (measured on ResNet-50's shapes; the kernels accept far more)
@@ -816,7 +817,7 @@ def _wgrad_h(gy: Tensor, x: Tensor, conv, stride: int):
     taps = w.shape[2] * w.shape[3]
     fn = getattr(_capi, "wgrad_h", None)
     if (fn is not None and ROUTING.wgrad16 and w.is_contiguous(memory_format=torch.channels_last)
-            and _capi.wgrad_h_ok(gy, x, taps, stride)):
+            and _capi.wgrad_h_ok(gy, x, taps, stride) and (taps == 1 or stride == 1 or ROUTING.wgrad16_s2 or ROUTING.force)):
         def run():
             dw = fn(gy, x, taps, stride)                  # [Cout, taps * Cin] fp32
             if taps == 9:

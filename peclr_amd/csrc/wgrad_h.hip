@@ -255,19 +255,36 @@ struct W3Args {
     int P;                               // padded slots: images * (H + 1) * (W + 1)
     int pchunk;                          // padded slots per slab (multiple of 32)
     const h16_t* zeros;
+    int s2;                              // stride 2: H x W are the OUTPUT pixels (dY), X holds 2H x 2W; blockIdx.z = parity plane of X
+    unsigned m_hw, s_hw, m_w, s_w;       // p / ((H + 1)(W + 1)) = mulhi(p, m_hw) >> s_hw for 0 <= p < 2^31; likewise / (W + 1)
 };
+
+// exact division of a 31-bit number by d >= 2 as a multiply-high and a shift (the loop's two DMA addresses per step took two
+// integer divisions each: ~60 vector instructions next to 18 products)
+inline void magic_div(unsigned d, unsigned& m, unsigned& sh) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;                         // ceil(log2 d) >= 1
+    m = (unsigned)(((1ull << (31 + l)) / d) + 1);
+    sh = l - 1;
+}
 
 // RINGP: slots of the X ring (power of two >= 2 * roundup(W + 2, 32) + 96: the k-step's 32 slots, lead and lag of the taps, and
 // the group in flight; 256 slots = 32 KiB serve W <= 62, i.e. every 3x3 of ResNet at 224 x 224 -- wider rows stay on MIOpen:
 // a 512-slot ring would leave the 64 KiB an LDS-DMA can address)
-template <bool F16, int RINGP>
+// Stride 2 (g.s2): output pixel (oh, ow) meets input pixel (2 oh + a - 1, 2 ow + b - 1) under tap (a, b).  Split X into its four
+// parity planes X_pq[i][j] = X[2 i + p][2 j + q] (each H x W, like dY): tap row a reads plane p = (a != 1) at row shift -1 (a = 0)
+// or 0, columns alike -- so plane (1, 1) serves the four corner taps, (1, 0) and (0, 1) two taps each, (0, 0) the centre, all with
+// shifts in {-1, 0}: the SAME padded space and ring, the plane picked by the addresses the DMA lanes fetch.  blockIdx.z = 2 p + q;
+// the four workgroups of a (tile, slab) write disjoint tap columns of the slab.
+template <bool F16, int RINGP, bool S2>
 __global__ __launch_bounds__(256, 2) void wgrad3_h_kernel(W3Args g) {
     constexpr int NSA = 3;                               // dY stages (two k-steps of run-ahead)
     constexpr int ASZ = 2 * 2048;                        // [2 blocks][32 slots][64 B]
-    constexpr int R0 = NSA * ASZ;                        // ring: [2 blocks][RINGP slots][64 B]
-    constexpr int RB = RINGP * 64;
-    static_assert(R0 + 2 * RB <= 65536, "LDS-DMA targets below 64 KiB");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[R0 + 2 * RB];
+    constexpr int RB = RINGP * 64;                       // ring: [2 blocks][RINGP slots][64 B], FIRST in the LDS: a slot's address is
+    constexpr int R0 = 0;                                // ((byte offset) & (RB - 1)) | (block base + channel bytes): two instructions
+    constexpr int A0 = 2 * RB;                           // dY stages behind it
+    static_assert(A0 + NSA * ASZ <= 65536 && (RB & (RB - 1)) == 0, "LDS-DMA targets below 64 KiB; power-of-two ring");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[A0 + NSA * ASZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     typedef __attribute__((address_space(3))) unsigned char* lptr_t;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)(lptr_t)lds);
@@ -281,30 +298,34 @@ __global__ __launch_bounds__(256, 2) void wgrad3_h_kernel(W3Args g) {
     const int nk = (p_end - p_begin + 31) / 32;
     const int mblk = wave >> 1, nblk = wave & 1;
 
-    f32x16 acc[9];
+    constexpr int NT = S2 ? 4 : 9;                        // accumulators: taps of the launch (stride 2: of the largest parity plane)
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int pp = S2 ? (int)(blockIdx.z >> 1) : 0, pq = S2 ? (int)(blockIdx.z & 1) : 0;     // parity plane of X (stride 2)
 
     // DMA: this wave moves piece (block = wave >> 1, 16-slot half = wave & 1) of every 32-slot group; lane = slot (lane >> 2) of
     // the half, channels 8 (lane & 3) .. + 7 of the block.  A padded slot p is real pixel (img, hh - 1, ww - 1) iff hh, ww >= 1.
     const int dblk = wave_s >> 1, dhalf = wave_s & 1;
     const int lch = 8 * (lane & 3);
-    auto src_of = [&](const h16_t* base, int ld, int ch0, int p, bool live) -> const h16_t* {
-        const int img = p / HW1, rem = p - img * HW1, hh = rem / W1, ww = rem - hh * W1;
+    auto src_of = [&](const h16_t* base, int ld, int ch0, int p, bool live, bool plane = false) -> const h16_t* {
+        const int img = (int)(__umulhi((unsigned)p, g.m_hw) >> g.s_hw), rem = p - img * HW1;     // (p < 0: garbage, not used)
+        const int hh = (int)(__umulhi((unsigned)rem, g.m_w) >> g.s_w), ww = rem - hh * W1;
         const bool real = live && p >= 0 && img < g.images && hh >= 1 && ww >= 1;
-        const size_t row = ((size_t)img * g.H + (hh - 1)) * g.W + (ww - 1);
+        const size_t row = plane ? ((size_t)img * 2 * g.H + 2 * (hh - 1) + pp) * (2 * g.W) + 2 * (ww - 1) + pq
+                                 : ((size_t)img * g.H + (hh - 1)) * g.W + (ww - 1);
         return real ? base + row * ld + ch0 + lch : g.zeros + lch;
     };
     auto issue_a = [&](int t) {                           // dY slots [p_begin + 32 t, + 32) -> stage t % NSA
         const int p = p_begin + 32 * t + 16 * dhalf + (lane >> 2);
-        wdma16(src_of(g.A, g.lda, m0 + 32 * dblk, p, p < p_end), lds0 + (t % NSA) * ASZ + dblk * 2048 + dhalf * 1024);
+        wdma16(src_of(g.A, g.lda, m0 + 32 * dblk, p, p < p_end), lds0 + A0 + (t % NSA) * ASZ + dblk * 2048 + dhalf * 1024);
     };
     auto issue_x = [&](int u) {                           // ring group u: X slots [p_begin - L + 32 u, + 32)
         const int p = p_begin - L + 32 * u + 16 * dhalf + (lane >> 2);
         const unsigned slot0 = (unsigned)(32 * u + 16 * dhalf) & (RINGP - 1);
-        wdma16(src_of(g.B, g.ldb, n0 + 32 * dblk, p, true), lds0 + R0 + dblk * RB + slot0 * 64);
+        wdma16(src_of(g.B, g.ldb, n0 + 32 * dblk, p, true, S2), lds0 + R0 + dblk * RB + slot0 * 64);
     };
     // k-step t reads ring groups t .. t + 2 L / 32 (slots [32 t, 32 t + 32 + 2 L) relative to p_begin - L); groups are issued two
     // steps ahead of their first use
@@ -324,19 +345,25 @@ __global__ __launch_bounds__(256, 2) void wgrad3_h_kernel(W3Args g) {
         asm volatile("" ::: "memory");
         if (t + 1 < nk) issue_x(t + G0 + 1);              // (the ring slot group it overwrites was last read in step t - 1 at the latest)
         if (t + 2 < nk) issue_a(t + 2);
-        const unsigned char* sa = lds + (t % NSA) * ASZ + mblk * 2048 + fch;
-        const unsigned char* sx = lds + R0 + nblk * RB + fch;
-        const int xbase = 32 * t + L + fpix;              // ring slot (before the wrap) of this lane's first pixel at shift 0
+        const unsigned char* sa = lds + A0 + (t % NSA) * ASZ + mblk * 2048 + fch;
+        const unsigned xor_ = (unsigned)(nblk * RB + fch);            // (block base + this lane's channel bytes: bits the mask clears)
+        const unsigned xb64 = (unsigned)(32 * t + L + fpix) * 64u;    // byte offset (before the wrap) of this lane's first pixel at shift 0
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const uint4 af = tr_frag(sa + (kk * 16 + fpix) * 64);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int shift = (tap / 3 - 1) * W1 + (tap % 3 - 1);
+            for (int tap = 0; tap < NT; ++tap) {
+                int shift = (tap / 3 - 1) * W1 + (tap % 3 - 1);
+                if constexpr (S2) {                       // accumulator `tap` < 4 = (ia, ib): filter row a = pp ? 2 ia : 1 at shift (pp && !ia ? -1 : 0)
+                    if (tap >= (1 + pp) * (1 + pq)) continue;
+                    const int ia = tap / (1 + pq), ib = tap - ia * (1 + pq);
+                    shift = (pp && ia == 0 ? -W1 : 0) + (pq && ib == 0 ? -1 : 0);
+                }
                 typedef __attribute__((address_space(3))) s16x4* lp;
-                const unsigned s0 = (unsigned)(xbase + kk * 16 + shift) & (RINGP - 1), s1 = (unsigned)(xbase + kk * 16 + shift + 4) & (RINGP - 1);
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(sx + s0 * 64));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(sx + s1 * 64));
+                const unsigned t0 = xb64 + (unsigned)((kk * 16 + shift) * 64);
+                const unsigned a0 = (t0 & (unsigned)(RB - 64)) | xor_, a1 = ((t0 + 256u) & (unsigned)(RB - 64)) | xor_;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds + a0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds + a1));
                 const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
                 acc[tap] = wmma<F16>(af, make_uint4(l2.x, l2.y, h2.x, h2.y), acc[tap]);
             }
@@ -346,9 +373,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3_h_kernel(W3Args g) {
     const int i = lane & 31, kh = lane >> 5;
     const int mb = m0 + 32 * mblk, nb = n0 + 32 * nblk;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < NT; ++tap) {
+        int ftap = tap;                                   // filter tap this accumulator belongs to
+        if constexpr (S2) {
+            if (tap >= (1 + pp) * (1 + pq)) continue;
+            const int ia = tap / (1 + pq), ib = tap - ia * (1 + pq);
+            ftap = 3 * (pp ? 2 * ia : 1) + (pq ? 2 * ib : 1);
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[(size_t)(mb + mfma32_row(r, kh)) * (9 * g.N) + tap * g.N + nb + i] = acc[tap][r];
+        for (int r = 0; r < 16; ++r) slab[(size_t)(mb + mfma32_row(r, kh)) * (9 * g.N) + ftap * g.N + nb + i] = acc[tap][r];
+    }
 }
 
 }  // namespace
@@ -382,9 +416,38 @@ extern "C" int peclr_wgrad3_h(int dtype, int M, int N, int images, int H, int W,
     g.P = images * (H + 1) * (W + 1);
     g.pchunk = ((g.P + n_slabs - 1) / n_slabs + 31) / 32 * 32;
     g.zeros = static_cast<const h16_t*>(zeros);
+    magic_div((unsigned)((H + 1) * (W + 1)), g.m_hw, g.s_hw);
+    magic_div((unsigned)(W + 1), g.m_w, g.s_w);
+    g.s2 = 0;
     const dim3 grid((M / 64) * (N / 64), n_slabs);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == PECLR_DTYPE_F16) hipLaunchKernelGGL((wgrad3_h_kernel<true, 256>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((wgrad3_h_kernel<false, 256>), grid, dim3(256), 0, s, g);
+    if (dtype == PECLR_DTYPE_F16) hipLaunchKernelGGL((wgrad3_h_kernel<true, 256, false>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((wgrad3_h_kernel<false, 256, false>), grid, dim3(256), 0, s, g);
+    return launch_status();
+}
+
+// ... of a 3x3 / padding-1 / STRIDE-2 convolution: dY [images, Ho, Wo, Cout], X [images, 2 Ho, 2 Wo, Cin]; slabs as above with
+// peclr_wgrad3_h_slabs(M, N, images, Ho, Wo).  Four workgroups per (tile, slab), one per parity plane of X.
+extern "C" int peclr_wgrad3_s2_h(int dtype, int M, int N, int images, int Ho, int Wo, const void* A, const void* B, float* slabs,
+                                 int n_slabs, const void* zeros, peclr_stream_t stream) {
+    if (!A || !B || !slabs || !zeros) return PECLR_ERR_NULL;
+    if (M <= 0 || N <= 0 || images <= 0 || Ho <= 0 || Wo <= 0 || M % 64 || N % 64 || Wo > 62) return PECLR_ERR_SHAPE;
+    if ((long)images * (Ho + 1) * (Wo + 1) > 0x7fffffffL / 8) return PECLR_ERR_SHAPE;
+    if (!aligned16(A) || !aligned16(B) || !aligned16(slabs) || !aligned16(zeros)) return PECLR_ERR_ALIGN;
+    if (n_slabs != peclr_wgrad3_h_slabs(M, N, images, Ho, Wo)) return PECLR_ERR_WORKSPACE;
+    if (dtype != PECLR_DTYPE_BF16 && dtype != PECLR_DTYPE_F16) return PECLR_ERR_UNSUPPORTED;
+    W3Args g;
+    g.A = static_cast<const h16_t*>(A); g.B = static_cast<const h16_t*>(B); g.slabs = slabs;
+    g.M = M; g.N = N; g.lda = M; g.ldb = N; g.H = Ho; g.W = Wo; g.images = images;
+    g.P = images * (Ho + 1) * (Wo + 1);
+    g.pchunk = ((g.P + n_slabs - 1) / n_slabs + 31) / 32 * 32;
+    g.zeros = static_cast<const h16_t*>(zeros);
+    magic_div((unsigned)((Ho + 1) * (Wo + 1)), g.m_hw, g.s_hw);
+    magic_div((unsigned)(Wo + 1), g.m_w, g.s_w);
+    g.s2 = 1;
+    const dim3 grid((M / 64) * (N / 64), n_slabs, 4);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == PECLR_DTYPE_F16) hipLaunchKernelGGL((wgrad3_h_kernel<true, 256, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((wgrad3_h_kernel<false, 256, true>), grid, dim3(256), 0, s, g);
     return launch_status();
 }
