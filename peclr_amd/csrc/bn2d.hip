@@ -220,6 +220,55 @@ __global__ __launch_bounds__(T) void bn2d_stats_kernel(const IO* __restrict__ x,
 constexpr int FT = 1024, FC = 32, FL = FT / FC;
 __device__ __forceinline__ void combine_partials(const float* __restrict__ partial, int n_split, int C, int c, int lane,
                                                  double (*red)[2][FC], double& a, double& b) {
+    if (C % 4 == 0 && n_split >= 256) {
+        // long tables (128-row GEMM tiles of the first layers: 3 000 - 12 000 rows; 19 - 26 us per launch with 32 row lanes of
+        // 4-byte loads): 128 row lanes x 8 channel quads, 16-byte loads, eight in flight per thread; the eight row lanes of a wave
+        // fold by shuffles (a fixed tree), the sixteen waves through `red` in order.  (Fewer channels per workgroup -- more CUs
+        // loading -- was measured too: 9 us at 64 channels, 29 at 256: 32-byte pieces of 128-byte lines.)
+        const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3;
+        const int c0 = blockIdx.x * FC + 4 * cq;
+        double s4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (c0 < C) {
+            const float* p = partial + c0;
+            int k = rl;
+            for (; k + 3 * 128 < n_split; k += 4 * 128) {
+                float4 sv[4], qv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    sv[u] = *reinterpret_cast<const float4*>(p + (size_t)(k + 128 * u) * 2 * C);
+                    qv[u] = *reinterpret_cast<const float4*>(p + (size_t)(k + 128 * u) * 2 * C + C);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s4[0] += (double)sv[u].x; s4[1] += (double)sv[u].y; s4[2] += (double)sv[u].z; s4[3] += (double)sv[u].w;
+                    q4[0] += (double)qv[u].x; q4[1] += (double)qv[u].y; q4[2] += (double)qv[u].z; q4[3] += (double)qv[u].w;
+                }
+            }
+            for (; k < n_split; k += 128) {
+                const float4 sv = *reinterpret_cast<const float4*>(p + (size_t)k * 2 * C);
+                const float4 qv = *reinterpret_cast<const float4*>(p + (size_t)k * 2 * C + C);
+                s4[0] += (double)sv.x; s4[1] += (double)sv.y; s4[2] += (double)sv.z; s4[3] += (double)sv.w;
+                q4[0] += (double)qv.x; q4[1] += (double)qv.y; q4[2] += (double)qv.z; q4[3] += (double)qv.w;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 8; off >>= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s4[j] += __shfl_down(s4[j], off, 64); q4[j] += __shfl_down(q4[j], off, 64); }
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) < 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { red[wv][0][4 * cq + j] = s4[j]; red[wv][1][4 * cq + j] = q4[j]; }
+        }
+        __syncthreads();
+        a = b = 0.0;
+        if (lane == 0)
+            for (int w = 0; w < FT / 64; ++w) {
+                a += red[w][0][threadIdx.x % FC];
+                b += red[w][1][threadIdx.x % FC];
+            }
+        return;
+    }
     double s = 0.0, q = 0.0;
     if (c < C) {
         int k = lane;
