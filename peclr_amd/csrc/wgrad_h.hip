@@ -59,17 +59,16 @@ __device__ __forceinline__ uint4 tr_frag(const unsigned char* base) {
 }
 
 // MB, NB: 32-channel blocks of dY / X per workgroup (MB * NB = 16: every wave a 64 x 64 output block = 2 x 2 MFMA tiles)
-#ifndef PECLR_WGRAD_H_STAGES
-#define PECLR_WGRAD_H_STAGES 2
-#endif
-template <bool F16, int MB, int NB, bool S2>
-__global__ __launch_bounds__(256, 4) void wgrad_h_kernel(WArgs g) {
+template <bool F16, int MB, int NB, bool S2, int NS = 2>
+__global__ __launch_bounds__(256, NS == 2 ? 4 : 2) void wgrad_h_kernel(WArgs g) {
     static_assert(MB * NB == 16, "four waves of 64 x 64");
-    constexpr int NS = PECLR_WGRAD_H_STAGES;             // stages (2: 32 - 40 KiB of LDS, four workgroups per CU)
+    // NS stages (2: 32 - 40 KiB of LDS, four workgroups per CU; 4: 64 - 80 KiB, two per CU with three steps of run-ahead each --
+    // the same bytes in flight from HALF the workgroups, i.e. half the slabs: see wgrad_plan; 4 x 4 block tiles only)
     constexpr int ASZ = MB * 2048, BSZ = NB * 2048;      // bytes per stage: [block][32 pixels][64 B]
     constexpr int STAGE = ASZ + BSZ;
     constexpr int NPA = MB * 2 / 4, NPB = NB * 2 / 4;    // DMA pieces (16 pixels x 64 B of one block) per wave and step
     constexpr int ND = NPA + NPB;
+    static_assert(NS * STAGE <= 65536, "LDS-DMA targets below 64 KiB");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     typedef __attribute__((address_space(3))) unsigned char* lptr_t;
@@ -185,11 +184,30 @@ WTile pick_tile(int M, int N) {
 
 using namespace peclr;
 
+namespace {
+// Stages and workgroups per launch.  Two stages x 512 workgroups is the general choice (probe: 512 beats 1024 by 15 - 25 % -- half
+// the slab traffic -- and 256 by 5 - 40 %).  The bottleneck shapes (one side four times the other) are served better by four
+// stages: from 256 workgroups where the slabs are a large share of the traffic (128 <-> 512, 256 <-> 1024: 74 -> 69, 54 -> 52 us with the
+// slab reduction), from 512 at 512 <-> 2048 (48.5 -> 44); 64 <- 64 and the stride-2 shortcuts (ratio 2) lose with either
+// (tools/exp/wgrad_h_probe.py over the two builds); the 2 x 8 / 8 x 2 block tiles of layer1 would need 80 KiB.
+struct WPlan { int stages; long target; };
+WPlan wgrad_plan(int M, int N) {
+    static const long forced = getenv("PECLR_WGRAD_H_WGS") ? atol(getenv("PECLR_WGRAD_H_WGS")) : 0;
+    static const int deep = getenv("PECLR_WGRAD_H_DEEP") ? atoi(getenv("PECLR_WGRAD_H_DEEP")) : 1;
+    const long mn = (long)M * N;
+    const bool ratio4 = (M == 4 * N || N == 4 * M) && M >= 128 && N >= 128;      // (the 4 x 4 block tile: four of its stages are 64 KiB)
+    WPlan p{2, 512};
+    if (deep && ratio4) p = mn <= 262144 ? WPlan{4, 256} : WPlan{4, 512};
+    if (forced > 0) p.target = forced;
+    return p;
+}
+}  // namespace
+
 extern "C" int peclr_wgrad_h_slabs(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || M % 32 || N % 32) return 0;
     const WTile t = pick_tile(M, N);
     const long tiles = (long)((M + 32 * t.mb - 1) / (32 * t.mb)) * ((N + 32 * t.nb - 1) / (32 * t.nb));
-    static const long target = getenv("PECLR_WGRAD_H_WGS") ? atol(getenv("PECLR_WGRAD_H_WGS")) : 512;   // workgroups per launch (probe: 512 beats 1024 by 15 - 25 % -- half the slab traffic -- and 256 by 5 - 40 %)
+    const long target = wgrad_plan(M, N).target;
     long s = (target + tiles - 1) / tiles;
     const long max_s = (K + 8 * WK - 1) / (8 * WK);      // at least eight k-steps per slab
     if (s > max_s) s = max_s;
@@ -218,17 +236,28 @@ extern "C" int peclr_wgrad_h(int dtype, int M, int N, int K, const void* A, int 
     const dim3 grid(((M + 32 * t.mb - 1) / (32 * t.mb)) * ((N + 32 * t.nb - 1) / (32 * t.nb)), n_slabs);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool f16 = dtype == PECLR_DTYPE_F16;
+    const bool deep = stride == 1 && wgrad_plan(M, N).stages == 4;
 #define PECLR_LAUNCH(MB_, NB_)                                                                                      \
+    do {                                                                                                            \
+        if (f16) { if (stride == 2) hipLaunchKernelGGL((wgrad_h_kernel<true, MB_, NB_, true>), grid, dim3(256), 0, s, g); \
+                   else if (deep) hipLaunchKernelGGL((wgrad_h_kernel<true, MB_, NB_, false, 4>), grid, dim3(256), 0, s, g); \
+                   else hipLaunchKernelGGL((wgrad_h_kernel<true, MB_, NB_, false>), grid, dim3(256), 0, s, g); }     \
+        else { if (stride == 2) hipLaunchKernelGGL((wgrad_h_kernel<false, MB_, NB_, true>), grid, dim3(256), 0, s, g); \
+               else if (deep) hipLaunchKernelGGL((wgrad_h_kernel<false, MB_, NB_, false, 4>), grid, dim3(256), 0, s, g); \
+               else hipLaunchKernelGGL((wgrad_h_kernel<false, MB_, NB_, false>), grid, dim3(256), 0, s, g); }        \
+    } while (0)
+#define PECLR_LAUNCH2(MB_, NB_)                                                                                     \
     do {                                                                                                            \
         if (f16) { if (stride == 2) hipLaunchKernelGGL((wgrad_h_kernel<true, MB_, NB_, true>), grid, dim3(256), 0, s, g); \
                    else hipLaunchKernelGGL((wgrad_h_kernel<true, MB_, NB_, false>), grid, dim3(256), 0, s, g); }     \
         else { if (stride == 2) hipLaunchKernelGGL((wgrad_h_kernel<false, MB_, NB_, true>), grid, dim3(256), 0, s, g); \
                else hipLaunchKernelGGL((wgrad_h_kernel<false, MB_, NB_, false>), grid, dim3(256), 0, s, g); }        \
     } while (0)
-    if (t.mb == 8) PECLR_LAUNCH(8, 2);
-    else if (t.mb == 2) PECLR_LAUNCH(2, 8);
+    if (t.mb == 8) PECLR_LAUNCH2(8, 2);
+    else if (t.mb == 2) PECLR_LAUNCH2(2, 8);
     else PECLR_LAUNCH(4, 4);
 #undef PECLR_LAUNCH
+#undef PECLR_LAUNCH2
     return launch_status();
 }
 
