@@ -219,8 +219,10 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
         }
     }
     const h16_t* const zsrc = TAPS == 9 ? g.zeros + 8 * achunk : nullptr;
+    // t / kpt without a division in the loop (t kpt < 2^32: exact)
+    const unsigned kmagic = 0xFFFFFFFFu / (unsigned)kpt + 1u;
     auto class_tap = [&](int t, int& rem, int& ftap, int& da, int& db) {      // s2d: k-step t = step `rem` of filter tap `ftap`
-        const int u = t / kpt;
+        const int u = (int)__umulhi((unsigned)t, kmagic);
         rem = t - u * kpt;
         const int ua = u / (1 + pw), ub = u - ua * (1 + pw);
         da = ph && ua == 0;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
         long off = (long)t * HK;
         int tap = 0;
         if constexpr (TAPS == 9) {
-            tap = t / kpt;
+            tap = (int)__umulhi((unsigned)t, kmagic);
             if (s2d) {
                 int rem, ftap, da, db;
                 class_tap(t, rem, ftap, da, db);
