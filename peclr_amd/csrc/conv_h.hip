@@ -43,6 +43,8 @@ struct BF16 {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
     static __device__ __forceinline__ float up(unsigned lo16) { return __uint_as_float(lo16 << 16); }
+    static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }           // the two halves of a word,
+    static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }   // one instruction each
     static __device__ __forceinline__ unsigned pack2(float a, float b) { return pk_bf16(a, b); }          // round to nearest even
 };
 struct F16 {
@@ -51,6 +53,8 @@ struct F16 {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
     }
     static __device__ __forceinline__ float up(unsigned lo16) { return (float)__builtin_bit_cast(_Float16, (unsigned short)lo16); }
+    static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)w); }
+    static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
     static __device__ __forceinline__ unsigned pack2(float a, float b) {
         const f32x2_t v = {a, b};
         return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2v));
@@ -543,33 +547,53 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
                 for (int r = 0; r < 16; ++r) wl[mfma32_row(r, kh) * XE + y2 * 32 + i] = acc[a][2 * yp + y2][r];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const int m = mt + er + 8 * jj;
                 float c[8];
                 *reinterpret_cast<float4*>(c) = *reinterpret_cast<const float4*>(wl + (er + 8 * jj) * XE + ec);
                 *reinterpret_cast<float4*>(c + 4) = *reinterpret_cast<const float4*>(wl + (er + 8 * jj) * XE + ec + 4);
+                // The epilogue of the fused entry gradients is bound by its vector instructions (four waves per SIMD each issuing
+                // all of this per row): the launch's modes are decided per ROW, not per element, words are split with one
+                // instruction per half, and the reduction's normalisation (x - mean) * invstd keeps its factor for the end.
                 const unsigned dw[4] = {dv[jj].x, dv[jj].y, dv[jj].z, dv[jj].w};
                 unsigned ow[4];
+                if (ADD && g.addend) {
+                    if (g.add_mask) {                     // 1-bit mask of the addend (an identity shortcut's (dy, mask) hand-over)
+                        const unsigned bits = ab[jj];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (ADD && g.addend) {
-                        c[2 * q] += (ab[jj] >> (2 * q)) & 1u ? H::up(dw[q] & 0xFFFFu) : 0.f;
-                        c[2 * q + 1] += (ab[jj] >> (2 * q + 1)) & 1u ? H::up(dw[q] >> 16) : 0.f;
+                        for (int q = 0; q < 4; ++q) {
+                            c[2 * q] += (bits >> (2 * q)) & 1u ? H::lo(dw[q]) : 0.f;
+                            c[2 * q + 1] += (bits >> (2 * q + 1)) & 1u ? H::hi(dw[q]) : 0.f;
+                        }
+                    } else {                              // dense, or compact with zeros where the row has no entry
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { c[2 * q] += H::lo(dw[q]); c[2 * q + 1] += H::hi(dw[q]); }
                     }
-                    ow[q] = H::pack2(c[2 * q], c[2 * q + 1]);
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ow[q] = H::pack2(c[2 * q], c[2 * q + 1]);
                 if (om[a][jj] >= 0) {
                     *reinterpret_cast<uint4*>(g.out + (size_t)om[a][jj] * g.ldo + nt + ec) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
                     if (BBF && g.bb_partial) {
                         const unsigned xw[4] = {xv[jj].x, xv[jj].y, xv[jj].z, xv[jj].w};
+                        float x[8], d[8];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            x[2 * q] = H::lo(xw[q]); x[2 * q + 1] = H::hi(xw[q]);
+                            d[2 * q] = H::lo(ow[q]); d[2 * q + 1] = H::hi(ow[q]);       // (the rounded outputs)
+                        }
+                        if (g.bb_relu) {
+                            if (g.bb_mask) {
+                                const unsigned bits = mb[jj];
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) d[q] = (bits >> q) & 1u ? d[q] : 0.f;
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) d[q] = fmaf(x[q], bsc[q], bsh[q]) > 0.f ? d[q] : 0.f;
+                            }
+                        }
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
-                            const float x = H::up((xw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu);
-                            const float dy = H::up((ow[q >> 1] >> (16 * (q & 1))) & 0xFFFFu);
-                            bool on = true;
-                            if (g.bb_relu) on = g.bb_mask ? (mb[jj] >> q) & 1u : fmaf(x, bsc[q], bsh[q]) > 0.f;
-                            const float d = on ? dy : 0.f;
-                            sb[q] += d;
-                            sg[q] = fmaf(d, (x - bmean[q]) * binv[q], sg[q]);
+                            sb[q] += d[q];
+                            sg[q] = fmaf(d[q], x[q] - bmean[q], sg[q]);
                         }
                     }
                 }
@@ -578,6 +602,7 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
         if (BBF && g.bb_partial) {                        // lanes with equal (lane & 7) hold the same eight columns
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
+                sg[q] *= binv[q];                         // (sum of d (x - mean), times invstd)
 #pragma unroll
                 for (int o = 8; o < 64; o <<= 1) { sb[q] += __shfl_xor(sb[q], o, 64); sg[q] += __shfl_xor(sg[q], o, 64); }
                 if (er == 0) { sl[(wave * 2) * 128 + yp * 64 + ec + q] = sb[q]; sl[(wave * 2 + 1) * 128 + yp * 64 + ec + q] = sg[q]; }
