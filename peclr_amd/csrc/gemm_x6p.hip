@@ -699,6 +699,13 @@ static void set_bb(X6PArgs& g, const peclr_bn_bwd_fuse* bb) {
     g.bb_partial = bb ? bb->partial : nullptr;
 }
 
+// outputs larger than the caches are written (and their addends read) with the non-temporal hint (PECLR_X6P_STREAM_OUT=0: never,
+// for A/B runs against the memory-side cache)
+static bool stream_past_caches(size_t bytes) {
+    static const int on = getenv("PECLR_X6P_STREAM_OUT") ? atoi(getenv("PECLR_X6P_STREAM_OUT")) : 1;
+    return on && bytes > ((size_t)64 << 20);
+}
+
 static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t stream, bool halo = false) {
     const int nrb = (g.M + tile_rows - 1) / tile_rows;
     // 64-column tiles (N a multiple of 64 only) -- and for the entry-gradient GEMMs with K <= 256 (layers 1-3: HBM-bound,
@@ -741,7 +748,7 @@ extern "C" int peclr_conv3x3_s2_dgrad_x6p_f32(int NB, int Ho, int Wo, int Cout, 
     X6PArgs g;
     g.A = dY; g.Bp = Bp; g.addend = nullptr; g.out = dX;
     g.M = M; g.N = Cin; g.K = 9 * Cout; g.lda = Cout; g.ldo = Cin; g.ldd = Cin; g.add_h = g.add_w = 0; g.add_mask = nullptr;
-    g.stream_out = (size_t)M * 4 * Cin * sizeof(float) > ((size_t)64 << 20);
+    g.stream_out = stream_past_caches((size_t)M * 4 * Cin * sizeof(float));
     g.stat_shift = nullptr; g.stat_partial = nullptr;
     g.H = Ho; g.W = Wo; g.flip = 1; g.zeros = zeros; g.stride = 1; g.Hin = Ho; g.Win = Wo; g.s2d = 1;
     set_bb(g, bb);
@@ -761,7 +768,7 @@ extern "C" int peclr_conv_s2_x6p_f32(int NB, int H, int W, int Cin, int Cout, in
     X6PArgs g;
     g.A = X; g.Bp = Bp; g.addend = nullptr; g.out = Y;
     g.M = M; g.N = Cout; g.K = taps * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout; g.add_h = g.add_w = 0; g.add_mask = nullptr;
-    g.stream_out = (size_t)M * Cout * sizeof(float) > ((size_t)64 << 20);
+    g.stream_out = stream_past_caches((size_t)M * Cout * sizeof(float));
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = Ho; g.W = Wo; g.flip = 0; g.zeros = zeros; g.stride = 2; g.Hin = H; g.Win = W; g.s2d = 0;
     set_bb(g, nullptr);
@@ -784,7 +791,7 @@ extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, co
     X6PArgs g;
     g.A = X; g.Bp = Bp; g.addend = addend; g.out = Y;
     g.M = M; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.ldo = Cout; g.ldd = Cout; g.add_h = g.add_w = 0; g.add_mask = nullptr;
-    g.stream_out = (size_t)M * Cout * sizeof(float) > ((size_t)64 << 20);
+    g.stream_out = stream_past_caches((size_t)M * Cout * sizeof(float));
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = H; g.W = W; g.flip = flip ? 1 : 0; g.zeros = zeros; g.stride = 1; g.Hin = H; g.Win = W; g.s2d = 0;
     set_bb(g, bb);
@@ -807,7 +814,7 @@ static int gemm_x6p_host(int M, int N, int K, const float* A, int lda, const voi
     g.A = A; g.Bp = Bp; g.addend = addend; g.out = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldc; g.ldd = ldd;
     g.add_h = add_h; g.add_w = add_w; g.add_mask = add_mask;
-    g.stream_out = (size_t)M * N * sizeof(float) > ((size_t)64 << 20);
+    g.stream_out = stream_past_caches((size_t)M * N * sizeof(float));
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = g.W = 1; g.flip = 0; g.zeros = nullptr; g.stride = 1; g.Hin = g.Win = 1; g.s2d = 0;
     set_bb(g, bb);
