@@ -379,7 +379,10 @@ int peclr_amp_update(peclr_amp_state* amp, float growth_factor, float backoff_fa
  * ReLU mask in the backward: recomputed from x when neither y nor relu_mask is given (valid only
  * if no residual was added); read from relu_mask ([R][C/32] uint32, 1 bit per element, written by
  * peclr_bn2d_apply when its relu_mask argument is non-null; needs C % 32 == 0) or, failing that,
- * from the forward output y.  d_residual (nullable) receives the masked dy.                  */
+ * from the forward output y.  d_residual (nullable) receives the masked dy.
+ * peclr_bn2d_finalize_f32 / peclr_bn2d_bwd_finalize_f32 CONSUME long partial tables: with n_split >= 2048 the rows are first
+ * summed in slices of 512 by a launch of their own that leaves each slice's sum in the slice's first row (in place, despite
+ * the const: a table is finalized once).                                                      */
 #define PECLR_DTYPE_F32 0
 #define PECLR_DTYPE_BF16 1
 #define PECLR_DTYPE_F16 2   /* IEEE half: precision=16 (native AMP), the reference's default */

@@ -218,8 +218,10 @@ __global__ __launch_bounds__(T) void bn2d_stats_kernel(const IO* __restrict__ x,
 // Finalize kernels: a 1024-thread workgroup owns 32 channels; its 32 row lanes each combine every 32nd
 // row-slice partial in float64 (coalesced 128-byte reads), then lane 0 adds the 32 lane sums in a fixed order.
 constexpr int FT = 1024, FC = 32, FL = FT / FC;
+// rs: floats between consecutive rows of the table (2 C, or a multiple of it when the table was folded: see
+// bn2d_fold_partials_kernel)
 __device__ __forceinline__ void combine_partials(const float* __restrict__ partial, int n_split, int C, int c, int lane,
-                                                 double (*red)[2][FC], double& a, double& b) {
+                                                 double (*red)[2][FC], double& a, double& b, size_t rs) {
     if (C % 4 == 0 && n_split >= 256) {
         // long tables (128-row GEMM tiles of the first layers: 3 000 - 12 000 rows; 19 - 26 us per launch with 32 row lanes of
         // 4-byte loads): 128 row lanes x 8 channel quads, 16-byte loads, eight in flight per thread; the eight row lanes of a wave
@@ -235,8 +237,8 @@ __device__ __forceinline__ void combine_partials(const float* __restrict__ parti
                 float4 sv[4], qv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    sv[u] = *reinterpret_cast<const float4*>(p + (size_t)(k + 128 * u) * 2 * C);
-                    qv[u] = *reinterpret_cast<const float4*>(p + (size_t)(k + 128 * u) * 2 * C + C);
+                    sv[u] = *reinterpret_cast<const float4*>(p + (size_t)(k + 128 * u) * rs);
+                    qv[u] = *reinterpret_cast<const float4*>(p + (size_t)(k + 128 * u) * rs + C);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -245,8 +247,8 @@ __device__ __forceinline__ void combine_partials(const float* __restrict__ parti
                 }
             }
             for (; k < n_split; k += 128) {
-                const float4 sv = *reinterpret_cast<const float4*>(p + (size_t)k * 2 * C);
-                const float4 qv = *reinterpret_cast<const float4*>(p + (size_t)k * 2 * C + C);
+                const float4 sv = *reinterpret_cast<const float4*>(p + (size_t)k * rs);
+                const float4 qv = *reinterpret_cast<const float4*>(p + (size_t)k * rs + C);
                 s4[0] += (double)sv.x; s4[1] += (double)sv.y; s4[2] += (double)sv.z; s4[3] += (double)sv.w;
                 q4[0] += (double)qv.x; q4[1] += (double)qv.y; q4[2] += (double)qv.z; q4[3] += (double)qv.w;
             }
@@ -273,16 +275,16 @@ __device__ __forceinline__ void combine_partials(const float* __restrict__ parti
     if (c < C) {
         int k = lane;
         for (; k + 3 * FL < n_split; k += 4 * FL) {  // 8 independent loads in flight
-            const float s0 = partial[(size_t)k * 2 * C + c], q0 = partial[(size_t)k * 2 * C + C + c];
-            const float s1 = partial[(size_t)(k + FL) * 2 * C + c], q1 = partial[(size_t)(k + FL) * 2 * C + C + c];
-            const float s2 = partial[(size_t)(k + 2 * FL) * 2 * C + c], q2 = partial[(size_t)(k + 2 * FL) * 2 * C + C + c];
-            const float s3 = partial[(size_t)(k + 3 * FL) * 2 * C + c], q3 = partial[(size_t)(k + 3 * FL) * 2 * C + C + c];
+            const float s0 = partial[(size_t)k * rs + c], q0 = partial[(size_t)k * rs + C + c];
+            const float s1 = partial[(size_t)(k + FL) * rs + c], q1 = partial[(size_t)(k + FL) * rs + C + c];
+            const float s2 = partial[(size_t)(k + 2 * FL) * rs + c], q2 = partial[(size_t)(k + 2 * FL) * rs + C + c];
+            const float s3 = partial[(size_t)(k + 3 * FL) * rs + c], q3 = partial[(size_t)(k + 3 * FL) * rs + C + c];
             s += (double)s0; s += (double)s1; s += (double)s2; s += (double)s3;
             q += (double)q0; q += (double)q1; q += (double)q2; q += (double)q3;
         }
         for (; k < n_split; k += FL) {
-            s += (double)partial[(size_t)k * 2 * C + c];
-            q += (double)partial[(size_t)k * 2 * C + C + c];
+            s += (double)partial[(size_t)k * rs + c];
+            q += (double)partial[(size_t)k * rs + C + c];
         }
     }
     red[lane][0][threadIdx.x % FC] = s;
@@ -296,18 +298,39 @@ __device__ __forceinline__ void combine_partials(const float* __restrict__ parti
         }
 }
 
+
+// Long tables are folded first: workgroup (channel block, slice) sums `chunk` consecutive rows of its 32 channels and leaves the
+// result IN the first row of its slice (its own rows, its own columns: no other workgroup touches them); the finalize kernels
+// then combine the slices' first rows (row stride chunk).  One CU loads ~115 GB/s: the 12 544-row tables of 448 x 448 inputs
+// took 25 - 50 us per finalize launch through one workgroup per channel block.
+__global__ __launch_bounds__(FT) void bn2d_fold_partials_kernel(float* partial, int n_split, int C, int chunk) {
+    __shared__ double red[FL][2][FC];
+    const int c = blockIdx.x * FC + threadIdx.x % FC, lane = threadIdx.x / FC;
+    const int k0 = blockIdx.y * chunk;
+    const int n = n_split - k0 < chunk ? n_split - k0 : chunk;
+    float* base = partial + (size_t)k0 * 2 * C;
+    double a, b;
+    combine_partials(base, n, C, c, lane, red, a, b, (size_t)2 * C);
+    if (lane != 0 || c >= C) return;
+    base[c] = (float)a;
+    base[C + c] = (float)b;
+}
+constexpr int kFoldRows = 2048, kFoldChunk = 512;       // tables of >= kFoldRows rows are folded in slices of kFoldChunk
+inline bool fold_on() { static const int on = getenv("PECLR_BN_FOLD") ? atoi(getenv("PECLR_BN_FOLD")) : 1; return on != 0; }
+
 __global__ __launch_bounds__(FT) void bn2d_stats_finalize_kernel(const float* __restrict__ partial, int n_split, int R, int C,
                                                                  float eps, float momentum, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float* running_mean,
                                                                  float* running_var, int64_t* nbt, float* __restrict__ save_mean,
-                                                                 float* __restrict__ save_invstd, float* __restrict__ scale_shift) {
+                                                                 float* __restrict__ save_invstd, float* __restrict__ scale_shift,
+                                                                 int fold, int shift_row) {
     __shared__ double red[FL][2][FC];
     const int c = blockIdx.x * FC + threadIdx.x % FC, lane = threadIdx.x / FC;
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
     double s, q;
-    combine_partials(partial, n_split, C, c, lane, red, s, q);
+    combine_partials(partial, n_split, C, c, lane, red, s, q, (size_t)fold * 2 * C);      // (n_split slices of `fold` rows each)
     if (lane != 0 || c >= C) return;
-    const double k0 = (double)partial[(size_t)n_split * 2 * C + c];
+    const double k0 = (double)partial[(size_t)shift_row * 2 * C + c];
     const double ms = s / R;                 // mean of (x - k0)
     double var = q / R - ms * ms;            // biased variance
     if (var < 0.0) var = 0.0;
@@ -332,7 +355,7 @@ __global__ __launch_bounds__(FT) void bn2d_combine_kernel(const float* __restric
     __shared__ double red[FL][2][FC];
     const int c = blockIdx.x * FC + threadIdx.x % FC, lane = threadIdx.x / FC;
     double a, b;
-    combine_partials(partial, n_split, C, c, lane, red, a, b);
+    combine_partials(partial, n_split, C, c, lane, red, a, b, (size_t)2 * C);
     if (lane != 0 || c >= C) return;
     totals[c] = a;
     totals[C + c] = b;
@@ -595,11 +618,11 @@ __global__ __launch_bounds__(T) void bn2d_bwd_reduce_kernel(const IO* __restrict
 __global__ __launch_bounds__(FT) void bn2d_bwd_finalize_kernel(const float* __restrict__ partial, int n_split, int R, int C,
                                                                int training, const float* __restrict__ scale_shift,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               float* __restrict__ coef) {
+                                                               float* __restrict__ coef, int fold) {
     __shared__ double red[FL][2][FC];
     const int c = blockIdx.x * FC + threadIdx.x % FC, lane = threadIdx.x / FC;
     double sb, sg;
-    combine_partials(partial, n_split, C, c, lane, red, sb, sg);
+    combine_partials(partial, n_split, C, c, lane, red, sb, sg, (size_t)fold * 2 * C);
     if (lane != 0 || c >= C) return;
     dbeta[c] = (float)sb;
     dgamma[c] = (float)sg;
@@ -1017,9 +1040,16 @@ extern "C" int peclr_bn2d_finalize_f32(const float* partial, int n_split, int R,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (training) {
         if (!partial || n_split < 1) return PECLR_ERR_NULL;
-        hipLaunchKernelGGL(bn2d_stats_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FT), 0, s, partial, n_split, R, C, eps,
+        int rows = n_split, fold = 1;
+        if (fold_on() && n_split >= kFoldRows && C % 4 == 0) {         // (folds the table IN PLACE: its rows are not read again)
+            fold = kFoldChunk;
+            rows = (n_split + fold - 1) / fold;
+            hipLaunchKernelGGL(bn2d_fold_partials_kernel, dim3((C + FC - 1) / FC, rows), dim3(FT), 0, s, const_cast<float*>(partial),
+                               n_split, C, fold);
+        }
+        hipLaunchKernelGGL(bn2d_stats_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FT), 0, s, partial, rows, R, C, eps,
                            momentum, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd,
-                           scale_shift);
+                           scale_shift, fold, n_split);
     } else {
         if (!running_mean || !running_var) return PECLR_ERR_NULL;
         hipLaunchKernelGGL(bn2d_eval_params_kernel, dim3((C + T - 1) / T), dim3(T), 0, s, C, eps, gamma, beta, running_mean,
@@ -1060,8 +1090,15 @@ extern "C" int peclr_bn2d_bwd_finalize_f32(const float* partial, int n_split, in
                                            peclr_stream_t stream) {
     if (!partial || !scale_shift || !dgamma || !dbeta || !coef) return PECLR_ERR_NULL;
     if (n_split < 1 || R <= 0 || C <= 0) return PECLR_ERR_SHAPE;
+    int rows = n_split, fold = 1;
+    if (fold_on() && n_split >= kFoldRows && C % 4 == 0) {             // (as peclr_bn2d_finalize_f32)
+        fold = kFoldChunk;
+        rows = (n_split + fold - 1) / fold;
+        hipLaunchKernelGGL(bn2d_fold_partials_kernel, dim3((C + FC - 1) / FC, rows), dim3(FT), 0, static_cast<hipStream_t>(stream),
+                           const_cast<float*>(partial), n_split, C, fold);
+    }
     hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FT), 0, static_cast<hipStream_t>(stream),
-                       partial, n_split, R, C, training, scale_shift, dgamma, dbeta, coef);
+                       partial, rows, R, C, training, scale_shift, dgamma, dbeta, coef, fold);
     return launch_status();
 }
 

@@ -106,7 +106,10 @@ def test_basicblock_input_with_two_consumers_gets_the_whole_batchnorm_reduction(
     assert tags.get("conv3x3_dgrad", 0) >= 4 and tags.get("conv3x3_fwd", 0) >= 5, tags     # the in-tree kernels did run
     assert B.end_backward() == 0 or True
     want = _run(ref, x.double(), gy.double())
-    print(_check(got, want, _run(stock, x, gy), {"y": 2e-5, "dx": 1e-4, "grad": 2e-4, "stat": 1e-5}, "BasicBlock x 3"))
+    # floors: a ReLU decision within round-off of zero taken differently by the forward and by the backward's recomputation costs
+    # 2e-4 .. 5e-4 norm-wise (seen as a second, equally deterministic outcome of this test: dx 2.3e-4, 1.bn2.bias 4.9e-4 in about
+    # one run in ten behind other tests); sums that miss the shortcut's contribution -- what this test is for -- are off by tens of %
+    print(_check(got, want, _run(stock, x, gy), {"y": 2e-5, "dx": 1e-3, "grad": 2e-3, "stat": 1e-5}, "BasicBlock x 3"))
 
 
 @pytest.mark.parametrize("arch,n,size", [("resnet50", 8, 224), ("resnet18", 16, 128)])

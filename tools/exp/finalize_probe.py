@@ -14,7 +14,7 @@ def timeit(fn, reps=50):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
 tot = 0.0
-for rows, c, count in ((802816, 64, 3), (802816, 256, 4), (200704, 128, 4), (200704, 512, 5), (50176, 256, 6), (50176, 1024, 7), (12544, 512, 3), (12544, 2048, 4),
+for rows, c, count in ((1605632, 64, 3), (1605632, 256, 4), (802816, 64, 3), (802816, 256, 4), (200704, 128, 4), (200704, 512, 5), (50176, 256, 6), (50176, 1024, 7), (12544, 512, 3), (12544, 2048, 4),
                        (802816 * 57 * 57 // (56 * 56) // 2, 64, 3), (200704 * 29 * 29 // (28 * 28) // 2, 128, 3), (50176 * 15 * 15 // (14 * 14) // 2, 256, 5), (12544 * 64 // 49 // 2, 512, 2)):
     ns = (rows + 127) // 128
     part = torch.randn(2 * ns + 1, c, device=DEV)
