@@ -47,3 +47,27 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _settle_device_state(request):
+    """GPU tests: after each test, finish the device's work, drop what the fused backbone's side channels still hold and
+    collect garbage NOW -- hipGraph objects and parked tensors are then destroyed between tests, not by a collection that
+    happens to run inside a later test's stream capture (seen twice as `Fatal Python error: Aborted` while collecting)."""
+    yield
+    if "gpu" not in request.keywords:
+        return
+    import gc
+
+    import torch
+
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        try:
+            from peclr_amd import bn2d
+
+            bn2d.end_backward()
+        except Exception:  # pragma: no cover -- the package failing to import is some test's own finding
+            pass
+        gc.collect()
+        torch.cuda.synchronize()
