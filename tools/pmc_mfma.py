@@ -55,7 +55,7 @@ def dispatches(db):
     c = sqlite3.connect(db)
     rows = c.execute("select dispatch_id, name, start, end, grid_x, grid_y, grid_z, workgroup_x, vgpr_count, "
                      "accum_vgpr_count, lds_size from kernels order by dispatch_id").fetchall()
-    ours = [r for r in rows if "peclr" in r[1]]
+    ours = [r for r in rows if "peclr" in r[1] and "fold_partials" not in r[1]]   # (the fold launch in front of a finalize is not a manifest entry of its own)
     counters = {}
     try:
         for did, cname, val in c.execute("select dispatch_id, counter_name, value from counters_collection"):

@@ -40,7 +40,7 @@ def main():
     order = order["order"]
     c = sqlite3.connect(db)
     rows = c.execute("select dispatch_id, name, end - start from kernels order by dispatch_id").fetchall()
-    ours = [r for r in rows if "peclr" in r[1]]
+    ours = [r for r in rows if "peclr" in r[1] and "fold_partials" not in r[1]]   # (the fold launch in front of a finalize is not a manifest entry of its own)
     wants = [EXPECT.get(name.split("::")[-1]) for name in order]
     for off in range(len(ours) - len(order) + 1):
         lo = len(ours) - len(order) - off
@@ -49,7 +49,8 @@ def main():
             break
     else:
         lo = len(ours) - len(order)
-        bad = [(k, order[k], ours[lo + k][1][:90]) for k, w in enumerate(wants) if w is not None and w not in ours[lo + k][1]][:5]
+        bad = [(k, order[k], ours[lo + k][1][:90]) for k, w in enumerate(wants)
+               if w is not None and not (any(x in ours[lo + k][1] for x in w) if isinstance(w, tuple) else w in ours[lo + k][1])][:5]
         raise SystemExit(f"measured pass not found: {len(ours)} peclr:: dispatches, manifest {len(order)}; first mismatches "
                          f"when aligned at the end: {bad}")
     tot = OrderedDict((k, [0.0, 0]) for k in CATS)
