@@ -694,12 +694,15 @@ class _ConvS2Gemm(torch.autograd.Function):
                   else _conv_wgrad(gy, x, weight, (2, 2), pad, conv.weight))
         dx = None
         if ctx.needs_input_grad[0]:
-            if ctx.compact and weight.shape[2] == 1 and not torch.is_anomaly_enabled():
-                # 1x1 shortcut whose input gradient goes straight into the block's fused entry gradient: dY . W over the
-                # OUTPUT pixels only; the consumer adds it at the even pixels (no 4x larger, three-quarters-zero tensor)
+            if weight.shape[2] == 1 and x.shape[2] == 2 * gy.shape[2] and x.shape[3] == 2 * gy.shape[3]:
+                # 1x1 shortcut: dY . W over the OUTPUT pixels only (three quarters of the input gradient are zeros).  Where it
+                # goes straight into the block's fused entry gradient it stays compact (the consumer adds it at the even
+                # pixels: no 4x larger tensor); elsewhere (BasicBlock networks: the block input is a plain tensor) it is
+                # scattered into zeros here -- never MIOpen's input gradient, whose fp32 1x1 / stride-2 solver adds with float
+                # atomics (a different last bit every run: tools/exp/two_outcome.py)
                 n, cout, ho, wo = gy.shape
                 dc = _capi.gemm_x6p(gy.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), _x6_planes(conv)[1], x.shape[1], tag="conv_s2_dgrad")
-                dx = _compact_grad(dc, x.shape)
+                dx = _compact_grad(dc, x.shape) if (ctx.compact and not torch.is_anomaly_enabled()) else _expand_compact(dc, x.shape)
             elif (ROUTING.conv_s2_dgrad_x6 and weight.shape[2] == 3 and x.shape[2] == 2 * gy.shape[2] and x.shape[3] == 2 * gy.shape[3]
                   and x.shape[1] % 64 == 0 and gy.shape[1] % 16 == 0):
                 # 3x3: one dense implicit GEMM per parity class of input pixels (1, 2, 2, 4 taps); dx is the gradient arriving
@@ -882,11 +885,13 @@ class _ConvH(torch.autograd.Function):
                 out = _capi.conv_h(gy, planes[1], cin, flip=True, tag="conv3x3_dgrad", bn_bwd=fuse)
             elif taps == 9:
                 out = _capi.conv3x3_s2_dgrad_h(gy, planes[1], cin, bn_bwd=fuse)
-            elif ctx.compact and not torch.is_anomaly_enabled():
-                # 1x1 / stride-2 shortcut: dY . W over the OUTPUT pixels only; the block's entry-gradient GEMM adds it at the even pixels
+            elif h == 2 * gy.shape[2] and w == 2 * gy.shape[3]:
+                # 1x1 / stride-2 shortcut: dY . W over the OUTPUT pixels only; the block's entry-gradient GEMM adds it at the even
+                # pixels, any other consumer gets it scattered into zeros (deterministic, unlike MIOpen's atomics)
                 ho, wo = gy.shape[2:]
                 dc = _capi.gemm_h(gy.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), planes[1], cin, tag="conv_s2_dgrad")
-                return _compact_grad(dc, x.shape), dw, None, None, None, None
+                lazy = ctx.compact and not torch.is_anomaly_enabled()
+                return (_compact_grad(dc, x.shape) if lazy else _expand_compact(dc, x.shape)), dw, None, None, None, None
             else:
                 w16 = conv.weight.detach().to(x.dtype)
                 return (torch.ops.aten.convolution_backward(gy, x, w16, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0],

@@ -58,7 +58,7 @@ def _errors(got, want):
 def _check(got, want, stock, floors, what):
     """In-tree fp32 against float64, CALIBRATED by stock fp32 ops (MIOpen + ATen) against the same float64 run: train-mode
     BatchNorm over few rows amplifies fp32 round-off (and a ReLU decision within round-off of zero flips a whole gradient
-    element) by an amount that depends on depth and batch, so the bar is 4 x what the stock fp32 path shows on the same
+    element) by an amount that depends on depth and batch, so the bar is 6 x what the stock fp32 path shows on the same
     data, with a floor.  A dropped term -- a shortcut gradient missing from a reduction, a parity class, stale weight
     planes -- is O(0.1 ... 1) and two to three orders above either."""
     mine, theirs = _errors(got, want), _errors(stock, want)
@@ -75,11 +75,66 @@ def _f32_stock_copy(net):
     return ref
 
 
-def test_basicblock_input_with_two_consumers_gets_the_whole_batchnorm_reduction():
-    """ResNet-18/34 topology: a block's input feeds conv1 (3x3) AND the shortcut.  conv1's input-gradient GEMM used to
-    register its BatchNorm backward sums for the buffer autograd then adds the shortcut's gradient INTO: the previous
-    block's bn2 popped sums that missed the shortcut term (advisor, round 3).  Three BasicBlocks at routed sizes (identity,
-    identity, stride 2 + downsample; 32 768 rows), fp32 in-tree against float64 stock ops."""
+def _rectifier_margins(ref64, x64):
+    """Run the float64 stock network on x64 and return {module name: pre-activation tensor} for every fused BatchNorm that is
+    followed by a ReLU (the value the rectifier decides on: bn(x) (+ residual)), recomputed from the module's inputs."""
+    from peclr_amd import bn2d as B
+
+    names = {m: n for n, m in ref64.named_modules()}
+    pre, hooks = {}, []
+
+    def hook(mod, args, out):
+        xin = args[0]
+        res = args[1] if len(args) > 1 else None
+        relu = args[2] if len(args) > 2 else mod.default_relu
+        if relu:
+            a = torch.nn.functional.batch_norm(xin, None, None, mod.weight, mod.bias, True, 0.0, mod.eps)
+            pre[names[mod]] = (a + res if res is not None else a).detach()
+
+    for m in ref64.modules():
+        if isinstance(m, B.FusedBatchNormAct2d):
+            hooks.append(m.register_forward_hook(hook))
+    with torch.no_grad():
+        ref64(x64)
+    for h in hooks:
+        h.remove()
+    return pre
+
+
+def _in_tree_activations(net, x):
+    """{module name: post-ReLU output} of every fused BatchNorm of the in-tree network (forward only, routing forced)."""
+    from peclr_amd import bn2d as B
+
+    names = {m: n for n, m in net.named_modules()}
+    outs, hooks = {}, []
+    for m in net.modules():
+        if isinstance(m, B.FusedBatchNormAct2d):
+            hooks.append(m.register_forward_hook(lambda mod, args, out: outs.__setitem__(names[mod], out.detach())))
+    with torch.no_grad(), B.routing(force=True):
+        net(x)
+    for h in hooks:
+        h.remove()
+    return outs
+
+
+def _rectifier_ties(pre64, act32, tol=1e-5):
+    """(decisions that differ from float64's although the float64 pre-activation is further than tol * scale from zero,
+    decisions that differ within it, elements within it) summed over the layers."""
+    wrong = ties = near = 0
+    for n, a in pre64.items():
+        if act32[n].shape != a.shape:        # stem (BatchNorm + ReLU + max-pool in one pass) / tail (+ average pool): no activation to compare
+            continue
+        scale = float(a.abs().max())
+        differ = (act32[n].double() > 0) != (a > 0)
+        close = a.abs() <= tol * scale
+        wrong += int((differ & ~close).sum())
+        ties += int((differ & close).sum())
+        near += int(close.sum())
+    return wrong, ties, near
+
+
+def _basicblock_arm():
+    """Three BasicBlocks at routed sizes (identity, identity, stride 2 + downsample; 32 768 rows), fresh from fixed seeds."""
     from peclr_amd import bn2d as B
     from peclr_amd import resnet
 
@@ -89,13 +144,22 @@ def test_basicblock_input_with_two_consumers_gets_the_whole_batchnorm_reduction(
                               resnet.BasicBlock(64, 64, norm_layer=B.FusedBatchNormAct2d),
                               resnet.BasicBlock(64, 128, 2, ds, norm_layer=B.FusedBatchNormAct2d))
     net = net.to(DEV).to(memory_format=torch.channels_last).train()
-    ref, stock = _f64_copy(net), _f32_stock_copy(net)
-    B.enable_hip_batchnorm(net)
     g = torch.Generator().manual_seed(3)
     x = _nhwc(torch.randn(32, 64, 32, 32, generator=g) * 0.7 + 0.3)
     gy = _nhwc(torch.randn(32, 128, 16, 16, generator=g))
-    from peclr_amd import _capi
+    return net, x, gy
 
+
+def test_basicblock_input_with_two_consumers_gets_the_whole_batchnorm_reduction():
+    """ResNet-18/34 topology: a block's input feeds conv1 (3x3) AND the shortcut.  conv1's input-gradient GEMM used to
+    register its BatchNorm backward sums for the buffer autograd then adds the shortcut's gradient INTO: the previous
+    block's bn2 popped sums that missed the shortcut term (advisor, round 3).  fp32 in-tree against float64 stock ops."""
+    from peclr_amd import _capi
+    from peclr_amd import bn2d as B
+
+    net, x, gy = _basicblock_arm()
+    ref, stock = _f64_copy(net), _f32_stock_copy(net)
+    B.enable_hip_batchnorm(net)
     _capi.EVENT_LOG = {}
     try:
         with B.routing(force=True):
@@ -104,12 +168,92 @@ def test_basicblock_input_with_two_consumers_gets_the_whole_batchnorm_reduction(
     finally:
         _capi.EVENT_LOG = None
     assert tags.get("conv3x3_dgrad", 0) >= 4 and tags.get("conv3x3_fwd", 0) >= 5, tags     # the in-tree kernels did run
-    assert B.end_backward() == 0 or True
+    assert tags.get("conv_s2_dgrad", 0) >= 1, tags      # the shortcut's input gradient too (not MIOpen's atomically added one)
+    assert B.end_backward() == 0
     want = _run(ref, x.double(), gy.double())
-    # floors: a ReLU decision within round-off of zero taken differently by the forward and by the backward's recomputation costs
-    # 2e-4 .. 5e-4 norm-wise (seen as a second, equally deterministic outcome of this test: dx 2.3e-4, 1.bn2.bias 4.9e-4 in about
-    # one run in ten behind other tests); sums that miss the shortcut's contribution -- what this test is for -- are off by tens of %
-    print(_check(got, want, _run(stock, x, gy), {"y": 2e-5, "dx": 1e-3, "grad": 2e-3, "stat": 1e-5}, "BasicBlock x 3"))
+    # every rectifier decision of the in-tree forward is float64's, except where float64's own pre-activation is within
+    # 1e-5 (relative) of zero -- a handful of the 1.1e7 decisions, each of which moves one element's gradient (2e-4 .. 5e-4
+    # norm-wise here, for ANY fp32 evaluation: the stock arm has its own)
+    fresh, _, _ = _basicblock_arm()
+    B.enable_hip_batchnorm(fresh)
+    wrong, ties, near = _rectifier_ties(_rectifier_margins(_f64_copy(fresh), x.double()), _in_tree_activations(fresh, x))
+    print(f"rectifier decisions that differ from float64's: {wrong} away from zero, {ties} of the {near} within 1e-5 of it")
+    assert wrong == 0 and ties <= 8
+    # sums that miss the shortcut's contribution -- what this test is for -- are off by tens of per cent
+    print(_check(got, want, _run(stock, x, gy), {"y": 2e-5, "dx": 1e-4, "grad": 2e-4, "stat": 1e-5}, "BasicBlock x 3"))
+
+
+def test_in_tree_basicblock_arm_gives_the_same_bits_every_time():
+    """Round 4 saw a second outcome of the test above (dx 2.3e-4, 1.bn2.bias 4.9e-4 against float64) about one run in ten
+    behind other tests.  Root cause (tools/exp/two_outcome.py: every forward tensor equal, the first difference is the
+    gradient arriving at block 1's bn2, and none under torch's deterministic mode): the ONE launch of the arm that was not
+    in-tree -- MIOpen's fp32 input gradient of the 1x1 / stride-2 shortcut -- accumulates with float atomics.  That gradient
+    is now the in-tree GEMM over the output pixels scattered into zeros, so the arm consists of bit-repeatable kernels only:
+    fresh networks from the same seeds give the same bits, with other kernels and other allocator states in between."""
+    from peclr_amd import _capi as capi
+    from peclr_amd import bn2d as B
+
+    def arm():
+        net, x, gy = _basicblock_arm()
+        B.enable_hip_batchnorm(net)
+        with B.routing(force=True):
+            out = _run(net, x, gy)
+        assert B.end_backward() == 0
+        return out
+
+    first = arm()
+    for i in range(5):
+        junk = [torch.randn(257 * (i + 1), 64 * (j + 1), device=DEV) for j in range(3)]       # another allocator state,
+        capi.gemm_x6t(torch.randn(4096, 128, device=DEV), torch.randn(4096, 256, device=DEV))  # other kernels in between
+        del junk
+        y, dx, gp, bufs = arm()
+        assert torch.equal(y, first[0]) and torch.equal(dx, first[1]), i
+        for n in first[2]:
+            assert torch.equal(gp[n], first[2][n]), (i, n)
+        for n in first[3]:
+            assert torch.equal(bufs[n], first[3][n]), (i, n)
+
+
+def _small_basicblock_arm(seed):
+    from peclr_amd import bn2d as B
+    from peclr_amd import resnet
+
+    torch.manual_seed(seed)
+    ds = torch.nn.Sequential(resnet.conv1x1(64, 128, 2), B.FusedBatchNormAct2d(128))
+    net = torch.nn.Sequential(resnet.BasicBlock(64, 64, norm_layer=B.FusedBatchNormAct2d),
+                              resnet.BasicBlock(64, 128, 2, ds, norm_layer=B.FusedBatchNormAct2d))
+    net = net.to(DEV).to(memory_format=torch.channels_last).train()
+    g = torch.Generator().manual_seed(seed + 1)
+    x = _nhwc(torch.randn(4, 64, 16, 16, generator=g) * 0.7 + 0.3)
+    gy = _nhwc(torch.randn(4, 128, 8, 8, generator=g))
+    return net, x, gy
+
+
+TIE_FREE_SEED = 12      # chosen with tools/exp/tie_free_seed.py: no float64 pre-activation within 1e-5 of zero
+
+
+def test_two_consumer_blocks_equal_float64_where_no_rectifier_decision_is_a_tie():
+    """The same composition (block input with two consumers, stride-2 shortcut scattered in-tree, BatchNorm reductions in the
+    GEMM epilogues) on data whose float64 pre-activations all lie further than 5e-6 from zero (fp32 round-off there: < 1e-6) -- asserted here --, so
+    that every rectifier decision of the fp32 arm IS float64's (asserted too) and the comparison needs no calibration by the
+    stock fp32 path and no allowance for flipped decisions: absolute bars, an order of magnitude under the ones above."""
+    from peclr_amd import bn2d as B
+
+    net, x, gy = _small_basicblock_arm(TIE_FREE_SEED)
+    ref = _f64_copy(net)
+    B.enable_hip_batchnorm(net)
+    pre = _rectifier_margins(copy.deepcopy(ref), x.double())     # (a copy: a training-mode forward moves the running statistics)
+    assert len(pre) == 4
+    margin = min(float(a.abs().min()) for a in pre.values())     # (BatchNorm outputs: unit scale)
+    assert margin > 5e-6, f"test data: a float64 pre-activation lies {margin:.1e} from zero -- pick another TIE_FREE_SEED"
+    act = _in_tree_activations(copy.deepcopy(net), x)       # (a copy: this forward moves the running statistics)
+    assert _rectifier_ties(pre, act)[:2] == (0, 0)
+    with B.routing(force=True):
+        got = _run(net, x, gy)
+    assert B.end_backward() == 0
+    e = _errors(got, _run(ref, x.double(), gy.double()))
+    print(e)
+    assert e["y"] <= 5e-6 and e["dx"] <= 5e-6 and e["grad"] <= 1e-5 and e["stat"] <= 2e-6, e
 
 
 @pytest.mark.parametrize("arch,n,size", [("resnet50", 8, 224), ("resnet18", 16, 128)])
@@ -147,6 +291,10 @@ def test_whole_network_in_tree_equals_float64_stock(arch, n, size):
                   "conv1x1_wgrad", "conv_s2_fwd", "conv_s2_dgrad", "conv3x3_s2_dgrad"):
             assert tags.get(t, 0) > 0, (t, tags)
         assert tags.get("bn2d_bwd_reduce", 0) <= 6, tags
+    fresh = copy.deepcopy(ref).float()
+    B.enable_hip_batchnorm(fresh)
+    wrong, ties, near = _rectifier_ties(_rectifier_margins(copy.deepcopy(ref), x.double()), _in_tree_activations(fresh, x), tol=1e-4)
+    print(f"{arch}: rectifier decisions that differ from float64's: {wrong} away from zero, {ties} of the {near} within 1e-4 of it")
     want = _run(ref, x.double(), gy.double())
     # fp32 round-off through 53 (20) train-mode BatchNorm layers over few rows; a dropped term (shortcut gradient, one parity
     # class, a stale reduction) is O(0.1 - 1) in the gradients of the layers below it
