@@ -103,7 +103,13 @@ def parse():
     ap.add_argument("--dry-dist", action="store_true",
                     help="form the process group (spawning the ranks if no launcher did), check that every rank is seen, "
                          "print {\"dry_dist\": ...} and stop: the N > 1 launch path without a step (runs over gloo on CPU)")
-    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs in the bounded CPU-baseline sample of the workload")
+    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs in the probe step (and in the bounded CPU-baseline sample when the whole workload does not fit the budget)")
+    ap.add_argument("--cpu-whole", type=int, default=-1,
+                    help="CPU baseline on the WHOLE workload (1 warm-up + 3 timed steps): 1 always, 0 never (bounded sample of "
+                         "2 x --cpu-pairs views), -1 (default) when a probe step predicts that it fits --cpu-budget")
+    ap.add_argument("--cpu-budget", type=float, default=400.0,
+                    help="seconds of CPU work the whole-workload baseline may be predicted to take (the default configuration, "
+                         "ResNet-50 2 x 128 @224, needs ~100 s on the MI355X hosts)")
     return ap.parse_args()
 
 
@@ -214,9 +220,10 @@ def pmc_traffic(kernel, args=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, gfx950 corrections applied by tools/pmc_traffic.py) --
     PMC counters cannot be collected from inside the timed run.  None if no profile covers it."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    # the committed passes were taken on the default workload; other shapes / dtypes have no PMC figure
-    default = args is None or (args.dtype == "fp32" and args.resnet == "50" and args.pairs == 128 and args.size == 224)
+    # the committed passes were taken on the default workload, one table per precision; other shapes have no PMC figure
+    dtype = "fp32" if args is None else args.dtype
+    default = args is None or (args.resnet == "50" and args.pairs == 128 and args.size == 224)
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if dtype == "fp32" else f"pmc_traffic_{dtype}.json")
     if not os.path.exists(path) or not default:
         return None
     with open(path) as f:
@@ -275,8 +282,8 @@ def cpu_baseline(args):
       (i)  head only  -- oracle K1..K8 forward + backward at C2's shape (M = 256, Din = 2048), >= 3 warm-up +
                          >= 10 timed, median;
       (ii) full step  -- C1 (ResNet-18, 2x32 @224, Din 512) with the same protocol, and the bench's own
-                         workload: all 2 x `--pairs` views if a probe step predicts <= 10 s per step, else a bounded
-                         sample of 2 x `--cpu-pairs` views (1 warm-up + 3 timed, median).
+                         workload: all 2 x `--pairs` views (1 warm-up + 3 timed, median) unless a probe step predicts
+                         more than `--cpu-budget` seconds for them, then a bounded sample of 2 x `--cpu-pairs` views.
     `value` is the workload line."""
     import numpy as np
 
@@ -331,7 +338,9 @@ def cpu_baseline(args):
     t0 = time.perf_counter()
     probe()
     per_pair = (time.perf_counter() - t0) / args.cpu_pairs
-    whole = per_pair * args.pairs <= 10.0       # measured steps come out ~1.5-2x the linear prediction
+    # the whole workload (4 steps of it) unless it is predicted past `--cpu-budget` seconds of CPU work: the default
+    # configuration (ResNet-50, 2 x 128 @224: ~24 s per step on the MI355X boxes' hosts, ~100 s in all) always fits
+    whole = args.cpu_whole == 1 or (args.cpu_whole < 0 and 4 * 2.0 * per_pair * args.pairs <= args.cpu_budget)
     ns = args.pairs if whole else args.cpu_pairs
     w_med, w_ts = _median_time(make_step(args.resnet, ns, args.size) if whole else probe, 1, 3)
     torch.set_num_threads(default_threads)
@@ -487,18 +496,53 @@ def spawn_ranks(n):
         # ranks > 0 print nothing on stdout by contract; whatever they do say goes to stderr
         procs.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), text=True,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    for ln in procs[0].stdout:
-        sys.stdout.write(ln)
-        sys.stdout.flush()
-    codes = [p.wait() for p in procs]
-    if any(codes):
-        raise SystemExit(f"bench.py: rank exit codes {codes}")
+    # rank 0's lines are forwarded by a reader thread while ALL children are polled: the first rank that exits non-zero
+    # (or the overall limit) terminates the others -- a rank that dies before or inside a collective would otherwise leave
+    # rank 0 blocked in it until the RCCL watchdog fires (10 min) or, over gloo, for ever, and this parent with it
+    import threading
+
+    def forward():
+        for ln in procs[0].stdout:
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+
+    reader = threading.Thread(target=forward, daemon=True)
+    reader.start()
+    limit = float(os.environ.get("PECLR_BENCH_RANKS_TIMEOUT", "3000"))
+    t0, failed = time.monotonic(), None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+        elif time.monotonic() - t0 > limit:
+            failed = f"no result after {limit:.0f} s"
+        if failed or all(c is not None for c in codes):
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=5)
+    codes = [p.returncode for p in procs]
+    if failed or any(codes):
+        raise SystemExit(f"bench.py: {failed or 'a rank failed'}; rank exit codes {codes}")
 
 
 def dry_dist(args):
     """--dry-dist: the launch path without a step.  Forms the group exactly as the measured run does and checks it."""
     from peclr_amd import dist as pdist
 
+    if os.environ.get("PECLR_BENCH_DRY_DIE_RANK") == os.environ.get("RANK", "0"):    # (tests: a rank that dies before the rendezvous)
+        raise SystemExit(3)
     local = pdist.init_from_env()
     world, rank = pdist.world_size(), pdist.rank()
     dev = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")

@@ -380,16 +380,17 @@ int peclr_amp_update(peclr_amp_state* amp, float growth_factor, float backoff_fa
  * if no residual was added); read from relu_mask ([R][C/32] uint32, 1 bit per element, written by
  * peclr_bn2d_apply when its relu_mask argument is non-null; needs C % 32 == 0) or, failing that,
  * from the forward output y.  d_residual (nullable) receives the masked dy.
- * peclr_bn2d_finalize_f32 / peclr_bn2d_bwd_finalize_f32 CONSUME long partial tables: with n_split >= 2048 the rows are first
- * summed in slices of 512 by a launch of their own that leaves each slice's sum in the slice's first row (in place, despite
- * the const: a table is finalized once).                                                      */
+ * peclr_bn2d_finalize_f32 / peclr_bn2d_bwd_finalize_f32 REWRITE long partial tables (hence no const): with n_split >= 2048 the
+ * rows are first summed in slices of 512 by a launch of their own that leaves each slice's sum in the slice's first row and
+ * zeros in its other rows -- the table keeps its totals, so a second finalize / combine of the same table gives the same
+ * result, but the individual row-block partials are gone.                                      */
 #define PECLR_DTYPE_F32 0
 #define PECLR_DTYPE_BF16 1
 #define PECLR_DTYPE_F16 2   /* IEEE half: precision=16 (native AMP), the reference's default */
 int peclr_bn2d_n_split(int R, int C, int io_dtype);
 int peclr_bn2d_stats(const void* x, int io_dtype, int R, int C, const float* shift,
                      float* partial, int n_split, peclr_stream_t stream);
-int peclr_bn2d_finalize_f32(const float* partial, int n_split, int R, int C, int training,
+int peclr_bn2d_finalize_f32(float* partial, int n_split, int R, int C, int training,
                             float eps, float momentum, const float* gamma, const float* beta,
                             float* running_mean, float* running_var,
                             int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
@@ -412,7 +413,7 @@ int peclr_bn2d_bwd_reduce(const void* dy, const void* x, const void* y, const ui
                           int io_dtype, int R, int C, int relu, const float* save_mean,
                           const float* save_invstd, const float* scale_shift, float* partial,
                           int n_split, peclr_stream_t stream);
-int peclr_bn2d_bwd_finalize_f32(const float* partial, int n_split, int R, int C, int training,
+int peclr_bn2d_bwd_finalize_f32(float* partial, int n_split, int R, int C, int training,
                                 const float* scale_shift, float* dgamma, float* dbeta,
                                 float* coef, peclr_stream_t stream);
 int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y, const uint32_t* relu_mask,

@@ -32,6 +32,22 @@ from . import _capi
 # identical (the kernels are deterministic).
 _RECOMPUTING = False
 _FIRST_RUN = False      # inside the no-grad first run of a checkpointed block (its BatchNorm layers note the statistics' shift)
+# The statistics' shifts of the checkpointed block that is running: id(BatchNorm layer) -> the copy of its running mean the
+# first run centred its sums on.  The dictionary belongs to ONE invocation (it lives on that invocation's autograd context):
+# the first run fills it, the re-run of the same invocation reads it back -- whatever other forward passes (a second view
+# pass, a no-grad evaluation, another accumulation micro-batch) went through the same layers in between.
+_CKPT_SHIFTS = None
+
+
+def _ckpt_shift_of(bn):
+    """First run of a checkpointed block: take (once) and return the copy of `bn`'s running mean that this invocation centres
+    its statistics on; re-run: the same copy; outside a checkpointed block: None."""
+    if _CKPT_SHIFTS is None or not (_FIRST_RUN or _RECOMPUTING):
+        return None
+    key = id(bn)
+    if _FIRST_RUN and key not in _CKPT_SHIFTS:
+        _CKPT_SHIFTS[key] = bn.running_mean.detach().clone()
+    return _CKPT_SHIFTS.get(key)
 
 
 class _CheckpointedBlock(torch.autograd.Function):
@@ -44,29 +60,37 @@ class _CheckpointedBlock(torch.autograd.Function):
         ctx.run = run
         ctx.autocast = (torch.is_autocast_enabled(x.device.type), torch.get_autocast_dtype(x.device.type))
         ctx.save_for_backward(x)
-        global _FIRST_RUN
-        was = _FIRST_RUN
-        _FIRST_RUN = True
+        ctx.shifts = {}
+        global _FIRST_RUN, _CKPT_SHIFTS
+        was = (_FIRST_RUN, _CKPT_SHIFTS)
+        _FIRST_RUN, _CKPT_SHIFTS = True, ctx.shifts
         try:
             with torch.no_grad():
                 return run(x)
         finally:
-            _FIRST_RUN = was
+            _FIRST_RUN, _CKPT_SHIFTS = was
 
     @staticmethod
     def backward(ctx, dy):
-        global _RECOMPUTING
+        global _RECOMPUTING, _CKPT_SHIFTS
         (x,) = ctx.saved_tensors
         x = x.detach().requires_grad_(True)
         enabled, dtype = ctx.autocast
-        was = _RECOMPUTING
-        _RECOMPUTING = True
+        was = (_RECOMPUTING, _CKPT_SHIFTS)
+        _RECOMPUTING, _CKPT_SHIFTS = True, ctx.shifts
         try:
             with torch.enable_grad(), torch.autocast(x.device.type, dtype=dtype, enabled=enabled):
                 y = ctx.run(x)
         finally:
-            _RECOMPUTING = was
-        torch.autograd.backward((y,), (dy.to(y.dtype),))
+            _RECOMPUTING, _CKPT_SHIFTS = was
+        ctx.shifts = None
+        global _NESTED_BACKWARD
+        _NESTED_BACKWARD += 1       # (its side-channel entries are drained with the enclosing pass: see _drain_after_backward)
+        try:
+            torch.autograd.backward((y,), (dy.to(y.dtype),))
+        finally:
+            _NESTED_BACKWARD -= 1
+        _drain_after_backward()
         return None, x.grad
 
 
@@ -206,6 +230,11 @@ class X6PackGroup:
         st = self._sets.setdefault(dtype, [None, None, [None] * len(self.convs), 0])
         ptrs = [c.weight.data_ptr() for c in self.convs]
         if st[0] is None or ptrs != st[1]:
+            if _capi.capture_id() != 0:
+                # building the plane set uploads its pointer table (a host-to-device copy) and allocates the planes: neither
+                # may be recorded into a hipGraph
+                raise _capi.PeclrHipError("X6PackGroup: the weight planes of this precision do not exist yet and cannot be created "
+                                          "while a hipGraph is being captured -- run one eager forward pass (same autocast dtype) first")
             st[0] = _capi.X6Planes(self._specs()) if dtype is None else _capi.HPlanes(self._specs(), dtype)
             st[1] = ptrs
         st[0].pack()
@@ -504,17 +533,11 @@ def _stat_shift_for(bn, cout: int):
     if (not isinstance(bn, FusedBatchNormAct2d) or not bn.hip or not bn.affine or bn.num_features != cout
             or bn.running_mean is None or not bn.training or not bn.running_mean.is_cuda):
         return None
-    if _RECOMPUTING and bn.sync_group is not None and getattr(bn, "_sync_shift", None) is not None:
-        return bn._sync_shift
     # activation checkpointing: the re-run centres its sums where the first run did (the running mean has moved in between),
     # so that it reproduces the first run's statistics bit for bit -- 16-bit activations amplify a last-bit difference in a
-    # scale into whole-ulp differences a few layers on
-    if _FIRST_RUN:
-        bn._ckpt_shift = bn.running_mean.detach().clone()
-        return bn._ckpt_shift
-    if _RECOMPUTING and getattr(bn, "_ckpt_shift", None) is not None:
-        return bn._ckpt_shift
-    return bn.running_mean
+    # scale into whole-ulp differences a few layers on; under synchronised statistics the same copy is the common shift
+    kept = _ckpt_shift_of(bn)
+    return kept if kept is not None else bn.running_mean
 
 
 def _wgrad_3x3_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, stride: int = 1, taps: int = 9):
@@ -739,6 +762,7 @@ def _lazy_grad(payload, shape, device, dtype=torch.float32) -> Tensor:
     ring[1] = (at + 1) % 64
     sentinel = buf[at:at + 1].view(1, 1, 1, 1).expand(shape)
     _COMPACT[sentinel.data_ptr()] = (payload, tuple(shape))
+    _drain_after_backward()
     return sentinel
 
 
@@ -788,8 +812,37 @@ def _bn_link_of(x: Tensor):
     return tuple(link) if link and ROUTING.bn_bwd_in_gemm else None
 
 
+_DRAIN_QUEUED = False
+_NESTED_BACKWARD = 0       # > 0 inside the backward pass a checkpointed block runs over its re-run graph
+
+
+def _drain_after_backward():
+    """Called by the producers of side-channel entries (they run inside a backward pass): have the autograd engine call
+    `end_backward()` when THIS backward pass is over, so that any training loop -- not only `Trainer`, which also calls it --
+    leaves no stale entry pinning device tensors behind (should a pass end without running its callbacks, the token / version
+    checks still keep a stale entry from ever being used, and the next pass drains it)."""
+    global _DRAIN_QUEUED
+    if _DRAIN_QUEUED or _NESTED_BACKWARD:
+        return
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_drained)
+        _DRAIN_QUEUED = True
+    except RuntimeError:        # not inside a backward pass (a kernel-level test calling a backward function by hand)
+        pass
+
+
+last_backward_leftovers = 0     # entries the engine-queued drain of the most recent backward pass had to drop (0 for the in-tree ResNets)
+
+
+def _drained():
+    global _DRAIN_QUEUED, last_backward_leftovers
+    _DRAIN_QUEUED = False
+    last_backward_leftovers = end_backward()
+
+
 def _note_bn_bwd(dx: Tensor, link, partial, ns):
     _BN_BWD_STATS[dx.data_ptr()] = (link[5], partial, ns, dx._version)
+    _drain_after_backward()
 
 
 def end_backward(strict: bool = False) -> int:
@@ -1153,10 +1206,12 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
         reproduces the first run's statistics exactly and updates nothing."""
         sync = training and self.sync_group is not None
         if training and _RECOMPUTING:
-            return None, None, None, (getattr(self, "_sync_shift", None) if sync else None)
+            return None, None, None, (_ckpt_shift_of(self) if sync else None)
         shift = None
         if sync:
-            shift = self._sync_shift = self.running_mean.detach().clone()
+            shift = _ckpt_shift_of(self)         # (first run of a checkpointed block: the copy kept for its re-run)
+            if shift is None:
+                shift = self.running_mean.detach().clone()
         return self.running_mean, self.running_var, self.num_batches_tracked, shift
 
     def forward(self, x: Tensor, residual: Optional[Tensor] = None, relu: Optional[bool] = None) -> Tensor:

@@ -138,6 +138,36 @@ template <int W> __device__ __forceinline__ Fv<W> zero() {
     for (int k = 0; k < W; ++k) r.v[k] = 0.f;
     return r;
 }
+// ---- FOUR elements per lane whatever the storage type (16-bit: 8-byte words).  For gather kernels whose register budget
+// is set by the number of words in flight, not by the width of one (bn2d_pool_bwd_apply: four candidate windows per element).
+template <typename IO> struct Quad;
+template <> struct Quad<float> {
+    static __device__ __forceinline__ Fv<4> load(const float* p) { return Word<float>::load(p); }
+    static __device__ __forceinline__ void store(float* p, const Fv<4>& a) { Word<float>::store(p, a); }
+};
+template <> struct Quad<bf16_t> {
+    static __device__ __forceinline__ Fv<4> load(const bf16_t* p) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        return {{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xFFFF0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xFFFF0000u)}};
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const Fv<4>& a) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(Word<bf16_t>::rne(a.v[0]) | (Word<bf16_t>::rne(a.v[1]) << 16),
+                                                  Word<bf16_t>::rne(a.v[2]) | (Word<bf16_t>::rne(a.v[3]) << 16));
+    }
+};
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <> struct Quad<f16_t> {
+    static __device__ __forceinline__ Fv<4> load(const f16_t* p) {
+        const f16x4 t = *reinterpret_cast<const f16x4*>(p);
+        return {{(float)t[0], (float)t[1], (float)t[2], (float)t[3]}};
+    }
+    static __device__ __forceinline__ void store(f16_t* p, const Fv<4>& a) {
+        f16x4 t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = (_Float16)a.v[k];
+        *reinterpret_cast<f16x4*>(p) = t;
+    }
+};
 
 // Geometry shared by every kernel: CW = C/W column groups; a block covers CGB = min(CW, 256) of them
 // (blockIdx.x = column block) and RPP = 256/CGB rows per pass; blockIdx.y = row slice.
@@ -300,7 +330,8 @@ __device__ __forceinline__ void combine_partials(const float* __restrict__ parti
 
 
 // Long tables are folded first: workgroup (channel block, slice) sums `chunk` consecutive rows of its 32 channels and leaves the
-// result IN the first row of its slice (its own rows, its own columns: no other workgroup touches them); the finalize kernels
+// result IN the first row of its slice and zeros in the others (its own rows, its own columns: no other workgroup touches them;
+// the table keeps its totals, so finalizing it again is harmless); the finalize kernels
 // then combine the slices' first rows (row stride chunk).  One CU loads ~115 GB/s: the 12 544-row tables of 448 x 448 inputs
 // took 25 - 50 us per finalize launch through one workgroup per channel block.
 __global__ __launch_bounds__(FT) void bn2d_fold_partials_kernel(float* partial, int n_split, int C, int chunk) {
@@ -310,8 +341,13 @@ __global__ __launch_bounds__(FT) void bn2d_fold_partials_kernel(float* partial, 
     const int n = n_split - k0 < chunk ? n_split - k0 : chunk;
     float* base = partial + (size_t)k0 * 2 * C;
     double a, b;
-    combine_partials(base, n, C, c, lane, red, a, b, (size_t)2 * C);
-    if (lane != 0 || c >= C) return;
+    combine_partials(base, n, C, c, lane, red, a, b, (size_t)2 * C);       // (ends behind a barrier: every row has been read)
+    if (c >= C) return;
+    // the slice's other rows become zeros, so that the table still SUMS to the same totals: finalizing it a second time (a
+    // re-run, a debugging comparison, a synchronised-statistics combine after a finalize) gives the same result instead of
+    // counting every slice twice
+    for (int k = 1 + lane; k < n; k += FL) base[(size_t)k * 2 * C + c] = 0.f, base[(size_t)k * 2 * C + C + c] = 0.f;
+    if (lane != 0) return;
     base[c] = (float)a;
     base[C + c] = (float)b;
 }
@@ -844,7 +880,9 @@ __global__ __launch_bounds__(T) void bn2d_pool_bwd_apply_kernel(const IO* __rest
                                                                 const float* __restrict__ save_invstd,
                                                                 const float* __restrict__ scale_shift,
                                                                 const float* __restrict__ coef, IO* __restrict__ dx) {
-    constexpr int W = Word<IO>::W;
+    // four channels per lane for every storage type (`Quad`): with the 16-bit types' eight, the four candidate windows in flight
+    // cost 130 VGPRs (3 waves per SIMD; 412 us at 2.4 TB/s against the fp32 instance's 344 us at 5.9 TB/s for twice the bytes)
+    constexpr int W = 4;
     const int cg = threadIdx.x % g.CW, pl = threadIdx.x / g.CW, col = cg * W;
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
     const Fv<W> mean = loadp<W>(save_mean + col), inv = loadp<W>(save_invstd + col);
@@ -858,7 +896,7 @@ __global__ __launch_bounds__(T) void bn2d_pool_bwd_apply_kernel(const IO* __rest
         if (q >= per_image) break;
         const int w = q % g.Wd, h = q / g.Wd;
         const long long r = (long long)n * per_image + q;
-        const Fv<W> v = Word<IO>::load(x + (size_t)r * g.C + col);
+        const Fv<W> v = Quad<IO>::load(x + (size_t)r * g.C + col);
         Fv<W> d = zero<W>();
         // windows holding (h, w): ph in {h/2, (h+1)/2}, pw in {w/2, (w+1)/2} (one or two each); all four
         // candidates are loaded together (predicated) so the loads overlap
@@ -873,7 +911,7 @@ __global__ __launch_bounds__(T) void bn2d_pool_bwd_apply_kernel(const IO* __rest
             on[i] = ph < g.PH && pw < g.PW && !((i >> 1) && phs[1] == phs[0]) && !((i & 1) && pws[1] == pws[0]);
             mine[i] = (unsigned char)(3 * (h - (2 * ph - 1)) + (w - (2 * pw - 1)));
             const size_t p = on[i] ? (((size_t)n * g.PH + ph) * g.PW + pw) * g.C + col : 0;
-            gy[i] = on[i] ? Word<IO>::load(dyp + p) : zero<W>();
+            gy[i] = on[i] ? Quad<IO>::load(dyp + p) : zero<W>();
 #pragma unroll
             for (int k = 0; k < W / 4; ++k) cw[i][k] = on[i] ? reinterpret_cast<const unsigned*>(code + p)[k] : 0xFFFFFFFFu;
         }
@@ -890,7 +928,7 @@ __global__ __launch_bounds__(T) void bn2d_pool_bwd_apply_kernel(const IO* __rest
             const float dy = fmaf(v.v[k], sc.v[k], sh.v[k]) > 0.f ? d.v[k] : 0.f;
             o.v[k] = fmaf(dy, sc.v[k], fmaf((v.v[k] - mean.v[k]) * inv.v[k], c1.v[k], c0.v[k]));
         }
-        Word<IO>::store(dx + (size_t)r * g.C + col, o);
+        Quad<IO>::store(dx + (size_t)r * g.C + col, o);
     }
 }
 
@@ -1031,7 +1069,7 @@ extern "C" int peclr_bn2d_bwd_finalize_totals_f32(const double* local_totals, co
     return launch_status();
 }
 
-extern "C" int peclr_bn2d_finalize_f32(const float* partial, int n_split, int R, int C, int training, float eps,
+extern "C" int peclr_bn2d_finalize_f32(float* partial, int n_split, int R, int C, int training, float eps,
                                        float momentum, const float* gamma, const float* beta, float* running_mean,
                                        float* running_var, int64_t* num_batches_tracked, float* save_mean,
                                        float* save_invstd, float* scale_shift, peclr_stream_t stream) {
@@ -1044,7 +1082,7 @@ extern "C" int peclr_bn2d_finalize_f32(const float* partial, int n_split, int R,
         if (fold_on() && n_split >= kFoldRows && C % 4 == 0) {         // (folds the table IN PLACE: its rows are not read again)
             fold = kFoldChunk;
             rows = (n_split + fold - 1) / fold;
-            hipLaunchKernelGGL(bn2d_fold_partials_kernel, dim3((C + FC - 1) / FC, rows), dim3(FT), 0, s, const_cast<float*>(partial),
+            hipLaunchKernelGGL(bn2d_fold_partials_kernel, dim3((C + FC - 1) / FC, rows), dim3(FT), 0, s, partial,
                                n_split, C, fold);
         }
         hipLaunchKernelGGL(bn2d_stats_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FT), 0, s, partial, rows, R, C, eps,
@@ -1085,7 +1123,7 @@ extern "C" int peclr_bn2d_bwd_reduce(const void* dy, const void* x, const void* 
     return launch_status();
 }
 
-extern "C" int peclr_bn2d_bwd_finalize_f32(const float* partial, int n_split, int R, int C, int training,
+extern "C" int peclr_bn2d_bwd_finalize_f32(float* partial, int n_split, int R, int C, int training,
                                            const float* scale_shift, float* dgamma, float* dbeta, float* coef,
                                            peclr_stream_t stream) {
     if (!partial || !scale_shift || !dgamma || !dbeta || !coef) return PECLR_ERR_NULL;
@@ -1095,7 +1133,7 @@ extern "C" int peclr_bn2d_bwd_finalize_f32(const float* partial, int n_split, in
         fold = kFoldChunk;
         rows = (n_split + fold - 1) / fold;
         hipLaunchKernelGGL(bn2d_fold_partials_kernel, dim3((C + FC - 1) / FC, rows), dim3(FT), 0, static_cast<hipStream_t>(stream),
-                           const_cast<float*>(partial), n_split, C, fold);
+                           partial, n_split, C, fold);
     }
     hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FT), 0, static_cast<hipStream_t>(stream),
                        partial, rows, R, C, training, scale_shift, dgamma, dbeta, coef, fold);
@@ -1178,6 +1216,9 @@ extern "C" int peclr_bn2d_pool_bwd_apply(const void* dy_pool, const void* x, con
     PoolGeo g;
     if (!pool_geo(io_dtype, N, H, W, C, g)) return PECLR_ERR_SHAPE;
     if (!all_aligned({dy_pool, x, code, dx})) return PECLR_ERR_ALIGN;
+    if (C % 4 || C / 4 > T || T % (C / 4)) return PECLR_ERR_SHAPE;
+    g.CW = C / 4;                 // this kernel moves four channels per lane whatever the storage type
+    g.PPB = T / g.CW;
     const int blocks = pool_blocks(g, H * W, 2 * kPoolIter);
     hipStream_t s = static_cast<hipStream_t>(stream);
     PECLR_IO_SWITCH(io_dtype, hipLaunchKernelGGL((bn2d_pool_bwd_apply_kernel<IO>), dim3(blocks), dim3(T), 0, s, static_cast<const IO*>(dy_pool),

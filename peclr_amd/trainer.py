@@ -9,6 +9,7 @@ Not a Lightning re-implementation: no loggers, no callbacks API, no dataloader m
 from __future__ import annotations
 
 import contextlib
+import gc
 import os
 from typing import Callable, Dict, Iterable, List, Optional
 
@@ -75,6 +76,42 @@ class Trainer:
         self.current_epoch = 0
         self._saved: List[tuple] = []
         self.model = self.optimizer = self.scheduler = self.reducer = None
+        self._graphs_alive: List[torch.cuda.CUDAGraph] = []    # every graph this trainer captured, until `close()`
+
+
+    # ---- hipGraph lifetime.  Destroying a hipGraph (or freeing graph-pool memory) while a stream capture is in progress
+    # aborts the process on this ROCm build (seen as `Fatal Python error: Aborted` when a cyclic garbage collection ran
+    # inside a capture and found a dead CUDAGraph).  So: (i) garbage is collected right BEFORE a capture starts, while
+    # nothing is being recorded; (ii) the collector is off for the duration of the capture (objects that become garbage in
+    # there wait for the next collection after it); (iii) the trainer keeps a strong reference to every graph it captured
+    # until `close()`, so that re-capturing (another batch shape, a new accumulation window) never drops the last
+    # reference to an executable graph from inside Python code that may itself be running under a capture.
+    @contextlib.contextmanager
+    def _capturing(self, graph: "torch.cuda.CUDAGraph", **kw):
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(graph, **kw):
+                yield graph
+        finally:
+            if was_enabled:
+                gc.enable()
+        self._graphs_alive.append(graph)
+
+    def close(self):
+        """Release every captured graph (and the graph-pool memory they pin): outside any capture, device idle."""
+        if torch.cuda.is_available():
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("Trainer.close() inside a stream capture")
+            torch.cuda.synchronize()
+        for name in ("_graph", "_graph_a", "_graph_b", "_graph_b2", "_graph_bs", "_static_out", "_static_grads", "_split_seams",
+                     "_split_stages", "_split_z", "_split_dz", "_micro_src", "_graph_worklist"):
+            if hasattr(self, name):
+                setattr(self, name, None)
+        self._graphs_alive.clear()
+        self._graph_sig = None
+        gc.collect()
 
     # ---- setup
     def attach(self, model):
@@ -317,7 +354,7 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with self._capturing(self._graph):
             with self._autocast():
                 out = self.model.training_step(self._static_batch, 0)
             self._scaled(out["loss"]).backward()
@@ -393,7 +430,7 @@ class Trainer:
             seams[at] = (t, t.detach().requires_grad_())
             return seams[at][1]
 
-        with torch.cuda.graph(self._graph_a, pool=pool, capture_error_mode="thread_local"):
+        with self._capturing(self._graph_a, pool=pool, capture_error_mode="thread_local"):
             with self._autocast():
                 z, row_stats, n_pairs = model._project(self._static_batch, cut=cut) if two_stage else \
                     model._project(self._static_batch)
@@ -408,7 +445,7 @@ class Trainer:
                 out, leaf = seams[sorted(seams, reverse=True)[k - 1]]
                 roots[k] = (out, leaf.grad)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+            with self._capturing(g, pool=pool, capture_error_mode="thread_local"):
                 torch.autograd.backward((roots[k][0],), (roots[k][1],))
                 self._join_wgrad()
             self._graph_bs.append(g)
@@ -488,7 +525,7 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with self._capturing(self._graph):
             with self._autocast():
                 out = self.model.training_step(self._static_batch, 0)
             self._scaled(out["loss"]).backward()
@@ -533,7 +570,7 @@ class Trainer:
         self._static_batch = self._clone_batch(batch)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with self._capturing(self._graph):
             with self._autocast():
                 g_out = self.model.training_step(self._static_batch, 0)
             self._scaled(g_out["loss"]).backward()

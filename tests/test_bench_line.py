@@ -87,3 +87,20 @@ def test_bench_without_a_gpu_fails_loudly_on_every_spawned_rank():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert p.returncode != 0 and "needs an MI355X" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.timeout(200)
+def test_a_rank_that_dies_takes_the_whole_launch_down_instead_of_hanging_it():
+    """Advisor, round 4: the self-spawning launcher waited on rank 0's output and then on every rank without a limit -- a rank
+    that died before a collective left rank 0 (and the parent) blocked in it.  Rank 1 exits before the rendezvous here: the
+    parent must come back non-zero within seconds, with rank 0 terminated."""
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["PECLR_BENCH_DRY_DIE_RANK"] = "1"
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-dist"],
+                       env=env, capture_output=True, text=True, timeout=180, cwd=ROOT)
+    assert p.returncode != 0 and "rank 1 exited with code 3" in p.stderr, p.stderr[-2000:]
+    assert time.monotonic() - t0 < 120
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

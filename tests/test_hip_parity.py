@@ -1391,8 +1391,9 @@ def test_activation_checkpointing_on_the_fused_glue(precision):
     batch = {k: v.to(DEV) for k, v in batch.items()}
     for k in ("transformed_image1", "transformed_image2"):
         batch[k] = batch[k].contiguous(memory_format=torch.channels_last)
-    res = {}
-    for ckpt in (False, True, None):           # None: a second plain run = the run-to-run noise of the stack itself
+    from peclr_amd import bn2d as B
+
+    def one_run(ckpt):
         model = copy.deepcopy(base)
         tr = Trainer(max_epochs=1, precision=precision, activation_checkpointing=bool(ckpt)).attach(model)
         tr.zero_grad()
@@ -1404,8 +1405,11 @@ def test_activation_checkpointing_on_the_fused_glue(precision):
         held = torch.cuda.memory_allocated() - before           # activations kept for the backward pass
         out["loss"].backward()
         torch.cuda.synchronize()
-        res[ckpt] = (float(out["loss"]), [p.grad.detach().clone() for p in model.parameters() if p.grad is not None], held,
-                     {k: v.clone() for k, v in model.named_buffers()})
+        B.end_backward()
+        return (float(out["loss"]), [p.grad.detach().clone() for p in model.parameters() if p.grad is not None], held,
+                {k: v.clone() for k, v in model.named_buffers()})
+
+    res = {ckpt: one_run(ckpt) for ckpt in (False, True, None)}   # None: a second plain run = the run-to-run noise of the stack itself
     (l0, g0, m0, b0), (l1, g1, m1, b1), (l2, g2, _, _) = res[False], res[True], res[None]
 
     def dev(ga, gb):
@@ -1424,6 +1428,13 @@ def test_activation_checkpointing_on_the_fused_glue(precision):
     # checkpointed one in a pass of its own: sums in another order, a last-bit difference in dgamma, whole-ulp flips of 16-bit
     # activations behind it, amplified through 50 layers: 1.7e-2 observed, 2.5e-4 per block pair in tools/exp/h_fuse_ab.py)
     assert len(g0) == len(g1) and dev(g0, g1) <= max(4 * grad_noise, 1e-3 if precision == "fp32" else 5e-2), (dev(g0, g1), grad_noise)
+    if precision == "bf16":
+        # the TIGHT bf16 bar (advisor, round 4: 5e-2 cannot catch a wrong statistics shift or a mis-fused reduction): with every
+        # BatchNorm backward reduction in a pass of its own in BOTH arms the two runs are the same arithmetic in the same order
+        with B.routing(bn_bwd_in_gemm=False):
+            (la, ga, _, _), (lb, gb, _, _) = one_run(False), one_run(True)
+        assert abs(la - lb) <= 2e-5 * abs(la), (la, lb)
+        assert dev(ga, gb) <= 1e-3, dev(ga, gb)
     for k in b0:
         # moved once (a second update would shift them by ~10 % of the batch statistic); the two runs' forward
         # convolutions agree to ~1e-6, not bit for bit
@@ -2458,3 +2469,47 @@ def test_gemm_x6_tn_matches_float64_and_is_deterministic(capi, k_rows, m, n):
     err = ((got.double() - ref).abs() / bound).max().item()
     assert err <= 2.0 ** -20, err                      # fp32 accumulation over up to 2e5 terms per slab + the slab sum
     assert torch.equal(capi.gemm_x6_tn(a, b), got)
+
+
+@pytest.mark.gpu
+def test_finalizing_a_long_partial_table_twice_gives_the_same_result(capi):
+    """peclr_bn2d_finalize_f32 / peclr_bn2d_bwd_finalize_f32 fold tables of >= 2048 row blocks in place before combining them
+    (advisor, round 4: a second finalize of the same table used to count every slice twice).  The fold now leaves zeros in the
+    rows it summed, so the table keeps its totals: finalize twice -> identical statistics, identical to float64 sums."""
+    import ctypes
+
+    c, ns, r = 64, 3000, 3000 * 128
+    g = torch.Generator(device=DEV).manual_seed(9)
+    partial = torch.randn(2 * ns + 1, c, device=DEV, generator=g)
+    partial[1:2 * ns:2].abs_()                                   # rows alternate (sum, sum of squares) per row block
+    partial[1:2 * ns:2] += 200.0
+    partial[2 * ns] = 0.0                                         # the shift row
+    want_s = partial[0:2 * ns:2].double().sum(0)
+    want_q = partial[1:2 * ns:2].double().sum(0)
+    gamma, beta = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+    outs = []
+    for _ in range(2):
+        save, ss = torch.empty(2, c, device=DEV), torch.empty(2, c, device=DEV)
+        rc = capi.lib().peclr_bn2d_finalize_f32(partial.data_ptr(), ns, r, c, 1, 1e-5, 0.1, gamma.data_ptr(), beta.data_ptr(), None, None,
+                                                None, save[0].data_ptr(), save[1].data_ptr(), ss.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append((save.clone(), ss.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    mean = want_s / r
+    var = want_q / r - mean * mean
+    assert torch.allclose(outs[0][0][0].double(), mean, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(outs[0][0][1].double(), 1.0 / torch.sqrt(var + 1e-5), rtol=1e-5)
+    # the backward finalize on a [2 * ns, C] table
+    pb = torch.randn(2 * ns, c, device=DEV, generator=g)
+    sums = (pb[0::2].double().sum(0), pb[1::2].double().sum(0))
+    res = []
+    for _ in range(2):
+        dg, db, coef = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty(2, c, device=DEV)
+        rc = capi.lib().peclr_bn2d_bwd_finalize_f32(pb.data_ptr(), ns, r, c, 1, outs[0][1].data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                                    coef.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        res.append((dg.clone(), db.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.allclose(res[0][1].double(), sums[0], rtol=1e-5, atol=1e-3) and torch.allclose(res[0][0].double(), sums[1], rtol=1e-5, atol=1e-3)

@@ -718,3 +718,104 @@ def test_compact_shortcut_gradient_protocol():
     s3 = B._lazy_grad(("mask", dy, mask), dy.shape, dy.device)
     dense = B._take_compact(s3)
     assert torch.equal(dense, dy * bits.view(2, 3, 3, 64).permute(0, 3, 1, 2)) and not B._COMPACT
+
+
+def test_capture_guard_holds_the_collector_and_restores_it(monkeypatch):
+    """Trainer._capturing (hipGraph lifetime): garbage is collected before the capture starts, the
+    cyclic collector is off while it records (also when the recorded code raises) and back afterwards; the graph object is
+    kept until close().  The capture itself is replaced by a recording stand-in (no GPU here)."""
+    import contextlib
+    import gc
+
+    from peclr_amd import Trainer
+
+    events = []
+
+    @contextlib.contextmanager
+    def fake_graph(graph, **kw):
+        events.append(("enter", gc.isenabled(), kw))
+        yield
+        events.append(("exit", gc.isenabled()))
+
+    monkeypatch.setattr(torch.cuda, "graph", fake_graph)
+    collected = []
+    monkeypatch.setattr(gc, "collect", lambda *a: collected.append(len(events)) or 0)
+    tr = Trainer()
+    g1, g2 = object(), object()
+    assert gc.isenabled()
+    with tr._capturing(g1, pool="p"):
+        assert not gc.isenabled()
+    assert gc.isenabled() and tr._graphs_alive == [g1]
+    assert events == [("enter", False, {"pool": "p"}), ("exit", False)] and collected == [0]   # collected BEFORE entering
+    with pytest.raises(RuntimeError):
+        with tr._capturing(g2):
+            raise RuntimeError("the recorded step failed")
+    assert gc.isenabled() and tr._graphs_alive == [g1]           # a failed capture is not kept
+    gc.disable()
+    try:
+        with tr._capturing(g2):
+            pass
+        assert not gc.isenabled()                                 # the caller's own setting is respected
+    finally:
+        gc.enable()
+
+
+def test_checkpoint_shifts_belong_to_the_invocation_not_to_the_layer():
+    """Advisor, round 4: the copy of the running mean a checkpointed block's first run centres its statistics on used to be
+    ONE slot per BatchNorm module, overwritten by every first run -- two checkpointed forward passes before one backward (two
+    view passes, a no-grad forward in between) made the first pass's re-run centre on the later mean.  It now lives on the
+    invocation's autograd context: every re-run reads back exactly what ITS first run took."""
+    from peclr_amd import bn2d as B
+
+    class FakeBN:
+        def __init__(self):
+            self.running_mean = torch.zeros(3)
+
+    bn = FakeBN()
+    seen = []
+
+    def run(x):
+        shift = B._ckpt_shift_of(bn)
+        seen.append(("first" if B._FIRST_RUN else "rerun", None if shift is None else float(shift[0])))
+        if B._FIRST_RUN:
+            bn.running_mean += 1.0              # what the statistics update does between the two passes
+        return x * 2.0
+
+    assert B._ckpt_shift_of(bn) is None          # outside a checkpointed block: nothing is kept
+    x1 = torch.ones(2, requires_grad=True)
+    x2 = torch.ones(2, requires_grad=True)
+    y1 = B.checkpoint_block(run, x1)             # first run #1 centres on 0
+    with torch.no_grad():
+        B.checkpoint_block(run, x1)              # a no-grad pass: plain, keeps nothing
+    y2 = B.checkpoint_block(run, x2)             # first run #2 centres on 2 (two updates so far)
+    (y1.sum() + y2.sum()).backward()             # re-runs in reverse order
+    assert seen == [("first", 0.0), ("rerun", None), ("first", 1.0), ("rerun", 1.0), ("rerun", 0.0)], seen
+    assert torch.equal(x1.grad, torch.full((2,), 2.0)) and B._CKPT_SHIFTS is None
+    assert not hasattr(bn, "_ckpt_shift") and not hasattr(bn, "_sync_shift")   # nothing parked on the module (deepcopy / pickle / .to())
+
+
+def test_side_channels_are_drained_by_the_autograd_engine_when_a_backward_pass_ends():
+    """Advisor, round 4: `_BN_BWD_STATS` / `_COMPACT` were emptied only by Trainer._join_wgrad and by a test fixture; any other
+    training loop left stale entries pinning device tensors.  Their producers now queue `end_backward` on the engine."""
+    from peclr_amd import bn2d as B
+
+    class Producer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            B._BN_BWD_STATS[12345] = ("token", None, 0, 0)       # what _note_bn_bwd parks: nobody will pop this one
+            B._drain_after_backward()
+            assert len(B._BN_BWD_STATS) == 1                      # still there while the pass runs
+            return g * 2.0
+
+    B.end_backward()
+    x = torch.ones(3, requires_grad=True)
+    Producer.apply(x).sum().backward()                            # a plain loop: no Trainer, no fixture
+    assert B._BN_BWD_STATS == {} and B._COMPACT == {} and B.last_backward_leftovers == 1 and not B._DRAIN_QUEUED
+    Producer.apply(x).sum().backward()
+    assert B.last_backward_leftovers == 1
+    B._drain_after_backward()                                     # outside a backward pass: nothing to queue on, no error
+    assert not B._DRAIN_QUEUED
