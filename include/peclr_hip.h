@@ -555,16 +555,26 @@ int peclr_wgrad3_x6r_f32(int M, int N, int images, int H, int W, const float* dY
 int peclr_wgrad3_h_slabs(int M, int N, int images, int H, int W);
 int peclr_wgrad3_h(int dtype, int M, int N, int images, int H, int W, const void* A, const void* B, float* slabs, int n_slabs,
                    const void* zeros, peclr_stream_t stream);
-/* ... and of the 3x3 / padding-1 / STRIDE-2 convolutions (the first block of layers 2 - 4): dY [images, Ho, Wo, M], X [images, 2 Ho,
- * 2 Wo, N].  X splits into four parity planes X_pq[i][j] = X[2 i + p][2 j + q]; tap row a reads plane p = (a != 1) at row shift
- * -1 (a = 0) or 0, columns alike: the same padded space and ring as peclr_wgrad3_h, four workgroups per (tile, slab) -- one per
- * plane, 4 / 2 / 2 / 1 taps -- writing disjoint tap columns of the slab.  n_slabs = peclr_wgrad3_h_slabs(M, N, images, Ho, Wo);
- * Wo <= 62.  Replaces MIOpen's last 16-bit weight gradients of the residual blocks (resnet_model.py:15). */
-int peclr_wgrad3_s2_h(int dtype, int M, int N, int images, int Ho, int Wo, const void* dY, const void* X, float* slabs,
-                      int n_slabs, const void* zeros, peclr_stream_t stream);
 int peclr_wgrad_h_slabs(int M, int N, int K);
 int peclr_wgrad_h(int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* slabs, int n_slabs,
                   int stride, int Ho, int Wo, const void* zeros, peclr_stream_t stream);
+
+/* The encoder's stem (csrc/stem.hip): y = conv2d(x, W, stride 2, padding 3) with W [64][3][7][7] -- torchvision ResNet `conv1`
+ * behind /root/reference/src/models/resnet_model.py:15 -- for fp32 NHWC images x [N][Hin][Win][3] -> y [N][Ho][Wo][64] NHWC,
+ * Ho = (Hin - 1) / 2 + 1.  fmt 0: fp32 output at fp32 accuracy (both operands split exactly into three bf16 numbers, six
+ * products, fp32 accumulation, as peclr_gemm_x6p_f32); fmt 1 / 2: bf16 / fp16 output, one product of the operands rounded
+ * to that format (what autocast computes; its cast of the images rides in the kernel's staging).  `planes`: the filter in
+ * fragment order, peclr_stem_pack_bytes(fmt) bytes written by peclr_stem_pack from the fp32 master weight (element strides of
+ * its four dimensions given: any memory format) -- once per optimiser step.  stat_shift / stat_partial (both or neither): the
+ * training statistics of y for the BatchNorm that follows, in peclr_bn2d_stats' partial layout with n_split =
+ * peclr_stem_workgroups(N, Hin, Win) row blocks: stat_partial [2 n_split + 1][64].  Replaces MIOpen's 7x7 forward (and,
+ * with the statistics, the last peclr_bn2d_stats pass of the step). */
+int peclr_stem_pack_bytes(int fmt);
+int peclr_stem_pack(const float* w, long long stride_n, long long stride_c, long long stride_h, long long stride_w, void* planes,
+                    int fmt, peclr_stream_t stream);
+int peclr_stem_workgroups(int N, int Hin, int Win);
+int peclr_stem_conv7x7_s2(const float* x, int N, int Hin, int Win, const void* planes, int fmt, void* y,
+                          const float* stat_shift, float* stat_partial, peclr_stream_t stream);
 
 #ifdef __cplusplus
 }

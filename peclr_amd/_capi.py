@@ -45,6 +45,10 @@ SIGNATURES = {
     "peclr_ntxent_finalize_f32": (c_int, [_P, c_int, _P, c_int, c_float, _P, _P, c_int, _P, _P]),
     "peclr_ntxent_bwd_f32": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, c_float, _P, _P, c_float, _P,
                                      c_int, _P]),
+    "peclr_stem_pack_bytes": (c_int, [c_int]),
+    "peclr_stem_pack": (c_int, [_P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, c_int, _P]),
+    "peclr_stem_workgroups": (c_int, [c_int, c_int, c_int]),
+    "peclr_stem_conv7x7_s2": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
     "peclr_bn2d_n_split": (c_int, [c_int, c_int, c_int]),
     "peclr_bn2d_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "peclr_bn2d_combine_f64": (c_int, [_P, c_int, c_int, _P, _P]),
@@ -92,7 +96,6 @@ SIGNATURES = {
     "peclr_wgrad3_x6r_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P]),
     "peclr_wgrad3_h_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "peclr_wgrad3_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
-    "peclr_wgrad3_s2_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "peclr_wgrad_h_slabs": (c_int, [c_int, c_int, c_int]),
     "peclr_wgrad_h": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "peclr_lars_sumsq_f32": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
@@ -866,8 +869,8 @@ def conv_h(x: torch.Tensor, planes: torch.Tensor, cout: int, taps: int = 9, stri
 def wgrad_h_ok(gy: torch.Tensor, x: torch.Tensor, taps: int, stride: int) -> bool:
     """Does peclr_wgrad_h take this weight gradient?  (1x1 convolutions, stride 1 or 2, channel counts multiples of 32.)"""
     cout, cin = gy.shape[1], x.shape[1]
-    if taps == 9:       # 3x3 / padding 1, stride 1 (peclr_wgrad3_h) or 2 (peclr_wgrad3_s2_h)
-        return (stride in (1, 2) and cout % 64 == 0 and cin % 64 == 0 and gy.dtype in _HALF_IO and x.dtype == gy.dtype
+    if taps == 9:       # 3x3 / padding 1 / stride 1 (peclr_wgrad3_h); the stride-2 ones stay on MIOpen (faster there)
+        return (stride == 1 and cout % 64 == 0 and cin % 64 == 0 and gy.dtype in _HALF_IO and x.dtype == gy.dtype
                 and x.shape[2] == stride * gy.shape[2] and x.shape[3] == stride * gy.shape[3] and gy.shape[3] <= 62
                 and gy.shape[0] * gy.shape[2] * gy.shape[3] >= 512)
     return (taps == 1 and stride in (1, 2) and cout % 32 == 0 and cin % 32 == 0 and gy.dtype in _HALF_IO and x.dtype == gy.dtype
@@ -877,7 +880,7 @@ def wgrad_h_ok(gy: torch.Tensor, x: torch.Tensor, taps: int, stride: int) -> boo
 
 def wgrad_h(gy: torch.Tensor, x: torch.Tensor, taps: int = 1, stride: int = 1, tag: str = "conv1x1_wgrad") -> torch.Tensor:
     """dW [Cout, taps * Cin] (fp32) of a 1x1 (taps = 1) or 3x3 / padding-1 (taps = 9) convolution, stride 1 or 2, from 16-bit NHWC
-    activations gy [N, Cout, Ho, Wo], x [N, Cin, H, W] (peclr_wgrad_h / peclr_wgrad3_h / peclr_wgrad3_s2_h +
+    activations gy [N, Cout, Ho, Wo], x [N, Cin, H, W] (peclr_wgrad_h / peclr_wgrad3_h +
     peclr_slab_reduce_f32: fixed-order split-K, deterministic)."""
     if not wgrad_h_ok(gy, x, taps, stride):
         raise PeclrHipError(f"wgrad_h: unsupported problem gy {tuple(gy.shape)} x {tuple(x.shape)} taps {taps} stride {stride}")
@@ -892,9 +895,8 @@ def wgrad_h(gy: torch.Tensor, x: torch.Tensor, taps: int = 1, stride: int = 1, t
         slabs = torch.empty((ns, cout, 9 * cin), device=gy.device, dtype=torch.float32)
         with _timed("conv3x3_wgrad" if tag == "conv1x1_wgrad" else tag, 2 * nb * ho * wo * (cout + cin) + 4 * ns * cout * 9 * cin,
                     18 * cout * cin * nb * ho * wo, kernel="wgrad3_h_kernel"):
-            entry = lib().peclr_wgrad3_h if stride == 1 else lib().peclr_wgrad3_s2_h
-            rc = entry(io, cout, cin, nb, ho, wo, gp, xp, slabs.data_ptr(), ns, _hzeros(gy.device, gy.dtype).data_ptr(), _stream())
-        _check(rc, "peclr_wgrad3_h" if stride == 1 else "peclr_wgrad3_s2_h")
+            rc = lib().peclr_wgrad3_h(io, cout, cin, nb, ho, wo, gp, xp, slabs.data_ptr(), ns, _hzeros(gy.device, gy.dtype).data_ptr(), _stream())
+        _check(rc, "peclr_wgrad3_h")
         return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
     k = nb * ho * wo
     ns = lib().peclr_wgrad_h_slabs(cout, cin, k)
@@ -933,6 +935,60 @@ def conv3x3_s2_dgrad_h(gy: torch.Tensor, planes: torch.Tensor, cin: int, tag: st
 
 # ------------------------------------------------------------------ backbone glue: BN2d (+add) (+ReLU), NHWC
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+# ------------------------------------------------------------------ stem (csrc/stem.hip)
+STEM_FMT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}      # output / arithmetic of peclr_stem_conv7x7_s2
+
+
+class StemPlanes:
+    """The 7x7 stem filter [64, 3, 7, 7] (any strides) in the fragment order of peclr_stem_conv7x7_s2: three bf16 planes for
+    fp32 runs (six products), one bf16 / fp16 plane for autocast runs.  `pack()` is one launch; call it after the weight changed."""
+
+    def __init__(self, weight: torch.Tensor, dtype=torch.float32):
+        if tuple(weight.shape) != (64, 3, 7, 7) or weight.dtype != torch.float32 or not weight.is_cuda:
+            raise PeclrHipError(f"StemPlanes: an fp32 HIP [64, 3, 7, 7] filter expected, got {weight.dtype} {tuple(weight.shape)} on {weight.device}")
+        self.fmt = STEM_FMT[dtype]
+        self.weight = weight
+        self.planes = torch.empty(lib().peclr_stem_pack_bytes(self.fmt), device=weight.device, dtype=torch.uint8)
+
+    def pack(self):
+        w = self.weight
+        with _timed("stem_pack", 4 * w.numel() + self.planes.numel(), kernel="stem_pack_kernel"):
+            rc = lib().peclr_stem_pack(w.data_ptr(), *w.stride(), self.planes.data_ptr(), self.fmt, _stream())
+        _check(rc, "peclr_stem_pack")
+        return self
+
+
+def stem_conv(x: torch.Tensor, planes: "StemPlanes", stat_shift: Optional[torch.Tensor] = None, tag: str = "stem_fwd"):
+    """y [N, 64, H/2, W/2] channels_last = conv2d(x, W, stride 2, padding 3) for fp32 channels_last images x [N, 3, H, W]
+    (peclr_stem_conv7x7_s2); y is fp32 (fp32 accuracy: six bf16 products) or bf16 / fp16 (one product of the rounded operands:
+    autocast) as `planes` was packed.  stat_shift (fp32 [64]): also the training statistics of y as (partial, n_split) in the
+    layout of peclr_bn2d_stats -> (y, partial, n_split)."""
+    if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous(memory_format=torch.channels_last):
+        raise PeclrHipError(f"stem_conv: fp32 channels_last HIP images [N, 3, H, W] expected, got {x.dtype} {tuple(x.shape)} on {x.device} "
+                            "(peclr_amd has no CPU path)")
+    n, _, h, w = x.shape
+    ns = lib().peclr_stem_workgroups(n, h, w)
+    if ns < 1:
+        raise PeclrHipError(f"stem_conv: unsupported image size {h} x {w}")
+    out_dtype = {v: k for k, v in STEM_FMT.items()}[planes.fmt]
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((n, 64, ho, wo), device=x.device, dtype=out_dtype, memory_format=torch.channels_last)
+    partial = None
+    if stat_shift is not None:
+        if stat_shift.numel() != 64:
+            raise PeclrHipError("stem_conv: stat_shift has 64 entries")
+        partial = torch.empty((2 * ns + 1, 64), device=x.device, dtype=torch.float32)
+    e = y.element_size()
+    k_mfma = 14 * 16                                        # the contraction the matrix cores run (147 padded to 224)
+    with _timed(tag, 4 * x.numel() + e * y.numel() + planes.planes.numel(), 2 * n * ho * wo * 64 * 147,
+                kernel="stem_fwd_kernel"):
+        rc = lib().peclr_stem_conv7x7_s2(x.data_ptr(), n, h, w, planes.planes.data_ptr(), planes.fmt, y.data_ptr(), _ptr(stat_shift),
+                                         partial.data_ptr() if partial is not None else None, _stream())
+    _check(rc, "peclr_stem_conv7x7_s2")
+    del k_mfma
+    return y if partial is None else (y, partial, ns)
+
+
 _IO = {torch.float32: (DTYPE_F32, 4), torch.bfloat16: (DTYPE_BF16, 2), torch.float16: (DTYPE_F16, 2)}
 
 
@@ -1146,11 +1202,13 @@ def bn2d_avgpool_bwd(d_pooled, x, mask, save, ss, training, sync_group=None):
     return dx, dparams[0], dparams[1], dres
 
 
-def bn2d_pool_fwd(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group=None, sync_shift=None):
-    """Stem: y = maxpool3x3/2(relu(bn(x))) in one pass; returns (y, tap codes, save, scale_shift)."""
+def bn2d_pool_fwd(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group=None, sync_shift=None,
+                  pre=None):
+    """Stem: y = maxpool3x3/2(relu(bn(x))) in one pass; returns (y, tap codes, save, scale_shift).
+    pre: (partial, n_split, shift) -- the statistics the stem convolution summed in its epilogue (no pass over x then)."""
     n, c, h, w = x.shape
     io, e = _IO[x.dtype]
-    save, ss = _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group, sync_shift)
+    save, ss = _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group, sync_shift, pre)
     ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     y = torch.empty((n, c, ph, pw), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
     x_at_max = torch.empty_like(y)

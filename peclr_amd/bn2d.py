@@ -139,7 +139,7 @@ class Routing:
     conv16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV16"))                # 16-bit (bf16 / fp16 autocast) convolutions in-tree
     wgrad3_ring: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD3_RING"))      # fp32 3x3 weight gradient: one split per element (LDS ring + transposing reads)
     wgrad16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD16"))              # ... and their weight gradients
-    wgrad16_s2: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD16_S2", "0"))   # ... the three 3x3 / stride-2 ones too (in-tree 171 - 196 us vs MIOpen 137 - 150: off)
+    stem: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_STEM"))                    # the 7x7 / stride-2 stem forward in-tree (csrc/stem.hip)
     force: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_ROUTE_FORCE", "0"))
 
     # ---- "does the in-tree kernel pay at this shape" (measured on ResNet-50's shapes; the kernels accept far more)
@@ -332,12 +332,13 @@ class _BN2dReluPool(torch.autograd.Function):
     """Stem: BatchNorm2d -> ReLU -> MaxPool2d(3, 2, 1) without ever writing the un-pooled activation."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, bn: "FusedBatchNormAct2d"):
+    def forward(ctx, x, weight, bias, bn: "FusedBatchNormAct2d", pre=None):
         training = bn.training or not bn.track_running_stats
         sync = bn.sync_group if training else None
         rm, rv, nbt, shift = bn._stat_buffers(training)
         y, x_at_max, code, save, ss = _capi.bn2d_pool_fwd(x, weight, bias, rm, rv, nbt, training, bn.eps,
-                                                bn.momentum if bn.momentum is not None else 0.1, sync_group=sync, sync_shift=shift)
+                                                bn.momentum if bn.momentum is not None else 0.1, sync_group=sync, sync_shift=shift,
+                                                pre=pre if training else None)
         ctx.save_for_backward(x, x_at_max, code, save, ss)
         ctx.cfg = (training, sync)
         return y
@@ -348,7 +349,7 @@ class _BN2dReluPool(torch.autograd.Function):
         training, sync = ctx.cfg
         dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         dx, dgamma, dbeta = _capi.bn2d_pool_bwd(dy, x, x_at_max, code, save, ss, training, sync_group=sync)
-        return dx, dgamma, dbeta, None
+        return dx, dgamma, dbeta, None, None
 
 
 class _BN2dAddReluAvgPool(torch.autograd.Function):
@@ -873,7 +874,7 @@ def _wgrad_h(gy: Tensor, x: Tensor, conv, stride: int):
     taps = w.shape[2] * w.shape[3]
     fn = getattr(_capi, "wgrad_h", None)
     if (fn is not None and ROUTING.wgrad16 and w.is_contiguous(memory_format=torch.channels_last)
-            and _capi.wgrad_h_ok(gy, x, taps, stride) and (taps == 1 or stride == 1 or ROUTING.wgrad16_s2 or ROUTING.force)):
+            and _capi.wgrad_h_ok(gy, x, taps, stride)):
         def run():
             dw = fn(gy, x, taps, stride)                  # [Cout, taps * Cin] fp32
             if taps == 9:
@@ -959,11 +960,71 @@ class _ConvH(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+class _StemConv(torch.autograd.Function):
+    """The encoder's 7x7 / stride-2 / padding-3 stem on fp32 NHWC images, in-tree (peclr_stem_conv7x7_s2): fp32 output at fp32
+    accuracy, or -- under bf16 / fp16 autocast -- 16-bit output from the operands rounded inside the kernel (no cast pass over
+    the images); the statistics of the BatchNorm behind it in the epilogue.  Weight gradient: MIOpen's (the images need no
+    gradient; one that is asked for comes from MIOpen too)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, conv, stats=None):
+        half = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
+        dtype = half if half in _HALF else torch.float32
+        planes = conv._stem_planes(dtype)
+        ctx.save_for_backward(x, weight)
+        ctx.conv, ctx.dtype = conv, dtype
+        shift = _stat_shift_for(stats[0], 64) if (stats and ROUTING.bn_stats_in_gemm) else None
+        if shift is not None:
+            y, partial, ns = _capi.stem_conv(x, planes, stat_shift=shift)
+            stats[:] = [partial, ns, shift, stats[0]]
+            return y
+        return _capi.stem_conv(x, planes)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        conv = ctx.conv
+        gy = gy.to(ctx.dtype).contiguous(memory_format=torch.channels_last)
+        xin = x if ctx.dtype == torch.float32 else x.to(ctx.dtype)          # (what autocast's convolution saw)
+        dw = _conv_wgrad(gy, xin, weight, (2, 2), (3, 3), conv.weight) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(gy, xin, weight.to(ctx.dtype), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0].to(x.dtype)
+        if dw is not None and dw.dtype != weight.dtype:
+            dw = dw.to(weight.dtype)
+        return dx, dw, None, None
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d (same parameters / state_dict) that routes through `_Conv2dSplitBackward` while the side-stream
     weight gradients are enabled and the input is a channels_last HIP tensor; the stock op otherwise."""
 
     hip_gemm = False   # enable_hip_batchnorm: fp32 1x1 / stride-1 convolutions as GEMMs on the bf16 matrix cores
+    hip_stem = False   # enable_hip_batchnorm: this is the 7x7 / stride-2 stem of 3-channel images (csrc/stem.hip)
+
+    def _stem_planes(self, dtype):
+        """The stem filter packed for `dtype` (fp32: three bf16 planes; bf16 / fp16: one plane), fresh: re-packed when the weight
+        changed since the last pack (`_version`, fused optimiser epoch, storage) and once per hipGraph capture -- the protocol
+        of `X6PackGroup.planes`."""
+        sets = self.__dict__.setdefault("_stem_sets", {})
+        st = sets.get(dtype)
+        w = self.weight
+        key = (w.data_ptr(), w._version, _capi.WEIGHTS_EPOCH)
+        cap = _capi.capture_id()
+        if st is None or st[0].weight.data_ptr() != w.data_ptr():
+            if cap != 0:
+                raise _capi.PeclrHipError("stem: the filter planes of this precision do not exist yet and cannot be created while a "
+                                          "hipGraph is being captured -- run one eager forward pass (same autocast dtype) first")
+            st = sets[dtype] = [_capi.StemPlanes(w.detach(), dtype), None, 0]
+        stale = st[1] != key
+        if cap != st[2]:
+            stale = stale or cap != 0
+            st[2] = cap
+        if stale:
+            st[0].pack()
+            st[1] = key
+        return st[0]
 
     def forward(self, x: Tensor, stats_for=None, sole_consumer: bool = False) -> Tensor:
         """stats_for: the BatchNorm2d that consumes the output -- when this convolution runs as an in-tree GEMM its
@@ -973,6 +1034,11 @@ class Conv2d(nn.Conv2d):
         may the input-gradient GEMM perform that layer's backward reduction in its epilogue.  A block input (x also feeds
         the shortcut) is not: BasicBlock.conv1 passes False."""
         bn_link = _bn_link_of if sole_consumer else (lambda t: None)
+        if (self.hip_stem and ROUTING.stem and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3
+                and x.shape[2] >= 8 and x.shape[3] >= 8 and x.is_contiguous(memory_format=torch.channels_last)
+                and self.weight.is_cuda and self.weight.dtype == torch.float32):
+            stats = [stats_for] if stats_for is not None else None
+            return _attach_stats(_StemConv.apply(x, self.weight, self, stats), stats)
         if self.hip_gemm and _h_ok(self, x) and (x.shape[2] % self.stride[0] == 0 and x.shape[3] % self.stride[1] == 0):
             stats = [stats_for] if stats_for is not None else None
             grad = torch.is_grad_enabled() and x.requires_grad
@@ -1220,13 +1286,13 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
         if self.hip:
             if not self.affine or (self.training and self.momentum is None):
                 raise _capi.PeclrHipError("fused BatchNorm2d needs affine=True and a fixed momentum")
-            if pool:
-                return _BN2dReluPool.apply(x, self.weight, self.bias, self)
             # statistics its producer already summed (a GEMM epilogue, `conv_stats_for`), valid for THIS layer in training
             pre = getattr(x, "_peclr_bn_stats", None)
             if pre is not None and (pre[3] is not self or not (self.training or not self.track_running_stats)):
                 pre = None
             pre = pre[:3] if pre is not None else None
+            if pool:
+                return _BN2dReluPool.apply(x, self.weight, self.bias, self, pre)
             if self.tail_avgpool and relu and residual is not None and self.num_features % 32 == 0:
                 return _BN2dAddReluAvgPool.apply(x, self.weight, self.bias, residual, self, pre)
             link = [] if (ROUTING.bn_bwd_in_gemm and torch.is_grad_enabled() and x.requires_grad) else None
@@ -1260,6 +1326,10 @@ def enable_hip_batchnorm(module: nn.Module, enabled: bool = True, sync_group=Non
             n += 1
         elif getattr(m, "fork_entry", False):   # bottleneck conv1 (resnet.Bottleneck marks it)
             m.hip_fork = enabled
+        if (isinstance(m, Conv2d) and m.kernel_size == (7, 7) and m.stride == (2, 2) and m.padding == (3, 3) and m.in_channels == 3
+                and m.out_channels == 64 and m.groups == 1 and m.bias is None and m.dilation == (1, 1)):
+            m.hip_stem = enabled
+            m.__dict__.pop("_stem_sets", None)
         if isinstance(m, Conv2d) and m.kernel_size in ((1, 1), (3, 3)) and m.stride in ((1, 1), (2, 2)):
             m.hip_gemm = enabled                # fp32 1x1 (where `_x6_pays`) and 3x3 stride-1 convolutions as in-tree GEMMs
             m.x6_group = None

@@ -84,6 +84,7 @@ struct HArgs {
     const unsigned* bb_mask;
     int bb_relu;
     float* bb_partial;
+    int stream_out;                      // the output (and its addend) is larger than the caches: non-temporal epilogue
 };
 
 // 16 bytes per lane, global -> LDS at (wave-uniform) dst + lane * 16 (inline assembly: see gemm_x6p.hip -- through the
@@ -532,7 +533,10 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
                         arow = ((size_t)img * (g.add_h >> 1) + (h >> 1)) * (g.add_w >> 1) + (w >> 1);
                     }
                     if (has) {
-                        dv[jj] = *reinterpret_cast<const uint4*>(g.addend + arow * g.ldd + nt + ec);
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4* asrc4 = reinterpret_cast<const u32x4*>(g.addend + arow * g.ldd + nt + ec);
+                        const u32x4 tv = g.stream_out ? __builtin_nontemporal_load(asrc4) : *asrc4;
+                        dv[jj] = make_uint4(tv[0], tv[1], tv[2], tv[3]);
                         ab[jj] = g.add_mask ? (g.add_mask[(size_t)m * (g.N >> 5) + ((nt + ec) >> 5)] >> (ec & 31)) & 0xFFu : 0xFFu;
                     }
                 }
@@ -571,7 +575,13 @@ __global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ow[q] = H::pack2(c[2 * q], c[2 * q + 1]);
                 if (om[a][jj] >= 0) {
-                    *reinterpret_cast<uint4*>(g.out + (size_t)om[a][jj] * g.ldo + nt + ec) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                    {
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        u32x4* dst4 = reinterpret_cast<u32x4*>(g.out + (size_t)om[a][jj] * g.ldo + nt + ec);
+                        const u32x4 tv = {ow[0], ow[1], ow[2], ow[3]};
+                        if (g.stream_out) __builtin_nontemporal_store(tv, dst4);
+                        else *dst4 = tv;
+                    }
                     if (BBF && g.bb_partial) {
                         const unsigned xw[4] = {xv[jj].x, xv[jj].y, xv[jj].z, xv[jj].w};
                         float x[8], d[8];
@@ -690,6 +700,13 @@ int ring_rows(int taps, int stride, int s2d, int W) {
     static const int on = getenv("PECLR_CONV3_RING") ? atoi(getenv("PECLR_CONV3_RING")) : 1;
     if (!on || taps != 9 || stride != 1 || s2d || W > 62) return 0;
     return 256 + 2 * (W + 2) <= 320 ? 320 : 384;
+}
+
+// experiment switch (default off: the consumer of a 16-bit output -- the next BatchNorm pass -- finds part of it in the
+// memory-side cache): PECLR_CONV_H_STREAM_OUT=<MB> writes outputs larger than that many MB (and reads their addends) non-temporally
+static bool stream_past_caches_h(size_t bytes) {
+    static const long mb = getenv("PECLR_CONV_H_STREAM_OUT") ? atol(getenv("PECLR_CONV_H_STREAM_OUT")) : 0;
+    return mb > 0 && bytes > ((size_t)mb << 20);
 }
 
 template <typename H, int EP>
@@ -814,6 +831,7 @@ extern "C" int peclr_gemm_h(int dtype, int M, int N, int K, const void* A, int l
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = g.W = 1; g.flip = 0; g.zeros = nullptr; g.stride = 1; g.Hin = g.Win = 1; g.s2d = 0; g.Mp = 0;
     set_bb(g, bb);
+    g.stream_out = stream_past_caches_h((size_t)M * N * 2);
     return dispatch(dtype, g, tile_rows, 1, static_cast<hipStream_t>(stream));
 }
 
@@ -841,6 +859,7 @@ extern "C" int peclr_conv_h(int dtype, int NB, int H, int W, int Cin, int Cout, 
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = Ho; g.W = Wo; g.flip = flip ? 1 : 0; g.zeros = static_cast<const h16_t*>(zeros); g.stride = stride; g.Hin = H; g.Win = W; g.s2d = 0;
     set_bb(g, bb);
+    g.stream_out = stream_past_caches_h((size_t)M * Cout * 2);
     return dispatch(dtype, g, tile_rows, taps, static_cast<hipStream_t>(stream));
 }
 
@@ -861,5 +880,6 @@ extern "C" int peclr_conv3x3_s2_dgrad_h(int dtype, int NB, int Ho, int Wo, int C
     g.stat_shift = nullptr; g.stat_partial = nullptr;
     g.H = Ho; g.W = Wo; g.flip = 1; g.zeros = static_cast<const h16_t*>(zeros); g.stride = 1; g.Hin = Ho; g.Win = Wo; g.s2d = 1; g.Mp = 0;
     set_bb(g, bb);
+    g.stream_out = stream_past_caches_h((size_t)M * 4 * Cin * 2);
     return dispatch(dtype, g, tile_rows, 9, static_cast<hipStream_t>(stream));
 }

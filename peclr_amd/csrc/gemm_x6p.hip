@@ -126,7 +126,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     constexpr int RAW0 = NB * CHL < 5 * 32 * 36 * 4 ? 5 * 32 * 36 * 4 : NB * CHL;   // (the epilogue's transposes + sums live here: 22.5 KiB)
     constexpr int PL0 = RAW0 + (AREG ? 0 : 4 * RM * 64);   // DMA targets first (LDS-DMA addresses < 64 KiB)
     constexpr int NPXM = TM + 2 * 62 + 2;                // HALO: pixels of the patch at most (W <= 62: six 16-byte loads per thread at TM = 256)
-    constexpr int PHALF = NPXM * 16, PPLANE = 2 * PHALF, PATCH = 3 * PPLANE;
+    // k-half pitch: the pixels' 16 bytes + padding to 64 bytes past a multiple of 128 -- ds_write_b64 is served in groups of 16
+    // lanes on 32 banks of 4 bytes, and a group of the patch store holds 4 pixels x both k-halves: with the bare pitch
+    // (1528 dwords = 24 mod 32 at TM = 256) the second half's banks overlapped the first's, a 2-way conflict on every store
+    // (0.187 of the kernel's LDS cycles, profiles/r04f_fp32_bench_mfma.txt; every other six-product kernel: <= 0.06)
+    constexpr int PHALF = (NPXM * 16 + 63) / 128 * 128 + 64, PPLANE = 2 * PHALF, PATCH = 3 * PPLANE;
     constexpr int ZOFF = RAW0 + PATCH;                   // HALO: 16 bytes of zeros
     // + 2.5 KiB at the end: the epilogue's per-column constants ([shift | mean | invstd | scale | shift'][128] floats), fetched
     // BEFORE the main loop -- in the epilogue each of the four column tiles used to wait a full memory round trip for them

@@ -14,7 +14,7 @@ import warnings
 from torch import nn
 
 from . import resnet as _resnet
-from .bn2d import FusedBatchNormAct2d
+from .bn2d import Conv2d, FusedBatchNormAct2d
 from .config import Config
 
 
@@ -26,6 +26,20 @@ class TailAvgPool(nn.AdaptiveAvgPool2d):
 
     def forward(self, x):
         return x if x.dim() == 2 else super().forward(x)
+
+
+class _Features(nn.Sequential):
+    """nn.Sequential (same indices, same state_dict keys) that tells the stem convolution which BatchNorm consumes its output,
+    so that an in-tree stem sums that layer's statistics in its epilogue (bn2d.Conv2d.forward(stats_for=...))."""
+
+    def forward(self, x):
+        mods = list(self)
+        if len(mods) >= 2 and isinstance(mods[0], Conv2d) and isinstance(mods[1], FusedBatchNormAct2d):
+            x = mods[1](mods[0](x, stats_for=mods[1]))
+            mods = mods[2:]
+        for m in mods:
+            x = m(x)
+        return x
 
 
 class ResNetModel(nn.Module):
@@ -48,7 +62,7 @@ class ResNetModel(nn.Module):
         # this module receives an already pooled 2-D tensor, which it passes through.
         last = model.layer4[-1]
         (last.bn3 if hasattr(last, "bn3") else last.bn2).tail_avgpool = True
-        self.features = nn.Sequential(model.conv1, model.bn1, nn.Identity(), nn.Identity(), model.layer1,
+        self.features = _Features(model.conv1, model.bn1, nn.Identity(), nn.Identity(), model.layer1,
                                       model.layer2, model.layer3, model.layer4, TailAvgPool())
         self.final_layer = nn.Sequential(nn.Linear(model.fc.in_features, 21 * 3 + 1))
 

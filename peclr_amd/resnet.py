@@ -142,7 +142,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x: Tensor) -> Tensor:
-        x = self.maxpool(_bn(self.bn1, self.conv1(x), relu=True))
+        x = self.maxpool(_bn(self.bn1, _conv(self.conv1, x, self.bn1), relu=True))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 

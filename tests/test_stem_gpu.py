@@ -1,0 +1,135 @@
+"""The encoder's stem in-tree (csrc/stem.hip: peclr_stem_conv7x7_s2 + peclr_stem_pack): torchvision ResNet `conv1` = Conv2d(3, 64,
+7, stride 2, padding 3, bias=False) behind /root/reference/src/models/resnet_model.py:15, on fp32 NHWC images.  fp32: held to the
+error class of an fp32 kernel against float64 (next to MIOpen on the same data); bf16 / fp16 (autocast): one rounding of the
+float64 convolution of the ROUNDED operands; fused BatchNorm statistics against a pass over the stored output; bit-repeatable."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _data(n, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(n, 3, h, w, generator=g) * 1.1 + 0.2).to(DEV).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(64, 3, 7, 7, generator=g) * 0.08).to(DEV)
+    return x, wt
+
+
+def _ref64(x, wt):
+    return torch.nn.functional.conv2d(x.double(), wt.double(), None, 2, 3)
+
+
+@pytest.mark.parametrize("n,h,w", [(4, 224, 224), (2, 64, 64), (3, 30, 46), (2, 225, 131), (1, 448, 448), (5, 9, 8)])
+@pytest.mark.parametrize("weight_format", ["contiguous", "channels_last"])
+def test_stem_fp32_is_an_fp32_convolution(n, h, w, weight_format):
+    from peclr_amd import _capi as capi
+
+    x, wt = _data(n, h, w, seed=h + w)
+    if weight_format == "channels_last":
+        wt = wt.contiguous(memory_format=torch.channels_last)
+    planes = capi.StemPlanes(wt).pack()
+    y = capi.stem_conv(x, planes)
+    ref = _ref64(x, wt)
+    assert y.shape == ref.shape and y.dtype == torch.float32 and y.is_contiguous(memory_format=torch.channels_last)
+    scale = float(ref.abs().max())
+    err = float((y.double() - ref).abs().max()) / scale
+    stock = float((torch.nn.functional.conv2d(x, wt, None, 2, 3).double() - ref).abs().max()) / scale
+    assert err <= max(4 * stock, 4e-6), (err, stock)
+    for _ in range(5):
+        assert torch.equal(capi.stem_conv(x, planes), y)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,h,w", [(4, 224, 224), (3, 30, 46), (1, 131, 225)])
+def test_stem_16_bit_is_one_rounding_of_the_product_of_the_rounded_operands(dtype, n, h, w):
+    from peclr_amd import _capi as capi
+
+    x, wt = _data(n, h, w, seed=h + 2 * w)
+    planes = capi.StemPlanes(wt, dtype).pack()
+    y = capi.stem_conv(x, planes)
+    assert y.dtype == dtype
+    ref = _ref64(x.to(dtype), wt.to(dtype))
+    # fp32 accumulation of exact products, then one rounding to the 16-bit format: half an ulp of the output (+ the fp32 sums)
+    ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+    bound = ref.abs() * ulp * 0.51 + 2e-5 * float(ref.abs().max())
+    assert bool(((y.double() - ref).abs() <= bound).all()), float(((y.double() - ref).abs() - bound).max())
+    for _ in range(3):
+        assert torch.equal(capi.stem_conv(x, planes), y)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,h,w", [(8, 224, 224), (3, 30, 46)])
+def test_stem_statistics_from_the_epilogue_equal_a_pass_over_the_output(dtype, n, h, w):
+    """The partial table goes through peclr_bn2d_finalize_f32 (bn2d_pool_fwd with `pre`) and must give the mean / invstd a
+    separate statistics pass over the stored tensor gives -- tile rows and pixels outside the image excluded."""
+    from peclr_amd import _capi as capi
+
+    x, wt = _data(n, h, w, seed=7)
+    planes = capi.StemPlanes(wt, dtype).pack()
+    g = torch.Generator().manual_seed(1)
+    shift = (torch.randn(64, generator=g) * 0.1).to(DEV)
+    y, partial, ns = capi.stem_conv(x, planes, stat_shift=shift)
+    assert torch.equal(y, capi.stem_conv(x, planes)) and partial.shape == (2 * ns + 1, 64)
+    gamma, beta = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
+
+    def stats(pre):
+        rm, rv, nbt = torch.zeros(64, device=DEV), torch.ones(64, device=DEV), torch.zeros((), device=DEV, dtype=torch.int64)
+        _, _, _, save, ss = capi.bn2d_pool_fwd(y, gamma, beta, rm, rv, nbt, True, 1e-5, 0.1, pre=pre)
+        return save, rm, rv
+
+    (s1, rm1, rv1), (s0, rm0, rv0) = stats((partial, ns, shift)), stats(None)
+    assert torch.allclose(s1[0], s0[0], rtol=1e-5, atol=2e-6) and torch.allclose(s1[1], s0[1], rtol=2e-5)
+    assert torch.allclose(rm1, rm0, rtol=1e-5, atol=1e-6) and torch.allclose(rv1, rv0, rtol=2e-5)
+    y64 = y.double()
+    assert torch.allclose(s1[0].double(), y64.mean(dim=(0, 2, 3)), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_encoder_routes_the_stem_in_tree_with_its_statistics_and_trains(precision):
+    """Through the module surface: `ResNetModel.features` hands the stem its BatchNorm, the stem runs in-tree (event log) with
+    the statistics fused (no bn2d_stats launch at all in the forward), forward and gradients equal the MIOpen-stem arm's."""
+    import copy
+
+    from peclr_amd import _capi as capi
+    from peclr_amd import bn2d as B
+    from peclr_amd.config import Config
+    from peclr_amd.encoder import get_wrapper_model
+
+    torch.manual_seed(3)
+    net = get_wrapper_model(Config({"resnet_size": "18"}), False).to(DEV).to(memory_format=torch.channels_last).train()
+    for p in net.final_layer.parameters():
+        p.requires_grad_(False)
+    other = copy.deepcopy(net)
+    B.enable_hip_batchnorm(net)
+    B.enable_hip_batchnorm(other)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(8, 3, 96, 96, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = (torch.randn(8, 512, generator=g) / 512).to(DEV)
+    cast = torch.autocast("cuda", dtype=torch.bfloat16, enabled=precision == "bf16")
+
+    def run(model, stem):
+        capi.EVENT_LOG = {}
+        try:
+            with B.routing(stem=stem), cast:
+                y = model(x)
+            y.float().backward(gy)
+            torch.cuda.synchronize()
+            tags = {k: len(v) for k, v in capi.EVENT_LOG.items()}
+        finally:
+            capi.EVENT_LOG = None
+        return y.detach().float(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}, tags
+
+    y1, g1, t1 = run(net, True)
+    y0, g0, t0 = run(other, False)
+    assert t1.get("stem_fwd") == 1 and t1.get("stem_pack") == 1 and "bn2d_stats" not in t1, t1
+    assert "stem_fwd" not in t0 and t0.get("bn2d_stats", 0) >= 1, t0
+    tol = 2e-4 if precision == "fp32" else 3e-2
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))   # noqa: E731
+    assert rel(y1, y0) <= tol, rel(y1, y0)
+    assert set(g1) == set(g0)
+    worst = max(rel(g1[n], g0[n]) for n in g0)
+    assert worst <= (2e-3 if precision == "fp32" else 0.2), worst
+    assert torch.allclose(net.features[1].running_mean, other.features[1].running_mean, rtol=1e-3, atol=1e-4)
+    assert int(net.features[1].num_batches_tracked) == 1
