@@ -1083,6 +1083,13 @@ class Conv2d(nn.Conv2d):
         return super().forward(x)
 
 
+def _entry_gemm(a: Tensor, planes: Tensor, n: int, addend=None, **kw):
+    """The block's entry gradient a . W (+ the shortcut's gradient, + the BatchNorm backward reduction): peclr_gemm_x6p_f32.
+    (Round 5 tried a barrier-free streaming kernel for the HBM-bound shapes here -- tools/exp/gemm_x6s.hip, bit-identical
+    output -- and measured it slower: docs/history.md.)"""
+    return _capi.gemm_x6p(a, planes, n, addend, tag="conv1x1_dgrad_add_x6", **kw)
+
+
 class _ForkConv1x1(torch.autograd.Function):
     """Bottleneck entry: (x, W) -> (conv1x1(x, W), x).  The block input feeds both the first convolution and
     the identity branch, so its gradient is dY W + d_identity: autograd runs MIOpen's dgrad and then an
@@ -1143,10 +1150,10 @@ class _ForkConv1x1(torch.autograd.Function):
                     kw = dict(addend=lazy[1].contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(r, cin), addend_mask=lazy[2])
                 link = ctx.link
                 if link is not None and link[0].shape == x.shape and cin % 32 == 0:
-                    out, partial, ns = _capi.gemm_x6p(a, ctx.planes[1], cin, tag="conv1x1_dgrad_add_x6", bn_bwd=link[:5], **kw)
+                    out, partial, ns = _entry_gemm(a, ctx.planes[1], cin, bn_bwd=link[:5], **kw)
                     _note_bn_bwd(out, link, partial, ns)
                 else:
-                    out = _capi.gemm_x6p(a, ctx.planes[1], cin, tag="conv1x1_dgrad_add_x6", **kw)
+                    out = _entry_gemm(a, ctx.planes[1], cin, **kw)
                 return out.view(n, h, w, cin).permute(0, 3, 1, 2), dw, None, None, None, None
             if lazy is not None:
                 gid = _dense_of(lazy, x.shape)
@@ -1161,10 +1168,10 @@ class _ForkConv1x1(torch.autograd.Function):
                 # the result is the gradient arriving at the previous block's last BatchNorm: reduced in the epilogue
                 link = ctx.link
                 if link is not None and link[0].shape == x.shape and cin % 32 == 0:
-                    out, partial, ns = _capi.gemm_x6p(a, ctx.planes[1], cin, d, tag="conv1x1_dgrad_add_x6", bn_bwd=link[:5])
+                    out, partial, ns = _entry_gemm(a, ctx.planes[1], cin, d, bn_bwd=link[:5])
                     _note_bn_bwd(out, link, partial, ns)
                 else:
-                    out = _capi.gemm_x6p(a, ctx.planes[1], cin, d, tag="conv1x1_dgrad_add_x6")
+                    out = _entry_gemm(a, ctx.planes[1], cin, d)
             elif ctx.use_bwd:
                 wt = weight.detach().reshape(cmid, cin).t().contiguous()
                 out = _capi.gemm_x6(a, wt, d, tag="conv1x1_dgrad_add_x6")

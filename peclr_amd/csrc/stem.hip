@@ -29,7 +29,7 @@ typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 
 constexpr int SK = 14;                   // k-steps of 16 (28 slices of 8: kh = slice >> 2, pixel pair = slice & 3)
 constexpr int TPX = 128;                 // output pixels of a row per workgroup
-constexpr int PWP = 2 * TPX + 8;         // staged pixels per patch row (261 used; the rest zeros)
+constexpr int PWP = 2 * TPX + 6;         // staged pixels per patch row (261 used, the last is read by the zero-weighted k; 16-byte pitch)
 constexpr int PROW = PWP * 8;            // bytes per patch row and plane
 constexpr int NROW = 9;                  // input rows under two output rows
 constexpr int XE = 68;                   // floats per row of the epilogue's 32 x 64 transposes
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemArgs g) {
     constexpr int NP = F::NP;
     constexpr int PLANE = NROW * PROW;                   // 19 008 bytes
     constexpr int CH = NP * 2 * 1024;                    // bytes of packed filter per k-step
-    constexpr int NB = 3;
+    constexpr int NB = 4;                                // filter stages: three steps of DMA run-ahead (a step is 768 MFMA clocks, an L2 round trip ~1 500)
     constexpr int B0 = 0, P0 = NB * CH;                  // filter stages first (LDS-DMA targets below 64 KiB), then the patch
     constexpr int EPI = 4 * 32 * XE * 4 + 4 * 2 * 64 * 4;
     constexpr int TOTAL = P0 + NP * PLANE > EPI ? P0 + NP * PLANE : EPI;
@@ -114,20 +114,23 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemArgs g) {
         }
     };
 
+    // the first filter chunks travel while the patch is being staged (their targets are not the patch's)
+    issue_b(0);
+    issue_b(1);
+    issue_b(2);
     // ---- the patch: nine input rows x PWP pixels, fp32 -> NP planes of (r, g, b, 0) 16-bit quadruples
-    constexpr int NSLOT = NROW * PWP;                    // 2 376 pixel slots
+    constexpr int NSLOT = NROW * PWP;                    // 2 358 pixel slots
     constexpr int NLD = (NSLOT + 255) / 256;             // 10 per thread
-    float px[NLD][3];
+    struct __attribute__((packed, aligned(4))) Rgb { float r, g, b; };       // one 12-byte load per pixel (4-byte aligned)
+    Rgb px[NLD];
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
         const int idx = tid + 256 * u;
         const int r = idx / PWP, p = idx - r * PWP;
         const int ih = ih0 + r, iw = iw0 + p;
         const bool in = idx < NSLOT && p < 2 * TPX + 5 && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
-        const float* src = g.x + (((size_t)img * g.Hin + (in ? ih : 0)) * g.Win + (in ? iw : 0)) * 3;
-        px[u][0] = in ? src[0] : 0.f;
-        px[u][1] = in ? src[1] : 0.f;
-        px[u][2] = in ? src[2] : 0.f;
+        const Rgb* src = reinterpret_cast<const Rgb*>(g.x + (((size_t)img * g.Hin + (in ? ih : 0)) * g.Win + (in ? iw : 0)) * 3);
+        px[u] = in ? *src : Rgb{0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
@@ -136,20 +139,19 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemArgs g) {
             unsigned char* d = lds + P0 + idx * 8;       // (row r, pixel p) = slot idx: rows are PWP slots apart
             if constexpr (NP == 3) {
                 unsigned h[2], m[2], l[2];
-                split3_pk(px[u][0], px[u][1], h[0], m[0], l[0]);
-                split3_pk(px[u][2], 0.f, h[1], m[1], l[1]);
+                split3_pk(px[u].r, px[u].g, h[0], m[0], l[0]);
+                split3_pk(px[u].b, 0.f, h[1], m[1], l[1]);
                 *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
                 *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(m[0], m[1]);
                 *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(l[0], l[1]);
             } else {
-                *reinterpret_cast<uint2*>(d) = make_uint2(F::pack2(px[u][0], px[u][1]), F::pack2(px[u][2], 0.f));
+                *reinterpret_cast<uint2*>(d) = make_uint2(F::pack2(px[u].r, px[u].g), F::pack2(px[u].b, 0.f));
             }
         }
     }
-    // every global load of the patch has been consumed (the stores above needed the data): from here on the only memory
-    // operations in flight are the filter DMAs, waited for by hand
-    issue_b(0);
-    issue_b(1);
+    // every global load of the patch has been consumed (the stores above needed the data -- the compiler's own waits, which
+    // retire the older filter requests with them): from here on the only memory operations in flight are filter DMAs,
+    // waited for by hand
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -162,17 +164,18 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemArgs g) {
     // this lane's fragment of (row a, step t): slice 2 t + half -> patch row 2 a + (slice >> 2), pixel 2 (32 wave + i) + 2 (slice & 3)
     const int fbase = P0 + (2 * (32 * wave + i)) * 8;
     for (int t = 0; t < SK; ++t) {
-        // filter chunk t has landed: younger than it is at most chunk t + 1 (this wave's pieces: 2 / 1 / 0 requests)
-        if (t + 1 < SK) {
-            if (NP == 3 && wave_s < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (NP == 3 || wave_s < 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        // filter chunk t has landed: younger than it are at most chunks t + 1 and t + 2 (this wave's pieces: 2 / 1 / 0 requests
+        // per chunk; the last two steps simply wait for everything)
+        if (t + 2 < SK) {
+            if (NP == 3 && wave_s < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (NP == 3 || wave_s < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (t == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the patch stores are in the LDS before the barrier publishes them
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 2 < SK) issue_b(t + 2);                   // into the stage step t - 1 read
+        if (t + 3 < SK) issue_b(t + 3);                   // into the stage step t - 1 read
         const int slice = 2 * t + half;
         const int kh = slice >> 2, s = slice & 3;
         uint4 af[2][NP], bf[2][NP];

@@ -51,9 +51,10 @@ def test_stem_16_bit_is_one_rounding_of_the_product_of_the_rounded_operands(dtyp
     y = capi.stem_conv(x, planes)
     assert y.dtype == dtype
     ref = _ref64(x.to(dtype), wt.to(dtype))
-    # fp32 accumulation of exact products, then one rounding to the 16-bit format: half an ulp of the output (+ the fp32 sums)
-    ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
-    bound = ref.abs() * ulp * 0.51 + 2e-5 * float(ref.abs().max())
+    # fp32 accumulation of exact products, then one rounding to the 16-bit format: half an ulp of the output -- at most 2^-8
+    # (bf16: 8 significand bits) / 2^-11 (fp16) of its magnitude -- plus the fp32 sums' own round-off
+    half_ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+    bound = ref.abs() * half_ulp * 1.01 + 2e-5 * float(ref.abs().max())
     assert bool(((y.double() - ref).abs() <= bound).all()), float(((y.double() - ref).abs() - bound).max())
     for _ in range(3):
         assert torch.equal(capi.stem_conv(x, planes), y)
@@ -123,8 +124,8 @@ def test_encoder_routes_the_stem_in_tree_with_its_statistics_and_trains(precisio
 
     y1, g1, t1 = run(net, True)
     y0, g0, t0 = run(other, False)
-    assert t1.get("stem_fwd") == 1 and t1.get("stem_pack") == 1 and "bn2d_stats" not in t1, t1
-    assert "stem_fwd" not in t0 and t0.get("bn2d_stats", 0) >= 1, t0
+    assert t1.get("stem_fwd") == 1 and t1.get("stem_pack") == 1 and "stem_fwd" not in t0, (t1, t0)
+    assert t0.get("bn2d_stats", 0) == t1.get("bn2d_stats", 0) + 1, (t1, t0)         # the stem BatchNorm's statistics pass is gone
     tol = 2e-4 if precision == "fp32" else 3e-2
     rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))   # noqa: E731
     assert rel(y1, y0) <= tol, rel(y1, y0)
