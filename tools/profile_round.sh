@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-4 rocprofv3 passes of the eager bench (fp32 default and bf16): kernel trace + stats, two SQ counter passes, FETCH_SIZE /
+# The per-round rocprofv3 passes (rounds 4 and 5) of the eager bench (fp32 default and bf16): kernel trace + stats, two SQ counter passes, FETCH_SIZE /
 # WRITE_SIZE passes (separate: TCC slots; counters only ever together with --kernel-trace).
-#   bash tools/profile_r04.sh <outdir> [fp32|bf16 ...]      (on the MI355X box, from the repo root)
+#   bash tools/profile_round.sh <outdir> [fp32|bf16 ...]      (on the MI355X box, from the repo root)
 set -u
-OUT=${1:-gpurun_out/r04_prof}; shift || true
+OUT=${1:-gpurun_out/r05_prof}; shift || true
 DTYPES=${*:-fp32 bf16}
 ROOT=$(pwd)
 mkdir -p "$OUT"

@@ -20,6 +20,7 @@ CATS = OrderedDict([
     ("MIOpen zero-fill / cast for split-K weight gradients", lambda n: "SubTensorOp" in n or "fillBufferAligned" in n),
     ("hand-written: 16-bit convolutions (conv_h: forward, input gradient, fused entry gradient; wgrad_h / wgrad3_h: weight gradients; h_pack)",
      lambda n: "peclr" in n and any(k in n for k in ("conv_h_kernel", "wgrad_h_kernel", "wgrad3_h_kernel", "h_pack_kernel"))),
+    ("hand-written: 7x7 stem forward + filter pack (stem_fwd_kernel, stem_pack_kernel)", lambda n: "peclr" in n and "stem_" in n),
     ("hand-written: BatchNorm2d glue (bn2d_*)", lambda n: "peclr" in n and "bn2d_" in n),
     ("hand-written: fused dgrad + residual GEMM (128x128)", lambda n: "peclr" in n and "gemm_f32_nn128" in n),
     ("hand-written: 3x3 convolutions on the bf16 matrix cores (forward, input gradient: gemm_x6p <.., 9>; weight gradient: gemm_x6w)",
