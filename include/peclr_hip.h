@@ -575,6 +575,16 @@ int peclr_stem_pack(const float* w, long long stride_n, long long stride_c, long
 int peclr_stem_workgroups(int N, int Hin, int Win);
 int peclr_stem_conv7x7_s2(const float* x, int N, int Hin, int Win, const void* planes, int fmt, void* y,
                           const float* stat_shift, float* stat_partial, peclr_stream_t stream);
+/* ... and its weight gradient: dW[n][kh][kw][c] = sum over (image, oh, ow) of dY[oh][ow][n] . x[2 oh - 3 + kh][2 ow - 3 + kw][c], with the
+ * output pixel as the contraction index of the matrix cores (dY transposed into LDS by 2-byte stores, the image patch
+ * gathered by eight ds_read_u16 per fragment).  dY [N][Ho][Wo][64]: fp32 (fmt 0: six products, fp32 accuracy) or bf16 / fp16
+ * (fmt 1 / 2: one product, the images rounded to that format as the forward rounds them).  Persistent workgroups each write
+ * one fp32 slab [64][224] -- column 32 kh + 4 kw + c; the kw = 7 and c = 3 columns carry no meaning -- slabs
+ * [peclr_stem_wgrad_slabs(N, Hin, Win, fmt)][64][224], summed in a fixed order by peclr_slab_reduce_f32 (deterministic, unlike
+ * MIOpen's atomically accumulated weight gradient: the last MIOpen kernel of the fp32 step).                                */
+int peclr_stem_wgrad_slabs(int N, int Hin, int Win, int fmt);
+int peclr_stem_wgrad(const float* x, const void* dY, int N, int Hin, int Win, int fmt, float* slabs, int n_slabs,
+                     peclr_stream_t stream);
 
 #ifdef __cplusplus
 }

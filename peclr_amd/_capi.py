@@ -49,6 +49,8 @@ SIGNATURES = {
     "peclr_stem_pack": (c_int, [_P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, c_int, _P]),
     "peclr_stem_workgroups": (c_int, [c_int, c_int, c_int]),
     "peclr_stem_conv7x7_s2": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
+    "peclr_stem_wgrad_slabs": (c_int, [c_int, c_int, c_int, c_int]),
+    "peclr_stem_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "peclr_bn2d_n_split": (c_int, [c_int, c_int, c_int]),
     "peclr_bn2d_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "peclr_bn2d_combine_f64": (c_int, [_P, c_int, c_int, _P, _P]),
@@ -987,6 +989,29 @@ def stem_conv(x: torch.Tensor, planes: "StemPlanes", stat_shift: Optional[torch.
     _check(rc, "peclr_stem_conv7x7_s2")
     del k_mfma
     return y if partial is None else (y, partial, ns)
+
+
+def stem_wgrad(gy: torch.Tensor, x: torch.Tensor, tag: str = "stem_wgrad") -> torch.Tensor:
+    """dW [64, 3, 7, 7] (fp32; a view of a [64, 7, 8, 4] buffer: the layout the kernel accumulates in) of the stem convolution
+    for channels_last gy [N, 64, H/2, W/2] (fp32, or bf16 / fp16 under autocast) and the fp32 channels_last images x [N, 3, H, W]
+    (peclr_stem_wgrad + peclr_slab_reduce_f32: fixed-order slabs, deterministic)."""
+    if (x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous(memory_format=torch.channels_last)
+            or gy.dtype not in STEM_FMT or gy.dim() != 4 or gy.shape[1] != 64 or not gy.is_contiguous(memory_format=torch.channels_last)):
+        raise PeclrHipError(f"stem_wgrad: fp32 channels_last images and a channels_last [N, 64, H/2, W/2] gradient expected, got "
+                            f"{x.dtype} {tuple(x.shape)}, {gy.dtype} {tuple(gy.shape)} (peclr_amd has no CPU path)")
+    n, _, h, w = x.shape
+    if tuple(gy.shape) != (n, 64, (h - 1) // 2 + 1, (w - 1) // 2 + 1):
+        raise PeclrHipError(f"stem_wgrad: gradient {tuple(gy.shape)} for images {tuple(x.shape)}")
+    fmt = STEM_FMT[gy.dtype]
+    ns = lib().peclr_stem_wgrad_slabs(n, h, w, fmt)
+    if ns < 1:
+        raise PeclrHipError(f"stem_wgrad: unsupported image size {h} x {w}")
+    slabs = torch.empty((ns, 64, 224), device=x.device, dtype=torch.float32)
+    with _timed(tag, 4 * x.numel() + gy.element_size() * gy.numel() + 4 * slabs.numel(), 2 * gy.numel() * 147, kernel="stem_wgrad_kernel"):
+        rc = lib().peclr_stem_wgrad(x.data_ptr(), gy.data_ptr(), n, h, w, fmt, slabs.data_ptr(), ns, _stream())
+    _check(rc, "peclr_stem_wgrad")
+    dw = slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
+    return dw.view(64, 7, 8, 4)[:, :, :7, :3].permute(0, 3, 1, 2)          # [n][kh][kw][c] -> [n][c][kh][kw]
 
 
 _IO = {torch.float32: (DTYPE_F32, 4), torch.bfloat16: (DTYPE_BF16, 2), torch.float16: (DTYPE_F16, 2)}

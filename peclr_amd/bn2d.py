@@ -139,6 +139,7 @@ class Routing:
     conv16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV16"))                # 16-bit (bf16 / fp16 autocast) convolutions in-tree
     wgrad3_ring: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD3_RING"))      # fp32 3x3 weight gradient: one split per element (LDS ring + transposing reads)
     wgrad16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD16"))              # ... and their weight gradients
+    stem_wgrad: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_STEM_WGRAD"))        # ... and its weight gradient
     stem: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_STEM"))                    # the 7x7 / stride-2 stem forward in-tree (csrc/stem.hip)
     force: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_ROUTE_FORCE", "0"))
 
@@ -960,11 +961,28 @@ class _ConvH(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+def _stem_wgrad(gy: Tensor, x: Tensor, param):
+    """d(weight) of the stem (peclr_stem_wgrad: fixed-order slabs, fp32 gradient of the fp32 master weight) in the parameter's
+    memory format; parked for `param` on the side stream when that mode is on."""
+    def run():
+        dw = _capi.stem_wgrad(gy, x)
+        return torch.empty_like(param).copy_(dw)                   # (9 408 elements: into the parameter's own strides)
+
+    st = _overlap_stream()
+    if st is None:
+        return run()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = run()
+    _WgradOverlap.parked.append((param, g, (gy, x)))
+    return None
+
+
 class _StemConv(torch.autograd.Function):
     """The encoder's 7x7 / stride-2 / padding-3 stem on fp32 NHWC images, in-tree (peclr_stem_conv7x7_s2): fp32 output at fp32
     accuracy, or -- under bf16 / fp16 autocast -- 16-bit output from the operands rounded inside the kernel (no cast pass over
-    the images); the statistics of the BatchNorm behind it in the epilogue.  Weight gradient: MIOpen's (the images need no
-    gradient; one that is asked for comes from MIOpen too)."""
+    the images); the statistics of the BatchNorm behind it in the epilogue.  Weight gradient: peclr_stem_wgrad (the images need no
+    gradient; one that is asked for comes from MIOpen)."""
 
     @staticmethod
     def forward(ctx, x, weight, conv, stats=None):
@@ -985,10 +1003,16 @@ class _StemConv(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         conv = ctx.conv
         gy = gy.to(ctx.dtype).contiguous(memory_format=torch.channels_last)
-        xin = x if ctx.dtype == torch.float32 else x.to(ctx.dtype)          # (what autocast's convolution saw)
-        dw = _conv_wgrad(gy, xin, weight, (2, 2), (3, 3), conv.weight) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if ROUTING.stem_wgrad:
+                dw = _stem_wgrad(gy, x, conv.weight)
+            else:
+                xin = x if ctx.dtype == torch.float32 else x.to(ctx.dtype)          # (what autocast's convolution saw)
+                dw = _conv_wgrad(gy, xin, weight, (2, 2), (3, 3), conv.weight)
         dx = None
         if ctx.needs_input_grad[0]:
+            xin = x if ctx.dtype == torch.float32 else x.to(ctx.dtype)
             dx = torch.ops.aten.convolution_backward(gy, xin, weight.to(ctx.dtype), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
                                                      [True, False, False])[0].to(x.dtype)
         if dw is not None and dw.dtype != weight.dtype:

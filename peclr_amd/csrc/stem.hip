@@ -18,6 +18,8 @@
 // L2) by LDS-DMA through three stages, and writes NHWC rows of 64 channels through wave-private transposes (16-byte stores).
 // Optional epilogue: the training statistics of the BatchNorm that follows (peclr_bn2d_stats' partial layout), so that the
 // one statistics pass left in the step goes too.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace peclr {
@@ -303,6 +305,269 @@ __global__ __launch_bounds__(128) void stem_pack_kernel(const float* w, long sn,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the stem: dW[n][kh][kw][c] = sum over (image, oh, ow) of dY[oh][ow][n] . X[2 oh - 3 + kh][2 ow - 3 + kw][c]
+// -- MIOpen's fp32 kernel for it (1.0 ms) was the last MIOpen launch of the fp32 step.  On the matrix cores the contraction index
+// is the OUTPUT PIXEL: C[n][(kh, kw, c4)] = sum_p A[n][p] . B[p][(kh, kw, c4)], 64 x 224 outputs (kw = 7 and c = 3 columns are
+// discarded), sixteen pixels per MFMA.  Both fragments want eight consecutive pixels per lane:
+//   * A = dY^T: a tile's 64 pixels x 64 channels are split (fp32) / taken as they are (16-bit) and stored TRANSPOSED into LDS,
+//     [plane][channel][pixel] with a 144-byte channel pitch (2-byte stores, a wave writes 128 contiguous bytes; the 16-byte
+//     fragment reads of 32 channels hit 32 distinct bank groups);
+//   * B = the image patch as the forward kernel stages it ([plane][row][pixel][r g b 0], 8 bytes per pixel).  The element of
+//     column (kw, c) for output pixel `ow` sits at pixel 2 ow + kw: consecutive output pixels are 16 bytes apart, so a lane
+//     gathers its eight k with eight ds_read_u16 at immediate offsets 16 e -- the 32 columns of a tile are 64
+//     contiguous bytes, the reads are conflict-free.
+// Workgroup: persistent, walks tiles of 64 output pixels of one output row (seven input rows x 134 pixels of patch), two LDS
+// stages (the next tile's global loads fly during the products, its split / stores follow them), one barrier per tile; wave w
+// owns filter rows kh = 2 w, 2 w + 1 (wave 3: kh = 6) x all 64 channels: four 32 x 32 accumulators; at the end one fp32 slab
+// [64][224] per workgroup, summed in a fixed order by peclr_slab_reduce_f32 (deterministic).
+constexpr int WPX = 64;                   // output pixels per tile
+constexpr int WPW = 2 * WPX + 6;          // patch pixels per row (133 used)
+constexpr int WROW = WPW * 8;             // 1 072 bytes
+constexpr int WAP = (WPX + 8) * 2;        // bytes per channel row of the transposed dY planes (144)
+
+struct StemWArgs {
+    const float* x;                       // [N][Hin][Win][3] fp32 images
+    const void* dy;                       // [N][Ho][Wo][64] fp32 / bf16 / fp16
+    float* slabs;                         // [gridDim.x][64][224]
+    int N, Hin, Win, Ho, Wo, tiles_w;
+    long long tiles;
+};
+
+// eight 16-bit values at addr + OFF + 16 e, each zero-extended into its own register (gfx950 runs with SRAM-ECC: its d16 loads
+// do NOT preserve the other half of the destination, so ds_read_u16_d16 / _d16_hi pairs cannot assemble a word in place; the
+// halves are merged by one v_lshl_or_b32 per pair after the wait)
+struct Gather {
+    unsigned lo[4], hi[4];                               // k = 2 q and k = 2 q + 1
+};
+template <int OFF>
+__device__ __forceinline__ void gather8(unsigned addr, Gather& r) {
+    asm volatile(
+        "ds_read_u16 %0, %8 offset:%9\n\t"
+        "ds_read_u16 %4, %8 offset:%10\n\t"
+        "ds_read_u16 %1, %8 offset:%11\n\t"
+        "ds_read_u16 %5, %8 offset:%12\n\t"
+        "ds_read_u16 %2, %8 offset:%13\n\t"
+        "ds_read_u16 %6, %8 offset:%14\n\t"
+        "ds_read_u16 %3, %8 offset:%15\n\t"
+        "ds_read_u16 %7, %8 offset:%16"
+        : "=v"(r.lo[0]), "=v"(r.lo[1]), "=v"(r.lo[2]), "=v"(r.lo[3]), "=v"(r.hi[0]), "=v"(r.hi[1]), "=v"(r.hi[2]), "=v"(r.hi[3])
+        : "v"(addr), "n"(OFF), "n"(OFF + 16), "n"(OFF + 32), "n"(OFF + 48), "n"(OFF + 64), "n"(OFF + 80), "n"(OFF + 96), "n"(OFF + 112)
+        : "memory");
+}
+// "the gathers of these fragments have landed" -- tied to their registers, so that nothing using them is scheduled above the wait
+// (the compiler does not know that the statements above read the LDS asynchronously)
+template <int NP>
+__device__ __forceinline__ void gather_fence(Gather (&g)[NP]) {
+    if constexpr (NP == 3) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(g[0].lo[0]), "+v"(g[0].lo[1]), "+v"(g[0].lo[2]), "+v"(g[0].lo[3]), "+v"(g[0].hi[0]), "+v"(g[0].hi[1]),
+                       "+v"(g[0].hi[2]), "+v"(g[0].hi[3]), "+v"(g[1].lo[0]), "+v"(g[1].lo[1]), "+v"(g[1].lo[2]), "+v"(g[1].lo[3]),
+                       "+v"(g[1].hi[0]), "+v"(g[1].hi[1]), "+v"(g[1].hi[2]), "+v"(g[1].hi[3]), "+v"(g[2].lo[0]), "+v"(g[2].lo[1]),
+                       "+v"(g[2].lo[2]), "+v"(g[2].lo[3]), "+v"(g[2].hi[0]), "+v"(g[2].hi[1]), "+v"(g[2].hi[2]), "+v"(g[2].hi[3])
+                     :: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(g[0].lo[0]), "+v"(g[0].lo[1]), "+v"(g[0].lo[2]), "+v"(g[0].lo[3]), "+v"(g[0].hi[0]), "+v"(g[0].hi[1]),
+                       "+v"(g[0].hi[2]), "+v"(g[0].hi[3])
+                     :: "memory");
+    }
+}
+__device__ __forceinline__ uint4 merge(const Gather& g) {
+    return make_uint4(g.lo[0] | (g.hi[0] << 16), g.lo[1] | (g.hi[1] << 16), g.lo[2] | (g.hi[2] << 16), g.lo[3] | (g.hi[3] << 16));
+}
+
+template <typename F>
+__global__ __launch_bounds__(256, F::NP == 3 ? 1 : 3) void stem_wgrad_kernel(StemWArgs g) {
+    constexpr int NP = F::NP;
+    constexpr int PPL = 7 * WROW;                        // bytes of one patch plane (7 504)
+    constexpr int APL = 64 * WAP;                        // bytes of one dY^T plane (9 216)
+    constexpr int STAGE = NP * (PPL + APL);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    typedef __attribute__((address_space(3))) unsigned char* lptr_t;
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(lptr_t)lds;
+    const int nkh = wave == 3 ? 1 : 2;                   // filter rows of this wave
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // ---- loaders.  Patch: 7 rows x WPW pixel slots (938) over 256 threads; dY: thread = (pixel tid & 63, channel group)
+    constexpr int NSLOT = 7 * WPW, NLD = (NSLOT + 255) / 256;
+    struct __attribute__((packed, aligned(4))) Rgb { float r, g, b; };
+    Rgb px[NLD];
+    constexpr int NDY = NP == 3 ? 4 : 2;                 // fp32: four channels per 16-byte load, sixteen groups; 16-bit: eight, eight groups
+    uint4 dyr[NDY];
+    auto tile_of = [&](long long t, int& img, int& oh, int& ow0) {
+        const int per_img = g.Ho * g.tiles_w;
+        img = (int)(t / per_img);
+        const int rem = (int)(t - (long long)img * per_img);
+        oh = rem / g.tiles_w;
+        ow0 = (rem - oh * g.tiles_w) * WPX;
+    };
+    auto gload = [&](long long t) {
+        int img, oh, ow0;
+        tile_of(t, img, oh, ow0);
+        const int ih0 = 2 * oh - 3, iw0 = 2 * ow0 - 3;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + 256 * u;
+            const int r = idx / WPW, p = idx - r * WPW;
+            const int ih = ih0 + r, iw = iw0 + p;
+            const bool in = idx < NSLOT && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
+            const Rgb* src = reinterpret_cast<const Rgb*>(g.x + (((size_t)img * g.Hin + (in ? ih : 0)) * g.Win + (in ? iw : 0)) * 3);
+            px[u] = in ? *src : Rgb{0.f, 0.f, 0.f};
+        }
+        const int p = tid & 63, ow = ow0 + p;
+        const bool live = ow < g.Wo;
+        const size_t row = ((size_t)img * g.Ho + oh) * g.Wo + (live ? ow : 0);
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) {
+            const int grp = (tid >> 6) + 4 * u;
+            const uint4* src = NP == 3 ? reinterpret_cast<const uint4*>(static_cast<const float*>(g.dy) + row * 64 + 4 * grp)
+                                       : reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(g.dy) + row * 64 + 8 * grp);
+            dyr[u] = live ? *src : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stage_store = [&](int st) {
+        unsigned char* base = lds + st * STAGE;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < NSLOT) {
+                unsigned char* d = base + idx * 8;
+                if constexpr (NP == 3) {
+                    unsigned h[2], m[2], l[2];
+                    split3_pk(px[u].r, px[u].g, h[0], m[0], l[0]);
+                    split3_pk(px[u].b, 0.f, h[1], m[1], l[1]);
+                    *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
+                    *reinterpret_cast<uint2*>(d + PPL) = make_uint2(m[0], m[1]);
+                    *reinterpret_cast<uint2*>(d + 2 * PPL) = make_uint2(l[0], l[1]);
+                } else {
+                    *reinterpret_cast<uint2*>(d) = make_uint2(F::pack2(px[u].r, px[u].g), F::pack2(px[u].b, 0.f));
+                }
+            }
+        }
+        unsigned char* ab = base + NP * PPL;
+        const int p = tid & 63;
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) {
+            const int grp = (tid >> 6) + 4 * u;
+            if constexpr (NP == 3) {
+                const unsigned w[4] = {dyr[u].x, dyr[u].y, dyr[u].z, dyr[u].w};
+                unsigned h[2], m[2], l[2];
+                split3_pk(__uint_as_float(w[0]), __uint_as_float(w[1]), h[0], m[0], l[0]);
+                split3_pk(__uint_as_float(w[2]), __uint_as_float(w[3]), h[1], m[1], l[1]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned short* d = reinterpret_cast<unsigned short*>(ab + (4 * grp + q) * WAP + p * 2);
+                    const int sh = (q & 1) * 16;
+                    d[0] = (unsigned short)(h[q >> 1] >> sh);
+                    d[APL / 2] = (unsigned short)(m[q >> 1] >> sh);
+                    d[APL] = (unsigned short)(l[q >> 1] >> sh);
+                }
+            } else {
+                const unsigned w[4] = {dyr[u].x, dyr[u].y, dyr[u].z, dyr[u].w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    *reinterpret_cast<unsigned short*>(ab + (8 * grp + q) * WAP + p * 2) = (unsigned short)(w[q >> 1] >> ((q & 1) * 16));
+            }
+        }
+    };
+
+    // this lane's gather base inside a patch plane: column j = lane & 31 -> 2 j bytes, k-half -> 8 output pixels = 128 bytes,
+    // the wave's first filter row; fragment base of the dY^T planes: channel i, k-half
+    const unsigned bbase = 2 * i + 128 * half + (2 * wave) * WROW;
+    const unsigned abase = NP * PPL + i * WAP + 16 * half;
+
+    long long t = blockIdx.x;
+    if (t < g.tiles) {
+        gload(t);
+        stage_store(0);
+    }
+    __syncthreads();
+    int st = 0;
+    for (; t < g.tiles; t += gridDim.x, st ^= 1) {
+        const bool more = t + gridDim.x < g.tiles;
+        if (more) gload(t + gridDim.x);
+        const unsigned sb = lds0 + st * STAGE;
+        const unsigned char* sa = lds + st * STAGE + abase;
+#pragma unroll
+        for (int ks = 0; ks < WPX / 16; ++ks) {
+            uint4 af[2][NP], bf[2][NP];
+            Gather gb[2][NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gb[1][p].lo[q] = gb[1][p].hi[q] = 0u;      // (wave 3 has one filter row)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) af[mt][p] = *reinterpret_cast<const uint4*>(sa + p * APL + mt * 32 * WAP + ks * 32);
+            // (immediates: plane p, k-step ks: p * PPL + 256 ks; the wave's second filter row: + WROW in the address)
+            auto row = [&](auto kc, int b) {
+                constexpr int KO = decltype(kc)::value * 256;
+                const unsigned addr = sb + bbase + b * WROW;
+                gather8<KO>(addr, gb[b][0]);
+                if constexpr (NP == 3) {
+                    gather8<PPL + KO>(addr, gb[b][1]);
+                    gather8<2 * PPL + KO>(addr, gb[b][2]);
+                }
+            };
+            auto both = [&](auto kc) { row(kc, 0); if (nkh == 2) row(kc, 1); };
+            if (ks == 0) both(std::integral_constant<int, 0>{});
+            else if (ks == 1) both(std::integral_constant<int, 1>{});
+            else if (ks == 2) both(std::integral_constant<int, 2>{});
+            else both(std::integral_constant<int, 3>{});
+            gather_fence<NP>(gb[0]);
+            gather_fence<NP>(gb[1]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) bf[b][p] = merge(gb[b][p]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (b < nkh) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        if constexpr (NP == 3) {
+                            acc[mt][b] = F::mma(af[mt][2], bf[b][0], acc[mt][b]);
+                            acc[mt][b] = F::mma(af[mt][0], bf[b][2], acc[mt][b]);
+                            acc[mt][b] = F::mma(af[mt][1], bf[b][1], acc[mt][b]);
+                            acc[mt][b] = F::mma(af[mt][1], bf[b][0], acc[mt][b]);
+                            acc[mt][b] = F::mma(af[mt][0], bf[b][1], acc[mt][b]);
+                            acc[mt][b] = F::mma(af[mt][0], bf[b][0], acc[mt][b]);
+                        } else {
+                            acc[mt][b] = F::mma(af[mt][0], bf[b][0], acc[mt][b]);
+                        }
+                    }
+                }
+            }
+        }
+        if (more) stage_store(st ^ 1);
+        __syncthreads();
+    }
+    // ---- the workgroup's slab: row n = 32 mt + (accumulator row), column 32 kh + j
+    float* slab = g.slabs + (size_t)blockIdx.x * 64 * 224;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b < nkh) {
+            const int kh = 2 * wave + b;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[(size_t)(32 * mt + mfma32_row(r, half)) * 224 + 32 * kh + i] = acc[mt][b][r];
+        }
+    }
+}
+
 }  // namespace
 }  // namespace peclr
 
@@ -347,5 +612,38 @@ extern "C" int peclr_stem_conv7x7_s2(const float* x, int N, int Hin, int Win, co
     if (fmt == 0) hipLaunchKernelGGL((stem_fwd_kernel<X6>), dim3(wgs), dim3(256), 0, s, g);
     else if (fmt == 1) hipLaunchKernelGGL((stem_fwd_kernel<HB>), dim3(wgs), dim3(256), 0, s, g);
     else hipLaunchKernelGGL((stem_fwd_kernel<HF>), dim3(wgs), dim3(256), 0, s, g);
+    return launch_status();
+}
+
+// Slabs (= workgroups) of the stem's weight-gradient launch: persistent workgroups, one per CU in fp32 (100 KiB of LDS), three in
+// 16-bit, never more than there are tiles of 64 output pixels.
+extern "C" int peclr_stem_wgrad_slabs(int N, int Hin, int Win, int fmt) {
+    if (N <= 0 || Hin < 8 || Win < 8 || fmt < 0 || fmt > 2) return PECLR_ERR_SHAPE;
+    const int Ho = (Hin - 1) / 2 + 1, Wo = (Win - 1) / 2 + 1;
+    const long long tiles = (long long)N * Ho * ((Wo + WPX - 1) / WPX);
+    const long long cap = fmt == 0 ? 256 : 768;
+    return (int)(tiles < cap ? tiles : cap);
+}
+
+// dW slabs [peclr_stem_wgrad_slabs(...)][64][224] (column 32 kh + 4 kw + c; kw = 7 and c = 3 columns carry no meaning) of
+// y = conv2d(x, W, stride 2, padding 3): x the fp32 NHWC images, dY [N][Ho][Wo][64] fp32 (fmt 0: six products of the exactly
+// split operands) or bf16 / fp16 (fmt 1 / 2: one product, the images rounded to that format as the forward rounds them).
+extern "C" int peclr_stem_wgrad(const float* x, const void* dY, int N, int Hin, int Win, int fmt, float* slabs, int n_slabs,
+                                peclr_stream_t stream) {
+    if (!x || !dY || !slabs) return PECLR_ERR_NULL;
+    const int want = peclr_stem_wgrad_slabs(N, Hin, Win, fmt);
+    if (want < 0) return want;
+    if (n_slabs != want) return PECLR_ERR_WORKSPACE;
+    if (!aligned16(dY) || !aligned16(slabs) || (reinterpret_cast<uintptr_t>(x) & 3u)) return PECLR_ERR_ALIGN;
+    StemWArgs g;
+    g.x = x; g.dy = dY; g.slabs = slabs;
+    g.N = N; g.Hin = Hin; g.Win = Win;
+    g.Ho = (Hin - 1) / 2 + 1; g.Wo = (Win - 1) / 2 + 1;
+    g.tiles_w = (g.Wo + WPX - 1) / WPX;
+    g.tiles = (long long)N * g.Ho * g.tiles_w;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (fmt == 0) hipLaunchKernelGGL((stem_wgrad_kernel<X6>), dim3(n_slabs), dim3(256), 0, s, g);
+    else if (fmt == 1) hipLaunchKernelGGL((stem_wgrad_kernel<HB>), dim3(n_slabs), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((stem_wgrad_kernel<HF>), dim3(n_slabs), dim3(256), 0, s, g);
     return launch_status();
 }

@@ -157,3 +157,86 @@ def test_encoder_routes_the_stem_in_tree_with_its_statistics_and_trains(precisio
     m1, m0 = sum(rel(g1[n], gr[n]) for n in gr) / len(gr), sum(rel(g0[n], gr[n]) for n in gr) / len(gr)
     print(f"bf16 vs fp32: in-tree stem worst {w1:.3f} mean {m1:.3f} | MIOpen stem worst {w0:.3f} mean {m0:.3f}")
     assert m1 <= 1.5 * m0 + 1e-2 and w1 <= 2.0 * w0 + 5e-2, (w1, w0, m1, m0)
+
+
+@pytest.mark.parametrize("n,h,w", [(4, 224, 224), (2, 64, 64), (3, 30, 46), (2, 225, 131), (1, 448, 448), (5, 9, 8), (37, 32, 32)])
+def test_stem_weight_gradient_fp32_is_an_fp32_weight_gradient(n, h, w):
+    """peclr_stem_wgrad, fp32: against float64 next to MIOpen's fp32 weight gradient on the same data; every tap, image borders
+    and ragged tiles (widths that are not multiples of 64 output pixels) included; bit-identical when repeated (fixed-order slabs;
+    MIOpen's kernel accumulates with atomics)."""
+    from peclr_amd import _capi as capi
+
+    x, wt = _data(n, h, w, seed=3 * h + w)
+    g = torch.Generator().manual_seed(h)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    gy = torch.randn(n, 64, ho, wo, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    dw = capi.stem_wgrad(gy, x)
+    assert dw.shape == (64, 3, 7, 7) and dw.dtype == torch.float32
+    ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), wt.double(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                              [False, True, False])[1]
+    stock = torch.ops.aten.convolution_backward(gy, x, wt, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    scale = float(ref.abs().max())
+    err, err_stock = float((dw.double() - ref).abs().max()) / scale, float((stock.double() - ref).abs().max()) / scale
+    assert err <= max(4 * err_stock, 4e-6), (err, err_stock)
+    for _ in range(4):
+        assert torch.equal(capi.stem_wgrad(gy, x), dw)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,h,w", [(4, 224, 224), (3, 30, 46), (2, 131, 225)])
+def test_stem_weight_gradient_16_bit_is_the_fp32_sum_of_the_rounded_operands_products(dtype, n, h, w):
+    """16-bit gradient, images rounded to the format: exact products accumulated in fp32 -> fp32 gradient of the master weight."""
+    from peclr_amd import _capi as capi
+
+    x, wt = _data(n, h, w, seed=h + 5 * w)
+    g = torch.Generator().manual_seed(w)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    gy = torch.randn(n, 64, ho, wo, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    dw = capi.stem_wgrad(gy, x)
+    ref = torch.ops.aten.convolution_backward(gy.double(), x.to(dtype).double(), wt.double(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                              [False, True, False])[1]
+    err = float((dw.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 3e-6 * max(1.0, (n * ho * wo / 4096) ** 0.5), err
+    for _ in range(3):
+        assert torch.equal(capi.stem_wgrad(gy, x), dw)
+
+
+def test_no_miopen_convolution_is_left_in_the_fp32_encoder_step():
+    """With the stem's forward and weight gradient in-tree every convolution launch of a ResNet-50 fp32 forward + backward is an
+    in-tree kernel: the event log (one entry per in-tree launch) accounts for 53 forward convolutions, and the stem's weight
+    gradient equals MIOpen's to fp32 round-off."""
+    import copy
+
+    from peclr_amd import _capi as capi
+    from peclr_amd import bn2d as B
+    from peclr_amd.config import Config
+    from peclr_amd.encoder import get_wrapper_model
+
+    torch.manual_seed(2)
+    net = get_wrapper_model(Config({"resnet_size": "50"}), False).to(DEV).to(memory_format=torch.channels_last).train()
+    for p in net.final_layer.parameters():
+        p.requires_grad_(False)
+    other = copy.deepcopy(net)
+    B.enable_hip_batchnorm(net)
+    B.enable_hip_batchnorm(other)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(8, 3, 224, 224, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = (torch.randn(8, 2048, generator=g) / 2048).to(DEV)
+
+    def run(model, on):
+        capi.EVENT_LOG = {}
+        try:
+            with B.routing(stem_wgrad=on, force=True):
+                model(x).backward(gy)
+            torch.cuda.synchronize()
+            return {k: len(v) for k, v in capi.EVENT_LOG.items()}
+        finally:
+            capi.EVENT_LOG = None
+
+    t1, t0 = run(net, True), run(other, False)
+    fwd = sum(t1.get(k, 0) + t1.get(k + "~hbm", 0) for k in ("stem_fwd", "conv1x1_fwd", "conv3x3_fwd", "conv_s2_fwd"))
+    assert fwd == 53, t1
+    assert t1.get("stem_wgrad") == 1 and "stem_wgrad" not in t0
+    a, b = net.features[0].weight.grad, other.features[0].weight.grad
+    assert a.stride() == b.stride()
+    assert float((a - b).norm() / b.norm()) <= 1e-4
