@@ -18,6 +18,8 @@
 // L2) by LDS-DMA through three stages, and writes NHWC rows of 64 channels through wave-private transposes (16-byte stores).
 // Optional epilogue: the training statistics of the BatchNorm that follows (peclr_bn2d_stats' partial layout), so that the
 // one statistics pass left in the step goes too.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.hpp"
@@ -333,6 +335,7 @@ struct StemWArgs {
     float* slabs;                         // [gridDim.x][64][224]
     int N, Hin, Win, Ho, Wo, tiles_w;
     long long tiles;
+    int abl;                              // experiments (PECLR_STEM_WGRAD_ABL): 1 no dY loads, 2 no dY stores, 4 no gathers, 8 no products, 16 no patch
 };
 
 // eight 16-bit values at addr + OFF + 16 e, each zero-extended into its own register (gfx950 runs with SRAM-ECC: its d16 loads
@@ -379,12 +382,16 @@ __device__ __forceinline__ uint4 merge(const Gather& g) {
 }
 
 template <typename F>
-__global__ __launch_bounds__(256, F::NP == 3 ? 1 : 3) void stem_wgrad_kernel(StemWArgs g) {
+__global__ __launch_bounds__(256, F::NP == 3 ? 2 : 3) void stem_wgrad_kernel(StemWArgs g) {
     constexpr int NP = F::NP;
     constexpr int PPL = 7 * WROW;                        // bytes of one patch plane (7 504)
     constexpr int APL = 64 * WAP;                        // bytes of one dY^T plane (9 216)
     constexpr int STAGE = NP * (PPL + APL);
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    // fp32: ONE stage (50 KiB: three workgroups per CU, whose phases -- global loads, split + transposing stores, gathers,
+    // products -- overlap each other; two stages at one workgroup per CU ran every phase of a tile back to back: 985 us);
+    // 16-bit: two stages (33 KiB)
+    constexpr int NST = NP == 3 ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, half = lane >> 5;
     typedef __attribute__((address_space(3))) unsigned char* lptr_t;
@@ -402,17 +409,17 @@ __global__ __launch_bounds__(256, F::NP == 3 ? 1 : 3) void stem_wgrad_kernel(Ste
     // ---- loaders.  Patch: 7 rows x WPW pixel slots (938) over 256 threads; dY: thread = (pixel tid & 63, channel group)
     constexpr int NSLOT = 7 * WPW, NLD = (NSLOT + 255) / 256;
     struct __attribute__((packed, aligned(4))) Rgb { float r, g, b; };
-    Rgb px[NLD];
+    Rgb pxs[2][NLD];                                     // two register sets: loads run TWO tiles ahead of the products
     constexpr int NDY = NP == 3 ? 4 : 2;                 // fp32: four channels per 16-byte load, sixteen groups; 16-bit: eight, eight groups
-    uint4 dyr[NDY];
-    auto tile_of = [&](long long t, int& img, int& oh, int& ow0) {
-        const int per_img = g.Ho * g.tiles_w;
-        img = (int)(t / per_img);
-        const int rem = (int)(t - (long long)img * per_img);
+    uint4 dyrs[2][NDY];
+    auto tile_of = [&](long long t64, int& img, int& oh, int& ow0) {
+        const int per_img = g.Ho * g.tiles_w, t = (int)t64;      // (tiles < 2^31: checked by the host)
+        img = t / per_img;
+        const int rem = t - img * per_img;
         oh = rem / g.tiles_w;
         ow0 = (rem - oh * g.tiles_w) * WPX;
     };
-    auto gload = [&](long long t) {
+    auto gload = [&](long long t, Rgb (&px)[NLD], uint4 (&dyr)[NDY]) {
         int img, oh, ow0;
         tile_of(t, img, oh, ow0);
         const int ih0 = 2 * oh - 3, iw0 = 2 * ow0 - 3;
@@ -423,20 +430,25 @@ __global__ __launch_bounds__(256, F::NP == 3 ? 1 : 3) void stem_wgrad_kernel(Ste
             const int ih = ih0 + r, iw = iw0 + p;
             const bool in = idx < NSLOT && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
             const Rgb* src = reinterpret_cast<const Rgb*>(g.x + (((size_t)img * g.Hin + (in ? ih : 0)) * g.Win + (in ? iw : 0)) * 3);
-            px[u] = in ? *src : Rgb{0.f, 0.f, 0.f};
+            px[u] = (in && !(g.abl & 16)) ? *src : Rgb{0.f, 0.f, 0.f};
         }
-        const int p = tid & 63, ow = ow0 + p;
-        const bool live = ow < g.Wo;
-        const size_t row = ((size_t)img * g.Ho + oh) * g.Wo + (live ? ow : 0);
+        // dY: item u of a thread = (pixel 16 u + (lane & 15), channel group 4 wave + (lane >> 4)) [fp32: groups of four channels;
+        // 16-bit: pixel 32 u + (lane & 31), group 2 wave + (lane >> 5) of eight] -- a load instruction reads 64 / 128-byte pieces of
+        // 16 / 32 pixel rows (lane = pixel alone read 64 different cache lines per instruction: 340 of the kernel's 1 160 us), and
+        // the 32 lanes of a transposing store group hit distinct banks
+        const size_t row0 = ((size_t)img * g.Ho + oh) * g.Wo;
 #pragma unroll
         for (int u = 0; u < NDY; ++u) {
-            const int grp = (tid >> 6) + 4 * u;
+            const int p = NP == 3 ? 16 * u + (lane & 15) : 32 * u + (lane & 31);
+            const int grp = NP == 3 ? 4 * wave + (lane >> 4) : 2 * wave + (lane >> 5);
+            const bool live = ow0 + p < g.Wo;
+            const size_t row = row0 + (live ? ow0 + p : 0);
             const uint4* src = NP == 3 ? reinterpret_cast<const uint4*>(static_cast<const float*>(g.dy) + row * 64 + 4 * grp)
                                        : reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(g.dy) + row * 64 + 8 * grp);
-            dyr[u] = live ? *src : make_uint4(0u, 0u, 0u, 0u);
+            dyr[u] = (live && !(g.abl & 1)) ? *src : make_uint4(0u, 0u, 0u, 0u);
         }
     };
-    auto stage_store = [&](int st) {
+    auto stage_store = [&](int st, const Rgb (&px)[NLD], const uint4 (&dyr)[NDY]) {
         unsigned char* base = lds + st * STAGE;
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
@@ -456,10 +468,11 @@ __global__ __launch_bounds__(256, F::NP == 3 ? 1 : 3) void stem_wgrad_kernel(Ste
             }
         }
         unsigned char* ab = base + NP * PPL;
-        const int p = tid & 63;
+        if (g.abl & 2) return;
 #pragma unroll
         for (int u = 0; u < NDY; ++u) {
-            const int grp = (tid >> 6) + 4 * u;
+            const int p = NP == 3 ? 16 * u + (lane & 15) : 32 * u + (lane & 31);
+            const int grp = NP == 3 ? 4 * wave + (lane >> 4) : 2 * wave + (lane >> 5);
             if constexpr (NP == 3) {
                 const unsigned w[4] = {dyr[u].x, dyr[u].y, dyr[u].z, dyr[u].w};
                 unsigned h[2], m[2], l[2];
@@ -487,16 +500,7 @@ __global__ __launch_bounds__(256, F::NP == 3 ? 1 : 3) void stem_wgrad_kernel(Ste
     const unsigned bbase = 2 * i + 128 * half + (2 * wave) * WROW;
     const unsigned abase = NP * PPL + i * WAP + 16 * half;
 
-    long long t = blockIdx.x;
-    if (t < g.tiles) {
-        gload(t);
-        stage_store(0);
-    }
-    __syncthreads();
-    int st = 0;
-    for (; t < g.tiles; t += gridDim.x, st ^= 1) {
-        const bool more = t + gridDim.x < g.tiles;
-        if (more) gload(t + gridDim.x);
+    auto products = [&](int st) {
         const unsigned sb = lds0 + st * STAGE;
         const unsigned char* sa = lds + st * STAGE + abase;
 #pragma unroll
@@ -522,7 +526,8 @@ __global__ __launch_bounds__(256, F::NP == 3 ? 1 : 3) void stem_wgrad_kernel(Ste
                 }
             };
             auto both = [&](auto kc) { row(kc, 0); if (nkh == 2) row(kc, 1); };
-            if (ks == 0) both(std::integral_constant<int, 0>{});
+            if (g.abl & 4) { }
+            else if (ks == 0) both(std::integral_constant<int, 0>{});
             else if (ks == 1) both(std::integral_constant<int, 1>{});
             else if (ks == 2) both(std::integral_constant<int, 2>{});
             else both(std::integral_constant<int, 3>{});
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(256, F::NP == 3 ? 1 : 3) void stem_wgrad_kernel(Ste
                 for (int p = 0; p < NP; ++p) bf[b][p] = merge(gb[b][p]);
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                if (b < nkh) {
+                if (b < nkh && !(g.abl & 8)) {
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         if constexpr (NP == 3) {
@@ -551,8 +556,32 @@ __global__ __launch_bounds__(256, F::NP == 3 ? 1 : 3) void stem_wgrad_kernel(Ste
                 }
             }
         }
-        if (more) stage_store(st ^ 1);
-        __syncthreads();
+    };
+    // Loads run two tiles ahead: a tile's 27 KiB (dY rows: 822 MB per launch in fp32 -- the kernel's main HBM stream) have two
+    // tiles' products to arrive in.  Invariant at the top of a step: the stage holds tile t, set `cur` holds the loads of
+    // tile t + step, the other set is free.
+    const long long step = gridDim.x;
+    long long t = blockIdx.x;
+    if (t < g.tiles) {
+        gload(t, pxs[0], dyrs[0]);
+        if (t + step < g.tiles) gload(t + step, pxs[1], dyrs[1]);
+        stage_store(0, pxs[0], dyrs[0]);
+    }
+    __syncthreads();
+    int st = 0;
+    while (t < g.tiles) {
+#pragma unroll
+        for (int cur = 1; cur >= 0; --cur) {              // cur = the set holding tile t + step's loads: 1, then 0, then 1 ...
+            if (t < g.tiles) {
+                if (t + 2 * step < g.tiles) gload(t + 2 * step, pxs[cur ^ 1], dyrs[cur ^ 1]);
+                products(st);
+                if constexpr (NST == 1) __syncthreads();  // every wave is done reading the stage
+                if (t + step < g.tiles) stage_store(st ^ (NST - 1), pxs[cur], dyrs[cur]);
+                __syncthreads();
+                t += step;
+                st ^= (NST - 1);
+            }
+        }
     }
     // ---- the workgroup's slab: row n = 32 mt + (accumulator row), column 32 kh + j
     float* slab = g.slabs + (size_t)blockIdx.x * 64 * 224;
@@ -615,13 +644,13 @@ extern "C" int peclr_stem_conv7x7_s2(const float* x, int N, int Hin, int Win, co
     return launch_status();
 }
 
-// Slabs (= workgroups) of the stem's weight-gradient launch: persistent workgroups, one per CU in fp32 (100 KiB of LDS), three in
-// 16-bit, never more than there are tiles of 64 output pixels.
+// Slabs (= workgroups) of the stem's weight-gradient launch: persistent workgroups, two (fp32: 228 registers) or three per CU,
+// never more than there are tiles of 64 output pixels.
 extern "C" int peclr_stem_wgrad_slabs(int N, int Hin, int Win, int fmt) {
     if (N <= 0 || Hin < 8 || Win < 8 || fmt < 0 || fmt > 2) return PECLR_ERR_SHAPE;
     const int Ho = (Hin - 1) / 2 + 1, Wo = (Win - 1) / 2 + 1;
     const long long tiles = (long long)N * Ho * ((Wo + WPX - 1) / WPX);
-    const long long cap = fmt == 0 ? 256 : 768;
+    const long long cap = fmt == 0 ? 512 : 768;
     return (int)(tiles < cap ? tiles : cap);
 }
 
@@ -641,6 +670,8 @@ extern "C" int peclr_stem_wgrad(const float* x, const void* dY, int N, int Hin, 
     g.Ho = (Hin - 1) / 2 + 1; g.Wo = (Win - 1) / 2 + 1;
     g.tiles_w = (g.Wo + WPX - 1) / WPX;
     g.tiles = (long long)N * g.Ho * g.tiles_w;
+    static const int abl = getenv("PECLR_STEM_WGRAD_ABL") ? atoi(getenv("PECLR_STEM_WGRAD_ABL")) : 0;
+    g.abl = abl;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (fmt == 0) hipLaunchKernelGGL((stem_wgrad_kernel<X6>), dim3(n_slabs), dim3(256), 0, s, g);
     else if (fmt == 1) hipLaunchKernelGGL((stem_wgrad_kernel<HB>), dim3(n_slabs), dim3(256), 0, s, g);

@@ -135,8 +135,10 @@ def test_encoder_routes_the_stem_in_tree_with_its_statistics_and_trains(precisio
         # (two fp32 evaluations of the stem that round differently: a ReLU decision within round-off of zero that falls the
         # other way moves one gradient element -- 3e-3 ... 9e-3 norm-wise in a network this small, tests/test_round4_gpu.py;
         # a wrong stem output or a missing statistics hand-over is O(0.1 - 1))
-        worst = max(rel(g1[n], g0[n]) for n in g0)
-        assert worst <= 2e-2, worst
+        # ... so the bar on single gradients is loose and the bar on their MEDIAN tight: a flipped decision touches a few
+        # parameters, a defect of the stem every one behind it)
+        rels = sorted(rel(g1[n], g0[n]) for n in g0)
+        assert rels[len(rels) // 2] <= 2e-3 and rels[-1] <= 1e-1, (rels[len(rels) // 2], rels[-1])
         return
     # bf16: eight images through twenty train-mode BatchNorm layers amplify one-ulp differences of the stem's output (the two
     # arms round differently: one rounding of the exact product here, MIOpen's kernel there) into O(1) differences of single
