@@ -125,8 +125,9 @@ __device__ unsigned long long conv_h_timing[8];
 // in half-line pieces -- the 3x3 launches ran at 0.19 - 0.26 of the matrix cores (93 - 127 us at every layer of ResNet-50).
 // Outputs at padding positions are not stored and not counted in the fused sums (7 % / 13 % / 23 % more rows at 28 / 14 / 7).
 template <typename H, int WM, int TAPS, int NTL, int EP, int RING = 0>
-__global__ __launch_bounds__(256, WM == 1 ? ((EP & 2) ? 3 : 4) : 2) void conv_h_kernel(HArgs g) {
-    static_assert(RING == 0 || (WM == 2 && TAPS == 9 && RING % 64 == 0), "ring stages: 3x3 on 256-row tiles");
+__global__ __launch_bounds__(256, (WM == 1 && RING == 0) ? ((EP & 2) ? 3 : 4) : 2) void conv_h_kernel(HArgs g) {
+    static_assert(RING == 0 || (TAPS == 9 && RING % 64 == 0 && (WM == 2 || (WM == 1 && RING == 384))),
+                  "ring stages: 3x3 on 256-row tiles (W <= 62) or, for rows of 63 ... 126 pixels, on 128-row tiles");
     constexpr bool ADD = (EP & 1) != 0, BBF = (EP & 2) != 0;
     constexpr int RM = 32 * WM, TM = 4 * RM;
     constexpr int NA = RING ? RING / 64 : RM / 16;       // A DMA instructions per wave and k-step / ring stage (16 rows x 64 B each)
@@ -696,9 +697,14 @@ void set_bb(HArgs& g, const peclr_bn_bwd_fuse* bb) {
 
 // rows of the ring stage a 3x3 / stride-1 launch over W-pixel rows needs (0: not eligible -- rows wider than 62 pixels, or
 // switched off: PECLR_CONV3_RING=0 for A/B runs)
+// (rows of 63 ... 126 pixels -- layer1 at 448 x 448 inputs, BASELINE config C5: 112 -- take 128-row tiles: 128 + 2 (W + 2) <= 384
+// rows per stage keep two stages + two W stages inside the 64 KiB an LDS-DMA can address; PECLR_CONV3_RING_WIDE=0 for A/B)
+int ring_tile(int W) { return W <= 62 ? 256 : 128; }
 int ring_rows(int taps, int stride, int s2d, int W) {
     static const int on = getenv("PECLR_CONV3_RING") ? atoi(getenv("PECLR_CONV3_RING")) : 1;
-    if (!on || taps != 9 || stride != 1 || s2d || W > 62) return 0;
+    static const int wide = getenv("PECLR_CONV3_RING_WIDE") ? atoi(getenv("PECLR_CONV3_RING_WIDE")) : 1;
+    if (!on || taps != 9 || stride != 1 || s2d || W > 126 || (W > 62 && !wide)) return 0;
+    if (W > 62) return 384;
     return 256 + 2 * (W + 2) <= 320 ? 320 : 384;
 }
 
@@ -715,10 +721,14 @@ int launch_h(const HArgs& g, int tile_rows, int taps, hipStream_t stream) {
         if (tile_rows == PECLR_CONV_H_RING) {
             const int rr = ring_rows(taps, g.stride, g.s2d, g.W);
             if (!rr) return PECLR_ERR_UNSUPPORTED;
-            const int nrb = (g.Mp + 255) / 256;
+            const int tm = ring_tile(g.W);
+            const int nrb = (g.Mp + tm - 1) / tm;
             const bool narrow = g.N % HN != 0;
             const dim3 grid(8 * ((nrb + 7) / 8) * (narrow ? g.N / 64 : g.N / HN));
-            if (rr == 320) {
+            if (tm == 128) {
+                if (narrow) hipLaunchKernelGGL((conv_h_kernel<H, 1, 9, 2, EP, 384>), grid, dim3(256), 0, stream, g);
+                else hipLaunchKernelGGL((conv_h_kernel<H, 1, 9, 4, EP, 384>), grid, dim3(256), 0, stream, g);
+            } else if (rr == 320) {
                 if (narrow) hipLaunchKernelGGL((conv_h_kernel<H, 2, 9, 2, EP, 320>), grid, dim3(256), 0, stream, g);
                 else hipLaunchKernelGGL((conv_h_kernel<H, 2, 9, 4, EP, 320>), grid, dim3(256), 0, stream, g);
             } else {
@@ -799,14 +809,14 @@ extern "C" int peclr_conv_h_tile_rows(int M, int N) {
 
 // Rows of the partial-sum tables (BatchNorm statistics / backward reduction) a peclr_conv_h launch with this tile_rows argument
 // writes: row blocks of the output pixels, or -- ring launches (tile_rows 0 picks them where they apply, PECLR_CONV_H_RING asks
-// for them) -- 256-pixel blocks of the padded space NB x (H + 1) x (W + 1).  0: unsupported arguments.
+// for them) -- 256-pixel (rows of 63 ... 126 pixels: 128-pixel) blocks of the padded space NB x (H + 1) x (W + 1).  0: unsupported.
 extern "C" int peclr_conv_h_row_blocks(int NB, int H, int W, int Cout, int taps, int stride, int tile_rows) {
     if (NB <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (stride != 1 && stride != 2) || H % stride || W % stride) return 0;
     const int Ho = H / stride, Wo = W / stride;
     const long M = (long)NB * Ho * Wo;
     const int rr = ring_rows(taps, stride, 0, Wo);
     if (tile_rows == 0) tile_rows = rr ? PECLR_CONV_H_RING : pick_rows((int)M, Cout);
-    if (tile_rows == PECLR_CONV_H_RING) return rr ? (int)(((long)NB * (Ho + 1) * (Wo + 1) + 255) / 256) : 0;
+    if (tile_rows == PECLR_CONV_H_RING) return rr ? (int)(((long)NB * (Ho + 1) * (Wo + 1) + ring_tile(Wo) - 1) / ring_tile(Wo)) : 0;
     if (tile_rows != 128 && tile_rows != 256) return 0;
     return (int)((M + tile_rows - 1) / tile_rows);
 }

@@ -140,9 +140,11 @@ RING = 1          # PECLR_CONV_H_RING
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("nb,cin,cout,h,w", [(2, 64, 64, 9, 7), (16, 128, 128, 28, 28), (6, 64, 64, 56, 56), (3, 256, 256, 14, 14), (33, 512, 512, 7, 7),
-                                             (1, 64, 128, 5, 62), (2, 128, 64, 1, 1), (1, 64, 192, 2, 40)])
+                                             (1, 64, 128, 5, 62), (2, 128, 64, 1, 1), (1, 64, 192, 2, 40),
+                                             (2, 64, 64, 112, 112), (1, 64, 128, 3, 63), (1, 128, 64, 4, 126), (3, 64, 64, 20, 100)])
 def test_conv_h_3x3_ring_form(capi, dtype, nb, cin, cout, h, w):
-    """3x3 / stride 1 over the padded pixel space (tile_rows = PECLR_CONV_H_RING): forward with the fused statistics, input gradient
+    """3x3 / stride 1 over the padded pixel space (tile_rows = PECLR_CONV_H_RING; rows up to 126 pixels: BASELINE config C5's layer1
+    has 112): forward with the fused statistics, input gradient
     with the fused BatchNorm backward reduction, against float64; padding positions are neither stored nor counted;
     bit-identical from launch to launch."""
     g = torch.Generator(device=DEV).manual_seed(nb + cin + cout + h + w)
@@ -154,7 +156,8 @@ def test_conv_h_3x3_ring_form(capi, dtype, nb, cin, cout, h, w):
     ref = torch.nn.functional.conv2d(x.double(), wd, padding=1)
     shift = (torch.randn(cout, device=DEV, generator=g) * 0.1).contiguous()
     y, partial, ns = capi.conv_h(x, pk.planes[0], cout, stat_shift=shift, tile_rows=RING)
-    assert ns == (nb * (h + 1) * (w + 1) + 255) // 256 == capi.lib().peclr_conv_h_row_blocks(nb, h, w, cout, 9, 1, RING)
+    tile = 256 if w <= 62 else 128          # rows of 63 ... 126 pixels (C5's layer1: 112): 128-row tiles, 384-row stages
+    assert ns == (nb * (h + 1) * (w + 1) + tile - 1) // tile == capi.lib().peclr_conv_h_row_blocks(nb, h, w, cout, 9, 1, RING)
     close(y, ref, dtype, "ring forward")
     d = y.double() - shift.double().view(1, -1, 1, 1)
     want = torch.stack([d.sum((0, 2, 3)), (d ** 2).sum((0, 2, 3))])
@@ -185,17 +188,19 @@ def test_conv_h_3x3_ring_form(capi, dtype, nb, cin, cout, h, w):
     assert float(((got - want).abs() / bound).max()) <= 1e-4
 
 
-def test_conv_h_ring_form_is_refused_for_rows_wider_than_62_pixels(capi):
-    x = nhwc(torch.randn(1, 64, 3, 63, device=DEV).to(torch.bfloat16))
+def test_conv_h_ring_form_is_refused_for_rows_wider_than_126_pixels(capi):
+    """(round 5: rows of 63 ... 126 pixels take 128-row ring tiles; wider ones still fall back to the per-tap form)"""
+    x = nhwc(torch.randn(1, 64, 3, 127, device=DEV).to(torch.bfloat16))
     wt = torch.randn(64, 9 * 64, device=DEV) * 0.05
     pk = capi.HPlanes([(wt, False)], torch.bfloat16).pack()
-    assert capi.lib().peclr_conv_h_row_blocks(1, 3, 63, 64, 9, 1, RING) == 0
-    assert capi.lib().peclr_conv_h_row_blocks(1, 3, 63, 64, 9, 1, 0) == 2          # 189 pixels, 128-row tiles
+    assert capi.lib().peclr_conv_h_row_blocks(1, 3, 127, 64, 9, 1, RING) == 0
+    assert capi.lib().peclr_conv_h_row_blocks(1, 3, 127, 64, 9, 1, 0) == 3          # 381 pixels, 128-row tiles
+    assert capi.lib().peclr_conv_h_row_blocks(1, 3, 63, 64, 9, 1, 0) == capi.lib().peclr_conv_h_row_blocks(1, 3, 63, 64, 9, 1, RING) == 2
     with pytest.raises(capi.PeclrHipError):
         capi.conv_h(x, pk.planes[0], 64, tile_rows=RING)
     y = capi.conv_h(x, pk.planes[0], 64)                                            # (the library's choice: per-tap form)
     ref = torch.nn.functional.conv2d(x.double(), wt.view(64, 3, 3, 64).permute(0, 3, 1, 2).to(torch.bfloat16).double(), padding=1)
-    close(y, ref, torch.bfloat16, "wide rows")
+    close(y, ref, torch.bfloat16, "per-tap fallback")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
