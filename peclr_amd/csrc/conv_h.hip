@@ -697,15 +697,22 @@ void set_bb(HArgs& g, const peclr_bn_bwd_fuse* bb) {
 
 // rows of the ring stage a 3x3 / stride-1 launch over W-pixel rows needs (0: not eligible -- rows wider than 62 pixels, or
 // switched off: PECLR_CONV3_RING=0 for A/B runs)
-// (rows of 63 ... 126 pixels -- layer1 at 448 x 448 inputs, BASELINE config C5: 112 -- take 128-row tiles: 128 + 2 (W + 2) <= 384
-// rows per stage keep two stages + two W stages inside the 64 KiB an LDS-DMA can address; PECLR_CONV3_RING_WIDE=0 for A/B)
+// (rows of 63 ... 126 pixels -- layer1 at 448 x 448 inputs, BASELINE config C5: 112 -- CAN take the ring form on 128-row tiles:
+// 128 + 2 (W + 2) <= 384 rows per stage keep two stages + two W stages inside the 64 KiB an LDS-DMA can address.  Built and
+// tested in round 5, and measured slower than the per-tap form there (C5 shape, bf16: 3x3 forward +29 us, input gradient +42 us
+// per layer1 launch -- a stage fetches 2.8 rows per output row and only two workgroups fit a CU), so the library's own choice
+// (tile_rows = 0) keeps the per-tap form for them; PECLR_CONV3_RING_WIDE=1 or an explicit PECLR_CONV_H_RING selects it.)
 int ring_tile(int W) { return W <= 62 ? 256 : 128; }
 int ring_rows(int taps, int stride, int s2d, int W) {
     static const int on = getenv("PECLR_CONV3_RING") ? atoi(getenv("PECLR_CONV3_RING")) : 1;
-    static const int wide = getenv("PECLR_CONV3_RING_WIDE") ? atoi(getenv("PECLR_CONV3_RING_WIDE")) : 1;
-    if (!on || taps != 9 || stride != 1 || s2d || W > 126 || (W > 62 && !wide)) return 0;
+    if (!on || taps != 9 || stride != 1 || s2d || W > 126) return 0;
     if (W > 62) return 384;
     return 256 + 2 * (W + 2) <= 320 ? 320 : 384;
+}
+// ... and whether the library picks it when the caller leaves the choice (tile_rows = 0)
+int ring_default(int taps, int stride, int s2d, int W) {
+    static const int wide = getenv("PECLR_CONV3_RING_WIDE") ? atoi(getenv("PECLR_CONV3_RING_WIDE")) : 0;
+    return (W <= 62 || wide) ? ring_rows(taps, stride, s2d, W) : 0;
 }
 
 // experiment switch (default off: the consumer of a 16-bit output -- the next BatchNorm pass -- finds part of it in the
@@ -815,7 +822,7 @@ extern "C" int peclr_conv_h_row_blocks(int NB, int H, int W, int Cout, int taps,
     const int Ho = H / stride, Wo = W / stride;
     const long M = (long)NB * Ho * Wo;
     const int rr = ring_rows(taps, stride, 0, Wo);
-    if (tile_rows == 0) tile_rows = rr ? PECLR_CONV_H_RING : pick_rows((int)M, Cout);
+    if (tile_rows == 0) tile_rows = ring_default(taps, stride, 0, Wo) ? PECLR_CONV_H_RING : pick_rows((int)M, Cout);
     if (tile_rows == PECLR_CONV_H_RING) return rr ? (int)(((long)NB * (Ho + 1) * (Wo + 1) + ring_tile(Wo) - 1) / ring_tile(Wo)) : 0;
     if (tile_rows != 128 && tile_rows != 256) return 0;
     return (int)((M + tile_rows - 1) / tile_rows);
@@ -858,7 +865,7 @@ extern "C" int peclr_conv_h(int dtype, int NB, int H, int W, int Cin, int Cout, 
     if ((long)NB * H * W > 0x7FFFFFFFL / 2) return PECLR_ERR_SHAPE;
     if (!aligned16(X) || !aligned16(Bp) || !aligned16(Y) || !aligned16(zeros)) return PECLR_ERR_ALIGN;
     const int Ho = H / stride, Wo = W / stride, M = NB * Ho * Wo;
-    if (tile_rows == 0) tile_rows = ring_rows(taps, stride, 0, Wo) ? PECLR_CONV_H_RING : pick_rows(M, Cout);
+    if (tile_rows == 0) tile_rows = ring_default(taps, stride, 0, Wo) ? PECLR_CONV_H_RING : pick_rows(M, Cout);
     if (tile_rows != 128 && tile_rows != 256 && tile_rows != PECLR_CONV_H_RING) return PECLR_ERR_UNSUPPORTED;
     if (tile_rows == PECLR_CONV_H_RING && ((long)NB * (H + 1) * (W + 1) > 0x7FFFFFFFL / 2 || !ring_rows(taps, stride, 0, Wo)))
         return PECLR_ERR_UNSUPPORTED;
