@@ -85,6 +85,8 @@ SIGNATURES = {
     "peclr_gemm_x6p_maskadd_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P]),
     "peclr_gemm_x6t_slabs": (c_int, [c_int, c_int, c_int, c_int]),
     "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "peclr_gemm_x6p_bnrelu_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+    "peclr_gemm_x6t_bnrelu_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_conv_s2_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_h_pack_bytes": (c_int64, [c_int, c_int]),
@@ -495,7 +497,7 @@ class X6Planes:
 
 def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[torch.Tensor] = None, tag: str = "gemm_x6p",
              tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None, addend_s2=None,
-             addend_mask: Optional[torch.Tensor] = None):
+             addend_mask: Optional[torch.Tensor] = None, a_scale_shift: Optional[torch.Tensor] = None):
     """C (fp32) [M, n] = A[M, K] . B_t^T (+ addend) with B_t given as packed planes (X6Planes): fp32 accuracy on the
     bf16 matrix cores, the weight operand split once per step (peclr_gemm_x6p_f32).
     stat_shift (fp32 [n]): also return the training-mode BatchNorm statistics of C as `(partial, n_split)` in the layout
@@ -505,8 +507,14 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
     addend_s2 = (H, W): the rows are the pixels of H x W images and `addend` [M / 4, n] holds every second pixel only (the
     compact input gradient of a 1x1 / stride-2 convolution): added at the even (h, w) rows (peclr_gemm_x6p_s2add_f32).
     addend_mask (int32 [M, n / 32], the 1-bit ReLU mask of peclr_bn2d_apply): addend elements whose bit is clear count as
-    zero (peclr_gemm_x6p_maskadd_f32)."""
+    zero (peclr_gemm_x6p_maskadd_f32).
+    a_scale_shift (fp32 [2, K], the table of peclr_bn2d_finalize_f32): A is the INPUT of a BatchNorm2d + ReLU layer and the
+    product consumes that layer's output, max(fmaf(a, scale, shift), 0) applied as the rows are split -- the output of
+    peclr_bn2d_apply without the pass or the tensor (peclr_gemm_x6p_bnrelu_f32; K <= 512, no addend / bn_bwd)."""
     m, k = a.shape
+    if a_scale_shift is not None and (addend is not None or bn_bwd is not None or k > 512 or a_scale_shift.numel() != 2 * k
+                                      or a_scale_shift.dtype != torch.float32 or not a_scale_shift.is_contiguous()):
+        raise PeclrHipError(f"gemm_x6p: a_scale_shift is the fp32 [2, K <= 512] table of a BatchNorm2d layer (no addend / bn_bwd); K = {k}")
     add_rows = m if addend_s2 is None else m // 4
     if planes.dtype != torch.uint8 or planes.numel() != 6 * ((n + 127) // 128 * 128) * k or (addend is not None and tuple(addend.shape) != (add_rows, n)):
         raise PeclrHipError(f"gemm_x6p: A {tuple(a.shape)}, planes of {planes.numel()} bytes for B_t[{n}, {k}]")
@@ -538,12 +546,16 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
             rc = lib().peclr_gemm_x6p_s2add_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
                                                 int(addend_s2[0]), int(addend_s2[1]), tile_rows,
                                                 ctypes.byref(fuse) if fuse is not None else None, _stream())
+        elif a_scale_shift is not None:
+            rc = lib().peclr_gemm_x6p_bnrelu_f32(m, n, k, _ptr(a), k, a_scale_shift.data_ptr(), _ptr(planes, torch.uint8), out.data_ptr(), n,
+                                                 tile_rows, _ptr(stat_shift), partial.data_ptr() if stat_shift is not None else None,
+                                                 _stream())
         else:
             rc = lib().peclr_gemm_x6p_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
                                           tile_rows, _ptr(stat_shift), partial.data_ptr() if stat_shift is not None else None,
                                           ctypes.byref(fuse) if fuse is not None else None, _stream())
     _check(rc, "peclr_gemm_x6p_maskadd_f32" if addend_mask is not None else "peclr_gemm_x6p_s2add_f32" if addend_s2 is not None
-           else "peclr_gemm_x6p_f32")
+           else "peclr_gemm_x6p_bnrelu_f32" if a_scale_shift is not None else "peclr_gemm_x6p_f32")
     return out if partial is None else (out, partial, ns)
 
 
@@ -652,12 +664,18 @@ def gemm_x6_tn(a: torch.Tensor, b: torch.Tensor, tag: str = "gemm_x6_tn") -> tor
     return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
 
 
-def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, stride: int = 1, tag: str = "gemm_x6t") -> torch.Tensor:
+def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, stride: int = 1, tag: str = "gemm_x6t",
+             b_scale_shift: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C[M, taps * N] (fp32) = sum over rows of A[K, M]^T . B[K (shifted by the tap), N] -- the weight gradient of a 1x1
     (taps = 1) or 3x3 / padding-1 (taps = 9, hw = (H, W) of the images A's rows are the pixels of) convolution on NHWC
     storage, on the bf16 matrix cores at fp32 accuracy (peclr_gemm_x6t_f32 + peclr_slab_reduce_f32: fixed-order split-K,
-    deterministic).  stride = 2: A = dY over the H x W output pixels, B = X over the 2H x 2W input pixels (4 K rows)."""
+    deterministic).  stride = 2: A = dY over the H x W output pixels, B = X over the 2H x 2W input pixels (4 K rows).
+    b_scale_shift (fp32 [2, N]; taps = 1, stride = 1): B is the INPUT of a BatchNorm2d + ReLU layer whose output the product
+    consumes (peclr_gemm_x6t_bnrelu_f32; the backward twin of gemm_x6p's a_scale_shift)."""
     (k, m), (k2, n) = a.shape, b.shape
+    if b_scale_shift is not None and (taps != 1 or stride != 1 or b_scale_shift.numel() != 2 * n or b_scale_shift.dtype != torch.float32
+                                      or not b_scale_shift.is_contiguous()):
+        raise PeclrHipError("gemm_x6t: b_scale_shift is the fp32 [2, N] table of a BatchNorm2d layer (1x1 / stride-1 products only)")
     if k * stride * stride != k2 or taps not in (1, 9) or stride not in (1, 2) or ((taps == 9 or stride == 2) and hw is None):
         raise PeclrHipError(f"gemm_x6t: shapes {tuple(a.shape)}^T x {tuple(b.shape)}, taps {taps}, stride {stride}")
     h, w = hw if hw is not None else (1, 1)
@@ -667,9 +685,13 @@ def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, stride: i
     slabs = torch.empty((ns, m, taps * n), device=a.device, dtype=torch.float32)
     with _timed(tag, 4 * (k * m + k2 * n // (stride * stride) * (1 if taps == 1 else stride * stride) + ns * m * n * taps),
                 2 * m * n * k * taps, kernel="gemm_x6t_kernel"):
-        rc = lib().peclr_gemm_x6t_f32(m, n, k, _ptr(a), a.stride(0), _ptr(b), b.stride(0), slabs.data_ptr(), ns, taps, h, w, stride,
-                                      _zeros(a.device).data_ptr(), _stream())
-    _check(rc, "peclr_gemm_x6t_f32")
+        if b_scale_shift is not None:
+            rc = lib().peclr_gemm_x6t_bnrelu_f32(m, n, k, _ptr(a), a.stride(0), _ptr(b), b.stride(0), b_scale_shift.data_ptr(),
+                                                 slabs.data_ptr(), ns, _zeros(a.device).data_ptr(), _stream())
+        else:
+            rc = lib().peclr_gemm_x6t_f32(m, n, k, _ptr(a), a.stride(0), _ptr(b), b.stride(0), slabs.data_ptr(), ns, taps, h, w, stride,
+                                          _zeros(a.device).data_ptr(), _stream())
+    _check(rc, "peclr_gemm_x6t_bnrelu_f32" if b_scale_shift is not None else "peclr_gemm_x6t_f32")
     return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
 
 
@@ -1099,8 +1121,21 @@ def _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, 
     return save, ss
 
 
+def bn2d_apply(x, ss, relu: bool = True):
+    """y = (relu)(fmaf(x, scale, shift)) from a finished scale / shift table: the apply pass of `bn2d_fwd` on its own (the
+    fallback of a layer whose apply was left to its consumer, `bn2d_fwd(..., apply=False)`)."""
+    n, c, h, w = x.shape
+    r = n * h * w
+    io, e = _IO[x.dtype]
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    with _timed("bn2d_apply", 2 * e * r * c):
+        rc = lib().peclr_bn2d_apply(_nhwc_ptr(x, "bn2d x"), None, io, r, c, ss.data_ptr(), int(relu), y.data_ptr(), None, _stream())
+    _check(rc, "peclr_bn2d_apply")
+    return y
+
+
 def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, relu,
-             want_mask=False, sync_group=None, sync_shift=None, pre=None):
+             want_mask=False, sync_group=None, sync_shift=None, pre=None, apply=True):
     """want_mask: also write the 1-bit ReLU mask ([R, C/32] int32) the backward reads instead of y.
     sync_group: a process group -> training statistics are those of the rows of ALL its ranks
     (mean/var of the global batch, as one device holding the concatenated batch would compute)."""
@@ -1110,6 +1145,10 @@ def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training,
     xp = _nhwc_ptr(x, "bn2d x")
     io, e = _IO[x.dtype]
     save, ss = _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group, sync_shift, pre)
+    if not apply:                        # statistics and the table only: the consumer applies them in its operand path
+        if residual is not None or want_mask:
+            raise PeclrHipError("bn2d_fwd(apply=False): plain BatchNorm (+ ReLU) layers only")
+        return None, save, ss, None
     y = torch.empty_like(x, memory_format=torch.channels_last)
     mask = torch.empty((r, c // 32), device=dev, dtype=torch.int32) if (want_mask and relu and c % 32 == 0) else None
     with _timed("bn2d_apply", (3 if residual is not None else 2) * e * r * c + (r * c // 8 if mask is not None else 0)):

@@ -124,6 +124,10 @@ class Routing:
     gemm_x6t: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_GEMM_X6T"))            # weight gradients on the 256 x 256-tile kernel
     bn_stats_in_gemm: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_BN_STATS_IN_GEMM"))   # BatchNorm statistics in the GEMM epilogue
     bn_bwd_in_gemm: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_BN_BWD_IN_GEMM"))       # BatchNorm backward reduction in the dgrad epilogue
+    # bn2 + ReLU applied in conv3's operand path (fp32 Bottleneck): no apply pass, no output tensor.  Bit-identical, and OFF by default:
+    # measured on one box (C2, fp32) the sixteen saved passes are worth 0.60 ms, the longer row splits of the GEMMs that absorb them
+    # cost 1.05 ms (their k-steps are latency chains: load -> split -> LDS -> barrier), 53.9 against 53.2 ms per step
+    bn_apply_in_gemm: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_BN_APPLY_IN_GEMM", "0"))
     x6_layer1: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_X6_LAYER1"))          # layer1's 64-channel 1x1 convolutions in-tree
     x6_layer1_fork: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_X6_LAYER1_FORK"))   # layer1's fused entry gradient (K = 64)
     x6_layer1_wgrad: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_X6_LAYER1_WGRAD"))  # layer1's 64-wide weight gradients
@@ -280,9 +284,12 @@ def _h_ok(conv, x: Tensor) -> bool:
 
 class _BN2dAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool, pre=None, link=None, lazy_res=False):
+    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool, pre=None, link=None, lazy_res=False, defer=None):
         """link: None or an empty list that receives what a consumer's input-gradient GEMM needs to perform this layer's
-        backward reduction in its epilogue: [x, save, scale_shift, relu mask or None, relu, token]."""
+        backward reduction in its epilogue: [x, save, scale_shift, relu mask or None, relu, token].
+        defer: None, or an empty list -- the layer (plain BatchNorm + ReLU) only finishes its statistics; the list comes back
+        as [x, scale_shift] and the result is a placeholder (`_deferred_view`) whose consumer applies the layer in its own
+        operand path (`Conv2d.forward`), or materialises it (`_Materialize`)."""
         training = bn.training or not bn.track_running_stats
         # the ReLU mask can be recomputed from x unless a residual was added before it; then the
         # forward writes a 1-bit mask (or, for C % 32 != 0, the backward re-reads y)
@@ -291,7 +298,10 @@ class _BN2dAct(torch.autograd.Function):
         y, save, ss, mask = _capi.bn2d_fwd(x, residual, weight, bias, rm, rv, nbt, training, bn.eps,
                                            bn.momentum if bn.momentum is not None else 0.1, relu, want_mask=need_mask,
                                            sync_group=bn.sync_group if training else None, sync_shift=shift,
-                                           pre=pre if training else None)
+                                           pre=pre if training else None, apply=defer is None)
+        if defer is not None:
+            defer[:] = [x, ss]
+            y = _deferred_view(x)
         keep = mask if mask is not None else (y if need_mask else None)
         ctx.save_for_backward(x, save, ss, *([keep] if keep is not None else []))
         ctx.cfg = (training, relu, residual is not None, keep is not None, mask is not None)
@@ -326,7 +336,38 @@ class _BN2dAct(torch.autograd.Function):
             dres = _lazy_grad(("mask", dy, mask), x.shape, x.device, x.dtype)
         elif has_res and dres is None and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dgamma, dbeta, dres, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+
+
+def _deferred_view(x: Tensor) -> Tensor:
+    """Stands for relu(bn(x)) where that tensor is never written: NaN under every index (one element, zero strides), so that a
+    reader that does not know the protocol cannot go unnoticed."""
+    ring = _NAN_RING.get((x.device, x.dtype))
+    if ring is None:
+        ring = _NAN_RING[(x.device, x.dtype)] = [torch.full((64,), float("nan"), device=x.device, dtype=x.dtype), 0]
+    return ring[0][63:64].view(1, 1, 1, 1).expand(x.shape)
+
+
+class _Materialize(torch.autograd.Function):
+    """The output of a BatchNorm + ReLU layer whose apply pass was left to its consumer, written after all (the consumer
+    turned out not to be the GEMM that applies it in its operand path): peclr_bn2d_apply on the finished table."""
+
+    @staticmethod
+    def forward(ctx, placeholder, deferred):
+        x, ss = deferred
+        return _capi.bn2d_apply(x, ss, relu=True)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy, None
+
+
+def _materialized(x: Tensor, deferred) -> Tensor:
+    y = _Materialize.apply(x, deferred)
+    link = getattr(x, "_peclr_bn_link", None)
+    if link:
+        y._peclr_bn_link = link
+    return y
 
 
 class _BN2dReluPool(torch.autograd.Function):
@@ -504,15 +545,17 @@ def _x6_wgrad_pays(rows: int, cout: int, cin: int) -> bool:
     return ROUTING.gemm_x6 and cout >= wide and cin >= wide and cout % 4 == 0 and cin % 4 == 0 and (rows >= 8192 or ROUTING.force)
 
 
-def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
+def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, b_scale_shift=None):
     """d(weight) of a 1x1 / stride-1 convolution as dY^T X on the bf16 matrix cores (fp32 accuracy, deterministic
-    split-K), shaped and strided like the weight; parked for `param` on the side stream when that mode is on."""
+    split-K), shaped and strided like the weight; parked for `param` on the side stream when that mode is on.
+    b_scale_shift: x is the INPUT of the BatchNorm + ReLU layer in front of the convolution (its output was never written)."""
     n, cin, h, w = x.shape
     cout = gy.shape[1]
 
     def run():
         gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
-        dw = _capi.gemm_x6t(gy2, x2, tag="conv1x1_wgrad") if ROUTING.gemm_x6t else _capi.gemm_x6_tn(gy2, x2, tag="conv1x1_wgrad")
+        dw = (_capi.gemm_x6t(gy2, x2, tag="conv1x1_wgrad", b_scale_shift=b_scale_shift) if ROUTING.gemm_x6t
+              else _capi.gemm_x6_tn(gy2, x2, tag="conv1x1_wgrad"))
         ref = param if param is not None else weight
         return dw.as_strided(ref.shape, ref.stride())       # same memory, the parameter's (channels_last) strides
 
@@ -578,13 +621,22 @@ class _Conv1x1Gemm(torch.autograd.Function):
     both operands split per workgroup: peclr_gemm_x6_f32); the other direction and small weight gradients stay on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, use_fwd: bool, use_bwd: bool, stats=None, link=None):
+    def forward(ctx, x, weight, conv, use_fwd: bool, use_bwd: bool, stats=None, link=None, deferred=None):
         """stats: None, or [bn] -- the BatchNorm2d that consumes the output; the GEMM epilogue then sums its statistics
-        and the list comes back as [partial, n_split, shift, bn] (left untouched when that is not possible)."""
-        ctx.save_for_backward(x, weight)
+        and the list comes back as [partial, n_split, shift, bn] (left untouched when that is not possible).
+        deferred: None, or (x_bn, scale_shift) -- `x` is the placeholder of a BatchNorm + ReLU layer that left its apply pass
+        to this convolution: the GEMM reads that layer's INPUT and applies it as it splits the rows (and so does the weight
+        gradient's); needs use_fwd and packed planes (`Conv2d._takes_deferred`)."""
+        ss = None
+        if deferred is not None:
+            x, ss = deferred                                  # (the graph edge stays on the placeholder; these are plain tensors)
+            x = x.detach()
+        ctx.save_for_backward(x, weight, *([ss] if ss is not None else []))
         planes = _x6_planes(conv) if (use_fwd or use_bwd) else None
         ctx.cfg = (conv, use_bwd, planes)
         ctx.link = link
+        if ss is not None and not (use_fwd and planes is not None):
+            raise _capi.PeclrHipError("a deferred BatchNorm layer needs the packed-plane forward GEMM (Conv2d._takes_deferred)")
         if not use_fwd:
             return F.conv2d(x, weight)
         n, cin, h, w = x.shape
@@ -592,17 +644,18 @@ class _Conv1x1Gemm(torch.autograd.Function):
         x2 = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
         shift = _stat_shift_for(stats[0], cout) if (stats and planes is not None and ROUTING.bn_stats_in_gemm) else None
         if shift is not None:
-            y, partial, ns = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd", stat_shift=shift)
+            y, partial, ns = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd", stat_shift=shift, a_scale_shift=ss)
             stats[:] = [partial, ns, shift, stats[0]]
         elif planes is not None:
-            y = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd")
+            y = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd", a_scale_shift=ss)
         else:
             y = _capi.gemm_x6(x2, weight.detach().reshape(cout, cin), tag="conv1x1_fwd")
         return y.view(n, h, w, cout).permute(0, 3, 1, 2)          # channels_last NCHW view of the NHWC result
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x, weight = ctx.saved_tensors[:2]
+        ss = ctx.saved_tensors[2] if len(ctx.saved_tensors) > 2 else None      # x is the input of the BatchNorm layer in front
         conv, use_bwd, planes = ctx.cfg
         param = conv.weight if conv is not None else None
         n, cin, h, w = x.shape
@@ -610,8 +663,12 @@ class _Conv1x1Gemm(torch.autograd.Function):
         gy = gy.contiguous(memory_format=torch.channels_last)
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = (_wgrad_1x1_x6(gy, x, weight, param) if _x6_wgrad_pays(n * h * w, cout, cin)
-                  else _conv_wgrad(gy, x, weight, (1, 1), (0, 0), param))
+            if ss is not None and _x6_wgrad_pays(n * h * w, cout, cin) and ROUTING.gemm_x6t:
+                dw = _wgrad_1x1_x6(gy, x, weight, param, b_scale_shift=ss)
+            else:
+                xa = x if ss is None else _capi.bn2d_apply(x, ss, relu=True)
+                dw = (_wgrad_1x1_x6(gy, xa, weight, param) if _x6_wgrad_pays(n * h * w, cout, cin)
+                      else _conv_wgrad(gy, xa, weight, (1, 1), (0, 0), param))
         dx = None
         if ctx.needs_input_grad[0]:
             if use_bwd:
@@ -629,7 +686,7 @@ class _Conv1x1Gemm(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
-        return dx, dw, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None
 
 
 
@@ -1050,6 +1107,16 @@ class Conv2d(nn.Conv2d):
             st[1] = key
         return st[0]
 
+    def _takes_deferred(self, x_bn: Tensor) -> bool:
+        """Can this convolution apply the BatchNorm + ReLU layer in front of it (input `x_bn`) in its own operand path?  The
+        fp32 1x1 / stride-1 GEMM on packed planes (peclr_gemm_x6p_bnrelu_f32: K <= 512 -- bn2 -> conv3 of every Bottleneck)."""
+        return bool(ROUTING.bn_apply_in_gemm and self.hip_gemm and ROUTING.gemm_x6p and getattr(self, "x6_group", None) is not None
+                    and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1
+                    and self.bias is None and self.in_channels <= 512 and self.in_channels % 16 == 0
+                    and x_bn.is_cuda and x_bn.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x_bn.dim() == 4
+                    and x_bn.shape[1] == self.in_channels and x_bn.is_contiguous(memory_format=torch.channels_last)
+                    and _x6_pays(x_bn.shape[0] * x_bn.shape[2] * x_bn.shape[3], self.out_channels, self.in_channels))
+
     def forward(self, x: Tensor, stats_for=None, sole_consumer: bool = False) -> Tensor:
         """stats_for: the BatchNorm2d that consumes the output -- when this convolution runs as an in-tree GEMM its
         epilogue sums that layer's training statistics (one pass over the activation less).
@@ -1058,6 +1125,18 @@ class Conv2d(nn.Conv2d):
         may the input-gradient GEMM perform that layer's backward reduction in its epilogue.  A block input (x also feeds
         the shortcut) is not: BasicBlock.conv1 passes False."""
         bn_link = _bn_link_of if sole_consumer else (lambda t: None)
+        deferred = getattr(x, "_peclr_deferred", None)
+        if deferred is not None:
+            # x stands for relu(bn(x_bn)), not written: this GEMM applies the layer as it splits the rows of x_bn -- or the
+            # tensor is written after all
+            if self._takes_deferred(deferred[0]):
+                grad = torch.is_grad_enabled() and x.requires_grad
+                rows = x.shape[0] * x.shape[2] * x.shape[3]
+                use_bwd = _x6_pays(rows, self.in_channels, self.out_channels) and grad
+                stats = [stats_for] if stats_for is not None else None
+                return _attach_stats(_Conv1x1Gemm.apply(x, self.weight, self, True, use_bwd, stats, bn_link(x) if use_bwd else None,
+                                                        tuple(deferred)), stats)
+            x = _materialized(x, tuple(deferred))
         if (self.hip_stem and ROUTING.stem and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3
                 and x.shape[2] >= 8 and x.shape[3] >= 8 and x.is_contiguous(memory_format=torch.channels_last)
                 and self.weight.is_cuda and self.weight.dtype == torch.float32):
@@ -1311,7 +1390,10 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
                 shift = self.running_mean.detach().clone()
         return self.running_mean, self.running_var, self.num_batches_tracked, shift
 
-    def forward(self, x: Tensor, residual: Optional[Tensor] = None, relu: Optional[bool] = None) -> Tensor:
+    def forward(self, x: Tensor, residual: Optional[Tensor] = None, relu: Optional[bool] = None, consumer=None) -> Tensor:
+        """consumer: the Conv2d that is the ONLY reader of the result (bn2 -> conv3 inside a Bottleneck).  Where that
+        convolution can apply this layer in its own operand path (`Conv2d._takes_deferred`), the layer only finishes its
+        statistics and returns a placeholder carrying `_peclr_deferred = [x, scale_shift]`: no apply pass, no output tensor."""
         relu = self.default_relu if relu is None else relu
         pool = self.default_pool and relu and residual is None
         if self.hip:
@@ -1329,9 +1411,13 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
             link = [] if (ROUTING.bn_bwd_in_gemm and torch.is_grad_enabled() and x.requires_grad) else None
             lazy_res = (ROUTING.lazy_residual_grad and relu and residual is not None and getattr(residual, "_peclr_compact_ok", False)
                         and torch.is_grad_enabled() and residual.requires_grad and self.num_features % 32 == 0)
-            y = _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre, link, lazy_res)
+            defer = ([] if (consumer is not None and relu and residual is None and isinstance(consumer, Conv2d)
+                            and consumer._takes_deferred(x)) else None)
+            y = _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre, link, lazy_res, defer)
             if link:
                 y._peclr_bn_link = link
+            if defer:
+                y._peclr_deferred = defer
             return y
         if self.sync_group is not None and self.training:
             raise _capi.PeclrHipError("synchronised statistics are implemented by the HIP kernels only (hip=True)")

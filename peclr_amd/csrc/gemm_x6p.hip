@@ -72,6 +72,10 @@ struct X6PArgs {
     // stride-1 input gradient (K order (tap, Cout)).
     int s2d;
     const float* zeros;                  // >= 64 bytes of zeros (source of the padding pixels)
+    // optional (TRA instantiations, TAPS = 1): A is the INPUT of a BatchNorm2d + ReLU layer whose output this product consumes;
+    // a_ss = [2][K] that layer's scale / shift: every element becomes max(fmaf(a, scale[k], shift[k]), 0) -- peclr_bn2d_apply's
+    // own expression -- in the registers of the wave that splits its row, and the layer's output never exists in memory
+    const float* a_ss;
     // optional: C is the gradient dY arriving at a BatchNorm2d(+ReLU) layer (this GEMM is the input gradient of the
     // convolution that consumed that layer's output).  The epilogue then performs the layer's backward REDUCTION on the tile
     // it holds: per row block and column, sum of dY' and of dY' * xhat with dY' = dY where the ReLU passed (recomputed from
@@ -109,8 +113,9 @@ __device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_offset)
 // ONCE into shared planes [plane][k-half][pixel][8 k] and every tap reads its A fragments from there at the tap's pixel offset
 // (border rows from a 16-byte zero slot) -- instead of each wave loading and splitting its rows once per tap (nine times).
 // K order of the loop: (chunk, tap); the packed filter chunks are indexed tap * chunks + chunk as before.  W <= 62.
-template <int WM, int ABL = 0, bool AREG = true, bool ILV = true, int TAPS = 1, int NTL = 4, bool HALO = false>
+template <int WM, int ABL = 0, bool AREG = true, bool ILV = true, int TAPS = 1, int NTL = 4, bool HALO = false, bool TRA = false>
 __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
+    static_assert(!TRA || (TAPS == 1 && AREG && !HALO), "the BatchNorm transform of the A rows: plain 1x1 products");
     constexpr int RM = 32 * WM;                          // rows per wave
     constexpr int TM = 4 * RM;                           // rows per workgroup
     constexpr int NRAW = RM / 16;                        // 1 KiB pieces of fp32 rows per wave and k-step
@@ -135,7 +140,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     // + 2.5 KiB at the end: the epilogue's per-column constants ([shift | mean | invstd | scale | shift'][128] floats), fetched
     // BEFORE the main loop -- in the epilogue each of the four column tiles used to wait a full memory round trip for them
     constexpr int CST0 = HALO ? ZOFF + 64 : PL0 + 4 * WAVE_PL;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[CST0 + 5 * 128 * 4];
+    constexpr int ASS0 = CST0 + 5 * 128 * 4;             // TRA: [scale | shift][K <= 512] of the BatchNorm layer in front of A
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[ASS0 + (TRA ? 2 * 512 * 4 : 0)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kh = lane >> 5;
     typedef __attribute__((address_space(3))) unsigned char* lptr_t;
@@ -179,6 +185,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         if (g.stat_partial) k0 = g.stat_shift[c];
         if (g.bb_partial) { k1 = g.bb_mean[c]; k2 = g.bb_invstd[c]; k3 = g.bb_ss[c]; k4 = g.bb_ss[g.N + c]; }
         if (tid < PNL0) { cst[tid] = k0; cst[128 + tid] = k1; cst[256 + tid] = k2; cst[384 + tid] = k3; cst[512 + tid] = k4; }
+    }
+    if constexpr (TRA) {
+        float* t = reinterpret_cast<float*>(lds + ASS0);
+        for (int c = tid; c < g.K; c += 256) { t[c] = g.a_ss[c]; t[512 + c] = g.a_ss[g.K + c]; }
+        __syncthreads();                                  // (the first rows are split before the loop's first barrier)
     }
     if constexpr (!HALO) {
     // this lane's fp32 source: rows (lane >> 2) + 16 c of the wave's block, k-quad lane & 3 (rows past M re-read row M - 1)
@@ -270,12 +281,22 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     // rows of the k-step just landed -> three planes [k-half][row][8 k] (this lane: row 16 c + (lane >> 2),
     // k = 4 (lane & 3) ... + 3, i.e. k-half (lane >> 1) & 1, 8-byte slot lane & 1)
     const int poff = ((lane >> 1) & 1) * HALF + (lane >> 2) * 16 + (lane & 1) * 8;
-    auto split_store = [&]() {
+    auto split_store = [&](int ts) {                      // ts: the k-step whose rows are being split (TRA: selects the channels)
+        f32x4 tsc, tsh;
+        if constexpr (TRA) {
+            const float* t = reinterpret_cast<const float*>(lds + ASS0) + ts * PK + 4 * (lane & 3);
+            tsc = *reinterpret_cast<const f32x4*>(t);
+            tsh = *reinterpret_cast<const f32x4*>(t + 512);
+        }
 #pragma unroll
         for (int c = 0; c < NRAW; ++c) {
             f32x4 v;
             if constexpr (AREG) v = ar[c];
             else v = *reinterpret_cast<const f32x4*>(raw + c * 1024 + lane * 16);
+            if constexpr (TRA) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaf(v[q], tsc[q], tsh[q]), 0.f);
+            }
             unsigned h[2], m[2], l[2];
             split3_pk(v[0], v[1], h[0], m[0], l[0]);
             split3_pk(v[2], v[3], h[1], m[1], l[1]);
@@ -294,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     issue_b(0);
     issue_a(0);
     if constexpr (!AREG) PECLR_VMCNT(0);
-    split_store();
+    split_store(0);
     if constexpr (!AREG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (nk > 1) { issue_b(1); issue_a(1); }
 
@@ -325,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
 #undef PECLR_X6
             if (half == 0 && SPLIT) {
                 if constexpr (!AREG) PECLR_VMCNT(0);
-                if constexpr (!(ABL & 1)) split_store();  // after this step's fragment reads in program (= LDS) order
+                if constexpr (!(ABL & 1)) split_store(t + 1);  // after this step's fragment reads in program (= LDS) order
                 else if constexpr (AREG) { asm volatile("" :: "v"(ar[0]), "v"(ar[NRAW - 1])); }
                 if constexpr (AREG && !(ABL & 9) && ILV) {
                     // one MFMA, then four of the split's VALU instructions (the two pipes run side by side), a plane store now and then
@@ -698,6 +719,7 @@ extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K) {
 extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K);
 
 static void set_bb(X6PArgs& g, const peclr_bn_bwd_fuse* bb) {
+    g.a_ss = nullptr;                    // (every launcher goes through here; peclr_gemm_x6p_bnrelu_f32 sets it afterwards)
     g.bb_x = bb ? bb->x : nullptr; g.bb_mean = bb ? bb->mean : nullptr; g.bb_invstd = bb ? bb->invstd : nullptr;
     g.bb_ss = bb ? bb->scale_shift : nullptr; g.bb_mask = bb ? bb->relu_mask : nullptr; g.bb_relu = bb ? bb->relu : 0;
     g.bb_partial = bb ? bb->partial : nullptr;
@@ -732,6 +754,14 @@ static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t str
         }
     } else if (taps == 9) {
         if (tile_rows == 256) PECLR_LAUNCH(2, 9); else PECLR_LAUNCH(1, 9);
+    } else if (g.a_ss) {                                  // the BatchNorm + ReLU in front of A applied in the row split
+        if (tile_rows == 256) {
+            if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<2, 0, true, true, 1, 2, false, true>), grid, dim3(256), 0, stream, g);
+            else hipLaunchKernelGGL((gemm_x6p_kernel<2, 0, true, true, 1, 4, false, true>), grid, dim3(256), 0, stream, g);
+        } else {
+            if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<1, 0, true, true, 1, 2, false, true>), grid, dim3(256), 0, stream, g);
+            else hipLaunchKernelGGL((gemm_x6p_kernel<1, 0, true, true, 1, 4, false, true>), grid, dim3(256), 0, stream, g);
+        }
     } else {
         if (tile_rows == 256) PECLR_LAUNCH(2, 1); else PECLR_LAUNCH(1, 1);
     }
@@ -805,7 +835,7 @@ extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, co
 static int gemm_x6p_host(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc, int add_h, int add_w,
                          const unsigned* add_mask,
                                   const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
-                                  const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
+                                  const peclr_bn_bwd_fuse* bb, peclr_stream_t stream, const float* a_ss = nullptr) {
     if (!A || !Bp || !C || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
     if (bb && (stat_partial || !bb->x || !bb->mean || !bb->invstd || !bb->scale_shift || !bb->partial || ldc != N)) return PECLR_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % PK) return PECLR_ERR_SHAPE;
@@ -822,7 +852,20 @@ static int gemm_x6p_host(int M, int N, int K, const float* A, int lda, const voi
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = g.W = 1; g.flip = 0; g.zeros = nullptr; g.stride = 1; g.Hin = g.Win = 1; g.s2d = 0;
     set_bb(g, bb);
+    if (a_ss && (K > 512 || addend || bb)) return PECLR_ERR_UNSUPPORTED;
+    g.a_ss = a_ss;
     return launch_x6p(g, tile_rows, 1, static_cast<hipStream_t>(stream));
+}
+
+// C = relu(bn(A)) . B_t^T: A is the INPUT of the BatchNorm2d + ReLU layer in front of this 1x1 convolution (conv -> bn -> relu -> conv
+// inside a torchvision Bottleneck), a_scale_shift = [2][K] the table peclr_bn2d_finalize_f32 wrote; the layer's apply pass and
+// its output tensor disappear.  K <= 512; optional statistics of C as in peclr_gemm_x6p_f32.
+extern "C" int peclr_gemm_x6p_bnrelu_f32(int M, int N, int K, const float* A, int lda, const float* a_scale_shift, const void* Bp,
+                                         float* C, int ldc, int tile_rows, const float* stat_shift, float* stat_partial,
+                                         peclr_stream_t stream) {
+    if (!a_scale_shift) return PECLR_ERR_NULL;
+    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, 0, 0, nullptr, nullptr, 0, tile_rows, stat_shift, stat_partial, nullptr, stream,
+                         a_scale_shift);
 }
 
 extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,

@@ -35,11 +35,12 @@ def _conv(conv, x, bn, sole_consumer=False):
     return conv(x, stats_for=bn, sole_consumer=sole_consumer) if isinstance(conv, Conv2d) else conv(x)
 
 
-def _bn(bn, x, residual=None, relu=False):
+def _bn(bn, x, residual=None, relu=False, consumer=None):
     """bn -> (+residual) -> (relu): one fused HIP pass when `bn` is a FusedBatchNormAct2d, the stock
-    three ops otherwise (any other norm_layer)."""
+    three ops otherwise (any other norm_layer).  consumer: the convolution that is the only reader of the result (it may
+    then apply the layer in its own operand path instead: FusedBatchNormAct2d.forward)."""
     if isinstance(bn, FusedBatchNormAct2d):
-        return bn(x, residual, relu)
+        return bn(x, residual, relu, consumer=consumer if isinstance(consumer, Conv2d) else None)
     y = bn(x)
     if residual is not None:
         y = y + residual
@@ -103,7 +104,7 @@ class Bottleneck(nn.Module):
             else:
                 identity = ds(identity)
         out = _bn(self.bn1, out, relu=True)
-        out = _bn(self.bn2, _conv(self.conv2, out, self.bn2, sole_consumer=True), relu=True)
+        out = _bn(self.bn2, _conv(self.conv2, out, self.bn2, sole_consumer=True), relu=True, consumer=self.conv3)
         return _bn(self.bn3, _conv(self.conv3, out, self.bn3, sole_consumer=True), identity, relu=True)
 
 

@@ -1,0 +1,178 @@
+"""BatchNorm2d + ReLU applied in the consumer's operand path (peclr_gemm_x6p_bnrelu_f32, peclr_gemm_x6t_bnrelu_f32): bn2 -> relu ->
+conv3 of the torchvision Bottleneck behind /root/reference/src/models/resnet_model.py:15 without the apply pass or its output
+tensor.  The bar is bit equality with the two-pass form (peclr_bn2d_apply, then the plain GEMM): the transform is the apply
+kernel's own expression, evaluated in the registers of the wave that splits the rows."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _table(k, seed):
+    g = torch.Generator().manual_seed(seed)
+    scale = torch.randn(k, generator=g) * 0.7 + 0.2          # both signs
+    shift = torch.randn(k, generator=g) * 0.5
+    return torch.stack([scale, shift]).contiguous().to(DEV)
+
+
+def _applied(capi, x2, ss):
+    m, k = x2.shape
+    x4 = x2.view(1, m, 1, k).permute(0, 3, 1, 2)               # NHWC rows as a channels_last tensor
+    return capi.bn2d_apply(x4, ss, relu=True).permute(0, 2, 3, 1).reshape(m, k)
+
+
+@pytest.mark.parametrize("m,n,k", [(6272, 256, 64), (3136, 512, 128), (1568, 1024, 256), (392, 2048, 512), (300, 128, 16),
+                                   (12544 + 37, 256, 64), (1000, 384, 32)])
+@pytest.mark.parametrize("with_stats", [False, True])
+def test_forward_gemm_with_the_layer_applied_in_the_row_split(m, n, k, with_stats):
+    from peclr_amd import _capi as capi
+
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) * torch.exp2(torch.randint(-4, 5, (m, 1), generator=g).float())).to(DEV)
+    bt = (torch.randn(n, k, generator=g) * 0.05).to(DEV)
+    ss = _table(k, k)
+    y = _applied(capi, x, ss)
+    # the apply kernel itself: one fused multiply-add in fp32, then the rectifier
+    fma = torch.clamp_min((x.double() * ss[0].double() + ss[1].double()), 0).float()
+    assert float((y - fma).abs().max()) <= 1e-6 * float(fma.abs().max())
+    planes = capi.X6Planes([(bt, False)]).pack().planes[0]
+    shift = (torch.randn(n, generator=g) * 0.1).to(DEV) if with_stats else None
+    for tile_rows in (0, 128, 256):
+        want = capi.gemm_x6p(y, planes, n, tile_rows=tile_rows, stat_shift=shift)
+        got = capi.gemm_x6p(x, planes, n, tile_rows=tile_rows, stat_shift=shift, a_scale_shift=ss)
+        if with_stats:
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and got[2] == want[2], tile_rows
+        else:
+            assert torch.equal(got, want), tile_rows
+
+
+def test_forward_gemm_refuses_what_it_does_not_cover():
+    from peclr_amd import _capi as capi
+
+    x = torch.randn(256, 1024, device=DEV)
+    bt = torch.randn(128, 1024, device=DEV)
+    planes = capi.X6Planes([(bt, False)]).pack().planes[0]
+    with pytest.raises(capi.PeclrHipError):                    # K > 512: the table does not fit the workgroup's LDS corner
+        capi.gemm_x6p(x, planes, 128, a_scale_shift=_table(1024, 0))
+    x = torch.randn(256, 64, device=DEV)
+    planes = capi.X6Planes([(bt[:, :64].contiguous(), False)]).pack().planes[0]
+    with pytest.raises(capi.PeclrHipError):                    # with an addend: not this entry point
+        capi.gemm_x6p(x, planes, 128, addend=torch.zeros(256, 128, device=DEV), a_scale_shift=_table(64, 0))
+    with pytest.raises(capi.PeclrHipError):                    # a table of the wrong width
+        capi.gemm_x6p(x, planes, 128, a_scale_shift=_table(32, 0))
+
+
+@pytest.mark.parametrize("rows,cout,cin", [(8 * 56 * 56, 256, 64), (8 * 28 * 28, 512, 128), (8 * 14 * 14, 1024, 256),
+                                           (16 * 7 * 7, 2048, 512), (1000 + 8, 128, 64), (5000, 64, 256), (4096 + 4, 132, 64)])
+def test_weight_gradient_gemm_with_the_layer_applied_to_its_x_operand(rows, cout, cin):
+    from peclr_amd import _capi as capi
+
+    g = torch.Generator().manual_seed(rows + cout + cin)
+    gy = (torch.randn(rows, cout, generator=g) * 0.1).to(DEV)
+    x = torch.randn(rows, cin, generator=g).to(DEV)
+    ss = _table(cin, cin + 1)
+    want = capi.gemm_x6t(gy, _applied(capi, x, ss))
+    got = capi.gemm_x6t(gy, x, b_scale_shift=ss)
+    assert got.shape == (cout, cin) and torch.equal(got, want)
+    with pytest.raises(capi.PeclrHipError):
+        capi.gemm_x6t(gy, x, b_scale_shift=ss[:, :cin - 4].contiguous())
+
+
+def _bottleneck(width, seed):
+    from peclr_amd import bn2d as B
+    from peclr_amd.resnet import Bottleneck
+
+    torch.manual_seed(seed)
+    blk = Bottleneck(4 * width, width, norm_layer=B.FusedBatchNormAct2d).to(DEV).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, B.FusedBatchNormAct2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+                m.running_mean.uniform_(-0.1, 0.1)
+    B.enable_hip_batchnorm(blk)
+    return blk.train()
+
+
+def _run_block(blk, x, gy, **route):
+    from peclr_amd import _capi as capi
+    from peclr_amd import bn2d as B
+
+    x = x.clone().requires_grad_(True)
+    capi.EVENT_LOG = {}
+    try:
+        with B.routing(force=True, **route):
+            y = blk(x)
+            y.backward(gy)
+        torch.cuda.synchronize()
+        tags = {k: len(v) for k, v in capi.EVENT_LOG.items()}
+    finally:
+        capi.EVENT_LOG = None
+    B.end_backward()
+    grads = {n: p.grad.clone() for n, p in blk.named_parameters()}
+    bufs = {n: b.clone() for n, b in blk.named_buffers()}
+    return y.detach(), x.grad.clone(), grads, bufs, tags
+
+
+@pytest.mark.parametrize("width,hw,n", [(64, 56, 4), (128, 28, 8), (256, 14, 16), (512, 7, 32)])
+def test_bottleneck_is_bit_identical_with_and_without_the_apply_pass(width, hw, n):
+    """Forward output, input gradient, every parameter gradient and the running statistics of a training-mode Bottleneck
+    agree bit for bit between the two forms; the fused form launches one BatchNorm apply less and never writes bn2's output."""
+    a = _bottleneck(width, seed=width)
+    b = copy.deepcopy(a)
+    from peclr_amd import bn2d as B
+    B.enable_hip_batchnorm(b)                                   # (its own plane group)
+    g = torch.Generator().manual_seed(hw)
+    x = torch.randn(n, 4 * width, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, 4 * width, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    ya, dxa, ga, ba, tags_a = _run_block(a, x, gy, bn_apply_in_gemm=True)
+    yb, dxb, gb, bb, tags_b = _run_block(b, x, gy, bn_apply_in_gemm=False)
+    assert torch.equal(ya, yb) and torch.equal(dxa, dxb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+    for k in ba:
+        assert torch.equal(ba[k], bb[k]), k
+    assert tags_b["bn2d_apply"] - tags_a["bn2d_apply"] == 1, (tags_a, tags_b)
+    assert not torch.isnan(ya).any()
+
+
+def test_any_other_reader_gets_the_tensor_written_after_all():
+    """The placeholder a deferred layer returns is NaN under every index; a convolution that cannot apply the layer itself (here: a
+    3x3) has the tensor materialised (peclr_bn2d_apply on the finished table) and autograd flows through as if nothing happened."""
+    from peclr_amd import bn2d as B
+
+    torch.manual_seed(3)
+    bn = B.FusedBatchNormAct2d(64).to(DEV)
+    conv1 = B.Conv2d(64, 256, 1, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    conv3 = B.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    net = torch.nn.ModuleList([bn, conv1, conv3])
+    B.enable_hip_batchnorm(net)
+    net.train()
+    x = torch.randn(4, 64, 28, 28, device=DEV).contiguous(memory_format=torch.channels_last)
+
+    def run(consumer, reader, deferred):
+        for p in net.parameters():
+            p.grad = None
+        xx = x.clone().requires_grad_(True)
+        with B.routing(force=True, bn_apply_in_gemm=deferred):
+            h = bn(xx, None, True, consumer=consumer)
+            assert (getattr(h, "_peclr_deferred", None) is not None) == deferred
+            if deferred:
+                assert torch.isnan(h).all() and h.shape == x.shape
+            y = reader(h, sole_consumer=True)
+            y.square().sum().backward()
+        B.end_backward()
+        return y.detach(), xx.grad.clone(), [p.grad.clone() for p in net.parameters() if p.grad is not None]
+
+    for reader in (conv3, conv1):
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+        y1, dx1, g1 = run(conv1, reader, True)
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+        y0, dx0, g0 = run(conv1, reader, False)
+        assert torch.equal(y1, y0) and torch.equal(dx1, dx0) and len(g1) == len(g0) == 3
+        for u, v in zip(g1, g0):
+            assert torch.equal(u, v)
