@@ -423,6 +423,13 @@ int peclr_bn2d_bwd_finalize_totals_f32(const double* local_totals, const double*
 int peclr_bn2d_apply(const void* x, const void* residual, int io_dtype, int R, int C,
                      const float* scale_shift, int relu, void* y, uint32_t* relu_mask,
                      peclr_stream_t stream);
+/* The last pass of a layer's FIRST block, whose shortcut is conv1x1 -> BatchNorm2d (torchvision Bottleneck.downsample behind
+ * resnet_model.py:15): y = (relu)(bn(x) + bn_s(res_x)).  res_x is the INPUT of the shortcut's BatchNorm, res_scale_shift its
+ * [2][C] table; the residual is fmaf(res_x, scale, shift) rounded to the storage format -- the value peclr_bn2d_apply would
+ * have written and this pass read back, so the result is bit-identical -- and the shortcut's apply pass and output tensor
+ * disappear.  relu_mask as in peclr_bn2d_apply.                                                                            */
+int peclr_bn2d_apply_res_bn(const void* x, const void* res_x, const float* res_scale_shift, int io_dtype, int R, int C,
+                            const float* scale_shift, int relu, void* y, uint32_t* relu_mask, peclr_stream_t stream);
 int peclr_bn2d_bwd_reduce(const void* dy, const void* x, const void* y, const uint32_t* relu_mask,
                           int io_dtype, int R, int C, int relu, const float* save_mean,
                           const float* save_invstd, const float* scale_shift, float* partial,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "peclr_bn2d_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P,
                                         _P, _P, _P]),
     "peclr_bn2d_apply": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
+    "peclr_bn2d_apply_res_bn": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
     "peclr_bn2d_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "peclr_bn2d_bwd_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_bn2d_bwd_apply": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
@@ -1135,8 +1136,10 @@ def bn2d_apply(x, ss, relu: bool = True):
 
 
 def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, relu,
-             want_mask=False, sync_group=None, sync_shift=None, pre=None, apply=True):
+             want_mask=False, sync_group=None, sync_shift=None, pre=None, apply=True, residual_bn=None):
     """want_mask: also write the 1-bit ReLU mask ([R, C/32] int32) the backward reads instead of y.
+    residual_bn = (x_s, scale_shift_s) instead of `residual`: the residual is the output of the shortcut's BatchNorm2d, which
+    was not written -- this pass computes it from that layer's input and table (peclr_bn2d_apply_res_bn).
     sync_group: a process group -> training statistics are those of the rows of ALL its ranks
     (mean/var of the global batch, as one device holding the concatenated batch would compute)."""
     n, c, h, w = x.shape
@@ -1151,6 +1154,15 @@ def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training,
         return None, save, ss, None
     y = torch.empty_like(x, memory_format=torch.channels_last)
     mask = torch.empty((r, c // 32), device=dev, dtype=torch.int32) if (want_mask and relu and c % 32 == 0) else None
+    if residual_bn is not None:
+        xs, ss_s = residual_bn
+        if residual is not None or tuple(xs.shape) != tuple(x.shape) or ss_s.numel() != 2 * c or ss_s.dtype != torch.float32:
+            raise PeclrHipError("bn2d_fwd: residual_bn = (input of the shortcut's BatchNorm, its fp32 [2, C] table), no residual tensor")
+        with _timed("bn2d_apply", 3 * e * r * c + (r * c // 8 if mask is not None else 0)):
+            rc = lib().peclr_bn2d_apply_res_bn(xp, _nhwc_ptr(xs, "bn2d shortcut x", x.dtype), ss_s.data_ptr(), io, r, c, ss.data_ptr(),
+                                               int(relu), y.data_ptr(), mask.data_ptr() if mask is not None else None, _stream())
+        _check(rc, "peclr_bn2d_apply_res_bn")
+        return y, save, ss, mask
     with _timed("bn2d_apply", (3 if residual is not None else 2) * e * r * c + (r * c // 8 if mask is not None else 0)):
         rc = lib().peclr_bn2d_apply(xp, _nhwc_ptr(residual, "bn2d residual", x.dtype) if residual is not None else None,
                                     io, r, c, ss.data_ptr(), int(relu), y.data_ptr(),

@@ -128,6 +128,8 @@ class Routing:
     # measured on one box (C2, fp32) the sixteen saved passes are worth 0.60 ms, the longer row splits of the GEMMs that absorb them
     # cost 1.05 ms (their k-steps are latency chains: load -> split -> LDS -> barrier), 53.9 against 53.2 ms per step
     bn_apply_in_gemm: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_BN_APPLY_IN_GEMM", "0"))
+    # the shortcut's BatchNorm (conv1x1 -> bn of a layer's first block) applied inside the block's last pass (bn3 + shortcut + ReLU)
+    bn_shortcut_in_add: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_BN_SHORTCUT_IN_ADD"))
     x6_layer1: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_X6_LAYER1"))          # layer1's 64-channel 1x1 convolutions in-tree
     x6_layer1_fork: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_X6_LAYER1_FORK"))   # layer1's fused entry gradient (K = 64)
     x6_layer1_wgrad: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_X6_LAYER1_WGRAD"))  # layer1's 64-wide weight gradients
@@ -284,23 +286,27 @@ def _h_ok(conv, x: Tensor) -> bool:
 
 class _BN2dAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool, pre=None, link=None, lazy_res=False, defer=None):
+    def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool, pre=None, link=None, lazy_res=False, defer=None,
+                res_deferred=None):
         """link: None or an empty list that receives what a consumer's input-gradient GEMM needs to perform this layer's
         backward reduction in its epilogue: [x, save, scale_shift, relu mask or None, relu, token].
         defer: None, or an empty list -- the layer (plain BatchNorm + ReLU) only finishes its statistics; the list comes back
         as [x, scale_shift] and the result is a placeholder (`_deferred_view`) whose consumer applies the layer in its own
-        operand path (`Conv2d.forward`), or materialises it (`_Materialize`)."""
+        operand path (`Conv2d.forward`), or materialises it (`_Materialize`).
+        res_deferred: None, or (x_s, scale_shift_s, False) -- `residual` is the placeholder of the shortcut's BatchNorm layer (no
+        ReLU), which left its apply pass to THIS pass: the residual is computed from that layer's input on the fly."""
         training = bn.training or not bn.track_running_stats
         # the ReLU mask can be recomputed from x unless a residual was added before it; then the
         # forward writes a 1-bit mask (or, for C % 32 != 0, the backward re-reads y)
         need_mask = relu and residual is not None
         rm, rv, nbt, shift = bn._stat_buffers(training)
-        y, save, ss, mask = _capi.bn2d_fwd(x, residual, weight, bias, rm, rv, nbt, training, bn.eps,
+        y, save, ss, mask = _capi.bn2d_fwd(x, None if res_deferred is not None else residual, weight, bias, rm, rv, nbt, training, bn.eps,
                                            bn.momentum if bn.momentum is not None else 0.1, relu, want_mask=need_mask,
                                            sync_group=bn.sync_group if training else None, sync_shift=shift,
-                                           pre=pre if training else None, apply=defer is None)
+                                           pre=pre if training else None, apply=defer is None,
+                                           residual_bn=res_deferred[:2] if res_deferred is not None else None)
         if defer is not None:
-            defer[:] = [x, ss]
+            defer[:] = [x, ss, relu]
             y = _deferred_view(x)
         keep = mask if mask is not None else (y if need_mask else None)
         ctx.save_for_backward(x, save, ss, *([keep] if keep is not None else []))
@@ -336,7 +342,7 @@ class _BN2dAct(torch.autograd.Function):
             dres = _lazy_grad(("mask", dy, mask), x.shape, x.device, x.dtype)
         elif has_res and dres is None and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
 def _deferred_view(x: Tensor) -> Tensor:
@@ -354,8 +360,8 @@ class _Materialize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, placeholder, deferred):
-        x, ss = deferred
-        return _capi.bn2d_apply(x, ss, relu=True)
+        x, ss, relu = deferred
+        return _capi.bn2d_apply(x, ss, relu=relu)
 
     @staticmethod
     def backward(ctx, gy):
@@ -629,7 +635,7 @@ class _Conv1x1Gemm(torch.autograd.Function):
         gradient's); needs use_fwd and packed planes (`Conv2d._takes_deferred`)."""
         ss = None
         if deferred is not None:
-            x, ss = deferred                                  # (the graph edge stays on the placeholder; these are plain tensors)
+            x, ss = deferred[:2]                              # (the graph edge stays on the placeholder; these are plain tensors)
             x = x.detach()
         ctx.save_for_backward(x, weight, *([ss] if ss is not None else []))
         planes = _x6_planes(conv) if (use_fwd or use_bwd) else None
@@ -1129,7 +1135,7 @@ class Conv2d(nn.Conv2d):
         if deferred is not None:
             # x stands for relu(bn(x_bn)), not written: this GEMM applies the layer as it splits the rows of x_bn -- or the
             # tensor is written after all
-            if self._takes_deferred(deferred[0]):
+            if deferred[2] and self._takes_deferred(deferred[0]):
                 grad = torch.is_grad_enabled() and x.requires_grad
                 rows = x.shape[0] * x.shape[2] * x.shape[3]
                 use_bwd = _x6_pays(rows, self.in_channels, self.out_channels) and grad
@@ -1390,10 +1396,19 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
                 shift = self.running_mean.detach().clone()
         return self.running_mean, self.running_var, self.num_batches_tracked, shift
 
+    def _takes_deferred_residual(self, x: Tensor) -> bool:
+        """Can this layer's pass compute the shortcut's BatchNorm itself (peclr_bn2d_apply_res_bn)?  The plain fused pass only
+        (not the stem's pooled form, not layer4's average-pooled tail)."""
+        return bool(ROUTING.bn_shortcut_in_add and self.hip and self.affine and x.is_cuda and x.dim() == 4
+                    and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+                    and not (self.tail_avgpool and self.num_features % 32 == 0) and not self.default_pool)
+
     def forward(self, x: Tensor, residual: Optional[Tensor] = None, relu: Optional[bool] = None, consumer=None) -> Tensor:
-        """consumer: the Conv2d that is the ONLY reader of the result (bn2 -> conv3 inside a Bottleneck).  Where that
-        convolution can apply this layer in its own operand path (`Conv2d._takes_deferred`), the layer only finishes its
-        statistics and returns a placeholder carrying `_peclr_deferred = [x, scale_shift]`: no apply pass, no output tensor."""
+        """consumer: the ONLY reader of the result.  A Conv2d (bn2 -> conv3 inside a Bottleneck) that can apply this layer in
+        its own operand path (`Conv2d._takes_deferred`), or -- for the BatchNorm of a shortcut (conv1x1 -> bn, no ReLU) -- the
+        block's last FusedBatchNormAct2d, which adds the shortcut in its own pass (`_takes_deferred_residual`): the layer then only
+        finishes its statistics and returns a placeholder carrying `_peclr_deferred = [x, scale_shift, relu]`: no apply pass, no
+        output tensor.  A residual that is such a placeholder is computed on the fly (or materialised)."""
         relu = self.default_relu if relu is None else relu
         pool = self.default_pool and relu and residual is None
         if self.hip:
@@ -1404,6 +1419,13 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
             if pre is not None and (pre[3] is not self or not (self.training or not self.track_running_stats)):
                 pre = None
             pre = pre[:3] if pre is not None else None
+            # a residual that is the placeholder of the shortcut's BatchNorm: computed inside this layer's pass, or written after all
+            res_deferred = getattr(residual, "_peclr_deferred", None) if residual is not None else None
+            if res_deferred is not None:
+                res_deferred = tuple(res_deferred)
+                if (res_deferred[2] or not self._takes_deferred_residual(x) or res_deferred[0].shape != x.shape
+                        or res_deferred[0].dtype != x.dtype):
+                    residual, res_deferred = _materialized(residual, res_deferred), None
             if pool:
                 return _BN2dReluPool.apply(x, self.weight, self.bias, self, pre)
             if self.tail_avgpool and relu and residual is not None and self.num_features % 32 == 0:
@@ -1411,9 +1433,13 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
             link = [] if (ROUTING.bn_bwd_in_gemm and torch.is_grad_enabled() and x.requires_grad) else None
             lazy_res = (ROUTING.lazy_residual_grad and relu and residual is not None and getattr(residual, "_peclr_compact_ok", False)
                         and torch.is_grad_enabled() and residual.requires_grad and self.num_features % 32 == 0)
-            defer = ([] if (consumer is not None and relu and residual is None and isinstance(consumer, Conv2d)
-                            and consumer._takes_deferred(x)) else None)
-            y = _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre, link, lazy_res, defer)
+            defer = None
+            if consumer is not None and residual is None:
+                if relu and isinstance(consumer, Conv2d) and consumer._takes_deferred(x):
+                    defer = []
+                elif not relu and isinstance(consumer, FusedBatchNormAct2d) and consumer._takes_deferred_residual(x):
+                    defer = []
+            y = _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre, link, lazy_res, defer, res_deferred)
             if link:
                 y._peclr_bn_link = link
             if defer:

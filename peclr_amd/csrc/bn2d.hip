@@ -53,6 +53,7 @@ template <> struct Word<float> {
     static __device__ __forceinline__ void store(float* p, const Fv<4>& a) {
         *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
     }
+    static __device__ __forceinline__ float round(float f) { return f; }       // the value a store + load would hand back
 };
 typedef uint16_t bf16_t;
 template <> struct Word<bf16_t> {
@@ -90,6 +91,7 @@ template <> struct Word<bf16_t> {
         for (int k = 0; k < 4; ++k) w[k] = rne(a.v[2 * k]) | (rne(a.v[2 * k + 1]) << 16);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    static __device__ __forceinline__ float round(float f) { return __uint_as_float(rne(f) << 16); }
 };
 // fp16 activations (the reference's default precision=16 = native AMP): same 8-per-word geometry as bf16
 typedef _Float16 f16_t;
@@ -117,6 +119,7 @@ template <> struct Word<f16_t> {
         for (int k = 0; k < 8; ++k) t[k] = (_Float16)a.v[k];   // round to nearest even; overflow -> inf (GradScaler's job)
         *reinterpret_cast<f16x8*>(p) = t;
     }
+    static __device__ __forceinline__ float round(float f) { return (float)(_Float16)f; }
 };
 // per-channel fp32 parameters: W consecutive floats
 template <int W> __device__ __forceinline__ Fv<W> loadp(const float* p) {
@@ -474,14 +477,20 @@ __device__ __forceinline__ unsigned mask_load(const unsigned* __restrict__ mask,
     return (mask[(size_t)row * (C / 32) + col / 32] >> ((threadIdx.x % LPW) * W)) & ((1u << W) - 1u);
 }
 
-template <typename IO, bool RES, bool RELU>
+// RES: 0 no residual; 1 a residual tensor; 2 `res` is the INPUT of the shortcut's BatchNorm2d (the downsample branch of a
+// layer's first block: conv1x1 -> bn, torchvision Bottleneck.downsample behind resnet_model.py:15) and res_ss its [2][C] scale /
+// shift: the residual is fmaf(res, scale, shift) rounded to the storage format -- the value peclr_bn2d_apply would have written
+// and this pass read back -- so that layer's apply pass and its output tensor disappear
+template <typename IO, int RES, bool RELU>
 __global__ __launch_bounds__(T) void bn2d_apply_kernel(const IO* __restrict__ x, const IO* __restrict__ res, Geo g,
                                                        const float* __restrict__ scale_shift, IO* __restrict__ y,
-                                                       unsigned* __restrict__ relu_mask) {
+                                                       unsigned* __restrict__ relu_mask, const float* __restrict__ res_ss) {
     constexpr int W = Word<IO>::W, U = Word<IO>::U;
     int col, r0, r1, rl;
     thread_geo<W>(g, col, r0, r1, rl);
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
+    Fv<W> rsc = sc, rsh = sh;
+    if (RES == 2) { rsc = loadp<W>(res_ss + col); rsh = loadp<W>(res_ss + g.C + col); }
     auto emit = [&](int row, const Fv<W>& v, const Fv<W>& w) {
         const size_t o = (size_t)row * g.C + col;
         Fv<W> t;
@@ -489,7 +498,8 @@ __global__ __launch_bounds__(T) void bn2d_apply_kernel(const IO* __restrict__ x,
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             float a = fmaf(v.v[k], sc.v[k], sh.v[k]);
-            if (RES) a += w.v[k];
+            if (RES == 1) a += w.v[k];
+            if (RES == 2) a += Word<IO>::round(fmaf(w.v[k], rsc.v[k], rsh.v[k]));
             if (RELU) bits |= (a > 0.f ? 1u : 0u) << k;
             t.v[k] = RELU ? fmaxf(a, 0.f) : a;
         }
@@ -983,14 +993,16 @@ inline bool all_aligned(std::initializer_list<const void*> ps) {
 
 template <typename IO>
 void launch_apply(const Plan& p, hipStream_t s, const void* x, const void* res, const float* ss, int relu, void* y,
-                  unsigned* mask) {
+                  unsigned* mask, const float* res_ss = nullptr) {
     const IO* xp = static_cast<const IO*>(x);
     const IO* rp = static_cast<const IO*>(res);
     IO* yp = static_cast<IO*>(y);
-    if (res && relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, true, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask);
-    else if (res) hipLaunchKernelGGL((bn2d_apply_kernel<IO, true, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask);
-    else if (relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, false, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask);
-    else hipLaunchKernelGGL((bn2d_apply_kernel<IO, false, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask);
+    if (res && res_ss && relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 2, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss);
+    else if (res && res_ss) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 2, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss);
+    else if (res && relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 1, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss);
+    else if (res) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 1, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss);
+    else if (relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 0, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss);
+    else hipLaunchKernelGGL((bn2d_apply_kernel<IO, 0, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss);
 }
 
 inline int mask_mode(int relu, const void* y, const void* mask) { return !relu ? 0 : (mask ? 3 : (y ? 2 : 1)); }
@@ -1106,6 +1118,20 @@ extern "C" int peclr_bn2d_apply(const void* x, const void* residual, int io_dtyp
     if (!all_aligned({x, y, scale_shift, residual})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     PECLR_IO_SWITCH(io_dtype, launch_apply<IO>(p, s, x, residual, scale_shift, relu, y, relu_mask));
+    return launch_status();
+}
+
+// y = (relu)(bn(x) + bn_s(res_x)): the last pass of a layer's FIRST block, whose shortcut is conv1x1 -> BatchNorm2d.  res_x is
+// that BatchNorm's input, res_scale_shift its [2][C] table; the shortcut's own apply pass and output tensor are not needed.
+extern "C" int peclr_bn2d_apply_res_bn(const void* x, const void* res_x, const float* res_scale_shift, int io_dtype, int R, int C,
+                                       const float* scale_shift, int relu, void* y, uint32_t* relu_mask, peclr_stream_t stream) {
+    if (!x || !res_x || !res_scale_shift || !scale_shift || !y) return PECLR_ERR_NULL;
+    Plan p;
+    if (!plan_for(io_dtype, R, C, 0, p)) return PECLR_ERR_SHAPE;
+    if (relu_mask && (C % 32 || !relu)) return PECLR_ERR_SHAPE;
+    if (!all_aligned({x, y, scale_shift, res_x, res_scale_shift})) return PECLR_ERR_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PECLR_IO_SWITCH(io_dtype, launch_apply<IO>(p, s, x, res_x, scale_shift, relu, y, relu_mask, res_scale_shift));
     return launch_status();
 }
 

@@ -40,7 +40,7 @@ def _bn(bn, x, residual=None, relu=False, consumer=None):
     three ops otherwise (any other norm_layer).  consumer: the convolution that is the only reader of the result (it may
     then apply the layer in its own operand path instead: FusedBatchNormAct2d.forward)."""
     if isinstance(bn, FusedBatchNormAct2d):
-        return bn(x, residual, relu, consumer=consumer if isinstance(consumer, Conv2d) else None)
+        return bn(x, residual, relu, consumer=consumer if isinstance(consumer, (Conv2d, FusedBatchNormAct2d)) else None)
     y = bn(x)
     if residual is not None:
         y = y + residual
@@ -66,7 +66,11 @@ class BasicBlock(nn.Module):
         return checkpoint_block(self._run, x) if self.checkpoint else self._run(x)
 
     def _run(self, x: Tensor) -> Tensor:
-        identity = x if self.downsample is None else self.downsample(x)
+        ds = self.downsample
+        if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[1], FusedBatchNormAct2d):
+            identity = _bn(ds[1], ds[0](x), consumer=self.bn2)                 # (its apply is left to bn2's pass, the only reader)
+        else:
+            identity = x if ds is None else ds(x)
         # x feeds conv1 AND the shortcut: conv1's input gradient is only one of the two terms of x's gradient
         out = _bn(self.bn1, _conv(self.conv1, x, self.bn1, sole_consumer=False), relu=True)
         return _bn(self.bn2, _conv(self.conv2, out, self.bn2, sole_consumer=True), identity, relu=True)
@@ -100,7 +104,8 @@ class Bottleneck(nn.Module):
         if self.downsample is not None:
             ds = self.downsample
             if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[1], FusedBatchNormAct2d):
-                identity = _bn(ds[1], _conv(ds[0], identity, ds[1]))      # (conv -> bn: statistics from the GEMM where in-tree)
+                # (conv -> bn: statistics from the GEMM where in-tree; the apply is left to bn3's pass, the only reader)
+                identity = _bn(ds[1], _conv(ds[0], identity, ds[1]), consumer=self.bn3)
             else:
                 identity = ds(identity)
         out = _bn(self.bn1, out, relu=True)
