@@ -40,18 +40,49 @@ constexpr int T = 256;
 // ---- W floats held in registers + the 16-byte global word they travel as
 template <int W> struct Fv { float v[W]; };
 
+// every activation word of the streaming kernels travels through these two.  PECLR_BN2D_NT (compile time; A/B builds): bit 0 = loads,
+// bit 1 = stores carry the non-temporal hint.  Loads do by default: a linear read of 822 MB runs at 6.8 TB/s with the hint and at 4.3
+// without (tools/exp/rw_mix.hip, cold caches); in the step `bn2d_apply` 96 -> 86 us, `bn2d_bwd_apply` 118 -> 110, `bn2d_bwd_reduce`
+// 158 -> 122 (same box, C2 fp32).  Stores gain nothing (5.2 - 5.5 TB/s either way; the consumer finds the tail of the tensor in the
+// memory-side cache).  The pooled stem kernels re-read rows across windows and LOSE with the hint (283 -> 380 us): `Quad` loads
+// stay plain.
+#ifndef PECLR_BN2D_NT
+#define PECLR_BN2D_NT 1
+#endif
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t ld128(const void* p) {
+#if PECLR_BN2D_NT & 1
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+#else
+    return *reinterpret_cast<const u32x4_t*>(p);
+#endif
+}
+__device__ __forceinline__ u32x4_t ld128_cached(const void* p) { return *reinterpret_cast<const u32x4_t*>(p); }   // rows read again soon
+__device__ __forceinline__ void st128(void* p, u32x4_t v) {
+#if PECLR_BN2D_NT & 2
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p));
+#else
+    *reinterpret_cast<u32x4_t*>(p) = v;
+#endif
+}
+
 template <typename IO> struct Word;
 template <> struct Word<float> {
     static constexpr int W = 4, U = 8;  // U = rows in flight per stream
     typedef float4 Raw;                 // the 16-byte word as it travels (kept raw while in flight: 4 registers)
-    static __device__ __forceinline__ Raw load_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ Raw load_raw(const float* p) {
+        const u32x4_t t = ld128(p);
+        return make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
+    }
     static __device__ __forceinline__ Fv<4> expand(const Raw& t) { return {{t.x, t.y, t.z, t.w}}; }
-    static __device__ __forceinline__ Fv<4> load(const float* p) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        return {{t.x, t.y, t.z, t.w}};
+    static __device__ __forceinline__ Fv<4> load(const float* p) { return expand(load_raw(p)); }
+    static __device__ __forceinline__ Fv<4> load_cached(const float* p) {
+        const u32x4_t t = ld128_cached(p);
+        return {{__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])}};
     }
     static __device__ __forceinline__ void store(float* p, const Fv<4>& a) {
-        *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+        const u32x4_t t = {__float_as_uint(a.v[0]), __float_as_uint(a.v[1]), __float_as_uint(a.v[2]), __float_as_uint(a.v[3])};
+        st128(p, t);
     }
     static __device__ __forceinline__ float round(float f) { return f; }       // the value a store + load would hand back
 };
@@ -59,7 +90,10 @@ typedef uint16_t bf16_t;
 template <> struct Word<bf16_t> {
     static constexpr int W = 8, U = 8;
     typedef uint4 Raw;
-    static __device__ __forceinline__ Raw load_raw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ Raw load_raw(const bf16_t* p) {
+        const u32x4_t t = ld128(p);
+        return make_uint4(t[0], t[1], t[2], t[3]);
+    }
     static __device__ __forceinline__ Fv<8> expand(const Raw& t) {
         const unsigned w[4] = {t.x, t.y, t.z, t.w};
         Fv<8> r;
@@ -70,16 +104,10 @@ template <> struct Word<bf16_t> {
         }
         return r;
     }
-    static __device__ __forceinline__ Fv<8> load(const bf16_t* p) {
-        const uint4 t = *reinterpret_cast<const uint4*>(p);
-        const unsigned w[4] = {t.x, t.y, t.z, t.w};
-        Fv<8> r;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            r.v[2 * k] = __uint_as_float(w[k] << 16);
-            r.v[2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u);
-        }
-        return r;
+    static __device__ __forceinline__ Fv<8> load(const bf16_t* p) { return expand(load_raw(p)); }
+    static __device__ __forceinline__ Fv<8> load_cached(const bf16_t* p) {
+        const u32x4_t t = ld128_cached(p);
+        return expand(make_uint4(t[0], t[1], t[2], t[3]));
     }
     static __device__ __forceinline__ unsigned rne(float f) {  // fp32 -> bf16, round to nearest even
         const unsigned u = __float_as_uint(f);
@@ -89,7 +117,8 @@ template <> struct Word<bf16_t> {
         unsigned w[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) w[k] = rne(a.v[2 * k]) | (rne(a.v[2 * k + 1]) << 16);
-        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+        const u32x4_t t = {w[0], w[1], w[2], w[3]};
+        st128(p, t);
     }
     static __device__ __forceinline__ float round(float f) { return __uint_as_float(rne(f) << 16); }
 };
@@ -99,25 +128,20 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <> struct Word<f16_t> {
     static constexpr int W = 8, U = 8;
     typedef f16x8 Raw;
-    static __device__ __forceinline__ Raw load_raw(const f16_t* p) { return *reinterpret_cast<const f16x8*>(p); }
+    static __device__ __forceinline__ Raw load_raw(const f16_t* p) { return __builtin_bit_cast(f16x8, ld128(p)); }
     static __device__ __forceinline__ Fv<8> expand(const Raw& t) {
         Fv<8> r;
 #pragma unroll
         for (int k = 0; k < 8; ++k) r.v[k] = (float)t[k];
         return r;
     }
-    static __device__ __forceinline__ Fv<8> load(const f16_t* p) {
-        const f16x8 t = *reinterpret_cast<const f16x8*>(p);
-        Fv<8> r;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) r.v[k] = (float)t[k];
-        return r;
-    }
+    static __device__ __forceinline__ Fv<8> load(const f16_t* p) { return expand(load_raw(p)); }
+    static __device__ __forceinline__ Fv<8> load_cached(const f16_t* p) { return expand(__builtin_bit_cast(f16x8, ld128_cached(p))); }
     static __device__ __forceinline__ void store(f16_t* p, const Fv<8>& a) {
         f16x8 t;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t[k] = (_Float16)a.v[k];   // round to nearest even; overflow -> inf (GradScaler's job)
-        *reinterpret_cast<f16x8*>(p) = t;
+        st128(p, __builtin_bit_cast(u32x4_t, t));
     }
     static __device__ __forceinline__ float round(float f) { return (float)(_Float16)f; }
 };
@@ -145,7 +169,10 @@ template <int W> __device__ __forceinline__ Fv<W> zero() {
 // is set by the number of words in flight, not by the width of one (bn2d_pool_bwd_apply: four candidate windows per element).
 template <typename IO> struct Quad;
 template <> struct Quad<float> {
-    static __device__ __forceinline__ Fv<4> load(const float* p) { return Word<float>::load(p); }
+    static __device__ __forceinline__ Fv<4> load(const float* p) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        return {{t.x, t.y, t.z, t.w}};
+    }
     static __device__ __forceinline__ void store(float* p, const Fv<4>& a) { Word<float>::store(p, a); }
 };
 template <> struct Quad<bf16_t> {
@@ -810,7 +837,7 @@ __global__ __launch_bounds__(T) void bn2d_pool_apply_kernel(const IO* __restrict
             for (int dw = 0; dw < 3; ++dw) {
                 const int w = 2 * pw - 1 + dw;
                 if (w < 0 || w >= g.Wd) continue;
-                const Fv<W> v = Word<IO>::load(x + (((size_t)n * g.H + h) * g.Wd + w) * g.C + col);
+                const Fv<W> v = Word<IO>::load_cached(x + (((size_t)n * g.H + h) * g.Wd + w) * g.C + col);   // (nine windows share a pixel)
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
                     const float t = fmaxf(fmaf(v.v[k], sc.v[k], sh.v[k]), 0.f);

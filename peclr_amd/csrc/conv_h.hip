@@ -93,6 +93,13 @@ __device__ __forceinline__ void hdma16(const void* src, unsigned lds_byte_offset
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                  :: "v"(src), "s"(lds_byte_offset) : "memory", "m0");
 }
+#ifndef PECLR_CONVH_NT          // A/B builds: bit 0 = the activation rows of the 1x1 products are fetched with the non-temporal hint
+#define PECLR_CONVH_NT 0
+#endif
+__device__ __forceinline__ void hdma16_nt(const void* src, unsigned lds_byte_offset) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
+                 :: "v"(src), "s"(lds_byte_offset) : "memory", "m0");
+}
 
 // ... the same with a wave-uniform 64-bit base (scalar registers) + a 32-bit lane offset + an immediate: no vector arithmetic
 // per request.  The instruction's immediate offset is added to the global address AND to the LDS address (M0 + offset +
@@ -278,6 +285,10 @@ __global__ __launch_bounds__(256, (WM == 1 && RING == 0) ? ((EP & 2) ? 3 : 4) : 
         for (int c = 0; c < NA; ++c) {
             const h16_t* src = asrc[c] + off;
             if constexpr (TAPS == 9) src = (tapmask[c] >> tap) & 1u ? src : zsrc;
+#if PECLR_CONVH_NT & 1
+            if constexpr (TAPS == 1) hdma16_nt(src, st + (wave_s * RM + 16 * c) * 64);
+            else
+#endif
             hdma16(src, st + (wave_s * RM + 16 * c) * 64);
         }
     };

@@ -33,6 +33,9 @@ namespace {
 typedef uint16_t bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef PECLR_X6P_NT            // A/B builds: bit 0 = the A rows of the 1x1 products, bit 1 = the epilogue's BatchNorm-x rows load with the non-temporal hint
+#define PECLR_X6P_NT 0
+#endif
 constexpr int PN = 128;                  // output columns per workgroup (and per packed chunk)
 constexpr int PK = 16;                   // k per step = one MFMA k-extent
 constexpr int CHUNK = 12 * 1024;         // bytes of packed B per (128 columns, 16 k)
@@ -274,7 +277,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         for (int c = 0; c < NRAW; ++c) {
             const float* src = asrc[c] + off;
             if constexpr (TAPS == 9) src = (tapmask[c] >> tap) & 1u ? src : zsrc;
-            if constexpr (AREG) ar[c] = *reinterpret_cast<const f32x4*>(src);
+            if constexpr (AREG) {
+#if PECLR_X6P_NT & 1
+                if constexpr (TAPS == 1) ar[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+                else
+#endif
+                ar[c] = *reinterpret_cast<const f32x4*>(src);
+            }
             else dma16(src, raw_a + c * 1024);
         }
     };
@@ -584,7 +593,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                     }
                 }
                 if (g.bb_partial && m < g.M) {
+#if PECLR_X6P_NT & 2
+                    xv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.bb_x + (size_t)om[a][jj] * g.N + nt + ec));
+#else
                     xv[jj] = *reinterpret_cast<const f32x4*>(g.bb_x + (size_t)om[a][jj] * g.N + nt + ec);
+#endif
                     mb[jj] = g.bb_mask ? g.bb_mask[(size_t)om[a][jj] * (g.N >> 5) + (nt >> 5)] >> ec : 0u;
                 }
             }

@@ -98,6 +98,10 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
             tsh = *reinterpret_cast<const f32x4*>(g.b_ss + g.N + n0 + col);
         }
     }
+    // rows that exactly ONE workgroup of a split reads (the operand whose other side fits one tile: both operands of layer1's
+    // 256 x 64 / 64 x 256 gradients) are loaded with the non-temporal hint: a linear read runs at 6.8 TB/s with it, 4.3 without
+    // (tools/exp/rw_mix.hip); `conv1x1_wgrad~hbm` 192 -> 180 us.  Rows several workgroups share keep the plain load (L2 reuse).
+    const bool once = is_a ? nct == 1 : (int)gridDim.x == nct;
     f32x4 ld4[PF][4];
     // GEO: pixel (oh, ow) of the first row of this thread's next block, advanced by 16 rows per k-step (no divisions in
     // the loop); gload() is called with t = 0, 1, 2, ... in order
@@ -120,7 +124,8 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
                 if (++ow == g.W) { ow = 0; oh = oh + 1 == g.H ? 0 : oh + 1; }
             }
             p = ok ? p : g.zeros;
-            ld4[q] = *reinterpret_cast<const f32x4*>(p);
+            if (once) ld4[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+            else ld4[q] = *reinterpret_cast<const f32x4*>(p);
         }
         if constexpr (GEO) {
             ow_t += TK;

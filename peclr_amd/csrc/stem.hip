@@ -335,7 +335,7 @@ struct StemWArgs {
     float* slabs;                         // [gridDim.x][64][224]
     int N, Hin, Win, Ho, Wo, tiles_w;
     long long tiles;
-    int abl;                              // experiments (PECLR_STEM_WGRAD_ABL): 1 no dY loads, 2 no dY stores, 4 no gathers, 8 no products, 16 no patch
+    int abl;                              // experiments (PECLR_STEM_WGRAD_ABL): 1 no dY loads, 2 no dY stores, 4 no gathers, 8 no products, 16 no patch, 32 dY loads non-temporal
 };
 
 // eight 16-bit values at addr + OFF + 16 e, each zero-extended into its own register (gfx950 runs with SRAM-ECC: its d16 loads
@@ -445,7 +445,13 @@ __global__ __launch_bounds__(256, F::NP == 3 ? 2 : 3) void stem_wgrad_kernel(Ste
             const size_t row = row0 + (live ? ow0 + p : 0);
             const uint4* src = NP == 3 ? reinterpret_cast<const uint4*>(static_cast<const float*>(g.dy) + row * 64 + 4 * grp)
                                        : reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(g.dy) + row * 64 + 8 * grp);
-            dyr[u] = (live && !(g.abl & 1)) ? *src : make_uint4(0u, 0u, 0u, 0u);
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            if (live && !(g.abl & 1)) {
+                if (g.abl & 32) {                         // (A/B: every dY row is read exactly once -- with the non-temporal hint)
+                    const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src));
+                    dyr[u] = make_uint4(t[0], t[1], t[2], t[3]);
+                } else dyr[u] = *src;
+            } else dyr[u] = make_uint4(0u, 0u, 0u, 0u);
         }
     };
     auto stage_store = [&](int st, const Rgb (&px)[NLD], const uint4 (&dyr)[NDY]) {

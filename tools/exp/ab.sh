@@ -4,7 +4,7 @@ ARGS=$1; TAGS=${2//,/ }; shift 2
 mkdir -p gpurun_out/ab
 for rep in 1 2; do
   for set in "$@"; do
-    name=$(echo "$set" | tr ',=' '__')
+    name=$(echo "$set" | tr ',=/' '___' | tail -c 40)
     envs=""; [ "$set" != "-" ] && envs=$(echo "$set" | tr ',' ' ')
     env $envs python bench.py $ARGS --no-cpu-baseline > gpurun_out/ab/${name}_$rep.log 2>/dev/null
     python tools/exp/ab_line.py gpurun_out/ab/${name}_$rep.log $TAGS | grep -v "^    \(\[\|/\)" | head -12
