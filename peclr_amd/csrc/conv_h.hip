@@ -93,7 +93,9 @@ __device__ __forceinline__ void hdma16(const void* src, unsigned lds_byte_offset
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                  :: "v"(src), "s"(lds_byte_offset) : "memory", "m0");
 }
-#ifndef PECLR_CONVH_NT          // A/B builds: bit 0 = the activation rows of the 1x1 products are fetched with the non-temporal hint
+// A/B builds: bit 0 = the activation rows of 1x1 products with ONE column tile are fetched with the non-temporal hint.  Measured
+// slower (round 5, same box, bf16: conv1x1_dgrad 74 -> 82 us, conv1x1_fwd 70 -> 72): off
+#ifndef PECLR_CONVH_NT
 #define PECLR_CONVH_NT 0
 #endif
 __device__ __forceinline__ void hdma16_nt(const void* src, unsigned lds_byte_offset) {
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256, (WM == 1 && RING == 0) ? ((EP & 2) ? 3 : 4) : 
             const h16_t* src = asrc[c] + off;
             if constexpr (TAPS == 9) src = (tapmask[c] >> tap) & 1u ? src : zsrc;
 #if PECLR_CONVH_NT & 1
-            if constexpr (TAPS == 1) hdma16_nt(src, st + (wave_s * RM + 16 * c) * 64);
+            if (TAPS == 1 && nct == 1) hdma16_nt(src, st + (wave_s * RM + 16 * c) * 64);   // (no other workgroup reads these rows)
             else
 #endif
             hdma16(src, st + (wave_s * RM + 16 * c) * 64);

@@ -33,7 +33,10 @@ namespace {
 typedef uint16_t bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef PECLR_X6P_NT            // A/B builds: bit 0 = the A rows of the 1x1 products, bit 1 = the epilogue's BatchNorm-x rows load with the non-temporal hint
+// A/B builds: bit 0 = the A rows of 1x1 products with ONE column tile, bit 1 = the epilogue's BatchNorm-x rows load with the non-temporal
+// hint.  Measured neutral (round 5, same box: every tag within 1 us; on ALL A rows, shared ones included: + 1.5 ms per step): these
+// kernels are not bound by their read path -- unlike the streaming BatchNorm passes (bn2d.hip), where the hint is worth 8 - 23 %
+#ifndef PECLR_X6P_NT
 #define PECLR_X6P_NT 0
 #endif
 constexpr int PN = 128;                  // output columns per workgroup (and per packed chunk)
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
             if constexpr (TAPS == 9) src = (tapmask[c] >> tap) & 1u ? src : zsrc;
             if constexpr (AREG) {
 #if PECLR_X6P_NT & 1
-                if constexpr (TAPS == 1) ar[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+                if (TAPS == 1 && nct == 1) ar[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));   // (no other workgroup reads these rows)
                 else
 #endif
                 ar[c] = *reinterpret_cast<const f32x4*>(src);
