@@ -831,10 +831,15 @@ static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t str
     // CU instead of three (420 -> 394 us per launch in the step; the plain 1x1 products of the same shapes lose 5 %: not them)
     const bool narrow = g.N % PN != 0 || (taps == 1 && g.addend != nullptr && g.K <= 256 && g.stride == 1);
     const dim3 grid(8 * ((nrb + 7) / 8) * (narrow ? g.N / 64 : g.N / PN), taps == 9 && g.s2d ? 4 : 1);
+// (ILV: A/B'd again in round 5 -- with it hipcc groups each accumulator's six products and puts the split behind them, without it
+// products and split alternate; every tag of the step within 1 % either way: the waves sharing a SIMD hide a wave's own order)
+#ifndef PECLR_X6P_ILV
+#define PECLR_X6P_ILV true
+#endif
 #define PECLR_LAUNCH(WM_, TAPS_)                                                                                      \
     do {                                                                                                              \
-        if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, true, TAPS_, 2>), grid, dim3(256), 0, stream, g); \
-        else hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, true, TAPS_, 4>), grid, dim3(256), 0, stream, g);       \
+        if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, PECLR_X6P_ILV, TAPS_, 2>), grid, dim3(256), 0, stream, g); \
+        else hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, PECLR_X6P_ILV, TAPS_, 4>), grid, dim3(256), 0, stream, g);       \
     } while (0)
     if (taps == 9 && halo) {
         if (tile_rows == 256) {
