@@ -345,13 +345,16 @@ class _BN2dAct(torch.autograd.Function):
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
+_NAN_PLACEHOLDER = {}
+
+
 def _deferred_view(x: Tensor) -> Tensor:
     """Stands for relu(bn(x)) where that tensor is never written: NaN under every index (one element, zero strides), so that a
     reader that does not know the protocol cannot go unnoticed."""
-    ring = _NAN_RING.get((x.device, x.dtype))
-    if ring is None:
-        ring = _NAN_RING[(x.device, x.dtype)] = [torch.full((64,), float("nan"), device=x.device, dtype=x.dtype), 0]
-    return ring[0][63:64].view(1, 1, 1, 1).expand(x.shape)
+    nan = _NAN_PLACEHOLDER.get((x.device, x.dtype))      # (its own element: never the address of one of `_lazy_grad`'s sentinels)
+    if nan is None:
+        nan = _NAN_PLACEHOLDER[(x.device, x.dtype)] = torch.full((1,), float("nan"), device=x.device, dtype=x.dtype)
+    return nan.view(1, 1, 1, 1).expand(x.shape)
 
 
 class _Materialize(torch.autograd.Function):

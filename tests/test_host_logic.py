@@ -819,3 +819,27 @@ def test_side_channels_are_drained_by_the_autograd_engine_when_a_backward_pass_e
     assert B.last_backward_leftovers == 1
     B._drain_after_backward()                                     # outside a backward pass: nothing to queue on, no error
     assert not B._DRAIN_QUEUED
+
+
+def test_deferred_batchnorm_placeholder_and_who_may_take_it():
+    """The placeholder a BatchNorm layer returns when it leaves its apply pass to its consumer: NaN under every index, one element,
+    zero strides, never the address of a lazy-gradient sentinel; on a CPU tensor no consumer takes the hand-over (the layer then
+    writes its output as always)."""
+    import torch
+    from peclr_amd import bn2d as B
+
+    x = torch.zeros(2, 8, 4, 5)
+    v = B._deferred_view(x)
+    assert v.shape == x.shape and v.dtype == x.dtype and not any(v.stride()) and bool(torch.isnan(v).all())
+    g = B._lazy_grad(("s2", torch.zeros(1)), (2, 8, 4, 5), x.device)
+    try:
+        assert g.data_ptr() != v.data_ptr()
+    finally:
+        B._COMPACT.clear()
+    conv = B.Conv2d(8, 16, 1, bias=False)
+    bn = B.FusedBatchNormAct2d(8)
+    assert not conv._takes_deferred(x) and not bn._takes_deferred_residual(x)
+    with B.routing(bn_apply_in_gemm=True, bn_shortcut_in_add=True):
+        assert not conv._takes_deferred(x) and not bn._takes_deferred_residual(x)      # (no HIP tensors, layers not switched to the HIP kernels)
+    y = bn(x, None, True, consumer=conv)                       # stock path: a real tensor, no placeholder
+    assert not hasattr(y, "_peclr_deferred") and not torch.isnan(y).any()
