@@ -969,6 +969,84 @@ __global__ __launch_bounds__(T) void bn2d_pool_bwd_apply_kernel(const IO* __rest
     }
 }
 
+// 16-bit storage, EIGHT channels per lane (16-byte accesses: the four-channel form above issues as many memory instructions per
+// pixel as the fp32 instance does and takes as long for half the bytes -- 345 against 355 us at 256 x 112 x 112 x 64).  What kept that
+// form from working before was registers (130 VGPRs with everything expanded to fp32): here the four candidate windows stay
+// packed until they are added (4 registers each), and the six per-channel constants live in LDS, fetched through an index the
+// compiler cannot hoist.  C <= 512.
+template <typename IO>
+__global__ __launch_bounds__(T) void bn2d_pool_bwd_apply16_kernel(const IO* __restrict__ dyp, const IO* __restrict__ x,
+                                                                  const uint8_t* __restrict__ code, PoolGeo g,
+                                                                  const float* __restrict__ save_mean,
+                                                                  const float* __restrict__ save_invstd,
+                                                                  const float* __restrict__ scale_shift,
+                                                                  const float* __restrict__ coef, IO* __restrict__ dx) {
+    constexpr int W = 8;
+    typedef typename Word<IO>::Raw Raw;
+    __shared__ __attribute__((aligned(16))) float cst[6 * 512];     // [scale | shift | mean | invstd | c0 | c1][C]
+    for (int c = threadIdx.x; c < g.C; c += T) {
+        cst[c] = scale_shift[c]; cst[g.C + c] = scale_shift[g.C + c];
+        cst[2 * g.C + c] = save_mean[c]; cst[3 * g.C + c] = save_invstd[c];
+        cst[4 * g.C + c] = coef[c]; cst[5 * g.C + c] = coef[g.C + c];
+    }
+    __syncthreads();
+    const int cg = threadIdx.x % g.CW, pl = threadIdx.x / g.CW, col = cg * W;
+    const int per_image = g.H * g.Wd, span = g.PPB * 2 * kPoolIter;
+    const XcdSlot slot = xcd_slot((per_image + span - 1) / span, g.rev);
+    if (slot.n >= g.N) return;
+    const int n = slot.n;
+    for (int it = 0; it < 2 * kPoolIter; ++it) {
+        const int q = slot.run * span + it * g.PPB + pl;
+        if (q >= per_image) break;
+        const int w = q % g.Wd, h = q / g.Wd;
+        const long long r = (long long)n * per_image + q;
+        const u32x4_t xr = ld128_cached(x + (size_t)r * g.C + col);
+        const int phs[2] = {h >> 1, (h + 1) >> 1}, pws[2] = {w >> 1, (w + 1) >> 1};
+        u32x4_t gr[4];
+        unsigned cw[4][2];
+        unsigned mine[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ph = phs[i >> 1], pw = pws[i & 1];
+            const bool on = ph < g.PH && pw < g.PW && !((i >> 1) && phs[1] == phs[0]) && !((i & 1) && pws[1] == pws[0]);
+            mine[i] = (unsigned)(3 * (h - (2 * ph - 1)) + (w - (2 * pw - 1)));
+            const size_t p = on ? (((size_t)n * g.PH + ph) * g.PW + pw) * g.C + col : 0;
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            gr[i] = on ? ld128_cached(dyp + p) : z;
+            const uint2 cc = on ? *reinterpret_cast<const uint2*>(code + p) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            cw[i][0] = cc.x; cw[i][1] = cc.y;
+        }
+        Fv<W> d = zero<W>();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const Fv<W> gy = Word<IO>::expand(__builtin_bit_cast(Raw, gr[i]));
+#pragma unroll
+            for (int k = 0; k < W; ++k)
+                if (((cw[i][k >> 2] >> (8 * (k & 3))) & 255u) == mine[i]) d.v[k] += gy.v[k];
+        }
+        const Fv<W> v = Word<IO>::expand(__builtin_bit_cast(Raw, xr));
+        int colo = col;
+        asm volatile("" : "+v"(colo));                    // (the constants are re-read per pixel: 48 registers they do not occupy)
+        const float* cp = cst + colo;
+        Fv<W> o;
+#pragma unroll
+        for (int k4 = 0; k4 < W; k4 += 4) {
+            const float4 sc = *reinterpret_cast<const float4*>(cp + k4), sh = *reinterpret_cast<const float4*>(cp + g.C + k4);
+            const float4 mean = *reinterpret_cast<const float4*>(cp + 2 * g.C + k4), inv = *reinterpret_cast<const float4*>(cp + 3 * g.C + k4);
+            const float4 c0 = *reinterpret_cast<const float4*>(cp + 4 * g.C + k4), c1 = *reinterpret_cast<const float4*>(cp + 5 * g.C + k4);
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, mv[4] = {mean.x, mean.y, mean.z, mean.w};
+            const float iv[4] = {inv.x, inv.y, inv.z, inv.w}, c0v[4] = {c0.x, c0.y, c0.z, c0.w}, c1v[4] = {c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k4 + j;
+                const float dy = fmaf(v.v[k], scv[j], shv[j]) > 0.f ? d.v[k] : 0.f;
+                o.v[k] = fmaf(dy, scv[j], fmaf((v.v[k] - mv[j]) * iv[j], c1v[j], c0v[j]));
+            }
+        }
+        Word<IO>::store(dx + (size_t)r * g.C + col, o);
+    }
+}
+
 struct Plan {
     Geo g;
     dim3 grid;
@@ -1269,11 +1347,22 @@ extern "C" int peclr_bn2d_pool_bwd_apply(const void* dy_pool, const void* x, con
     PoolGeo g;
     if (!pool_geo(io_dtype, N, H, W, C, g)) return PECLR_ERR_SHAPE;
     if (!all_aligned({dy_pool, x, code, dx})) return PECLR_ERR_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static const int wide16 = getenv("PECLR_POOL_BWD16") ? atoi(getenv("PECLR_POOL_BWD16")) : 1;      // (0: the four-channel form, A/B)
+    if (wide16 && io_dtype != PECLR_DTYPE_F32 && C <= 512) {      // 16-bit storage: eight channels per lane (pool_geo's own geometry)
+        const int blocks16 = pool_blocks(g, H * W, 2 * kPoolIter);
+        if (io_dtype == PECLR_DTYPE_BF16)
+            hipLaunchKernelGGL((bn2d_pool_bwd_apply16_kernel<bf16_t>), dim3(blocks16), dim3(T), 0, s, static_cast<const bf16_t*>(dy_pool),
+                               static_cast<const bf16_t*>(x), code, g, save_mean, save_invstd, scale_shift, coef, static_cast<bf16_t*>(dx));
+        else
+            hipLaunchKernelGGL((bn2d_pool_bwd_apply16_kernel<f16_t>), dim3(blocks16), dim3(T), 0, s, static_cast<const f16_t*>(dy_pool),
+                               static_cast<const f16_t*>(x), code, g, save_mean, save_invstd, scale_shift, coef, static_cast<f16_t*>(dx));
+        return launch_status();
+    }
     if (C % 4 || C / 4 > T || T % (C / 4)) return PECLR_ERR_SHAPE;
     g.CW = C / 4;                 // this kernel moves four channels per lane whatever the storage type
     g.PPB = T / g.CW;
     const int blocks = pool_blocks(g, H * W, 2 * kPoolIter);
-    hipStream_t s = static_cast<hipStream_t>(stream);
     PECLR_IO_SWITCH(io_dtype, hipLaunchKernelGGL((bn2d_pool_bwd_apply_kernel<IO>), dim3(blocks), dim3(T), 0, s, static_cast<const IO*>(dy_pool),
                            static_cast<const IO*>(x), code, g, save_mean, save_invstd, scale_shift, coef,
                            static_cast<IO*>(dx)));
