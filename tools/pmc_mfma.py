@@ -44,7 +44,7 @@ EXPECT = {
     "lars_sumsq": "sumsq_kernel", "lars_adam_update": "lars_adam_kernel", "bn2d_stats": "bn2d_stats_kernel",
     "bn2d_finalize": "finalize", "bn2d_apply": "bn2d_apply_kernel", "bn2d_bwd_reduce": "bn2d_bwd_reduce_kernel",
     "bn2d_bwd_finalize": "finalize", "bn2d_bwd_apply": "bn2d_bwd_apply_kernel", "bn2d_pool_apply": "bn2d_pool_apply_kernel",
-    "bn2d_pool_bwd_reduce": "bn2d_pool_bwd_reduce_kernel", "bn2d_pool_bwd_apply": "bn2d_pool_bwd_apply_kernel",
+    "bn2d_pool_bwd_reduce": "bn2d_pool_bwd_reduce_kernel", "bn2d_pool_bwd_apply": ("bn2d_pool_bwd_apply_kernel", "bn2d_pool_bwd_apply16_kernel"),
     "bn2d_apply_avgpool": "bn2d_apply_avgpool_kernel", "bn2d_bwd_reduce_avgpool": "bn2d_bwd_reduce_kernel",
     "bn2d_bwd_apply_avgpool": "bn2d_bwd_apply_kernel",
 }
