@@ -100,6 +100,10 @@ def parse():
                          "around its collectives (Trainer.capture_split_graphs), falling back to eager on all ranks "
                          "if any rank's capture raises")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bf16-companion", type=int, default=1,
+                    help="fp32 runs at --gpus 1: after the fp32 measurement, and outside it, time the same K steps under --dtype bf16 "
+                         "in a child process and attach {ms_per_step, value, roofline} as `bf16_companion` (BASELINE configs C3 / C5 "
+                         "are bf16 configurations; 0 = skip)")
     ap.add_argument("--dry-dist", action="store_true",
                     help="form the process group (spawning the ranks if no launcher did), check that every rank is seen, "
                          "print {\"dry_dist\": ...} and stop: the N > 1 launch path without a step (runs over gloo on CPU)")
@@ -446,6 +450,8 @@ def compact_line(full):
         out["dist"]["grad_buckets"] = len(d.get("grad_buckets", []))
         cbs = d.get("collective_bytes_per_step") or {}
         out["dist"]["all_reduce_total_bytes"] = cbs.get("all_reduce_total")
+    if full.get("bf16_companion"):
+        out["bf16_companion"] = full["bf16_companion"]
     out["details"] = full.get("details", "BENCH_DETAILS line above")
     line = json.dumps(out)
     if len(line) > COMPACT_LIMIT:      # never let free text push the judged keys out of the recorded tail again
@@ -580,6 +586,53 @@ def try_graph_child():
     return None, f"graph child exited with {p.returncode}"
 
 
+def companion_from_line(line_obj):
+    """What the fp32 line keeps of a 16-bit run of the same command: the step time, the aggregate rate, the loss and that run's own
+    roofline object (the dominant hand-written kernel of THAT precision)."""
+    roof = line_obj.get("roofline") or {}
+    return {"dtype": line_obj.get("dtype"), "ms_per_step": line_obj.get("ms_per_step"), "value": line_obj.get("value"),
+            "unit": line_obj.get("unit"), "steps": line_obj.get("steps"), "warmup": line_obj.get("warmup"), "loss": line_obj.get("loss"),
+            "launch": _short((line_obj.get("config") or {}).get("launch") or "", 60),
+            "loss_delta_vs_oracle": line_obj.get("loss_delta_vs_oracle"),
+            "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_us", "launches_per_step",
+                                                  "algorithmic_bytes", "traffic") if k in roof},
+            "how": "same command with --dtype bf16 in a child process, after the fp32 timed region and outside it"}
+
+
+def bf16_companion():
+    """The default fp32 run's second measurement: this command once more under --dtype bf16 (bf16 autocast backbone on the in-tree
+    16-bit kernels, fp32 head / loss / optimiser), its own warm-up, capture and K timed replays, no CPU baseline.  Runs AFTER the
+    fp32 measurement, in its own process: nothing of it is inside the fp32 timed region."""
+    import subprocess
+
+    argv, skip = [], False
+    for a in sys.argv[1:]:
+        if skip:
+            skip = False
+        elif a in ("--dtype", "--graph", "--bf16-companion"):
+            skip = True
+        elif not a.startswith(("--dtype=", "--graph=", "--bf16-companion=")):
+            argv.append(a)
+    cmd = [sys.executable, os.path.abspath(__file__), *argv, "--dtype", "bf16", "--no-cpu-baseline", "--bf16-companion", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("PECLR_BENCH_CHILD", "PECLR_BENCH_DETAILS", "PECLR_LAUNCH_MANIFEST")}
+    env["PECLR_BENCH_DETAILS"] = os.devnull
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    except subprocess.TimeoutExpired:
+        return {"error": "bf16 companion run timed out"}
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        sys.stderr.write("# bf16 companion failed; the end of its stderr:\n" + "\n".join(p.stderr.splitlines()[-12:]) + "\n")
+        return {"error": f"bf16 companion run exited with {p.returncode}"}
+    return companion_from_line(json.loads(lines[-1]))
+
+
+def wants_companion(args):
+    # (--no-cpu-baseline = "only the measurement itself": profiling / A-B commands carry it, and get no companion either)
+    return bool(args.bf16_companion and not args.no_cpu_baseline and args.dtype == "fp32" and args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1
+                and not os.environ.get("PECLR_BENCH_CHILD"))
+
+
 def fp32_gemm_check(device):
     """Untimed, before the timed region: the error of the six-product kernels that carry the backbone's GEMM-shaped fp32 work
     (fp32 operands as three bf16 numbers, six MFMA products: peclr_gemm_x6p_f32 forward / input gradient,
@@ -627,6 +680,16 @@ def main():
         if single and not os.environ.get("PECLR_BENCH_CHILD"):
             line, graph_note = try_graph_child()
             if line is not None:
+                if wants_companion(args):
+                    # the fp32 measurement is complete (its child has exited): attach the bf16 run of the same command
+                    parts = line.split("\n")
+                    obj = json.loads(parts[-1])
+                    obj["bf16_companion"] = bf16_companion()
+                    parts[-1] = json.dumps(obj)
+                    if len(parts[-1]) > COMPACT_LIMIT:
+                        obj["bf16_companion"].pop("how", None)
+                        parts[-1] = json.dumps(obj)
+                    line = "\n".join(parts)
                 print(line, flush=True)
                 return
             args.graph = "0"
@@ -944,6 +1007,8 @@ def main():
             "count": sum(k["launches"] for t, k in kernels.items() if t.split("~")[0] in small) // (table_steps * args.accum),
             "ms": round(sum(k["launches"] * k["avg_us"] for t, k in kernels.items() if t.split("~")[0] in small)
                         / (table_steps * args.accum) / 1e3, 3)}
+        if wants_companion(args):           # (eager fallback of the default run: the child-process route above did not print)
+            result["bf16_companion"] = bf16_companion()
         emit(result)
     if world > 1:
         torch.distributed.destroy_process_group()

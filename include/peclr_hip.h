@@ -186,20 +186,6 @@ int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* 
 int peclr_gemm_x6t_slabs(int M, int N, int K, int taps);
 int peclr_gemm_x6t_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs, int n_slabs,
                        int taps, int H, int W, int stride, const float* zeros, peclr_stream_t stream);
-/* BatchNorm2d + ReLU applied in the CONSUMER's operand path (conv2 -> bn2 -> relu -> conv3 of a torchvision Bottleneck,
- * resnet_model.py:15; training mode: the statistics come from conv2's epilogue, peclr_bn2d_finalize_f32 writes the table).
- * Instead of peclr_bn2d_apply writing relu(bn(X)) and the 1x1 convolution reading it back, the GEMM reads X and applies
- * max(fmaf(x, scale[k], shift[k]), 0) -- the apply kernel's own expression, so the result is bit-identical to the two-pass form --
- * in the registers of the wave that splits its rows; the layer's output tensor never exists.
- *   peclr_gemm_x6p_bnrelu_f32: C[M,N] = relu(bn(A))[M,K] . B_t^T (forward; a_scale_shift = float [2][K], K <= 512; statistics
- *                              of C as in peclr_gemm_x6p_f32);
- *   peclr_gemm_x6t_bnrelu_f32: slabs of A^T . relu(bn(B)) (the same convolution's weight gradient, taps = 1 / stride = 1;
- *                              b_scale_shift = float [2][N], 16-byte aligned; n_slabs = peclr_gemm_x6t_slabs(M, N, K, 1)).   */
-int peclr_gemm_x6p_bnrelu_f32(int M, int N, int K, const float* A, int lda, const float* a_scale_shift, const void* Bp,
-                              float* C, int ldc, int tile_rows, const float* stat_shift, float* stat_partial,
-                              peclr_stream_t stream);
-int peclr_gemm_x6t_bnrelu_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* b_scale_shift,
-                              float* slabs, int n_slabs, const float* zeros, peclr_stream_t stream);
 /* Input gradient of the 3x3 / padding-1 / STRIDE-2 convolution of a layer's first block (resnet_model.py:15), on the same
  * kernel: dY [NB, Ho, Wo, Cout] NHWC -> dX [NB, 2 Ho, 2 Wo, Cin].  Input pixel (2 i + ph, 2 j + pw) receives filter row a only
  * where ph + 1 - a is even, so the transposed convolution splits into four dense ones, one per parity class (ph, pw), with

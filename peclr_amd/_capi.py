@@ -86,8 +86,6 @@ SIGNATURES = {
     "peclr_gemm_x6p_maskadd_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P]),
     "peclr_gemm_x6t_slabs": (c_int, [c_int, c_int, c_int, c_int]),
     "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
-    "peclr_gemm_x6p_bnrelu_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P]),
-    "peclr_gemm_x6t_bnrelu_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P]),
     "peclr_conv_s2_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_h_pack_bytes": (c_int64, [c_int, c_int]),
@@ -498,7 +496,7 @@ class X6Planes:
 
 def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[torch.Tensor] = None, tag: str = "gemm_x6p",
              tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None, addend_s2=None,
-             addend_mask: Optional[torch.Tensor] = None, a_scale_shift: Optional[torch.Tensor] = None):
+             addend_mask: Optional[torch.Tensor] = None):
     """C (fp32) [M, n] = A[M, K] . B_t^T (+ addend) with B_t given as packed planes (X6Planes): fp32 accuracy on the
     bf16 matrix cores, the weight operand split once per step (peclr_gemm_x6p_f32).
     stat_shift (fp32 [n]): also return the training-mode BatchNorm statistics of C as `(partial, n_split)` in the layout
@@ -508,14 +506,8 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
     addend_s2 = (H, W): the rows are the pixels of H x W images and `addend` [M / 4, n] holds every second pixel only (the
     compact input gradient of a 1x1 / stride-2 convolution): added at the even (h, w) rows (peclr_gemm_x6p_s2add_f32).
     addend_mask (int32 [M, n / 32], the 1-bit ReLU mask of peclr_bn2d_apply): addend elements whose bit is clear count as
-    zero (peclr_gemm_x6p_maskadd_f32).
-    a_scale_shift (fp32 [2, K], the table of peclr_bn2d_finalize_f32): A is the INPUT of a BatchNorm2d + ReLU layer and the
-    product consumes that layer's output, max(fmaf(a, scale, shift), 0) applied as the rows are split -- the output of
-    peclr_bn2d_apply without the pass or the tensor (peclr_gemm_x6p_bnrelu_f32; K <= 512, no addend / bn_bwd)."""
+    zero (peclr_gemm_x6p_maskadd_f32)."""
     m, k = a.shape
-    if a_scale_shift is not None and (addend is not None or bn_bwd is not None or k > 512 or a_scale_shift.numel() != 2 * k
-                                      or a_scale_shift.dtype != torch.float32 or not a_scale_shift.is_contiguous()):
-        raise PeclrHipError(f"gemm_x6p: a_scale_shift is the fp32 [2, K <= 512] table of a BatchNorm2d layer (no addend / bn_bwd); K = {k}")
     add_rows = m if addend_s2 is None else m // 4
     if planes.dtype != torch.uint8 or planes.numel() != 6 * ((n + 127) // 128 * 128) * k or (addend is not None and tuple(addend.shape) != (add_rows, n)):
         raise PeclrHipError(f"gemm_x6p: A {tuple(a.shape)}, planes of {planes.numel()} bytes for B_t[{n}, {k}]")
@@ -547,16 +539,12 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
             rc = lib().peclr_gemm_x6p_s2add_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
                                                 int(addend_s2[0]), int(addend_s2[1]), tile_rows,
                                                 ctypes.byref(fuse) if fuse is not None else None, _stream())
-        elif a_scale_shift is not None:
-            rc = lib().peclr_gemm_x6p_bnrelu_f32(m, n, k, _ptr(a), k, a_scale_shift.data_ptr(), _ptr(planes, torch.uint8), out.data_ptr(), n,
-                                                 tile_rows, _ptr(stat_shift), partial.data_ptr() if stat_shift is not None else None,
-                                                 _stream())
         else:
             rc = lib().peclr_gemm_x6p_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
                                           tile_rows, _ptr(stat_shift), partial.data_ptr() if stat_shift is not None else None,
                                           ctypes.byref(fuse) if fuse is not None else None, _stream())
     _check(rc, "peclr_gemm_x6p_maskadd_f32" if addend_mask is not None else "peclr_gemm_x6p_s2add_f32" if addend_s2 is not None
-           else "peclr_gemm_x6p_bnrelu_f32" if a_scale_shift is not None else "peclr_gemm_x6p_f32")
+           else "peclr_gemm_x6p_f32")
     return out if partial is None else (out, partial, ns)
 
 
@@ -665,18 +653,12 @@ def gemm_x6_tn(a: torch.Tensor, b: torch.Tensor, tag: str = "gemm_x6_tn") -> tor
     return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
 
 
-def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, stride: int = 1, tag: str = "gemm_x6t",
-             b_scale_shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, stride: int = 1, tag: str = "gemm_x6t") -> torch.Tensor:
     """C[M, taps * N] (fp32) = sum over rows of A[K, M]^T . B[K (shifted by the tap), N] -- the weight gradient of a 1x1
     (taps = 1) or 3x3 / padding-1 (taps = 9, hw = (H, W) of the images A's rows are the pixels of) convolution on NHWC
     storage, on the bf16 matrix cores at fp32 accuracy (peclr_gemm_x6t_f32 + peclr_slab_reduce_f32: fixed-order split-K,
-    deterministic).  stride = 2: A = dY over the H x W output pixels, B = X over the 2H x 2W input pixels (4 K rows).
-    b_scale_shift (fp32 [2, N]; taps = 1, stride = 1): B is the INPUT of a BatchNorm2d + ReLU layer whose output the product
-    consumes (peclr_gemm_x6t_bnrelu_f32; the backward twin of gemm_x6p's a_scale_shift)."""
+    deterministic).  stride = 2: A = dY over the H x W output pixels, B = X over the 2H x 2W input pixels (4 K rows)."""
     (k, m), (k2, n) = a.shape, b.shape
-    if b_scale_shift is not None and (taps != 1 or stride != 1 or b_scale_shift.numel() != 2 * n or b_scale_shift.dtype != torch.float32
-                                      or not b_scale_shift.is_contiguous()):
-        raise PeclrHipError("gemm_x6t: b_scale_shift is the fp32 [2, N] table of a BatchNorm2d layer (1x1 / stride-1 products only)")
     if k * stride * stride != k2 or taps not in (1, 9) or stride not in (1, 2) or ((taps == 9 or stride == 2) and hw is None):
         raise PeclrHipError(f"gemm_x6t: shapes {tuple(a.shape)}^T x {tuple(b.shape)}, taps {taps}, stride {stride}")
     h, w = hw if hw is not None else (1, 1)
@@ -686,13 +668,9 @@ def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, stride: i
     slabs = torch.empty((ns, m, taps * n), device=a.device, dtype=torch.float32)
     with _timed(tag, 4 * (k * m + k2 * n // (stride * stride) * (1 if taps == 1 else stride * stride) + ns * m * n * taps),
                 2 * m * n * k * taps, kernel="gemm_x6t_kernel"):
-        if b_scale_shift is not None:
-            rc = lib().peclr_gemm_x6t_bnrelu_f32(m, n, k, _ptr(a), a.stride(0), _ptr(b), b.stride(0), b_scale_shift.data_ptr(),
-                                                 slabs.data_ptr(), ns, _zeros(a.device).data_ptr(), _stream())
-        else:
-            rc = lib().peclr_gemm_x6t_f32(m, n, k, _ptr(a), a.stride(0), _ptr(b), b.stride(0), slabs.data_ptr(), ns, taps, h, w, stride,
-                                          _zeros(a.device).data_ptr(), _stream())
-    _check(rc, "peclr_gemm_x6t_bnrelu_f32" if b_scale_shift is not None else "peclr_gemm_x6t_f32")
+        rc = lib().peclr_gemm_x6t_f32(m, n, k, _ptr(a), a.stride(0), _ptr(b), b.stride(0), slabs.data_ptr(), ns, taps, h, w, stride,
+                                      _zeros(a.device).data_ptr(), _stream())
+    _check(rc, "peclr_gemm_x6t_f32")
     return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
 
 

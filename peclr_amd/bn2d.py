@@ -83,7 +83,8 @@ class _CheckpointedBlock(torch.autograd.Function):
                 y = ctx.run(x)
         finally:
             _RECOMPUTING, _CKPT_SHIFTS = was
-        ctx.shifts = None
+        # (ctx.shifts stays with the context: a second backward over a retained graph re-runs the block centred where the first
+        # run was and reproduces it bit for bit; the copies -- one running mean per BatchNorm layer of the block -- go with the graph)
         global _NESTED_BACKWARD
         _NESTED_BACKWARD += 1       # (its side-channel entries are drained with the enclosing pass: see _drain_after_backward)
         try:
@@ -124,10 +125,6 @@ class Routing:
     gemm_x6t: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_GEMM_X6T"))            # weight gradients on the 256 x 256-tile kernel
     bn_stats_in_gemm: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_BN_STATS_IN_GEMM"))   # BatchNorm statistics in the GEMM epilogue
     bn_bwd_in_gemm: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_BN_BWD_IN_GEMM"))       # BatchNorm backward reduction in the dgrad epilogue
-    # bn2 + ReLU applied in conv3's operand path (fp32 Bottleneck): no apply pass, no output tensor.  Bit-identical, and OFF by default:
-    # measured on one box (C2, fp32) the sixteen saved passes are worth 0.60 ms, the longer row splits of the GEMMs that absorb them
-    # cost 1.05 ms (their k-steps are latency chains: load -> split -> LDS -> barrier), 53.9 against 53.2 ms per step
-    bn_apply_in_gemm: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_BN_APPLY_IN_GEMM", "0"))
     # the shortcut's BatchNorm (conv1x1 -> bn of a layer's first block) applied inside the block's last pass (bn3 + shortcut + ReLU)
     bn_shortcut_in_add: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_BN_SHORTCUT_IN_ADD"))
     x6_layer1: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_X6_LAYER1"))          # layer1's 64-channel 1x1 convolutions in-tree
@@ -290,9 +287,9 @@ class _BN2dAct(torch.autograd.Function):
                 res_deferred=None):
         """link: None or an empty list that receives what a consumer's input-gradient GEMM needs to perform this layer's
         backward reduction in its epilogue: [x, save, scale_shift, relu mask or None, relu, token].
-        defer: None, or an empty list -- the layer (plain BatchNorm + ReLU) only finishes its statistics; the list comes back
-        as [x, scale_shift] and the result is a placeholder (`_deferred_view`) whose consumer applies the layer in its own
-        operand path (`Conv2d.forward`), or materialises it (`_Materialize`).
+        defer: None, or an empty list -- the layer (a shortcut's BatchNorm, no ReLU) only finishes its statistics; the list comes
+        back as [x, scale_shift, relu] and the result is a placeholder (`_deferred_view`) whose consumer -- the block's last
+        BatchNorm pass -- computes the layer on the fly; any other reader materialises it (`_Materialize`).
         res_deferred: None, or (x_s, scale_shift_s, False) -- `residual` is the placeholder of the shortcut's BatchNorm layer (no
         ReLU), which left its apply pass to THIS pass: the residual is computed from that layer's input on the fly."""
         training = bn.training or not bn.track_running_stats
@@ -358,8 +355,8 @@ def _deferred_view(x: Tensor) -> Tensor:
 
 
 class _Materialize(torch.autograd.Function):
-    """The output of a BatchNorm + ReLU layer whose apply pass was left to its consumer, written after all (the consumer
-    turned out not to be the GEMM that applies it in its operand path): peclr_bn2d_apply on the finished table."""
+    """The output of a BatchNorm layer whose apply pass was left to its consumer, written after all (the reader turned out
+    not to be the pass that computes it on the fly): peclr_bn2d_apply on the finished table."""
 
     @staticmethod
     def forward(ctx, placeholder, deferred):
@@ -554,16 +551,15 @@ def _x6_wgrad_pays(rows: int, cout: int, cin: int) -> bool:
     return ROUTING.gemm_x6 and cout >= wide and cin >= wide and cout % 4 == 0 and cin % 4 == 0 and (rows >= 8192 or ROUTING.force)
 
 
-def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, b_scale_shift=None):
+def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
     """d(weight) of a 1x1 / stride-1 convolution as dY^T X on the bf16 matrix cores (fp32 accuracy, deterministic
-    split-K), shaped and strided like the weight; parked for `param` on the side stream when that mode is on.
-    b_scale_shift: x is the INPUT of the BatchNorm + ReLU layer in front of the convolution (its output was never written)."""
+    split-K), shaped and strided like the weight; parked for `param` on the side stream when that mode is on."""
     n, cin, h, w = x.shape
     cout = gy.shape[1]
 
     def run():
         gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
-        dw = (_capi.gemm_x6t(gy2, x2, tag="conv1x1_wgrad", b_scale_shift=b_scale_shift) if ROUTING.gemm_x6t
+        dw = (_capi.gemm_x6t(gy2, x2, tag="conv1x1_wgrad") if ROUTING.gemm_x6t
               else _capi.gemm_x6_tn(gy2, x2, tag="conv1x1_wgrad"))
         ref = param if param is not None else weight
         return dw.as_strided(ref.shape, ref.stride())       # same memory, the parameter's (channels_last) strides
@@ -630,22 +626,13 @@ class _Conv1x1Gemm(torch.autograd.Function):
     both operands split per workgroup: peclr_gemm_x6_f32); the other direction and small weight gradients stay on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, use_fwd: bool, use_bwd: bool, stats=None, link=None, deferred=None):
+    def forward(ctx, x, weight, conv, use_fwd: bool, use_bwd: bool, stats=None, link=None):
         """stats: None, or [bn] -- the BatchNorm2d that consumes the output; the GEMM epilogue then sums its statistics
-        and the list comes back as [partial, n_split, shift, bn] (left untouched when that is not possible).
-        deferred: None, or (x_bn, scale_shift) -- `x` is the placeholder of a BatchNorm + ReLU layer that left its apply pass
-        to this convolution: the GEMM reads that layer's INPUT and applies it as it splits the rows (and so does the weight
-        gradient's); needs use_fwd and packed planes (`Conv2d._takes_deferred`)."""
-        ss = None
-        if deferred is not None:
-            x, ss = deferred[:2]                              # (the graph edge stays on the placeholder; these are plain tensors)
-            x = x.detach()
-        ctx.save_for_backward(x, weight, *([ss] if ss is not None else []))
+        and the list comes back as [partial, n_split, shift, bn] (left untouched when that is not possible)."""
+        ctx.save_for_backward(x, weight)
         planes = _x6_planes(conv) if (use_fwd or use_bwd) else None
         ctx.cfg = (conv, use_bwd, planes)
         ctx.link = link
-        if ss is not None and not (use_fwd and planes is not None):
-            raise _capi.PeclrHipError("a deferred BatchNorm layer needs the packed-plane forward GEMM (Conv2d._takes_deferred)")
         if not use_fwd:
             return F.conv2d(x, weight)
         n, cin, h, w = x.shape
@@ -653,18 +640,17 @@ class _Conv1x1Gemm(torch.autograd.Function):
         x2 = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
         shift = _stat_shift_for(stats[0], cout) if (stats and planes is not None and ROUTING.bn_stats_in_gemm) else None
         if shift is not None:
-            y, partial, ns = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd", stat_shift=shift, a_scale_shift=ss)
+            y, partial, ns = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd", stat_shift=shift)
             stats[:] = [partial, ns, shift, stats[0]]
         elif planes is not None:
-            y = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd", a_scale_shift=ss)
+            y = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd")
         else:
             y = _capi.gemm_x6(x2, weight.detach().reshape(cout, cin), tag="conv1x1_fwd")
         return y.view(n, h, w, cout).permute(0, 3, 1, 2)          # channels_last NCHW view of the NHWC result
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors[:2]
-        ss = ctx.saved_tensors[2] if len(ctx.saved_tensors) > 2 else None      # x is the input of the BatchNorm layer in front
+        x, weight = ctx.saved_tensors
         conv, use_bwd, planes = ctx.cfg
         param = conv.weight if conv is not None else None
         n, cin, h, w = x.shape
@@ -672,12 +658,8 @@ class _Conv1x1Gemm(torch.autograd.Function):
         gy = gy.contiguous(memory_format=torch.channels_last)
         dw = None
         if ctx.needs_input_grad[1]:
-            if ss is not None and _x6_wgrad_pays(n * h * w, cout, cin) and ROUTING.gemm_x6t:
-                dw = _wgrad_1x1_x6(gy, x, weight, param, b_scale_shift=ss)
-            else:
-                xa = x if ss is None else _capi.bn2d_apply(x, ss, relu=True)
-                dw = (_wgrad_1x1_x6(gy, xa, weight, param) if _x6_wgrad_pays(n * h * w, cout, cin)
-                      else _conv_wgrad(gy, xa, weight, (1, 1), (0, 0), param))
+            dw = (_wgrad_1x1_x6(gy, x, weight, param) if _x6_wgrad_pays(n * h * w, cout, cin)
+                  else _conv_wgrad(gy, x, weight, (1, 1), (0, 0), param))
         dx = None
         if ctx.needs_input_grad[0]:
             if use_bwd:
@@ -695,7 +677,7 @@ class _Conv1x1Gemm(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
-        return dx, dw, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 
@@ -894,7 +876,7 @@ def _drain_after_backward():
         return
     try:
         torch.autograd.Variable._execution_engine.queue_callback(_drained)
-        _DRAIN_QUEUED = True
+        _DRAIN_QUEUED = True          # (reset by the callback -- or by end_backward(), should a pass raise and skip its callbacks)
     except RuntimeError:        # not inside a backward pass (a kernel-level test calling a backward function by hand)
         pass
 
@@ -918,6 +900,8 @@ def end_backward(strict: bool = False) -> int:
     whose gradient tensor was merged into another consumer's buffer and never arrived under its own address, a lazy
     payload whose NaN view nobody took -- so that nothing pins device memory or meets a recycled address later.  Returns
     the number of entries dropped; strict=True raises instead (tests: the in-tree ResNets leave none behind)."""
+    global _DRAIN_QUEUED
+    _DRAIN_QUEUED = False        # (a pass that raised skipped its engine callbacks: the next one queues its drain again)
     n = len(_BN_BWD_STATS) + len(_COMPACT)
     _BN_BWD_STATS.clear()
     _COMPACT.clear()
@@ -1116,16 +1100,6 @@ class Conv2d(nn.Conv2d):
             st[1] = key
         return st[0]
 
-    def _takes_deferred(self, x_bn: Tensor) -> bool:
-        """Can this convolution apply the BatchNorm + ReLU layer in front of it (input `x_bn`) in its own operand path?  The
-        fp32 1x1 / stride-1 GEMM on packed planes (peclr_gemm_x6p_bnrelu_f32: K <= 512 -- bn2 -> conv3 of every Bottleneck)."""
-        return bool(ROUTING.bn_apply_in_gemm and self.hip_gemm and ROUTING.gemm_x6p and getattr(self, "x6_group", None) is not None
-                    and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1
-                    and self.bias is None and self.in_channels <= 512 and self.in_channels % 16 == 0
-                    and x_bn.is_cuda and x_bn.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x_bn.dim() == 4
-                    and x_bn.shape[1] == self.in_channels and x_bn.is_contiguous(memory_format=torch.channels_last)
-                    and _x6_pays(x_bn.shape[0] * x_bn.shape[2] * x_bn.shape[3], self.out_channels, self.in_channels))
-
     def forward(self, x: Tensor, stats_for=None, sole_consumer: bool = False) -> Tensor:
         """stats_for: the BatchNorm2d that consumes the output -- when this convolution runs as an in-tree GEMM its
         epilogue sums that layer's training statistics (one pass over the activation less).
@@ -1136,16 +1110,7 @@ class Conv2d(nn.Conv2d):
         bn_link = _bn_link_of if sole_consumer else (lambda t: None)
         deferred = getattr(x, "_peclr_deferred", None)
         if deferred is not None:
-            # x stands for relu(bn(x_bn)), not written: this GEMM applies the layer as it splits the rows of x_bn -- or the
-            # tensor is written after all
-            if deferred[2] and self._takes_deferred(deferred[0]):
-                grad = torch.is_grad_enabled() and x.requires_grad
-                rows = x.shape[0] * x.shape[2] * x.shape[3]
-                use_bwd = _x6_pays(rows, self.in_channels, self.out_channels) and grad
-                stats = [stats_for] if stats_for is not None else None
-                return _attach_stats(_Conv1x1Gemm.apply(x, self.weight, self, True, use_bwd, stats, bn_link(x) if use_bwd else None,
-                                                        tuple(deferred)), stats)
-            x = _materialized(x, tuple(deferred))
+            x = _materialized(x, tuple(deferred))       # a BatchNorm layer's placeholder (its apply pass was left to another reader): written after all
         if (self.hip_stem and ROUTING.stem and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3
                 and x.shape[2] >= 8 and x.shape[3] >= 8 and x.is_contiguous(memory_format=torch.channels_last)
                 and self.weight.is_cuda and self.weight.dtype == torch.float32):
@@ -1407,14 +1372,20 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
                     and not (self.tail_avgpool and self.num_features % 32 == 0) and not self.default_pool)
 
     def forward(self, x: Tensor, residual: Optional[Tensor] = None, relu: Optional[bool] = None, consumer=None) -> Tensor:
-        """consumer: the ONLY reader of the result.  A Conv2d (bn2 -> conv3 inside a Bottleneck) that can apply this layer in
-        its own operand path (`Conv2d._takes_deferred`), or -- for the BatchNorm of a shortcut (conv1x1 -> bn, no ReLU) -- the
-        block's last FusedBatchNormAct2d, which adds the shortcut in its own pass (`_takes_deferred_residual`): the layer then only
+        """consumer: the ONLY reader of the result.  For the BatchNorm of a shortcut (conv1x1 -> bn, no ReLU) it is the block's
+        last FusedBatchNormAct2d, which adds the shortcut in its own pass (`_takes_deferred_residual`): the layer then only
         finishes its statistics and returns a placeholder carrying `_peclr_deferred = [x, scale_shift, relu]`: no apply pass, no
-        output tensor.  A residual that is such a placeholder is computed on the fly (or materialised)."""
+        output tensor.  A residual that is such a placeholder is computed on the fly (or materialised).  (A Conv2d consumer that
+        applied the layer in its own operand path was built in round 5 and taken out in round 6: docs/history.md E.)"""
         relu = self.default_relu if relu is None else relu
         pool = self.default_pool and relu and residual is None
         if self.hip:
+            global _DRAIN_QUEUED
+            if _DRAIN_QUEUED and not _RECOMPUTING and not _NESTED_BACKWARD:
+                # a forward pass outside any backward: the drain queued by the last backward pass never ran (that pass raised, and
+                # autograd skips its final callbacks then) -- loops that do not call end_backward() would never queue one again
+                _DRAIN_QUEUED = False
+                end_backward()
             if not self.affine or (self.training and self.momentum is None):
                 raise _capi.PeclrHipError("fused BatchNorm2d needs affine=True and a fixed momentum")
             # statistics its producer already summed (a GEMM epilogue, `conv_stats_for`), valid for THIS layer in training
@@ -1438,9 +1409,7 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
                         and torch.is_grad_enabled() and residual.requires_grad and self.num_features % 32 == 0)
             defer = None
             if consumer is not None and residual is None:
-                if relu and isinstance(consumer, Conv2d) and consumer._takes_deferred(x):
-                    defer = []
-                elif not relu and isinstance(consumer, FusedBatchNormAct2d) and consumer._takes_deferred_residual(x):
+                if not relu and isinstance(consumer, FusedBatchNormAct2d) and consumer._takes_deferred_residual(x):
                     defer = []
             y = _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre, link, lazy_res, defer, res_deferred)
             if link:

@@ -78,10 +78,6 @@ struct X6PArgs {
     // stride-1 input gradient (K order (tap, Cout)).
     int s2d;
     const float* zeros;                  // >= 64 bytes of zeros (source of the padding pixels)
-    // optional (TRA instantiations, TAPS = 1): A is the INPUT of a BatchNorm2d + ReLU layer whose output this product consumes;
-    // a_ss = [2][K] that layer's scale / shift: every element becomes max(fmaf(a, scale[k], shift[k]), 0) -- peclr_bn2d_apply's
-    // own expression -- in the registers of the wave that splits its row, and the layer's output never exists in memory
-    const float* a_ss;
     // optional: C is the gradient dY arriving at a BatchNorm2d(+ReLU) layer (this GEMM is the input gradient of the
     // convolution that consumed that layer's output).  The epilogue then performs the layer's backward REDUCTION on the tile
     // it holds: per row block and column, sum of dY' and of dY' * xhat with dY' = dY where the ReLU passed (recomputed from
@@ -119,18 +115,11 @@ __device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_offset)
 // ONCE into shared planes [plane][k-half][pixel][8 k] and every tap reads its A fragments from there at the tap's pixel offset
 // (border rows from a 16-byte zero slot) -- instead of each wave loading and splitting its rows once per tap (nine times).
 // K order of the loop: (chunk, tap); the packed filter chunks are indexed tap * chunks + chunk as before.  W <= 62.
-// PERSIST (plain 1x1 products, stride 1): gridDim.x workgroups (a multiple of 8 x column tiles, about as many as the chip holds at
-// once) walk the virtual block indices b, b + gridDim.x, ... -- the same index -> (row block, column tile) map, so a workgroup keeps
-// its column tile (per-column constants fetched once) -- and request the first k-step's rows of their NEXT tile before the
-// epilogue of the current one: the epilogue's stores drain, and the next rows arrive, while the other does its work; no workgroup
-// launch / address set-up / first-load round trip per tile.
-template <int WM, int ABL = 0, bool AREG = true, bool ILV = true, int TAPS = 1, int NTL = 4, bool HALO = false, bool TRA = false,
-          bool PERSIST = false>
-__global__ __launch_bounds__(256, !PERSIST ? 2 : WM == 1 ? (NTL == 2 ? 4 : 3) : (NTL == 2 ? 3 : 2)) void gemm_x6p_kernel(X6PArgs g) {
-    // (PERSIST: the register budget of the workgroups-per-CU its one-tile twin reaches without being asked -- left alone, the
-    // compiler keeps the loop's invariants in registers: 116 -> 172 VGPRs at 128 x 64, and two workgroups per CU where four fit)
-    static_assert(!TRA || (TAPS == 1 && AREG && !HALO), "the BatchNorm transform of the A rows: plain 1x1 products");
-    static_assert(!PERSIST || (TAPS == 1 && AREG && !HALO && ABL == 0), "persistent workgroups: plain 1x1 products");
+// (Two more forms were built in round 5, measured slower and taken out of the library in round 6 -- persistent workgroups walking the
+// tile index space, and the BatchNorm + ReLU in front of A applied in the row split: tools/exp/x6p_persist_tra.patch, numbers in
+// docs/history.md E.)
+template <int WM, int ABL = 0, bool AREG = true, bool ILV = true, int TAPS = 1, int NTL = 4, bool HALO = false>
+__global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     constexpr int RM = 32 * WM;                          // rows per wave
     constexpr int TM = 4 * RM;                           // rows per workgroup
     constexpr int NRAW = RM / 16;                        // 1 KiB pieces of fp32 rows per wave and k-step
@@ -155,37 +144,13 @@ __global__ __launch_bounds__(256, !PERSIST ? 2 : WM == 1 ? (NTL == 2 ? 4 : 3) : 
     // + 2.5 KiB at the end: the epilogue's per-column constants ([shift | mean | invstd | scale | shift'][128] floats), fetched
     // BEFORE the main loop -- in the epilogue each of the four column tiles used to wait a full memory round trip for them
     constexpr int CST0 = HALO ? ZOFF + 64 : PL0 + 4 * WAVE_PL;
-    constexpr int ASS0 = CST0 + 5 * 128 * 4;             // TRA: [scale | shift][K <= 512] of the BatchNorm layer in front of A
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[ASS0 + (TRA ? 2 * 512 * 4 : 0)];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[CST0 + 5 * 128 * 4];
     typedef __attribute__((address_space(3))) unsigned char* lptr_t;
     constexpr int PNL = 32 * NTL;                        // output columns per workgroup
     const int nct = (g.N + PNL - 1) / PNL;
     f32x4 ar[NRAW];                                       // AREG: the next k-step's rows, in flight / landed
-    // PERSIST: virtual block indices of this workgroup; the one after `vb` whose row block exists (-1: none)
-    const int nvb = 8 * (((g.M + TM - 1) / TM + 7) / 8) * nct;
-    auto row_block_of = [&](int b) { return 8 * ((b / 8) / nct) + b % 8; };
-    auto next_block = [&](int b) {
-        for (b += (int)gridDim.x; b < nvb; b += (int)gridDim.x)
-            if (row_block_of(b) * TM < g.M) return b;
-        return -1;
-    };
-    bool rows_requested = false;                          // PERSIST: ar[] holds (or awaits) step 0 of the tile about to start
-    bool first_tile = true;
-    // barriers between phases that hand over LDS contents only.  __syncthreads() also orders GLOBAL memory (a release fence:
-    // vmcnt(0)), which would make a persistent workgroup wait for the rows it has just requested for its next tile
-    auto lds_barrier = [&]() {
-        if constexpr (PERSIST) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        } else __syncthreads();
-    };
-    for (int vb = blockIdx.x; vb >= 0; vb = PERSIST ? next_block(vb) : -1) {
-    // (PERSIST: everything derived from the thread index is re-derived per tile from a value the compiler cannot see through --
-    // hoisted out of the tile loop, those invariants cost 56 VGPRs and a workgroup per CU)
-    int tid_ = threadIdx.x;
-    if constexpr (PERSIST) asm volatile("" : "+v"(tid_));
-    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
+    const int vb = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kh = lane >> 5;
     const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(lptr_t)lds;        // LDS byte address of the array
     unsigned char* const planes = lds + PL0 + wave * WAVE_PL;
@@ -196,10 +161,7 @@ __global__ __launch_bounds__(256, !PERSIST ? 2 : WM == 1 ? (NTL == 2 ? 4 : 3) : 
 
     const int j = vb / 8;
     const int row_block = 8 * (j / nct) + vb % 8;         // all column tiles of a row block on one XCD
-    if (row_block * TM >= g.M) {
-        if constexpr (PERSIST) continue; else return;
-    }
-    if (PERSIST && !first_tile) lds_barrier();            // every wave is done with the previous tile's epilogue (it lives in the B buffers)
+    if (row_block * TM >= g.M) return;
     const int m0 = row_block * TM + wave * RM, ct = j % nct, n0 = ct * PNL;
     // s2d: parity class of this workgroup (the four-tap class first: longest workgroups first)
     const bool s2d = TAPS == 9 && g.s2d;
@@ -221,18 +183,13 @@ __global__ __launch_bounds__(256, !PERSIST ? 2 : WM == 1 ? (NTL == 2 ? 4 : 3) : 
             for (int r = 0; r < 16; ++r) acc[a][y][r] = 0.f;
 
     float* const cst = reinterpret_cast<float*>(lds + CST0);
-    if (first_tile) {                                     // (a persistent workgroup keeps its column tile)
+    {
         constexpr int PNL0 = 32 * NTL;
         const int c = (int)(blockIdx.x / 8 % ((g.N + PNL0 - 1) / PNL0)) * PNL0 + (tid < PNL0 ? tid : PNL0 - 1);
         float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f, k4 = 0.f;
         if (g.stat_partial) k0 = g.stat_shift[c];
         if (g.bb_partial) { k1 = g.bb_mean[c]; k2 = g.bb_invstd[c]; k3 = g.bb_ss[c]; k4 = g.bb_ss[g.N + c]; }
         if (tid < PNL0) { cst[tid] = k0; cst[128 + tid] = k1; cst[256 + tid] = k2; cst[384 + tid] = k3; cst[512 + tid] = k4; }
-    }
-    if (TRA && first_tile) {
-        float* t = reinterpret_cast<float*>(lds + ASS0);
-        for (int c = tid; c < g.K; c += 256) { t[c] = g.a_ss[c]; t[512 + c] = g.a_ss[g.K + c]; }
-        __syncthreads();                                  // (the first rows are split before the loop's first barrier)
     }
     if constexpr (!HALO) {
     // this lane's fp32 source: rows (lane >> 2) + 16 c of the wave's block, k-quad lane & 3 (rows past M re-read row M - 1)
@@ -329,22 +286,12 @@ __global__ __launch_bounds__(256, !PERSIST ? 2 : WM == 1 ? (NTL == 2 ? 4 : 3) : 
     // rows of the k-step just landed -> three planes [k-half][row][8 k] (this lane: row 16 c + (lane >> 2),
     // k = 4 (lane & 3) ... + 3, i.e. k-half (lane >> 1) & 1, 8-byte slot lane & 1)
     const int poff = ((lane >> 1) & 1) * HALF + (lane >> 2) * 16 + (lane & 1) * 8;
-    auto split_store = [&](int ts) {                      // ts: the k-step whose rows are being split (TRA: selects the channels)
-        f32x4 tsc, tsh;
-        if constexpr (TRA) {
-            const float* t = reinterpret_cast<const float*>(lds + ASS0) + ts * PK + 4 * (lane & 3);
-            tsc = *reinterpret_cast<const f32x4*>(t);
-            tsh = *reinterpret_cast<const f32x4*>(t + 512);
-        }
+    auto split_store = [&]() {
 #pragma unroll
         for (int c = 0; c < NRAW; ++c) {
             f32x4 v;
             if constexpr (AREG) v = ar[c];
             else v = *reinterpret_cast<const f32x4*>(raw + c * 1024 + lane * 16);
-            if constexpr (TRA) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaf(v[q], tsc[q], tsh[q]), 0.f);
-            }
             unsigned h[2], m[2], l[2];
             split3_pk(v[0], v[1], h[0], m[0], l[0]);
             split3_pk(v[2], v[3], h[1], m[1], l[1]);
@@ -361,9 +308,9 @@ __global__ __launch_bounds__(256, !PERSIST ? 2 : WM == 1 ? (NTL == 2 ? 4 : 3) : 
     // they are DMAs too) implies "my pieces of the older B chunk have landed"; the barrier at the top of step t + 2
     // publishes them.  Three B buffers: t being read, t + 1 landed, t + 2 landing.
     issue_b(0);
-    if (!(PERSIST && rows_requested)) issue_a(0);         // (PERSIST: requested before the previous tile's epilogue)
+    issue_a(0);
     if constexpr (!AREG) PECLR_VMCNT(0);
-    split_store(0);
+    split_store();
     if constexpr (!AREG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (nk > 1) { issue_b(1); issue_a(1); }
 
@@ -394,7 +341,7 @@ __global__ __launch_bounds__(256, !PERSIST ? 2 : WM == 1 ? (NTL == 2 ? 4 : 3) : 
 #undef PECLR_X6
             if (half == 0 && SPLIT) {
                 if constexpr (!AREG) PECLR_VMCNT(0);
-                if constexpr (!(ABL & 1)) split_store(t + 1);  // after this step's fragment reads in program (= LDS) order
+                if constexpr (!(ABL & 1)) split_store();       // after this step's fragment reads in program (= LDS) order
                 else if constexpr (AREG) { asm volatile("" :: "v"(ar[0]), "v"(ar[NRAW - 1])); }
                 if constexpr (AREG && !(ABL & 9) && ILV) {
                     // one MFMA, then four of the split's VALU instructions (the two pipes run side by side), a plane store now and then
@@ -416,19 +363,6 @@ __global__ __launch_bounds__(256, !PERSIST ? 2 : WM == 1 ? (NTL == 2 ? 4 : 3) : 
     PECLR_VMCNT(0);                                       // (B chunk 0; for nk > 1 also what was just issued)
     for (int t = 0; t + 1 < nk; ++t) kstep(t, std::true_type{});
     kstep(nk - 1, std::false_type{});
-    if constexpr (PERSIST) {                              // the next tile's first rows travel while this tile's epilogue runs
-        const int nb = next_block(vb);
-        rows_requested = nb >= 0;
-        if (rows_requested) {
-            const int nm0 = row_block_of(nb) * TM + wave * RM;
-#pragma unroll
-            for (int c = 0; c < NRAW; ++c) {
-                int row = nm0 + 16 * c + (lane >> 2);
-                row = row < g.M ? row : g.M - 1;
-                ar[c] = *reinterpret_cast<const f32x4*>(g.A + (size_t)row * g.lda + 4 * (lane & 3));
-            }
-        }
-    }
     } else {
         static_assert(!HALO || (TAPS == 9 && AREG && ABL == 0), "HALO is the 3x3 / stride-1 path");
         constexpr int NLD = (NPXM * 4 + 255) / 256;      // 16-byte loads per thread and chunk
@@ -559,7 +493,7 @@ __global__ __launch_bounds__(256, !PERSIST ? 2 : WM == 1 ? (NTL == 2 ? 4 : 3) : 
     }
 
     // epilogue: wave-private 32 x 32 transposes through LDS (the B buffers, once every wave is done with them), 16 bytes per lane
-    lds_barrier();
+    __syncthreads();
     float* wlds = reinterpret_cast<float*>(lds + wave * (32 * XEPL * 4));
     if (g.stat_partial) {
         // column statistics of this workgroup's TM x 128 block straight from the accumulators: a lane holds column
@@ -581,7 +515,7 @@ __global__ __launch_bounds__(256, !PERSIST ? 2 : WM == 1 ? (NTL == 2 ? 4 : 3) : 
             sq += __shfl_xor(sq, 32, 64);
             if (kh == 0) { sl[(wave * 2) * 128 + y * 32 + i] = sum; sl[(wave * 2 + 1) * 128 + y * 32 + i] = sq; }
         }
-        lds_barrier();
+        __syncthreads();
         {
             const int which = tid >> 7, col = tid & 127;
             if (col < PNL) {
@@ -688,7 +622,7 @@ __global__ __launch_bounds__(256, !PERSIST ? 2 : WM == 1 ? (NTL == 2 ? 4 : 3) : 
         }
     }
     if (g.bb_partial) {
-        lds_barrier();
+        __syncthreads();
         const int which = tid >> 7, col = tid & 127;
         if (col < PNL) {
             const float v = ((sl[(0 * 2 + which) * 128 + col] + sl[(1 * 2 + which) * 128 + col]) +
@@ -698,8 +632,6 @@ __global__ __launch_bounds__(256, !PERSIST ? 2 : WM == 1 ? (NTL == 2 ? 4 : 3) : 
             g.bb_partial[(rb * 2 + which) * g.N + n0 + col] = v;
         }
     }
-    first_tile = false;
-    }   // tiles of this workgroup
 }
 
 // ---- weight packing: W[N][K] fp32 (or its transpose) -> fragment-ordered bf16 planes.  One workgroup per
@@ -786,7 +718,6 @@ extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K) {
 extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K);
 
 static void set_bb(X6PArgs& g, const peclr_bn_bwd_fuse* bb) {
-    g.a_ss = nullptr;                    // (every launcher goes through here; peclr_gemm_x6p_bnrelu_f32 sets it afterwards)
     g.bb_x = bb ? bb->x : nullptr; g.bb_mean = bb ? bb->mean : nullptr; g.bb_invstd = bb ? bb->invstd : nullptr;
     g.bb_ss = bb ? bb->scale_shift : nullptr; g.bb_mask = bb ? bb->relu_mask : nullptr; g.bb_relu = bb ? bb->relu : 0;
     g.bb_partial = bb ? bb->partial : nullptr;
@@ -797,31 +728,6 @@ static void set_bb(X6PArgs& g, const peclr_bn_bwd_fuse* bb) {
 static bool stream_past_caches(size_t bytes) {
     static const int on = getenv("PECLR_X6P_STREAM_OUT") ? atoi(getenv("PECLR_X6P_STREAM_OUT")) : 1;
     return on && bytes > ((size_t)64 << 20);
-}
-
-// PECLR_X6P_PERSIST=1: persistent workgroups for the plain 1x1 products (read per launch: tests flip it).  OFF by default -- built
-// for the review's "persistent double-tile" item and measured slower (round 5, same box, C2 fp32): with the register budget of its
-// one-tile twin the loop spills (20 - 25 VGPRs at 128-row tiles after re-deriving every lane constant per tile, 47 - 150 before):
-// conv1x1_fwd 172.6 -> 173.6 us, conv1x1_fwd~hbm 212 -> 218, conv1x1_dgrad~hbm 213 -> 227, conv1x1_dgrad_add_x6~hbm 388 -> 507
-// (+ 1.6 ms per step); without the budget it takes 172 - 244 VGPRs and loses a workgroup per CU (+ 2.3 ms).  Three or four
-// independent workgroups per CU already overlap one tile's epilogue with another's main loop; what a persistent workgroup saves
-// (launch, address set-up, the first rows' round trip) does not pay for the registers its loop state costs.
-static bool persistent_x6p() {
-    const char* v = getenv("PECLR_X6P_PERSIST");
-    return v && atoi(v) != 0;
-}
-static int cu_count() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return n;
-}
-static int resident_blocks(const void* kernel) {          // workgroups of 256 threads one CU holds at once
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess || n < 1) n = 2;
-    return n;
 }
 
 static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t stream, bool halo = false) {
@@ -851,30 +757,6 @@ static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t str
         }
     } else if (taps == 9) {
         if (tile_rows == 256) PECLR_LAUNCH(2, 9); else PECLR_LAUNCH(1, 9);
-    } else if (g.a_ss) {                                  // the BatchNorm + ReLU in front of A applied in the row split
-        if (tile_rows == 256) {
-            if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<2, 0, true, true, 1, 2, false, true>), grid, dim3(256), 0, stream, g);
-            else hipLaunchKernelGGL((gemm_x6p_kernel<2, 0, true, true, 1, 4, false, true>), grid, dim3(256), 0, stream, g);
-        } else {
-            if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<1, 0, true, true, 1, 2, false, true>), grid, dim3(256), 0, stream, g);
-            else hipLaunchKernelGGL((gemm_x6p_kernel<1, 0, true, true, 1, 4, false, true>), grid, dim3(256), 0, stream, g);
-        }
-    } else if (g.stride == 1 && persistent_x6p()) {
-        // persistent workgroups: as many as the chip holds at once, rounded down to whole groups of 8 x column tiles (so that a
-        // workgroup keeps its column tile), never more than there are blocks
-        const int nct = narrow ? g.N / 64 : g.N / PN;
-        const int unit = 8 * nct;
-#define PECLR_PERSIST(WM_, NTL_)                                                                                                   \
-    do {                                                                                                                          \
-        static const int per_cu = resident_blocks(reinterpret_cast<const void*>(&gemm_x6p_kernel<WM_, 0, true, true, 1, NTL_, false, false, true>)); \
-        int gsz = (int)grid.x;                                                                                                    \
-        const int fit = per_cu * cu_count() / unit * unit;                                                                        \
-        if (fit >= unit && fit < gsz) gsz = fit;                                                                                  \
-        hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, true, 1, NTL_, false, false, true>), dim3(gsz), dim3(256), 0, stream, g);  \
-    } while (0)
-        if (tile_rows == 256) { if (narrow) PECLR_PERSIST(2, 2); else PECLR_PERSIST(2, 4); }
-        else { if (narrow) PECLR_PERSIST(1, 2); else PECLR_PERSIST(1, 4); }
-#undef PECLR_PERSIST
     } else {
         if (tile_rows == 256) PECLR_LAUNCH(2, 1); else PECLR_LAUNCH(1, 1);
     }
@@ -948,7 +830,7 @@ extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, co
 static int gemm_x6p_host(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc, int add_h, int add_w,
                          const unsigned* add_mask,
                                   const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
-                                  const peclr_bn_bwd_fuse* bb, peclr_stream_t stream, const float* a_ss = nullptr) {
+                                  const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
     if (!A || !Bp || !C || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
     if (bb && (stat_partial || !bb->x || !bb->mean || !bb->invstd || !bb->scale_shift || !bb->partial || ldc != N)) return PECLR_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % PK) return PECLR_ERR_SHAPE;
@@ -965,20 +847,7 @@ static int gemm_x6p_host(int M, int N, int K, const float* A, int lda, const voi
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = g.W = 1; g.flip = 0; g.zeros = nullptr; g.stride = 1; g.Hin = g.Win = 1; g.s2d = 0;
     set_bb(g, bb);
-    if (a_ss && (K > 512 || addend || bb)) return PECLR_ERR_UNSUPPORTED;
-    g.a_ss = a_ss;
     return launch_x6p(g, tile_rows, 1, static_cast<hipStream_t>(stream));
-}
-
-// C = relu(bn(A)) . B_t^T: A is the INPUT of the BatchNorm2d + ReLU layer in front of this 1x1 convolution (conv -> bn -> relu -> conv
-// inside a torchvision Bottleneck), a_scale_shift = [2][K] the table peclr_bn2d_finalize_f32 wrote; the layer's apply pass and
-// its output tensor disappear.  K <= 512; optional statistics of C as in peclr_gemm_x6p_f32.
-extern "C" int peclr_gemm_x6p_bnrelu_f32(int M, int N, int K, const float* A, int lda, const float* a_scale_shift, const void* Bp,
-                                         float* C, int ldc, int tile_rows, const float* stat_shift, float* stat_partial,
-                                         peclr_stream_t stream) {
-    if (!a_scale_shift) return PECLR_ERR_NULL;
-    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, 0, 0, nullptr, nullptr, 0, tile_rows, stat_shift, stat_partial, nullptr, stream,
-                         a_scale_shift);
 }
 
 extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,

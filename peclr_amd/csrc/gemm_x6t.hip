@@ -36,9 +36,6 @@ struct X6TArgs {
     int taps, H, W;                  // taps = 9: the nine 3x3 filter taps; H x W: image extents of A's rows (output pixels)
     int stride;                      // 2: B's rows are the pixels of 2H x 2W images, read at (2 oh + dh, 2 ow + dw)
     const float* zeros;
-    // TRB instantiations: B is the INPUT of a BatchNorm2d + ReLU layer whose output the product consumes; b_ss = [2][N] that
-    // layer's scale / shift, applied -- max(fmaf(b, scale[n], shift[n]), 0), peclr_bn2d_apply's expression -- as the rows are split
-    const float* b_ss;
 };
 
 __device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, f32x16 acc) {
@@ -52,7 +49,7 @@ __device__ __forceinline__ int slot_of(int i) { return (i & 3) * 8 + ((i >> 2) ^
 // PF: k-steps of global loads in flight per thread (register stages).  (Measured on the 64-wide gradients, whose k-steps
 // are short: PF = 2 changes nothing -- hipcc's wait-count pass still drains every load before the split -- and PF = 4
 // costs the second workgroup per CU its registers, 262 -> 298 us.  PF = 1 everywhere.)
-template <int MT, int NT, int WGM, bool GEO, int PF, bool TRB = false>
+template <int MT, int NT, int WGM, bool GEO, int PF>
 __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
     constexpr int WGN = 8 / WGM;
     constexpr int TM = 32 * WGM * MT, TN = 32 * WGN * NT;
@@ -89,15 +86,6 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
     const int st_base = (kq >> 1) * (is_a ? HALF_A : HALF_B) + tile * 512 + (kq & 1) * 8 + (is_a ? 0 : 3 * PL_A);
     const int st_plane = is_a ? PL_A : PL_B;
 
-    // TRB: this thread's four columns of B keep their BatchNorm constants in registers for the whole split.  Rows past the
-    // split's end read zeros on BOTH sides, so what the transform makes of B's zeros there meets A's zeros: + 0 exactly.
-    f32x4 tsc = {0.f, 0.f, 0.f, 0.f}, tsh = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (TRB) {
-        if (!is_a && col_ok) {
-            tsc = *reinterpret_cast<const f32x4*>(g.b_ss + n0 + col);
-            tsh = *reinterpret_cast<const f32x4*>(g.b_ss + g.N + n0 + col);
-        }
-    }
     // rows that exactly ONE workgroup of a split reads (the operand whose other side fits one tile: both operands of layer1's
     // 256 x 64 / 64 x 256 gradients) are loaded with the non-temporal hint: a linear read runs at 6.8 TB/s with it, 4.3 without
     // (tools/exp/rw_mix.hip); `conv1x1_wgrad~hbm` 192 -> 180 us.  Rows several workgroups share keep the plain load (L2 reuse).
@@ -141,12 +129,6 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
         for (int j = 0; j < 4; ++j) {
             unsigned h[2], m[2], l[2];
             float v[4] = {ld4[0][j], ld4[1][j], ld4[2][j], ld4[3][j]};
-            if constexpr (TRB) {
-                if (!is_a) {                                  // (wave-uniform)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaf(v[q], tsc[j], tsh[j]), 0.f);
-                }
-            }
             split3_pk(v[0], v[1], h[0], m[0], l[0]);
             split3_pk(v[2], v[3], h[1], m[1], l[1]);
             unsigned char* d = base + slot_of(cin + j) * 16;
@@ -415,10 +397,9 @@ extern "C" int peclr_gemm_x6t_slabs(int M, int N, int K, int taps) {
 
 // stride 2: A's K rows are the H x W output pixels of a stride-2 convolution (1x1 without padding, or 3x3 with padding 1),
 // B's 4 K rows the 2H x 2W input pixels.
-static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* b_ss, float* slabs,
+static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs,
                          int n_slabs, int taps, int H, int W, int stride, const float* zeros, peclr_stream_t stream) {
     if (!A || !B || !slabs || !zeros) return PECLR_ERR_NULL;
-    if (b_ss && (taps != 1 || stride != 1 || !aligned16(b_ss))) return PECLR_ERR_UNSUPPORTED;
     if (M <= 0 || N <= 0 || K <= 0 || n_slabs < 1 || (taps != 1 && taps != 9) || (stride != 1 && stride != 2)) return PECLR_ERR_SHAPE;
     if (M % 4 || N % 4 || lda % 4 || ldb % 4 || lda < M || ldb < N) return PECLR_ERR_SHAPE;
     if ((taps == 9 || stride == 2) && (H <= 0 || W < 6 || K % (H * W))) return PECLR_ERR_SHAPE;
@@ -429,7 +410,7 @@ static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const flo
     g.A = A; g.B = B; g.slabs = slabs;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = taps * N;
     g.kchunk = ((K + n_slabs - 1) / n_slabs + TK - 1) / TK * TK;
-    g.taps = taps; g.H = H; g.W = W; g.stride = stride; g.zeros = zeros; g.b_ss = b_ss;
+    g.taps = taps; g.H = H; g.W = W; g.stride = stride; g.zeros = zeros;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (taps == 9) {
         if (M <= 64) hipLaunchKernelGGL(gemm_x6w_kernel<2>, dim3(((M + 63) / 64) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
@@ -441,7 +422,6 @@ static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const flo
 #define PECLR_LAUNCH(MT_, NT_, WGM_, PF_)                                                                            \
     do {                                                                                                             \
         if (stride == 2) hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, true, PF_>), grid, dim3(512), 0, s, g); \
-        else if (b_ss) hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, false, PF_, true>), grid, dim3(512), 0, s, g); \
         else hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, false, PF_>), grid, dim3(512), 0, s, g);            \
     } while (0)
     if (t.wgm == 2) {
@@ -460,14 +440,5 @@ static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const flo
 
 extern "C" int peclr_gemm_x6t_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs,
                                   int n_slabs, int taps, int H, int W, int stride, const float* zeros, peclr_stream_t stream) {
-    return gemm_x6t_host(M, N, K, A, lda, B, ldb, nullptr, slabs, n_slabs, taps, H, W, stride, zeros, stream);
-}
-
-// slabs of A^T . relu(bn(B)): the weight gradient of the 1x1 convolution BEHIND a BatchNorm2d + ReLU layer whose output was never
-// written (peclr_gemm_x6p_bnrelu_f32 was its forward): B is that layer's input, b_scale_shift = [2][N] its scale / shift table.
-extern "C" int peclr_gemm_x6t_bnrelu_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                                         const float* b_scale_shift, float* slabs, int n_slabs, const float* zeros,
-                                         peclr_stream_t stream) {
-    if (!b_scale_shift) return PECLR_ERR_NULL;
-    return gemm_x6t_host(M, N, K, A, lda, B, ldb, b_scale_shift, slabs, n_slabs, 1, 0, 0, 1, zeros, stream);
+    return gemm_x6t_host(M, N, K, A, lda, B, ldb, slabs, n_slabs, taps, H, W, stride, zeros, stream);
 }

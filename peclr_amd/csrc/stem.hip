@@ -188,6 +188,14 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemArgs g) {
 #pragma unroll
             for (int p = 0; p < NP; ++p)
                 af[a][p] = *reinterpret_cast<const uint4*>(lds + fbase + p * PLANE + (2 * a + kh) * PROW + s * 16);
+        if (s == 3) {
+            // the pair's second pixel is the padding tap kw = 7: a REAL neighbouring pixel under a zero weight.  Zero the operand too,
+            // so that a non-finite pixel there cannot reach this output through 0 * inf (a true 7x7 convolution never reads it)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) af[a][p].z = af[a][p].w = 0u;
+        }
         const unsigned char* bt = lds + B0 + (t % NB) * CH + lane * 16;
 #pragma unroll
         for (int y = 0; y < 2; ++y)
@@ -656,6 +664,7 @@ extern "C" int peclr_stem_wgrad_slabs(int N, int Hin, int Win, int fmt) {
     if (N <= 0 || Hin < 8 || Win < 8 || fmt < 0 || fmt > 2) return PECLR_ERR_SHAPE;
     const int Ho = (Hin - 1) / 2 + 1, Wo = (Win - 1) / 2 + 1;
     const long long tiles = (long long)N * Ho * ((Wo + WPX - 1) / WPX);
+    if (tiles >= (1ll << 31)) return PECLR_ERR_SHAPE;          // (the kernel walks the tile index space with 32-bit arithmetic)
     const long long cap = fmt == 0 ? 512 : 768;
     return (int)(tiles < cap ? tiles : cap);
 }

@@ -37,8 +37,8 @@ def _conv(conv, x, bn, sole_consumer=False):
 
 def _bn(bn, x, residual=None, relu=False, consumer=None):
     """bn -> (+residual) -> (relu): one fused HIP pass when `bn` is a FusedBatchNormAct2d, the stock
-    three ops otherwise (any other norm_layer).  consumer: the convolution that is the only reader of the result (it may
-    then apply the layer in its own operand path instead: FusedBatchNormAct2d.forward)."""
+    three ops otherwise (any other norm_layer).  consumer: the layer that is the only reader of the result (a block's last
+    BatchNorm pass computes the shortcut's BatchNorm itself: FusedBatchNormAct2d.forward)."""
     if isinstance(bn, FusedBatchNormAct2d):
         return bn(x, residual, relu, consumer=consumer if isinstance(consumer, (Conv2d, FusedBatchNormAct2d)) else None)
     y = bn(x)
@@ -68,6 +68,8 @@ class BasicBlock(nn.Module):
     def _run(self, x: Tensor) -> Tensor:
         ds = self.downsample
         if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[1], FusedBatchNormAct2d):
+            # (ds[0] / ds[1] are called directly: forward hooks on the `downsample` Sequential ITSELF do not fire on this path --
+            # hooks on its convolution and BatchNorm do; state_dict keys are unchanged)
             identity = _bn(ds[1], ds[0](x), consumer=self.bn2)                 # (its apply is left to bn2's pass, the only reader)
         else:
             identity = x if ds is None else ds(x)

@@ -99,6 +99,15 @@ class Trainer:
                 gc.enable()
         self._graphs_alive.append(graph)
 
+    def _release_superseded(self):
+        """A new capture (another batch shape, another model, a second `attach`) supersedes what this trainer captured before:
+        release those graphs and the pool memory they pin NOW -- outside any capture, device idle -- instead of keeping every
+        generation alive until `close()`."""
+        if self._graphs_alive:
+            sig = self._graph_sig
+            self.close()
+            self._graph_sig = sig              # (`_graph_step` sets it before it captures)
+
     def close(self):
         """Release every captured graph (and the graph-pool memory they pin): outside any capture, device idle."""
         if torch.cuda.is_available():
@@ -115,6 +124,8 @@ class Trainer:
 
     # ---- setup
     def attach(self, model):
+        if getattr(self, "_graphs_alive", None):       # re-attach: the graphs of the previous model go (see `_release_superseded`)
+            self.close()
         model.trainer = self
         model.process_group = self.process_group
         model.setup("fit")
@@ -329,6 +340,7 @@ class Trainer:
     # (tools/exp/graph_capture_sizes.py: capture-first works at every size tried, eager-first never).
     def capture_step_graph(self, example_batch: Dict[str, torch.Tensor], warmup: int = 3):
         self._no_fp16_graphs()
+        self._release_superseded()
         if self.world_size > 1 or self.reducer is not None:
             raise RuntimeError("capture_step_graph is single-process only (no gradient buckets)")
         if self.accumulate_grad_batches != 1:
@@ -394,6 +406,7 @@ class Trainer:
         their buckets and all-reduced ASYNCHRONOUSLY while the next stage replays (RN-50: 65 MB, then 28 MB, travel
         under the remaining backward), so only the last stage's ~6 MB stay exposed."""
         self._no_fp16_graphs()
+        self._release_superseded()
         if self.reducer is None:
             raise RuntimeError("capture_split_graphs works on the flat gradient buckets: Trainer(grad_buckets=True) "
                                "or world_size > 1")
@@ -512,6 +525,7 @@ class Trainer:
     # the reference's Lightning loop.
     def capture_micro_graph(self, example_batch: Dict[str, torch.Tensor], warmup_windows: int = 1):
         self._no_fp16_graphs()
+        self._release_superseded()
         k = self.accumulate_grad_batches
         if self.world_size > 1 or self.reducer is not None:
             raise RuntimeError("capture_micro_graph is single-process only (no gradient buckets)")

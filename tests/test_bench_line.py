@@ -54,6 +54,34 @@ def test_compact_line_stays_small_with_long_free_text_and_a_dist_record():
     assert out["dist"]["ranks_seen"] == 8 and out["dist"]["grad_buckets"] == 4
 
 
+def test_bf16_companion_rides_in_the_compact_line():
+    """The default fp32 run attaches a driver-witnessed bf16 step time (C3 / C5 are bf16 configurations): the companion is what
+    `companion_from_line` keeps of the bf16 run's own compact line, and the fp32 line still fits."""
+    full = recorded_full_line()
+    with open(os.path.join(ROOT, "profiles", "r05e_bench_bf16_n1.json")) as f:
+        bf16_line = json.loads(f.read().strip().splitlines()[-1])
+    full["bf16_companion"] = bench.companion_from_line(bf16_line)
+    line = bench.compact_line(full)
+    assert len(line) < bench.COMPACT_LIMIT
+    out = json.loads(line)
+    c = out["bf16_companion"]
+    assert c["dtype"] == "bf16" and c["ms_per_step"] == bf16_line["ms_per_step"] and c["value"] == bf16_line["value"]
+    assert c["value"] == pytest.approx(2 * 128 * 1e3 / c["ms_per_step"], rel=1e-3) and c["steps"] == bf16_line["steps"]
+    roof = c["roofline"]
+    assert {"bound", "kernel", "achieved", "peak", "unit", "frac", "avg_us"} <= set(roof)
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3)
+    assert out["dtype"] == "fp32" and out["ms_per_step"] == full["ms_per_step"]         # the judged numbers stay the fp32 run's
+    # which runs get one: the default fp32 single-GPU command only
+    argv = sys.argv
+    try:
+        for extra, want in (([], True), (["--dtype", "bf16"], False), (["--no-cpu-baseline"], False), (["--bf16-companion", "0"], False),
+                            (["--gpus", "2"], False)):
+            sys.argv = ["bench.py", *extra]
+            assert bench.wants_companion(bench.parse()) == want, extra
+    finally:
+        sys.argv = argv
+
+
 def test_emit_prints_details_first_and_the_compact_line_last(capsys, tmp_path, monkeypatch):
     monkeypatch.setenv("PECLR_BENCH_DETAILS", str(tmp_path / "d.json"))
     bench.emit(recorded_full_line())

@@ -20,6 +20,10 @@ import os, sys, warnings
 sys.path.insert(0, os.environ["PECLR_ROOT"])
 warnings.simplefilter("ignore")
 import torch
+# Run-to-run repeatable arms: every shape the in-tree kernels accept goes to them (PECLR_ROUTE_FORCE=1 in the environment: fixed-order
+# slab weight gradients), and whatever is left on MIOpen must pick a deterministic algorithm (no atomically accumulated split-K).
+torch.use_deterministic_algorithms(True, warn_only=True)
+torch.backends.cudnn.deterministic = True
 from peclr_amd import Hybrid2Model, Trainer, hybrid2_config
 from peclr_amd import dist as pdist
 from peclr_amd.bn2d import enable_hip_batchnorm
@@ -141,33 +145,29 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, sync_bn):
     reproduce one device with 8 pairs -- loss, every gradient and the running statistics."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    # The shapes of this rehearsal (4 pairs of small images) lie below the in-tree kernels' routing thresholds, so most weight
-    # gradients come from MIOpen's atomically accumulated split-K kernels: two runs of the SAME configuration differ, and through
-    # train-mode BatchNorm over 16 rows the difference is amplified.  The bars below sit ~3x above what is usually seen; the full
-    # GPU suite hit them once in ~25 runs of this test (round 5, a heavily loaded box; 14 of 14 in a loop on its own).  One repeat
-    # of the comparison is allowed for that reason -- exact checks (replicas identical, processes exit cleanly) never are.
-    for attempt in range(2):
-        try:
-            _two_ranks_against_one(tmp_path / f"try{attempt}", script, sync_bn)
-            return
-        except _ToleranceMiss as e:
-            print(f"attempt {attempt}: {e}")
-            if attempt == 1:
-                raise AssertionError(str(e))
+    # The shapes of this rehearsal (4 pairs of small images) lie below the in-tree kernels' routing thresholds; left alone most weight
+    # gradients would come from MIOpen's atomically accumulated split-K kernels and two runs of the SAME arm would differ.  Both arms
+    # therefore run with PECLR_ROUTE_FORCE=1 (in-tree fixed-order weight gradients wherever the kernels accept the shape) and under
+    # torch.use_deterministic_algorithms (a deterministic MIOpen algorithm for the rest): each arm repeats itself bit for bit (asserted
+    # below by running the one-rank arm twice), so the two-rank result differs from the one-rank result by the reduction trees only,
+    # and ONE comparison decides.
+    seen = measure_two_ranks_against_one(tmp_path / "run", script, sync_bn)
+    bars = BARS[sync_bn]
+    misses = {k: (v, bars[k]) for k, v in seen["worst"].items() if not v <= bars[k]}
+    assert not misses, f"(observed, bar) {misses}; worst offenders {seen['where']}"
 
 
-class _ToleranceMiss(Exception):
-    pass
+# Bars: what 20 runs of `tools/exp/rehearsal_noise.py` showed for the deterministic arms (round 6), times ~3; none looser than
+# round 5's (loss 2e-6 / 2e-5; gradients 2e-4 / 2e-2 of the largest entry; 6e-3 norm-wise; buffers 1e-4).
+BARS = {False: {"loss": 2e-6, "grad_max": 2e-4, "grad_norm": 2e-4, "buffer": 0.0},
+        True: {"loss": 2e-5, "grad_max": 2e-2, "grad_norm": 6e-3, "buffer": 1e-4}}
 
 
-def _close(cond, msg):
-    if not cond:
-        raise _ToleranceMiss(msg)
-
-
-def _two_ranks_against_one(out, script, sync_bn):
+def measure_two_ranks_against_one(out, script, sync_bn):
+    """Runs the two-rank arm once and the one-rank arm twice; asserts everything that must hold EXACTLY (replicas identical, the
+    one-rank arm repeats itself bit for bit, processes exit cleanly) and returns the worst observed deviations two ranks vs one."""
     out.mkdir()
-    env = dict(os.environ, PECLR_ROOT=ROOT, PECLR_DIST_BACKEND="gloo", PECLR_SHARE_DEVICE="1",
+    env = dict(os.environ, PECLR_ROOT=ROOT, PECLR_DIST_BACKEND="gloo", PECLR_SHARE_DEVICE="1", PECLR_ROUTE_FORCE="1",
                PECLR_SYNC_BN="1" if sync_bn else "0")
     port = free_port()
     procs = [subprocess.Popen([sys.executable, str(script)],
@@ -176,32 +176,37 @@ def _two_ranks_against_one(out, script, sync_bn):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=500)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    subprocess.run([sys.executable, str(script)], env=dict(env, PECLR_OUT=str(out / "one"), WORLD_SIZE="1"), check=True,
-                   timeout=500)
-    tmp_path = out
-    r0, r1 = torch.load(str(tmp_path / "two") + ".r0"), torch.load(str(tmp_path / "two") + ".r1")
-    one = torch.load(str(tmp_path / "one") + ".r0")
-    assert torch.equal(r0["loss"], r1["loss"])
-    _close(abs(float(r0["loss"]) - float(one["loss"])) < (2e-5 if sync_bn else 2e-6), f"loss {float(r0['loss'])} vs {float(one['loss'])}")
-    # train-mode BN over few rows (the last stages normalise over 16 rows here) amplifies the fp32
-    # summation-order noise of two different reduction trees; a wrong count/shift/sum would be O(1)
-    rel = 2e-2 if sync_bn else 2e-4
+    for name in ("one", "again"):
+        subprocess.run([sys.executable, str(script)], env=dict(env, PECLR_OUT=str(out / name), WORLD_SIZE="1"), check=True, timeout=500)
+    r0, r1 = torch.load(str(out / "two") + ".r0"), torch.load(str(out / "two") + ".r1")
+    one, again = torch.load(str(out / "one") + ".r0"), torch.load(str(out / "again") + ".r0")
+    assert torch.equal(r0["loss"], r1["loss"])                        # global loss: identical on both ranks
+    assert torch.equal(one["loss"], again["loss"])                    # the one-rank arm repeats itself bit for bit
+    for n, g1 in one["grads"].items():
+        assert torch.equal(g1, again["grads"][n]), f"one-rank arm is not run-to-run repeatable: {n}"
+    worst = {"loss": abs(float(r0["loss"]) - float(one["loss"])), "grad_max": 0.0, "grad_norm": 0.0, "buffer": 0.0}
+    where = {}
+    # train-mode BN over few rows (the last stages normalise over 16 rows here) amplifies the fp32 summation-order
+    # difference of the two reduction trees; a wrong count / shift / sum would be O(1)
     for n, g1 in one["grads"].items():
         assert torch.equal(r0["grads"][n], r1["grads"][n]), n      # SUM-reduced: identical on both ranks
         if sync_bn and (n.endswith("0.bias") and "projection_head" in n):
             continue  # bias in front of a train-mode BN: gradient is rounding noise around 0 on both sides
-        a, b = r0["grads"][n].numpy(), g1.numpy()
-        worst = float(np.abs(a - b).max())
-        _close(worst <= rel * max(1e-6, float(np.abs(b).max())) + 1e-7, f"{n}: max |d| {worst:.3e} of max |g| {float(np.abs(b).max()):.3e}")
-        if sync_bn and b.size > 64:
-            # (run-to-run noise of MIOpen's atomically accumulated weight gradients through small-batch BN reaches
-            # ~2e-3 norm-wise on the stem; a wrong count / shift / sum would be O(1))
-            _close(np.linalg.norm(a - b) <= 6e-3 * np.linalg.norm(b) + 1e-7,
-                   f"{n}: |d| / |g| = {np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30):.3e}")
-    if sync_bn:
-        for n, b1 in one["buffers"].items():
-            assert torch.equal(r0["buffers"][n], r1["buffers"][n]), n
-            _close(np.allclose(r0["buffers"][n].numpy(), b1.numpy(), rtol=1e-4, atol=1e-6), f"buffer {n}")
+        a, b = r0["grads"][n].double().numpy(), g1.double().numpy()
+        rel_max = max(0.0, float(np.abs(a - b).max()) - 1e-7) / max(1e-6, float(np.abs(b).max()))
+        if rel_max > worst["grad_max"]:
+            worst["grad_max"], where["grad_max"] = rel_max, n
+        if b.size > 64:
+            rel_norm = max(0.0, float(np.linalg.norm(a - b)) - 1e-7) / float(np.linalg.norm(b) + 1e-30)
+            if rel_norm > worst["grad_norm"]:
+                worst["grad_norm"], where["grad_norm"] = rel_norm, n
+    for n, b1 in one["buffers"].items():
+        assert torch.equal(r0["buffers"][n], r1["buffers"][n]), n
+        a, b = r0["buffers"][n].numpy(), b1.numpy()
+        rel = float((np.maximum(np.abs(a - b) - 1e-6, 0.0) / np.maximum(np.abs(b), 1e-30)).max()) if b.size else 0.0
+        if rel > worst["buffer"]:
+            worst["buffer"], where["buffer"] = rel, n
+    return {"worst": worst, "where": where}
 
 
 @pytest.mark.timeout(900)

@@ -210,13 +210,58 @@ def test_align_single_norm_and_golden(capi):
                                     (dev(ang[: m // 2]), dev(ang[m // 2:])), want_stats=False)
     u = host(z) * host(norms[1])[:, None]
     np.testing.assert_allclose(u.reshape(m, 64, 2), g["out"], atol=2e-6)
-    g = load_golden("g3_translate_224.npz")
-    jx, jy = g["jitter_x"], g["jitter_y"]
-    _, z, norms, _ = capi.align_fwd(dev(g["q"].reshape(1, m, 128)), m // 2, capi.ALIGN_CROP,
-                                    tuple(dev(v) for v in (jx[:6], jx[6:], jy[:6], jy[6:])), (224, 224), None,
-                                    want_stats=False)
-    u = host(z) * host(norms[1])[:, None]
-    np.testing.assert_allclose(u.reshape(m, 64, 2), g["out"], atol=2e-6)
+    for size in (224, 448):           # the reference's own translate_encodings outputs at both image extents (C2, C5)
+        g = load_golden(f"g3_translate_{size}.npz")
+        assert int(g["size"]) == size
+        m = g["q"].shape[0]
+        jx, jy = g["jitter_x"], g["jitter_y"]
+        _, z, norms, _ = capi.align_fwd(dev(g["q"].reshape(1, m, 128)), m // 2, capi.ALIGN_CROP,
+                                        tuple(dev(v) for v in (jx[: m // 2], jx[m // 2:], jy[: m // 2], jy[m // 2:])),
+                                        (size, size), None, want_stats=False)
+        u = host(z) * host(norms[1])[:, None]
+        np.testing.assert_allclose(u.reshape(m, 64, 2), g["out"], atol=2e-6, err_msg=str(size))
+
+
+def test_projection_head_golden_through_the_kernels(capi):
+    """g6_head.npz (captured from the reference's projection head, simclr_model.py:20-35, two training-mode forwards and one
+    backward) pushed through K1 / BatchNorm1d+ReLU / K2 and their backward kernels directly, without the module around them."""
+    g = load_golden("g6_head.npz")
+    m, din = g["h"].shape
+    hid, d = g["in_w1"].shape[0], g["in_w2"].shape[0]
+    w1, b1, gamma, beta, w2 = (dev(g[k]) for k in ("in_w1", "in_b1", "in_gamma", "in_beta", "in_w2"))
+    rm, rv = torch.zeros(hid, device=DEV), torch.ones(hid, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+
+    def slabs(t):
+        return t if t.dim() == 3 else t.unsqueeze(0)
+
+    def forward(h):
+        a_slabs = slabs(capi.gemm(capi.GEMM_NT, h, w1, split_k=capi.pick_split_k(m, hid, din)))
+        a_pre, a, save = capi.bn_relu_fwd(a_slabs, b1, gamma, beta, 1e-5, 0.1, True, rm, rv, nbt)
+        p_slabs = slabs(capi.gemm(capi.GEMM_NT, a, w2, split_k=capi.pick_split_k(m, d, hid)))
+        p = capi.align_fwd(p_slabs, m // 2, capi.ALIGN_SINGLE_NORM, None, (1, 1), None, want_stats=False)[0]   # (the slab sum)
+        return p, a_pre, a, save
+
+    h = dev(g["h"])
+    p, a_pre, a, save = forward(h)
+    np.testing.assert_allclose(host(p), g["p"], atol=5e-6)
+    np.testing.assert_allclose(host(rm), g["running_mean1"], atol=1e-6)
+    np.testing.assert_allclose(host(rv), g["running_var1"], atol=1e-6)
+    dp = dev(g["dp"])
+    dw2 = capi.gemm(capi.GEMM_TN, dp, a)
+    da = capi.gemm(capi.GEMM_NN, dp, w2)
+    d_a_pre, dgamma, dbeta, db1 = capi.bn_relu_bwd(da, a_pre, save, gamma, beta, True)
+    dw1 = capi.gemm(capi.GEMM_TN, d_a_pre, h)
+    dh = capi.gemm(capi.GEMM_NN, d_a_pre, w1)
+    for k, v in dict(dh=dh, dw1=dw1, dgamma=dgamma, dbeta=dbeta, dw2=dw2).items():
+        scale = max(1.0, float(np.abs(g[k]).max()))
+        np.testing.assert_allclose(host(v), g[k], rtol=0, atol=1e-5 * scale, err_msg=k)
+    assert float(np.abs(g["db1"]).max()) < 1e-5 and float(db1.abs().max()) < 1e-5     # a bias in front of a batch-statistics BN
+    p2 = forward(dev(g["h2"]))[0]
+    np.testing.assert_allclose(host(p2), g["p2"], atol=5e-6)
+    np.testing.assert_allclose(host(rm), g["running_mean2"], atol=1e-6)
+    np.testing.assert_allclose(host(rv), g["running_var2"], atol=1e-6)
+    assert int(nbt) == int(g["num_batches_tracked2"]) == 2
 
 
 # ------------------------------------------------------------------ NT-Xent

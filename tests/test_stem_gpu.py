@@ -41,6 +41,27 @@ def test_stem_fp32_is_an_fp32_convolution(n, h, w, weight_format):
         assert torch.equal(capi.stem_conv(x, planes), y)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem_non_finite_pixel_reaches_exactly_the_outputs_a_7x7_window_connects_it_to(dtype):
+    """K is padded with a zero-weighted eighth tap per filter row that points at a real neighbouring pixel; that operand is zeroed
+    as well, so an inf there does not turn into a NaN (0 * inf) in an output a true 7x7 convolution keeps finite."""
+    from peclr_amd import _capi as capi
+
+    x, wt = _data(2, 40, 72, seed=11)
+    bad = [(0, 1, 17, 33), (1, 0, 0, 0), (1, 2, 39, 71), (0, 0, 20, 8)]
+    for (n, c, h, w) in bad:
+        x[n, c, h, w] = float("inf")
+    y = capi.stem_conv(x, capi.StemPlanes(wt, dtype).pack()).float()
+    touched = torch.zeros(2, 1, 20, 36, dtype=torch.bool, device=DEV)
+    for (n, c, h, w) in bad:
+        for oh in range(20):
+            for ow in range(36):
+                if 0 <= h - (2 * oh - 3) < 7 and 0 <= w - (2 * ow - 3) < 7:
+                    touched[n, 0, oh, ow] = True
+    finite = torch.isfinite(y).all(dim=1, keepdim=True)
+    assert bool((finite == ~touched).all()), (int((~finite & ~touched).sum()), int((finite & touched).sum()))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("n,h,w", [(4, 224, 224), (3, 30, 46), (1, 131, 225)])
 def test_stem_16_bit_is_one_rounding_of_the_product_of_the_rounded_operands(dtype, n, h, w):

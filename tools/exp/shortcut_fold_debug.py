@@ -2,7 +2,7 @@
 import copy, sys
 import torch
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
-from test_bn_apply_in_gemm_gpu import _first_block, DEV
+from test_bn_shortcut_in_add_gpu import _first_block, DEV
 from peclr_amd import bn2d as B
 
 a = _first_block("bottleneck", 256, 128, 2, seed=128)
