@@ -120,6 +120,20 @@ typedef struct {
     float* partial;
 } peclr_bn_bwd_fuse;
 
+/* "Pair" arithmetic of the packed-weight GEMMs below (round 6; every entry point that takes `pair`: NULL = the six-product
+ * arithmetic on planes of peclr_x6_pack_f32).  Non-NULL: Bp holds planes of peclr_x6_pack_pair_f32 -- the weight multiplied by a
+ * power of two (*w_scale) and split into TWO fp16 numbers hi + lo -- and the activation operand is scaled and split the same way in
+ * the kernel by the power of two that puts *a_absmax (= max |A| over the whole tensor; written by the pass that produced A:
+ * `absmax_out` of the peclr_bn2d_* entry points) into [2^14, 2^15).  Three products (hi.hi, hi.lo, lo.hi) on
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation instead of six on the bf16 instruction; the accumulators are multiplied by
+ * 1 / (s_a s_w) (exact).  22 - 23 of fp32's 24 significand bits per operand: error against float64 in the class of an fp32 BLAS
+ * GEMM (measured per layer on real tensors: tools/exp/fp16_pair_probe.py, tools/exp/pair_probe.py).
+ * Both pointers are DEVICE pointers to one float, read by the kernel: no host synchronisation.                                 */
+typedef struct {
+    const float* a_absmax;
+    const float* w_scale;
+} peclr_x6_pair;
+
 /* Second generation of the same scheme for a WEIGHT operand (a parameter: constant for a whole step, used by forward,
  * input gradient and fused entry gradient of a 1x1 convolution, resnet_model.py:15): peclr_x6_pack_f32 splits the
  * weight ONCE into three bf16 planes in MFMA fragment order (per 128 output columns x 16 k one 12 KiB chunk of twelve
@@ -138,10 +152,16 @@ typedef struct {
  *   synchronised route's peclr_bn2d_combine_f64) takes it with n_split = ceil(M / tile_rows).  Fixed summation order. */
 int64_t peclr_x6_pack_bytes(int N, int K);
 int peclr_x6_pack_f32(const void* desc_table, int count, int total_chunks, peclr_stream_t stream);
+/* ... and as fp16 pairs (see peclr_x6_pair): same descriptor table, dst of peclr_x6_pack_pair_bytes(n, k) = 4 n k bytes (8 KiB
+ * chunks of eight pieces [32-column block][hi | lo]); absmax: float [count] scratch (the per-matrix maxima, found by a first
+ * launch over the same grid); scales: float [count], entry d = the power of two matrix d was multiplied by (-> w_scale).   */
+int64_t peclr_x6_pack_pair_bytes(int N, int K);
+int peclr_x6_pack_pair_f32(const void* desc_table, int count, int total_chunks, float* absmax, float* scales,
+                           peclr_stream_t stream);
 int peclr_gemm_x6p_tile_rows(int M, int N, int K);
 int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                        const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
-                       const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
+                       const peclr_bn_bwd_fuse* bn_bwd, const peclr_x6_pair* pair, peclr_stream_t stream);
 /* The same product when the addend is the COMPACT input gradient of a 1x1 / stride-2 convolution: the M rows are the pixels
  * of H x W images (H, W even, M a multiple of H * W), addend_half = [images][H / 2][W / 2][ldd], and only the rows at even
  * (h, w) add addend_half[(h / 2, w / 2)].  This is the entry gradient of a ResNet layer's first block -- dY1 . W1 (main
@@ -149,7 +169,7 @@ int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void*
  * input gradient writes and the addend pass reads (resnet_model.py:15; torchvision Bottleneck.downsample).               */
 int peclr_gemm_x6p_s2add_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                              const float* addend_half, int ldd, int H, int W, int tile_rows, const peclr_bn_bwd_fuse* bn_bwd,
-                             peclr_stream_t stream);
+                             const peclr_x6_pair* pair, peclr_stream_t stream);
 /* ... and when the addend is a gradient that still has to pass a ReLU: addend_mask = the 1-bit mask peclr_bn2d_apply wrote
  * for that ReLU ([M][N / 32] words, bit c % 32 of word c / 32 = output c was positive); addend elements whose bit is clear
  * count as zero.  This is the entry gradient of a residual block whose shortcut is the identity: dY1 . W1 +
@@ -157,7 +177,7 @@ int peclr_gemm_x6p_s2add_f32(int M, int N, int K, const float* A, int lda, const
  * residual's gradient (4 B per element written, then read back here).  N % 32 == 0.                                       */
 int peclr_gemm_x6p_maskadd_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                                const float* addend, int ldd, const unsigned* addend_mask, int tile_rows,
-                               const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
+                               const peclr_bn_bwd_fuse* bn_bwd, const peclr_x6_pair* pair, peclr_stream_t stream);
 /* 3x3 / stride-1 / padding-1 convolution of an NHWC fp32 tensor (the middle convolution of the torchvision Bottleneck,
  * resnet_model.py:15) as an implicit GEMM on the same kernel: rows = output pixels, K = 9 * Cin ordered (tap, channel); the
  * activation rows of a k-step come from the pixel the tap points at (zeros outside the image: `zeros` = >= 64 bytes of
@@ -167,7 +187,7 @@ int peclr_gemm_x6p_maskadd_f32(int M, int N, int K, const float* A, int lda, con
  * statistics outputs as in peclr_gemm_x6p_f32.  Cin % 16 == 0, Cout % 128 == 0.                                      */
 int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* X, const void* Bp, float* Y,
                           const float* addend, int flip, int tile_rows, int variant, const float* zeros, const float* stat_shift,
-                          float* stat_partial, const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
+                          float* stat_partial, const peclr_bn_bwd_fuse* bn_bwd, const peclr_x6_pair* pair, peclr_stream_t stream);
 /* (variant 0: every wave loads and splits its rows once per tap; 1: per 16-channel chunk the workgroup splits the pixels its
  *  nine taps touch once into shared planes and the taps read their fragments at the tap's offset -- W <= 64, else as 0.)  */
 /* Weight gradients, second generation: C[M, taps * N] = sum_k A[k, M] . B[k shifted by the tap, N], the contraction over the
@@ -195,14 +215,15 @@ int peclr_gemm_x6t_f32(int M, int N, int K, const float* A, int lda, const float
  * (partial: 4 * ceil(NB Ho Wo / tile_rows) row blocks, class by class).  Cin % 64 == 0, Cout % 16 == 0.  Replaces MIOpen's
  * igemm_bwd on these three convolutions.                                                                                  */
 int peclr_conv3x3_s2_dgrad_x6p_f32(int NB, int Ho, int Wo, int Cout, int Cin, const float* dY, const void* Bp, float* dX,
-                                   int tile_rows, const float* zeros, const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
+                                   int tile_rows, const float* zeros, const peclr_bn_bwd_fuse* bn_bwd, const peclr_x6_pair* pair,
+                                   peclr_stream_t stream);
 /* Forward of the STRIDE-2 convolutions of a ResNet layer's first block on the same kernel: taps = 9 the 3x3 / padding-1
  * convolution, taps = 1 the 1x1 downsample convolution; X [NB, H, W, Cin] NHWC (H, W even), Y [NB, H/2, W/2, Cout]; output pixel
  * (oh, ow) reads input pixel (2 oh + dh, 2 ow + dw).  Planes packed as for the stride-1 forward; optional BatchNorm
  * statistics of Y.  (Weight gradients: peclr_gemm_x6t_f32 with stride = 2; input gradients: above / peclr_gemm_x6p_s2add_f32.)  */
 int peclr_conv_s2_x6p_f32(int NB, int H, int W, int Cin, int Cout, int taps, const float* X, const void* Bp, float* Y,
                           int tile_rows, const float* zeros, const float* stat_shift, float* stat_partial,
-                          peclr_stream_t stream);
+                          const peclr_x6_pair* pair, peclr_stream_t stream);
 int peclr_gemm_pick_split_k(int M, int N, int K);
 
 /* out[i] = sum_s slabs[s][i] (+ bias[i % cols] if non-null), i < rows*cols. */
@@ -406,8 +427,13 @@ int peclr_bn2d_bwd_finalize_totals_f32(const double* local_totals, const double*
                                        int C, int training, const float* scale_shift,
                                        float* dgamma, float* dbeta, float* coef,
                                        peclr_stream_t stream);
+/* absmax_out (nullable, here and in the other passes that take it): the pass also leaves max |value it wrote| in *absmax_out -- one
+ * atomic maximum per wave on a float its caller ZEROED beforehand (non-negative floats order like their bit patterns; a maximum
+ * does not depend on the order, so the result is deterministic).  It costs the pass nothing measurable (it is HBM-bound) and is
+ * what the "pair" GEMMs that consume the tensor take as peclr_x6_pair.a_absmax: every activation and every gradient a residual
+ * block's convolution reads is written by one of these passes.                                                                  */
 int peclr_bn2d_apply(const void* x, const void* residual, int io_dtype, int R, int C,
-                     const float* scale_shift, int relu, void* y, uint32_t* relu_mask,
+                     const float* scale_shift, int relu, void* y, uint32_t* relu_mask, float* absmax_out,
                      peclr_stream_t stream);
 /* The last pass of a layer's FIRST block, whose shortcut is conv1x1 -> BatchNorm2d (torchvision Bottleneck.downsample behind
  * resnet_model.py:15): y = (relu)(bn(x) + bn_s(res_x)).  res_x is the INPUT of the shortcut's BatchNorm, res_scale_shift its
@@ -415,7 +441,8 @@ int peclr_bn2d_apply(const void* x, const void* residual, int io_dtype, int R, i
  * have written and this pass read back, so the result is bit-identical -- and the shortcut's apply pass and output tensor
  * disappear.  relu_mask as in peclr_bn2d_apply.                                                                            */
 int peclr_bn2d_apply_res_bn(const void* x, const void* res_x, const float* res_scale_shift, int io_dtype, int R, int C,
-                            const float* scale_shift, int relu, void* y, uint32_t* relu_mask, peclr_stream_t stream);
+                            const float* scale_shift, int relu, void* y, uint32_t* relu_mask, float* absmax_out,
+                            peclr_stream_t stream);
 int peclr_bn2d_bwd_reduce(const void* dy, const void* x, const void* y, const uint32_t* relu_mask,
                           int io_dtype, int R, int C, int relu, const float* save_mean,
                           const float* save_invstd, const float* scale_shift, float* partial,
@@ -426,7 +453,7 @@ int peclr_bn2d_bwd_finalize_f32(float* partial, int n_split, int R, int C, int t
 int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y, const uint32_t* relu_mask,
                          int io_dtype, int R, int C, int relu, const float* save_mean,
                          const float* save_invstd, const float* scale_shift, const float* coef,
-                         void* dx, void* d_residual, peclr_stream_t stream);
+                         void* dx, void* d_residual, float* absmax_out, peclr_stream_t stream);
 
 /* Encoder tail: the last residual block's BatchNorm2d + `out += identity` + ReLU, then
  * AdaptiveAvgPool2d((1,1)) and `.flatten(1)` (features[7][-1].bn*, features[8] and the flatten of
@@ -448,7 +475,7 @@ int peclr_bn2d_bwd_reduce_avgpool(const float* d_pooled, const void* x, const ui
 int peclr_bn2d_bwd_apply_avgpool(const float* d_pooled, const void* x, const uint32_t* relu_mask,
                                  int io_dtype, int N, int HW, int C, const float* save_mean,
                                  const float* save_invstd, const float* scale_shift, const float* coef,
-                                 void* dx, void* d_residual, peclr_stream_t stream);
+                                 void* dx, void* d_residual, float* absmax_out, peclr_stream_t stream);
 
 /* Stem: BatchNorm2d + ReLU + MaxPool2d(3, stride 2, padding 1) in one pass (features[1..3] of the
  * torchvision ResNet the reference wraps, resnet_model.py:15-26); x is [N][H][W][C] NHWC, the pooled
@@ -462,7 +489,7 @@ int peclr_bn2d_bwd_apply_avgpool(const float* d_pooled, const void* x, const uin
  * windows that hold it).  C/4 (fp32) or C/8 (bf16) must divide 256. */
 int peclr_bn2d_pool_n_split(int N, int H, int W, int C, int io_dtype);
 int peclr_bn2d_pool_apply(const void* x, int io_dtype, int N, int H, int W, int C,
-                          const float* scale_shift, void* y, void* x_at_max, uint8_t* code,
+                          const float* scale_shift, void* y, void* x_at_max, uint8_t* code, float* absmax_out,
                           peclr_stream_t stream);
 int peclr_bn2d_pool_bwd_reduce(const void* dy_pool, const void* x_at_max, int io_dtype, int N, int H,
                                int W, int C, const float* save_mean, const float* save_invstd,

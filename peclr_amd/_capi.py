@@ -59,16 +59,16 @@ SIGNATURES = {
     "peclr_bn2d_bwd_finalize_totals_f32": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_bn2d_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P,
                                         _P, _P, _P]),
-    "peclr_bn2d_apply": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
-    "peclr_bn2d_apply_res_bn": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
+    "peclr_bn2d_apply": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
+    "peclr_bn2d_apply_res_bn": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
     "peclr_bn2d_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "peclr_bn2d_bwd_finalize_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
-    "peclr_bn2d_bwd_apply": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "peclr_bn2d_bwd_apply": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "peclr_bn2d_apply_avgpool": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "peclr_bn2d_bwd_reduce_avgpool": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
-    "peclr_bn2d_bwd_apply_avgpool": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "peclr_bn2d_bwd_apply_avgpool": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "peclr_bn2d_pool_n_split": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "peclr_bn2d_pool_apply": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "peclr_bn2d_pool_apply": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "peclr_bn2d_pool_bwd_reduce": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "peclr_bn2d_pool_bwd_apply": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "peclr_augment_warp_crop_u8": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
@@ -79,15 +79,17 @@ SIGNATURES = {
     "peclr_gemm_x6_tn_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
     "peclr_x6_pack_bytes": (c_int64, [c_int, c_int]),
     "peclr_x6_pack_f32": (c_int, [_P, c_int, c_int, _P]),
+    "peclr_x6_pack_pair_bytes": (c_int64, [c_int, c_int]),
+    "peclr_x6_pack_pair_f32": (c_int, [_P, c_int, c_int, _P, _P, _P]),
     "peclr_gemm_x6p_tile_rows": (c_int, [c_int, c_int, c_int]),
-    "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P]),
-    "peclr_conv3x3_s2_dgrad_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
-    "peclr_gemm_x6p_s2add_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
-    "peclr_gemm_x6p_maskadd_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P]),
+    "peclr_gemm_x6p_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "peclr_conv3x3_s2_dgrad_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    "peclr_gemm_x6p_s2add_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "peclr_gemm_x6p_maskadd_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
     "peclr_gemm_x6t_slabs": (c_int, [c_int, c_int, c_int, c_int]),
     "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
-    "peclr_conv_s2_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
-    "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "peclr_conv_s2_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "peclr_h_pack_bytes": (c_int64, [c_int, c_int]),
     "peclr_h_pack": (c_int, [_P, c_int, c_int, _P]),
     "peclr_conv_h_tile_rows": (c_int, [c_int, c_int]),
@@ -463,10 +465,13 @@ class X6Planes:
     built once (the tensors' storage must stay where it is: parameters do); `pack()` is ONE launch that re-splits every
     matrix from its current values -- call it after the weights changed (once per optimiser step)."""
 
-    def __init__(self, specs):
+    def __init__(self, specs, pair: bool = False):
+        """pair: the fp16-pair format of peclr_x6_pack_pair_f32 (two planes, one power of two per matrix: `scale(i)`) instead of
+        the three bf16 planes."""
         if not specs:
             raise PeclrHipError("X6Planes: nothing to pack")
         dev = specs[0][0].device
+        self.pair = bool(pair)
         rows, self.planes, self.shapes, chunk = [], [], [], 0
         for w, transposed in specs:
             _ptr(w, what="x6 weight")
@@ -474,7 +479,7 @@ class X6Planes:
                 raise PeclrHipError("X6Planes: 2-D weight matrices expected")
             t = int(transposed)                     # 0 plain, 1 transposed, T > 1: T-tap filter [Cout * T, Cin] for its input gradient
             n, k = (w.shape[1], w.shape[0]) if t else (w.shape[0], w.shape[1])
-            nbytes = lib().peclr_x6_pack_bytes(n, k)
+            nbytes = lib().peclr_x6_pack_pair_bytes(n, k) if self.pair else lib().peclr_x6_pack_bytes(n, k)
             if nbytes <= 0:
                 raise PeclrHipError(f"X6Planes: B_t[{n}, {k}] needs n % 64 == 0 and k % 16 == 0")
             planes = torch.empty(nbytes, device=dev, dtype=torch.uint8)
@@ -486,17 +491,48 @@ class X6Planes:
         self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
         self.count, self.chunks = len(rows), chunk
         self.nbytes = sum(p.numel() for p in self.planes) + 4 * sum(w.numel() for w in self._sources)
+        if self.pair:
+            self.nbytes += 4 * sum(w.numel() for w in self._sources)      # (the maxima's pass reads the weights once more)
+            self.absmax = torch.zeros(self.count, device=dev, dtype=torch.float32)
+            self.scales = torch.ones(self.count, device=dev, dtype=torch.float32)
+
+    def scale(self, i: int) -> torch.Tensor:
+        """The device float holding the power of two matrix i was multiplied by (pair format)."""
+        return self.scales[i:i + 1]
 
     def pack(self):
+        if self.pair:
+            with _timed("x6_pack", self.nbytes, kernel="x6_pair_kernel"):
+                rc = lib().peclr_x6_pack_pair_f32(self.table.data_ptr(), self.count, self.chunks, self.absmax.data_ptr(),
+                                                  self.scales.data_ptr(), _stream())
+            _check(rc, "peclr_x6_pack_pair_f32")
+            return self
         with _timed("x6_pack", self.nbytes, kernel="x6_pack_kernel"):
             rc = lib().peclr_x6_pack_f32(self.table.data_ptr(), self.count, self.chunks, _stream())
         _check(rc, "peclr_x6_pack_f32")
         return self
 
 
+class _X6Pair(ctypes.Structure):
+    _fields_ = [("a_absmax", ctypes.c_void_p), ("w_scale", ctypes.c_void_p)]
+
+
+def _pair_arg(pair, who: str):
+    """pair = None (six-product arithmetic on bf16-triple planes) or (a_absmax, w_scale): one-element fp32 HIP tensors -- the
+    maximum of |A| over the whole activation tensor (written by the pass that produced it) and the weight planes' power of two
+    (`X6Planes(pair=True).scale(i)`).  Returns (struct or None to pass, bytes per weight element of the planes)."""
+    if pair is None:
+        return None, 6
+    a_absmax, w_scale = pair
+    for t, name in ((a_absmax, "a_absmax"), (w_scale, "w_scale")):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.numel() == 1):
+            raise PeclrHipError(f"{who}: pair.{name} is a one-element fp32 HIP tensor")
+    return _X6Pair(a_absmax.data_ptr(), w_scale.data_ptr()), 4
+
+
 def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[torch.Tensor] = None, tag: str = "gemm_x6p",
              tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None, addend_s2=None,
-             addend_mask: Optional[torch.Tensor] = None):
+             addend_mask: Optional[torch.Tensor] = None, pair=None):
     """C (fp32) [M, n] = A[M, K] . B_t^T (+ addend) with B_t given as packed planes (X6Planes): fp32 accuracy on the
     bf16 matrix cores, the weight operand split once per step (peclr_gemm_x6p_f32).
     stat_shift (fp32 [n]): also return the training-mode BatchNorm statistics of C as `(partial, n_split)` in the layout
@@ -506,10 +542,13 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
     addend_s2 = (H, W): the rows are the pixels of H x W images and `addend` [M / 4, n] holds every second pixel only (the
     compact input gradient of a 1x1 / stride-2 convolution): added at the even (h, w) rows (peclr_gemm_x6p_s2add_f32).
     addend_mask (int32 [M, n / 32], the 1-bit ReLU mask of peclr_bn2d_apply): addend elements whose bit is clear count as
-    zero (peclr_gemm_x6p_maskadd_f32)."""
+    zero (peclr_gemm_x6p_maskadd_f32).
+    pair (see `_pair_arg`): fp16-pair arithmetic, `planes` of `X6Planes(pair=True)`."""
     m, k = a.shape
     add_rows = m if addend_s2 is None else m // 4
-    if planes.dtype != torch.uint8 or planes.numel() != 6 * ((n + 127) // 128 * 128) * k or (addend is not None and tuple(addend.shape) != (add_rows, n)):
+    pst, wb = _pair_arg(pair, "gemm_x6p")
+    pref = ctypes.byref(pst) if pst is not None else None
+    if planes.dtype != torch.uint8 or planes.numel() != wb * ((n + 127) // 128 * 128) * k or (addend is not None and tuple(addend.shape) != (add_rows, n)):
         raise PeclrHipError(f"gemm_x6p: A {tuple(a.shape)}, planes of {planes.numel()} bytes for B_t[{n}, {k}]")
     if addend_s2 is not None and (addend is None or stat_shift is not None or addend_mask is not None):
         raise PeclrHipError("gemm_x6p: addend_s2 needs the compact addend (and has no statistics output / mask)")
@@ -529,20 +568,20 @@ def gemm_x6p(a: torch.Tensor, planes: torch.Tensor, n: int, addend: Optional[tor
     elif bn_bwd is not None:
         fuse, partial, ns = _bn_bwd_fuse(bn_bwd, m, n, tile_rows)
     add_elems = 0 if addend is None else addend.numel() + (0 if addend_mask is None else addend_mask.numel())
-    with _timed(tag, 4 * (m * k + m * n + add_elems + (m * n if fuse is not None else 0)) + 6 * k * n, 2 * m * n * k,
-                kernel="gemm_x6p_kernel"):
+    with _timed(tag, 4 * (m * k + m * n + add_elems + (m * n if fuse is not None else 0)) + wb * k * n, 2 * m * n * k,
+                kernel="gemm_x6p_kernel" if pst is None else "gemm_x6p_kernel<pair>"):
         if addend_mask is not None:
             rc = lib().peclr_gemm_x6p_maskadd_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
                                                   _ptr(addend_mask, torch.int32), tile_rows,
-                                                  ctypes.byref(fuse) if fuse is not None else None, _stream())
+                                                  ctypes.byref(fuse) if fuse is not None else None, pref, _stream())
         elif addend_s2 is not None:
             rc = lib().peclr_gemm_x6p_s2add_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
                                                 int(addend_s2[0]), int(addend_s2[1]), tile_rows,
-                                                ctypes.byref(fuse) if fuse is not None else None, _stream())
+                                                ctypes.byref(fuse) if fuse is not None else None, pref, _stream())
         else:
             rc = lib().peclr_gemm_x6p_f32(m, n, k, _ptr(a), k, _ptr(planes, torch.uint8), out.data_ptr(), n, _ptr(addend), n,
                                           tile_rows, _ptr(stat_shift), partial.data_ptr() if stat_shift is not None else None,
-                                          ctypes.byref(fuse) if fuse is not None else None, _stream())
+                                          ctypes.byref(fuse) if fuse is not None else None, pref, _stream())
     _check(rc, "peclr_gemm_x6p_maskadd_f32" if addend_mask is not None else "peclr_gemm_x6p_s2add_f32" if addend_s2 is not None
            else "peclr_gemm_x6p_f32")
     return out if partial is None else (out, partial, ns)
@@ -560,14 +599,16 @@ def _zeros(device):
 
 
 def conv3x3_x6p(x: torch.Tensor, planes: torch.Tensor, cout: int, flip: bool = False, addend: Optional[torch.Tensor] = None,
-                tag: str = "conv3x3_x6p", tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None, variant: Optional[int] = None):
+                tag: str = "conv3x3_x6p", tile_rows: int = 0, stat_shift: Optional[torch.Tensor] = None, bn_bwd=None, variant: Optional[int] = None,
+                pair=None):
     """3x3 / stride-1 / padding-1 convolution of an NHWC (channels_last) fp32 tensor x [N, Cin, H, W] as an implicit GEMM on
     the bf16 matrix cores at fp32 accuracy (peclr_conv3x3_x6p_f32); `planes` = X6Planes of W seen as [Cout, 9 * Cin]
     (flip=False) or, for the input gradient (flip=True, x = dY), of [Cout_w * 9, Cin_w] packed with transposed = 9.
     Returns y [N, cout, H, W] channels_last (and (partial, n_split) when stat_shift or bn_bwd is given, as in gemm_x6p)."""
     nb, cin, h, w = x.shape
     xp = _nhwc_ptr(x, "conv3x3 x", torch.float32)
-    if planes.dtype != torch.uint8 or planes.numel() != 6 * ((cout + 127) // 128 * 128) * 9 * cin:
+    pst, wb = _pair_arg(pair, "conv3x3_x6p")
+    if planes.dtype != torch.uint8 or planes.numel() != wb * ((cout + 127) // 128 * 128) * 9 * cin:
         raise PeclrHipError(f"conv3x3_x6p: planes of {planes.numel()} bytes for [{cout}, 9 * {cin}]")
     y = torch.empty((nb, cout, h, w), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     m = nb * h * w
@@ -580,24 +621,27 @@ def conv3x3_x6p(x: torch.Tensor, planes: torch.Tensor, cout: int, flip: bool = F
     elif bn_bwd is not None:
         fuse, partial, ns = _bn_bwd_fuse(bn_bwd, m, cout, tile_rows)
     ap = _nhwc_ptr(addend, "conv3x3 addend", torch.float32) if addend is not None else None
-    with _timed(tag, 4 * (m * cin + (2 if addend is not None else 1) * m * cout + (m * cout if fuse is not None else 0)) + 54 * cin * cout,
-                18 * m * cin * cout, kernel="gemm_x6p_kernel (3x3)"):
+    with _timed(tag, 4 * (m * cin + (2 if addend is not None else 1) * m * cout + (m * cout if fuse is not None else 0)) + 9 * wb * cin * cout,
+                18 * m * cin * cout, kernel="gemm_x6p_kernel (3x3)" if pst is None else "gemm_x6p_kernel<pair> (3x3)"):
         rc = lib().peclr_conv3x3_x6p_f32(nb, h, w, cin, cout, xp, _ptr(planes, torch.uint8), y.data_ptr(), ap, int(flip), tile_rows,
                                          _CONV3X3_VARIANT if variant is None else int(variant), _zeros(x.device).data_ptr(), _ptr(stat_shift),
                                          partial.data_ptr() if stat_shift is not None else None,
-                                         ctypes.byref(fuse) if fuse is not None else None, _stream())
+                                         ctypes.byref(fuse) if fuse is not None else None,
+                                         ctypes.byref(pst) if pst is not None else None, _stream())
     _check(rc, "peclr_conv3x3_x6p_f32")
     return y if partial is None else (y, partial, ns)
 
 
-def conv3x3_s2_dgrad_x6p(gy: torch.Tensor, planes: torch.Tensor, cin: int, tag: str = "conv3x3_s2_dgrad", tile_rows: int = 0, bn_bwd=None):
+def conv3x3_s2_dgrad_x6p(gy: torch.Tensor, planes: torch.Tensor, cin: int, tag: str = "conv3x3_s2_dgrad", tile_rows: int = 0, bn_bwd=None,
+                         pair=None):
     """Input gradient of a 3x3 / padding-1 / stride-2 convolution: gy [N, Cout, Ho, Wo] channels_last fp32 -> dx
     [N, cin, 2 Ho, 2 Wo], one implicit GEMM per parity class of input pixels (1, 2, 2 and 4 of the nine taps:
     peclr_conv3x3_s2_dgrad_x6p_f32); `planes` as for the stride-1 input gradient ([Cout * 9, Cin] packed with
     transposed = 9).  bn_bwd: as in gemm_x6p (the BatchNorm layer dx arrives at) -> (dx, partial, n_split)."""
     nb, cout, ho, wo = gy.shape
     gp = _nhwc_ptr(gy, "conv_s2 dgrad gy", torch.float32)
-    if planes.dtype != torch.uint8 or planes.numel() != 6 * ((cin + 127) // 128 * 128) * 9 * cout:
+    pst, wb = _pair_arg(pair, "conv3x3_s2_dgrad_x6p")
+    if planes.dtype != torch.uint8 or planes.numel() != wb * ((cin + 127) // 128 * 128) * 9 * cout:
         raise PeclrHipError(f"conv3x3_s2_dgrad_x6p: planes of {planes.numel()} bytes for [{cin}, 9 * {cout}]")
     dx = torch.empty((nb, cin, 2 * ho, 2 * wo), device=gy.device, dtype=torch.float32, memory_format=torch.channels_last)
     mc = nb * ho * wo
@@ -605,22 +649,24 @@ def conv3x3_s2_dgrad_x6p(gy: torch.Tensor, planes: torch.Tensor, cin: int, tag: 
     if bn_bwd is not None:
         tile_rows = tile_rows or lib().peclr_gemm_x6p_tile_rows(mc, cin, 4 * cout)
         fuse, partial, ns = _bn_bwd_fuse(bn_bwd, 4 * mc, cin, tile_rows, groups=4)
-    with _timed(tag, 4 * (mc * cout + 4 * mc * cin * (2 if fuse is not None else 1)) + 54 * cin * cout, 18 * mc * cin * cout,
-                kernel="gemm_x6p_kernel (3x3)"):
+    with _timed(tag, 4 * (mc * cout + 4 * mc * cin * (2 if fuse is not None else 1)) + 9 * wb * cin * cout, 18 * mc * cin * cout,
+                kernel="gemm_x6p_kernel (3x3)" if pst is None else "gemm_x6p_kernel<pair> (3x3)"):
         rc = lib().peclr_conv3x3_s2_dgrad_x6p_f32(nb, ho, wo, cout, cin, gp, _ptr(planes, torch.uint8), dx.data_ptr(), tile_rows,
-                                                  _zeros(gy.device).data_ptr(), ctypes.byref(fuse) if fuse is not None else None, _stream())
+                                                  _zeros(gy.device).data_ptr(), ctypes.byref(fuse) if fuse is not None else None,
+                                                  ctypes.byref(pst) if pst is not None else None, _stream())
     _check(rc, "peclr_conv3x3_s2_dgrad_x6p_f32")
     return dx if partial is None else (dx, partial, ns)
 
 
 def conv_s2_x6p(x: torch.Tensor, planes: torch.Tensor, cout: int, taps: int, tag: str = "conv_s2_x6p", tile_rows: int = 0,
-                stat_shift: Optional[torch.Tensor] = None):
+                stat_shift: Optional[torch.Tensor] = None, pair=None):
     """Forward of a stride-2 convolution (taps = 9: 3x3 / padding 1; taps = 1: 1x1) of an NHWC fp32 tensor x [N, Cin, H, W]
     (H, W even) on the six-product kernel (peclr_conv_s2_x6p_f32) -> y [N, cout, H/2, W/2] channels_last (and
     (partial, n_split) of the output's BatchNorm statistics when stat_shift is given)."""
     nb, cin, h, w = x.shape
     xp = _nhwc_ptr(x, "conv_s2 x", torch.float32)
-    if planes.dtype != torch.uint8 or planes.numel() != 6 * ((cout + 127) // 128 * 128) * taps * cin or h % 2 or w % 2:
+    pst, wb = _pair_arg(pair, "conv_s2_x6p")
+    if planes.dtype != torch.uint8 or planes.numel() != wb * ((cout + 127) // 128 * 128) * taps * cin or h % 2 or w % 2:
         raise PeclrHipError(f"conv_s2_x6p: planes of {planes.numel()} bytes for [{cout}, {taps} * {cin}], input {h} x {w}")
     y = torch.empty((nb, cout, h // 2, w // 2), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     m = nb * (h // 2) * (w // 2)
@@ -629,9 +675,11 @@ def conv_s2_x6p(x: torch.Tensor, planes: torch.Tensor, cout: int, taps: int, tag
         tile_rows = tile_rows or lib().peclr_gemm_x6p_tile_rows(m, cout, taps * cin)
         ns = (m + tile_rows - 1) // tile_rows
         partial = torch.empty((2 * ns + 1, cout), device=x.device, dtype=torch.float32)
-    with _timed(tag, 4 * (nb * h * w * cin + m * cout) + 6 * taps * cin * cout, 2 * m * taps * cin * cout, kernel="gemm_x6p_kernel (stride 2)"):
+    with _timed(tag, 4 * (nb * h * w * cin + m * cout) + wb * taps * cin * cout, 2 * m * taps * cin * cout,
+                kernel="gemm_x6p_kernel (stride 2)" if pst is None else "gemm_x6p_kernel<pair> (stride 2)"):
         rc = lib().peclr_conv_s2_x6p_f32(nb, h, w, cin, cout, taps, xp, _ptr(planes, torch.uint8), y.data_ptr(), tile_rows,
-                                         _zeros(x.device).data_ptr(), _ptr(stat_shift), _ptr(partial), _stream())
+                                         _zeros(x.device).data_ptr(), _ptr(stat_shift), _ptr(partial),
+                                         ctypes.byref(pst) if pst is not None else None, _stream())
     _check(rc, "peclr_conv_s2_x6p_f32")
     return y if stat_shift is None else (y, partial, ns)
 
@@ -1100,7 +1148,33 @@ def _bn2d_scale_shift(x, gamma, beta, running_mean, running_var, nbt, training, 
     return save, ss
 
 
-def bn2d_apply(x, ss, relu: bool = True):
+_ABSMAX_SLABS: dict = {}
+
+
+def absmax_slot(device) -> torch.Tensor:
+    """A zeroed one-element fp32 tensor for a pass's `absmax_out` (the "pair" GEMMs' peclr_x6_pair.a_absmax).  Slots are views of a
+    256-float slab that ONE fill launch zeroes; a new slab is taken when the current one is used up -- and whenever a stream capture
+    begins, so that the fill is part of the captured graph and every replay starts from zeros."""
+    key = (device, capture_id())
+    slab = _ABSMAX_SLABS.get(key)
+    if slab is None or slab[1] >= slab[0].numel():
+        for k in [k for k in _ABSMAX_SLABS if k[0] == device and k != key]:
+            del _ABSMAX_SLABS[k]                       # (slots handed out stay alive through their views)
+        slab = _ABSMAX_SLABS[key] = [torch.zeros(256, device=device, dtype=torch.float32), 0]
+    i = slab[1]
+    slab[1] += 1
+    return slab[0][i:i + 1]
+
+
+def _absmax_ptr(absmax, x):
+    if absmax is None:
+        return None
+    if x.dtype != torch.float32 or not (absmax.is_cuda and absmax.dtype == torch.float32 and absmax.numel() == 1):
+        raise PeclrHipError("absmax: a zeroed one-element fp32 HIP tensor, for fp32 passes")
+    return absmax.data_ptr()
+
+
+def bn2d_apply(x, ss, relu: bool = True, absmax=None):
     """y = (relu)(fmaf(x, scale, shift)) from a finished scale / shift table: the apply pass of `bn2d_fwd` on its own (the
     fallback of a layer whose apply was left to its consumer, `bn2d_fwd(..., apply=False)`)."""
     n, c, h, w = x.shape
@@ -1108,14 +1182,16 @@ def bn2d_apply(x, ss, relu: bool = True):
     io, e = _IO[x.dtype]
     y = torch.empty_like(x, memory_format=torch.channels_last)
     with _timed("bn2d_apply", 2 * e * r * c):
-        rc = lib().peclr_bn2d_apply(_nhwc_ptr(x, "bn2d x"), None, io, r, c, ss.data_ptr(), int(relu), y.data_ptr(), None, _stream())
+        rc = lib().peclr_bn2d_apply(_nhwc_ptr(x, "bn2d x"), None, io, r, c, ss.data_ptr(), int(relu), y.data_ptr(), None,
+                                    _absmax_ptr(absmax, x), _stream())
     _check(rc, "peclr_bn2d_apply")
     return y
 
 
 def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, relu,
-             want_mask=False, sync_group=None, sync_shift=None, pre=None, apply=True, residual_bn=None):
+             want_mask=False, sync_group=None, sync_shift=None, pre=None, apply=True, residual_bn=None, absmax=None):
     """want_mask: also write the 1-bit ReLU mask ([R, C/32] int32) the backward reads instead of y.
+    absmax: a zeroed one-element fp32 tensor (`absmax_slot`) that receives max |y|.
     residual_bn = (x_s, scale_shift_s) instead of `residual`: the residual is the output of the shortcut's BatchNorm2d, which
     was not written -- this pass computes it from that layer's input and table (peclr_bn2d_apply_res_bn).
     sync_group: a process group -> training statistics are those of the rows of ALL its ranks
@@ -1138,18 +1214,19 @@ def bn2d_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, training,
             raise PeclrHipError("bn2d_fwd: residual_bn = (input of the shortcut's BatchNorm, its fp32 [2, C] table), no residual tensor")
         with _timed("bn2d_apply", 3 * e * r * c + (r * c // 8 if mask is not None else 0)):
             rc = lib().peclr_bn2d_apply_res_bn(xp, _nhwc_ptr(xs, "bn2d shortcut x", x.dtype), ss_s.data_ptr(), io, r, c, ss.data_ptr(),
-                                               int(relu), y.data_ptr(), mask.data_ptr() if mask is not None else None, _stream())
+                                               int(relu), y.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                               _absmax_ptr(absmax, x), _stream())
         _check(rc, "peclr_bn2d_apply_res_bn")
         return y, save, ss, mask
     with _timed("bn2d_apply", (3 if residual is not None else 2) * e * r * c + (r * c // 8 if mask is not None else 0)):
         rc = lib().peclr_bn2d_apply(xp, _nhwc_ptr(residual, "bn2d residual", x.dtype) if residual is not None else None,
                                     io, r, c, ss.data_ptr(), int(relu), y.data_ptr(),
-                                    mask.data_ptr() if mask is not None else None, _stream())
+                                    mask.data_ptr() if mask is not None else None, _absmax_ptr(absmax, x), _stream())
     _check(rc, "peclr_bn2d_apply")
     return y, save, ss, mask
 
 
-def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres, sync_group=None, pre=None):
+def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres, sync_group=None, pre=None, absmax=None):
     """ReLU mask source: `mask` (bit mask from the forward) > `y` (forward output) > recomputed from x.
     sync_group: as in bn2d_fwd; dgamma/dbeta stay this rank's local sums (the gradient all-reduce sums
     them later), dx uses the global sums."""
@@ -1193,7 +1270,7 @@ def bn2d_bwd(dy, x, y, mask, save, ss, training, relu, want_dres, sync_group=Non
     with _timed("bn2d_bwd_apply", (3 + (1 if want_dres else 0)) * e * r * c + extra):
         rc = lib().peclr_bn2d_bwd_apply(dyp, xp, yp, mp, io, r, c, int(relu), save[0].data_ptr(), save[1].data_ptr(),
                                         ss.data_ptr(), coef.data_ptr(), dx.data_ptr(),
-                                        dres.data_ptr() if dres is not None else None, _stream())
+                                        dres.data_ptr() if dres is not None else None, _absmax_ptr(absmax, x), _stream())
     _check(rc, "peclr_bn2d_bwd_apply")
     return dx, dparams[0], dparams[1], dres
 
@@ -1217,7 +1294,7 @@ def bn2d_avgpool_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, t
     return pooled, mask, save, ss
 
 
-def bn2d_avgpool_bwd(d_pooled, x, mask, save, ss, training, sync_group=None):
+def bn2d_avgpool_bwd(d_pooled, x, mask, save, ss, training, sync_group=None, absmax=None):
     """Backward of bn2d_avgpool_fwd from the fp32 [N, C] gradient of the pooled output: (dx, dgamma, dbeta,
     d_residual)."""
     n, c, h, w = x.shape
@@ -1251,13 +1328,14 @@ def bn2d_avgpool_bwd(d_pooled, x, mask, save, ss, training, sync_group=None):
         _check(rc, "peclr_bn2d_bwd_finalize_f32")
     with _timed("bn2d_bwd_apply_avgpool", 3 * e * r * c + r * c // 8 + 4 * n * c):
         rc = lib().peclr_bn2d_bwd_apply_avgpool(dp, xp, mp, io, n, h * w, c, save[0].data_ptr(), save[1].data_ptr(),
-                                                ss.data_ptr(), coef.data_ptr(), dx.data_ptr(), dres.data_ptr(), _stream())
+                                                ss.data_ptr(), coef.data_ptr(), dx.data_ptr(), dres.data_ptr(),
+                                                _absmax_ptr(absmax, x), _stream())
     _check(rc, "peclr_bn2d_bwd_apply_avgpool")
     return dx, dparams[0], dparams[1], dres
 
 
 def bn2d_pool_fwd(x, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, sync_group=None, sync_shift=None,
-                  pre=None):
+                  pre=None, absmax=None):
     """Stem: y = maxpool3x3/2(relu(bn(x))) in one pass; returns (y, tap codes, save, scale_shift).
     pre: (partial, n_split, shift) -- the statistics the stem convolution summed in its epilogue (no pass over x then)."""
     n, c, h, w = x.shape
@@ -1269,7 +1347,7 @@ def bn2d_pool_fwd(x, gamma, beta, running_mean, running_var, nbt, training, eps,
     code = torch.empty((n, ph, pw, c), device=x.device, dtype=torch.uint8)
     with _timed("bn2d_pool_apply", e * n * c * (h * w + 2 * ph * pw) + n * c * ph * pw):
         rc = lib().peclr_bn2d_pool_apply(_nhwc_ptr(x, "bn2d x"), io, n, h, w, c, ss.data_ptr(), y.data_ptr(),
-                                         x_at_max.data_ptr(), code.data_ptr(), _stream())
+                                         x_at_max.data_ptr(), code.data_ptr(), _absmax_ptr(absmax, x), _stream())
     _check(rc, "peclr_bn2d_pool_apply")
     return y, x_at_max, code, save, ss
 

@@ -133,6 +133,7 @@ class Routing:
     conv3x3_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV3X3_X6"))        # 3x3 stride-1 convolutions as implicit GEMMs
     conv3x3_wgrad_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV3X3_WGRAD_X6"))   # their weight gradients (nine taps, one launch)
     conv3x3_tile_rows: int = dataclasses.field(default_factory=lambda: int(os.environ.get("PECLR_CONV3X3_TILE_ROWS", "256")))
+    conv3x3_pair_tile_rows: int = dataclasses.field(default_factory=lambda: int(os.environ.get("PECLR_CONV3X3_PAIR_TILE_ROWS", "256")))
     conv_s2_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV_S2_X6"))        # forward of the stride-2 convolutions
     conv_s2_wgrad_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV_S2_WGRAD_X6"))
     conv_s2_dgrad_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV_S2_DGRAD_X6"))   # 3x3 / stride-2 input gradient by parity classes
@@ -140,6 +141,10 @@ class Routing:
     s2_dgrad_compact: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_S2_DGRAD_COMPACT"))   # the shortcut's compact input gradient
     lazy_residual_grad: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_LAZY_RESIDUAL_GRAD"))   # identity shortcut: (dy, mask) hand-over
     conv16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV16"))                # 16-bit (bf16 / fp16 autocast) convolutions in-tree
+    # fp32 forward / input-gradient GEMMs in "pair" arithmetic (round 6): operands scaled by a per-tensor power of two and split into
+    # two fp16 numbers, three MFMA products instead of six -- where the operand tensor carries its maximum (`_peclr_absmax`, written
+    # by the BatchNorm pass that produced it); anything else runs the six-product kernels as before
+    x6_pair: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_X6_PAIR"))
     wgrad3_ring: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD3_RING"))      # fp32 3x3 weight gradient: one split per element (LDS ring + transposing reads)
     wgrad16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD16"))              # ... and their weight gradients
     stem_wgrad: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_STEM_WGRAD"))        # ... and its weight gradient
@@ -239,14 +244,16 @@ class X6PackGroup:
                 # may be recorded into a hipGraph
                 raise _capi.PeclrHipError("X6PackGroup: the weight planes of this precision do not exist yet and cannot be created "
                                           "while a hipGraph is being captured -- run one eager forward pass (same autocast dtype) first")
-            st[0] = _capi.X6Planes(self._specs()) if dtype is None else _capi.HPlanes(self._specs(), dtype)
+            st[0] = (_capi.X6Planes(self._specs()) if dtype is None else _capi.X6Planes(self._specs(), pair=True) if dtype == "pair"
+                     else _capi.HPlanes(self._specs(), dtype))
             st[1] = ptrs
         st[0].pack()
         st[2] = [self._key(c) for c in self.convs]
 
     def planes(self, conv, dtype=None):
         """(forward planes of W [Cout, Cin], input-gradient planes of W^T), fresh; dtype None: the fp32 kernels' three-plane
-        format, torch.bfloat16 / torch.float16: the 16-bit kernels' format."""
+        format, "pair": their fp16-pair format (`pair_scales` gives the matrices' powers of two), torch.bfloat16 / torch.float16:
+        the 16-bit kernels' format."""
         at = conv.x6_index
         if at >= len(self.convs) or self.convs[at] is not conv:
             raise _capi.PeclrHipError("X6PackGroup: convolution is not a member of its group (call enable_hip_batchnorm again)")
@@ -260,6 +267,11 @@ class X6PackGroup:
             self.pack(dtype)
         return st[0].planes[2 * at], st[0].planes[2 * at + 1]
 
+    def pair_scales(self, conv):
+        """The device floats holding the powers of two of `conv`'s two pair-format matrices (after `planes(conv, "pair")`)."""
+        st = self._sets["pair"][0]
+        return st.scale(2 * conv.x6_index), st.scale(2 * conv.x6_index + 1)
+
 
 def _x6_planes(conv):
     """Packed planes of `conv`'s weight, or None when the convolution is not in a pack group (then the GEMMs split the
@@ -267,7 +279,42 @@ def _x6_planes(conv):
     group = getattr(conv, "x6_group", None) if conv is not None else None
     if group is None or not ROUTING.gemm_x6p or not conv.weight.is_cuda or conv.weight.dtype != torch.float32:
         return None
-    return group.planes(conv)
+    return _LazyPlanes(group, conv)
+
+
+class _LazyPlanes:
+    """`planes[0]` / `planes[1]` of a convolution's six-product plane set, asked of the group (which re-packs a stale set: one launch
+    for all members) only when a launch really takes them -- with `ROUTING.x6_pair` most launches take the pair set instead, and
+    a step in which nothing falls back never packs the three-plane set at all."""
+
+    __slots__ = ("group", "conv")
+
+    def __init__(self, group, conv):
+        self.group, self.conv = group, conv
+
+    def __getitem__(self, which):
+        return self.group.planes(self.conv)[which]
+
+
+def _absmax_of(t):
+    """The device float holding max |t| if the pass that wrote `t` left one (fp32 tensors, `ROUTING.x6_pair`), else None."""
+    return getattr(t, "_peclr_absmax", None) if (ROUTING.x6_pair and t is not None) else None
+
+
+def _new_absmax(x: Tensor):
+    """A zeroed slot for the maximum of a tensor a BatchNorm pass is about to write (None: not wanted)."""
+    return _capi.absmax_slot(x.device) if (ROUTING.x6_pair and ROUTING.gemm_x6p and x.is_cuda and x.dtype == torch.float32) else None
+
+
+def _pair_planes(conv, amax, which: int, planes):
+    """What a packed-weight GEMM of `conv` runs on: (planes, {"pair": (amax, w_scale)}) -- the fp16-pair planes of matrix `which`
+    (0 forward, 1 input gradient) when the activation operand's maximum `amax` is known -- else (planes[which], {}): the
+    six-product arithmetic."""
+    group = getattr(conv, "x6_group", None) if conv is not None else None
+    if amax is None or group is None or not ROUTING.x6_pair:
+        return planes[which], {}
+    pp = group.planes(conv, "pair")
+    return pp[which], {"pair": (amax, group.pair_scales(conv)[which])}
 
 
 _HALF = (torch.bfloat16, torch.float16)
@@ -284,24 +331,28 @@ def _h_ok(conv, x: Tensor) -> bool:
 class _BN2dAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, bn: "FusedBatchNormAct2d", relu: bool, pre=None, link=None, lazy_res=False, defer=None,
-                res_deferred=None):
+                res_deferred=None, amax=None):
         """link: None or an empty list that receives what a consumer's input-gradient GEMM needs to perform this layer's
         backward reduction in its epilogue: [x, save, scale_shift, relu mask or None, relu, token].
         defer: None, or an empty list -- the layer (a shortcut's BatchNorm, no ReLU) only finishes its statistics; the list comes
         back as [x, scale_shift, relu] and the result is a placeholder (`_deferred_view`) whose consumer -- the block's last
         BatchNorm pass -- computes the layer on the fly; any other reader materialises it (`_Materialize`).
         res_deferred: None, or (x_s, scale_shift_s, False) -- `residual` is the placeholder of the shortcut's BatchNorm layer (no
-        ReLU), which left its apply pass to THIS pass: the residual is computed from that layer's input on the fly."""
+        ReLU), which left its apply pass to THIS pass: the residual is computed from that layer's input on the fly.
+        amax: None, or an empty list that receives the device float holding max |y| (the "pair" GEMMs' operand scale)."""
         training = bn.training or not bn.track_running_stats
         # the ReLU mask can be recomputed from x unless a residual was added before it; then the
         # forward writes a 1-bit mask (or, for C % 32 != 0, the backward re-reads y)
         need_mask = relu and residual is not None
         rm, rv, nbt, shift = bn._stat_buffers(training)
+        slot = _new_absmax(x) if (amax is not None and defer is None) else None
         y, save, ss, mask = _capi.bn2d_fwd(x, None if res_deferred is not None else residual, weight, bias, rm, rv, nbt, training, bn.eps,
                                            bn.momentum if bn.momentum is not None else 0.1, relu, want_mask=need_mask,
                                            sync_group=bn.sync_group if training else None, sync_shift=shift,
                                            pre=pre if training else None, apply=defer is None,
-                                           residual_bn=res_deferred[:2] if res_deferred is not None else None)
+                                           residual_bn=res_deferred[:2] if res_deferred is not None else None, absmax=slot)
+        if slot is not None:
+            amax[:] = [slot]
         if defer is not None:
             defer[:] = [x, ss, relu]
             y = _deferred_view(x)
@@ -333,13 +384,17 @@ class _BN2dAct(torch.autograd.Function):
         if ent is not None and ent[0] is ctx.token and ent[3] == dy._version:
             pre = ent[1:3]
         lazy = ctx.lazy_res and has_res and ctx.needs_input_grad[3] and ROUTING.lazy_residual_grad and not torch.is_anomaly_enabled()
+        slot = _new_absmax(x)
         dx, dgamma, dbeta, dres = _capi.bn2d_bwd(dy, x, y, mask, save, ss, training, relu,
-                                                 has_res and ctx.needs_input_grad[3] and not lazy, sync_group=ctx.sync_group, pre=pre)
+                                                 has_res and ctx.needs_input_grad[3] and not lazy, sync_group=ctx.sync_group, pre=pre,
+                                                 absmax=slot)
+        if slot is not None:
+            dx._peclr_absmax = slot             # (the convolution whose output x is reads it off its `gy`: same tensor object)
         if lazy:
             dres = _lazy_grad(("mask", dy, mask), x.shape, x.device, x.dtype)
         elif has_res and dres is None and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
 
 _NAN_PLACEHOLDER = {}
@@ -359,17 +414,23 @@ class _Materialize(torch.autograd.Function):
     not to be the pass that computes it on the fly): peclr_bn2d_apply on the finished table."""
 
     @staticmethod
-    def forward(ctx, placeholder, deferred):
+    def forward(ctx, placeholder, deferred, amax=None):
         x, ss, relu = deferred
-        return _capi.bn2d_apply(x, ss, relu=relu)
+        slot = _new_absmax(x) if amax is not None else None
+        if slot is not None:
+            amax[:] = [slot]
+        return _capi.bn2d_apply(x, ss, relu=relu, absmax=slot)
 
     @staticmethod
     def backward(ctx, gy):
-        return gy, None
+        return gy, None, None
 
 
 def _materialized(x: Tensor, deferred) -> Tensor:
-    y = _Materialize.apply(x, deferred)
+    amax = []
+    y = _Materialize.apply(x, deferred, amax)
+    if amax:
+        y._peclr_absmax = amax[0]
     link = getattr(x, "_peclr_bn_link", None)
     if link:
         y._peclr_bn_link = link
@@ -380,13 +441,16 @@ class _BN2dReluPool(torch.autograd.Function):
     """Stem: BatchNorm2d -> ReLU -> MaxPool2d(3, 2, 1) without ever writing the un-pooled activation."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, bn: "FusedBatchNormAct2d", pre=None):
+    def forward(ctx, x, weight, bias, bn: "FusedBatchNormAct2d", pre=None, amax=None):
         training = bn.training or not bn.track_running_stats
         sync = bn.sync_group if training else None
         rm, rv, nbt, shift = bn._stat_buffers(training)
+        slot = _new_absmax(x) if amax is not None else None
+        if slot is not None:
+            amax[:] = [slot]
         y, x_at_max, code, save, ss = _capi.bn2d_pool_fwd(x, weight, bias, rm, rv, nbt, training, bn.eps,
                                                 bn.momentum if bn.momentum is not None else 0.1, sync_group=sync, sync_shift=shift,
-                                                pre=pre if training else None)
+                                                pre=pre if training else None, absmax=slot)
         ctx.save_for_backward(x, x_at_max, code, save, ss)
         ctx.cfg = (training, sync)
         return y
@@ -397,7 +461,7 @@ class _BN2dReluPool(torch.autograd.Function):
         training, sync = ctx.cfg
         dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         dx, dgamma, dbeta = _capi.bn2d_pool_bwd(dy, x, x_at_max, code, save, ss, training, sync_group=sync)
-        return dx, dgamma, dbeta, None, None
+        return dx, dgamma, dbeta, None, None, None
 
 
 class _BN2dAddReluAvgPool(torch.autograd.Function):
@@ -421,8 +485,11 @@ class _BN2dAddReluAvgPool(torch.autograd.Function):
     def backward(ctx, d_pooled):
         x, mask, save, ss = ctx.saved_tensors
         training, sync = ctx.cfg
+        slot = _new_absmax(x)
         dx, dgamma, dbeta, dres = _capi.bn2d_avgpool_bwd(d_pooled.float().contiguous(), x, mask, save, ss, training,
-                                                         sync_group=sync)
+                                                         sync_group=sync, absmax=slot)
+        if slot is not None:
+            dx._peclr_absmax = slot
         return dx, dgamma, dbeta, dres, None, None
 
 
@@ -626,9 +693,10 @@ class _Conv1x1Gemm(torch.autograd.Function):
     both operands split per workgroup: peclr_gemm_x6_f32); the other direction and small weight gradients stay on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, use_fwd: bool, use_bwd: bool, stats=None, link=None):
+    def forward(ctx, x, weight, conv, use_fwd: bool, use_bwd: bool, stats=None, link=None, amax=None):
         """stats: None, or [bn] -- the BatchNorm2d that consumes the output; the GEMM epilogue then sums its statistics
-        and the list comes back as [partial, n_split, shift, bn] (left untouched when that is not possible)."""
+        and the list comes back as [partial, n_split, shift, bn] (left untouched when that is not possible).
+        amax: the device float holding max |x| (`_absmax_of`) -> the forward runs in pair arithmetic."""
         ctx.save_for_backward(x, weight)
         planes = _x6_planes(conv) if (use_fwd or use_bwd) else None
         ctx.cfg = (conv, use_bwd, planes)
@@ -639,11 +707,13 @@ class _Conv1x1Gemm(torch.autograd.Function):
         cout = weight.shape[0]
         x2 = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
         shift = _stat_shift_for(stats[0], cout) if (stats and planes is not None and ROUTING.bn_stats_in_gemm) else None
+        if planes is not None:
+            pl, kw = _pair_planes(conv, amax, 0, planes)
         if shift is not None:
-            y, partial, ns = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd", stat_shift=shift)
+            y, partial, ns = _capi.gemm_x6p(x2, pl, cout, tag="conv1x1_fwd", stat_shift=shift, **kw)
             stats[:] = [partial, ns, shift, stats[0]]
         elif planes is not None:
-            y = _capi.gemm_x6p(x2, planes[0], cout, tag="conv1x1_fwd")
+            y = _capi.gemm_x6p(x2, pl, cout, tag="conv1x1_fwd", **kw)
         else:
             y = _capi.gemm_x6(x2, weight.detach().reshape(cout, cin), tag="conv1x1_fwd")
         return y.view(n, h, w, cout).permute(0, 3, 1, 2)          # channels_last NCHW view of the NHWC result
@@ -665,11 +735,13 @@ class _Conv1x1Gemm(torch.autograd.Function):
             if use_bwd:
                 gy2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout)
                 link = ctx.link
+                if planes is not None:
+                    pl, kw = _pair_planes(conv, _absmax_of(gy), 1, planes)
                 if planes is not None and link is not None and link[0].shape == x.shape and cin % 32 == 0:
-                    dx, partial, ns = _capi.gemm_x6p(gy2, planes[1], cin, tag="conv1x1_dgrad", bn_bwd=link[:5])
+                    dx, partial, ns = _capi.gemm_x6p(gy2, pl, cin, tag="conv1x1_dgrad", bn_bwd=link[:5], **kw)
                     _note_bn_bwd(dx, link, partial, ns)
                 elif planes is not None:
-                    dx = _capi.gemm_x6p(gy2, planes[1], cin, tag="conv1x1_dgrad")
+                    dx = _capi.gemm_x6p(gy2, pl, cin, tag="conv1x1_dgrad", **kw)
                 else:
                     wt = weight.detach().reshape(cout, cin).t().contiguous()          # [Cin][Cout]: K-contiguous B operand
                     dx = _capi.gemm_x6(gy2, wt, tag="conv1x1_dgrad")
@@ -677,7 +749,7 @@ class _Conv1x1Gemm(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
-        return dx, dw, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None
 
 
 
@@ -690,18 +762,20 @@ class _Conv3x3Gemm(torch.autograd.Function):
     (`_wgrad_3x3_x6`)."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, stats=None, link=None):
+    def forward(ctx, x, weight, conv, stats=None, link=None, amax=None):
         ctx.save_for_backward(x, weight)
         planes = _x6_planes(conv)
         ctx.cfg = (conv, planes)
         ctx.link = link
         cout = weight.shape[0]
         shift = _stat_shift_for(stats[0], cout) if (stats and ROUTING.bn_stats_in_gemm) else None
+        pl, kw = _pair_planes(conv, amax, 0, planes)
+        tile_rows = ROUTING.conv3x3_pair_tile_rows if kw else ROUTING.conv3x3_tile_rows
         if shift is not None:
-            y, partial, ns = _capi.conv3x3_x6p(x, planes[0], cout, tag="conv3x3_fwd", tile_rows=ROUTING.conv3x3_tile_rows, stat_shift=shift)
+            y, partial, ns = _capi.conv3x3_x6p(x, pl, cout, tag="conv3x3_fwd", tile_rows=tile_rows, stat_shift=shift, **kw)
             stats[:] = [partial, ns, shift, stats[0]]
             return y
-        return _capi.conv3x3_x6p(x, planes[0], cout, tag="conv3x3_fwd", tile_rows=ROUTING.conv3x3_tile_rows)
+        return _capi.conv3x3_x6p(x, pl, cout, tag="conv3x3_fwd", tile_rows=tile_rows, **kw)
 
     @staticmethod
     def backward(ctx, gy):
@@ -717,14 +791,16 @@ class _Conv3x3Gemm(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             link = ctx.link
+            pl, kw = _pair_planes(conv, _absmax_of(gy), 1, planes)
+            tile_rows = ROUTING.conv3x3_pair_tile_rows if kw else ROUTING.conv3x3_tile_rows
             if link is not None and link[0].shape == x.shape and x.shape[1] % 32 == 0:
                 # dx is the gradient arriving at the BatchNorm layer whose output x is: reduce it in the epilogue
-                dx, partial, ns = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=ROUTING.conv3x3_tile_rows,
-                                                    bn_bwd=link[:5])
+                dx, partial, ns = _capi.conv3x3_x6p(gy, pl, x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=tile_rows,
+                                                    bn_bwd=link[:5], **kw)
                 _note_bn_bwd(dx, link, partial, ns)
             else:
-                dx = _capi.conv3x3_x6p(gy, planes[1], x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=ROUTING.conv3x3_tile_rows)
-        return dx, dw, None, None, None
+                dx = _capi.conv3x3_x6p(gy, pl, x.shape[1], flip=True, tag="conv3x3_dgrad", tile_rows=tile_rows, **kw)
+        return dx, dw, None, None, None, None
 
 
 
@@ -737,7 +813,7 @@ class _ConvS2Gemm(torch.autograd.Function):
     entry-gradient GEMM (`_compact_grad`) where that is its consumer, else MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, stats=None, compact=False, link=None):
+    def forward(ctx, x, weight, conv, stats=None, compact=False, link=None, amax=None):
         ctx.save_for_backward(x, weight)
         ctx.conv = conv
         ctx.compact = compact
@@ -745,11 +821,12 @@ class _ConvS2Gemm(torch.autograd.Function):
         planes = _x6_planes(conv)
         cout, taps = weight.shape[0], weight.shape[2] * weight.shape[3]
         shift = _stat_shift_for(stats[0], cout) if (stats and ROUTING.bn_stats_in_gemm) else None
+        pl, kw = _pair_planes(conv, amax, 0, planes)
         if shift is not None:
-            y, partial, ns = _capi.conv_s2_x6p(x, planes[0], cout, taps, tag="conv_s2_fwd", stat_shift=shift, tile_rows=ROUTING.s2_tile_rows if taps == 9 else 0)
+            y, partial, ns = _capi.conv_s2_x6p(x, pl, cout, taps, tag="conv_s2_fwd", stat_shift=shift, tile_rows=ROUTING.s2_tile_rows if taps == 9 else 0, **kw)
             stats[:] = [partial, ns, shift, stats[0]]
             return y
-        return _capi.conv_s2_x6p(x, planes[0], cout, taps, tag="conv_s2_fwd", tile_rows=ROUTING.s2_tile_rows if taps == 9 else 0)
+        return _capi.conv_s2_x6p(x, pl, cout, taps, tag="conv_s2_fwd", tile_rows=ROUTING.s2_tile_rows if taps == 9 else 0, **kw)
 
     @staticmethod
     def backward(ctx, gy):
@@ -774,22 +851,23 @@ class _ConvS2Gemm(torch.autograd.Function):
                 # scattered into zeros here -- never MIOpen's input gradient, whose fp32 1x1 / stride-2 solver adds with float
                 # atomics (a different last bit every run: tools/exp/two_outcome.py)
                 n, cout, ho, wo = gy.shape
-                dc = _capi.gemm_x6p(gy.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), _x6_planes(conv)[1], x.shape[1], tag="conv_s2_dgrad")
+                pl, kw = _pair_planes(conv, _absmax_of(gy), 1, _x6_planes(conv))
+                dc = _capi.gemm_x6p(gy.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), pl, x.shape[1], tag="conv_s2_dgrad", **kw)
                 dx = _compact_grad(dc, x.shape) if (ctx.compact and not torch.is_anomaly_enabled()) else _expand_compact(dc, x.shape)
             elif (ROUTING.conv_s2_dgrad_x6 and weight.shape[2] == 3 and x.shape[2] == 2 * gy.shape[2] and x.shape[3] == 2 * gy.shape[3]
                   and x.shape[1] % 64 == 0 and gy.shape[1] % 16 == 0):
                 # 3x3: one dense implicit GEMM per parity class of input pixels (1, 2, 2, 4 taps); dx is the gradient arriving
                 # at the BatchNorm layer whose output x is: reduced in the epilogue
-                planes = _x6_planes(conv)
+                pl, kw = _pair_planes(conv, _absmax_of(gy), 1, _x6_planes(conv))
                 link = ctx.link
                 if link is not None and link[0].shape == x.shape and x.shape[1] % 32 == 0:
-                    dx, partial, ns = _capi.conv3x3_s2_dgrad_x6p(gy, planes[1], x.shape[1], bn_bwd=link[:5], tile_rows=ROUTING.s2_tile_rows)
+                    dx, partial, ns = _capi.conv3x3_s2_dgrad_x6p(gy, pl, x.shape[1], bn_bwd=link[:5], tile_rows=ROUTING.s2_tile_rows, **kw)
                     _note_bn_bwd(dx, link, partial, ns)
                 else:
-                    dx = _capi.conv3x3_s2_dgrad_x6p(gy, planes[1], x.shape[1], tile_rows=ROUTING.s2_tile_rows)
+                    dx = _capi.conv3x3_s2_dgrad_x6p(gy, pl, x.shape[1], tile_rows=ROUTING.s2_tile_rows, **kw)
             else:
                 dx = torch.ops.aten.convolution_backward(gy, x, weight, None, [2, 2], pad, [1, 1], False, [0, 0], 1, [True, False, False])[0]
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 # ---- gradients handed to a block's entry-gradient GEMM in another form than a dense tensor.  An autograd function may only
@@ -1132,7 +1210,7 @@ class Conv2d(nn.Conv2d):
                          and self.weight.requires_grad)
             if use_fwd or use_bwd or use_wgrad:
                 stats = [stats_for] if (stats_for is not None and use_fwd) else None
-                return _attach_stats(_Conv1x1Gemm.apply(x, self.weight, self, use_fwd, use_bwd, stats, bn_link(x) if use_bwd else None), stats)
+                return _attach_stats(_Conv1x1Gemm.apply(x, self.weight, self, use_fwd, use_bwd, stats, bn_link(x) if use_bwd else None, _absmax_of(x)), stats)
         if (self.hip_gemm and ROUTING.conv_s2_x6 and ROUTING.gemm_x6p and getattr(self, "x6_group", None) is not None and self.stride == (2, 2)
                 and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x.dim() == 4
                 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
@@ -1141,14 +1219,14 @@ class Conv2d(nn.Conv2d):
             compact = (ROUTING.s2_dgrad_compact and self.kernel_size == (1, 1) and getattr(x, "_peclr_compact_ok", False)
                        and torch.is_grad_enabled() and x.requires_grad)
             link = bn_link(x) if (torch.is_grad_enabled() and x.requires_grad and self.kernel_size == (3, 3)) else None
-            return _attach_stats(_ConvS2Gemm.apply(x, self.weight, self, stats, compact, link), stats)
+            return _attach_stats(_ConvS2Gemm.apply(x, self.weight, self, stats, compact, link, _absmax_of(x)), stats)
         if (self.hip_gemm and ROUTING.conv3x3_x6 and ROUTING.gemm_x6p and getattr(self, "x6_group", None) is not None and self.kernel_size == (3, 3)
                 and self.stride == (1, 1)
                 and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and x.dim() == 4
                 and x.is_contiguous(memory_format=torch.channels_last)
                 and (x.shape[0] * x.shape[2] * x.shape[3] >= 8192 or ROUTING.force)):
             stats = [stats_for] if stats_for is not None else None
-            return _attach_stats(_Conv3x3Gemm.apply(x, self.weight, self, stats, bn_link(x)), stats)
+            return _attach_stats(_Conv3x3Gemm.apply(x, self.weight, self, stats, bn_link(x), _absmax_of(x)), stats)
         if (_overlap_stream() is not None and x.is_cuda and torch.is_grad_enabled() and self.bias is None
                 and self.groups == 1 and self.dilation == (1, 1) and isinstance(self.padding, tuple)
                 and x.is_contiguous(memory_format=torch.channels_last) and self.weight.requires_grad):
@@ -1174,10 +1252,11 @@ class _ForkConv1x1(torch.autograd.Function):
     identity gradient added in the epilogue.  Small shapes' forward and weight gradient stay on MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, stats=None, link=None, flags=None):
+    def forward(ctx, x, weight, conv, stats=None, link=None, flags=None, amax=None):
         ctx.save_for_backward(x, weight)
         ctx.param = weight if isinstance(weight, nn.Parameter) else None
         ctx.link = link
+        ctx.conv = conv
         n, cin, h, w = x.shape
         cmid = weight.shape[0]
         r = n * h * w
@@ -1193,11 +1272,13 @@ class _ForkConv1x1(torch.autograd.Function):
         if use_fwd:
             x2 = x.permute(0, 2, 3, 1).reshape(r, cin)
             shift = _stat_shift_for(stats[0], cmid) if (stats and ctx.planes is not None and ROUTING.bn_stats_in_gemm) else None
+            if ctx.planes is not None:
+                pl, kw = _pair_planes(conv, amax, 0, ctx.planes)
             if shift is not None:
-                y, partial, ns = _capi.gemm_x6p(x2, ctx.planes[0], cmid, tag="conv1x1_fwd", stat_shift=shift)
+                y, partial, ns = _capi.gemm_x6p(x2, pl, cmid, tag="conv1x1_fwd", stat_shift=shift, **kw)
                 stats[:] = [partial, ns, shift, stats[0]]
             elif ctx.planes is not None:
-                y = _capi.gemm_x6p(x2, ctx.planes[0], cmid, tag="conv1x1_fwd")
+                y = _capi.gemm_x6p(x2, pl, cmid, tag="conv1x1_fwd", **kw)
             else:
                 y = _capi.gemm_x6(x2, weight.detach().reshape(cmid, cin), tag="conv1x1_fwd")
             return y.view(n, h, w, cmid).permute(0, 3, 1, 2), x.view_as(x)
@@ -1226,12 +1307,14 @@ class _ForkConv1x1(torch.autograd.Function):
                 else:
                     kw = dict(addend=lazy[1].contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(r, cin), addend_mask=lazy[2])
                 link = ctx.link
+                pl, pkw = _pair_planes(ctx.conv, _absmax_of(gy), 1, ctx.planes)
+                kw.update(pkw)
                 if link is not None and link[0].shape == x.shape and cin % 32 == 0:
-                    out, partial, ns = _entry_gemm(a, ctx.planes[1], cin, bn_bwd=link[:5], **kw)
+                    out, partial, ns = _entry_gemm(a, pl, cin, bn_bwd=link[:5], **kw)
                     _note_bn_bwd(out, link, partial, ns)
                 else:
-                    out = _entry_gemm(a, ctx.planes[1], cin, **kw)
-                return out.view(n, h, w, cin).permute(0, 3, 1, 2), dw, None, None, None, None
+                    out = _entry_gemm(a, pl, cin, **kw)
+                return out.view(n, h, w, cin).permute(0, 3, 1, 2), dw, None, None, None, None, None
             if lazy is not None:
                 gid = _dense_of(lazy, x.shape)
             gid = gid.to(x.dtype).contiguous(memory_format=torch.channels_last)
@@ -1244,18 +1327,19 @@ class _ForkConv1x1(torch.autograd.Function):
                 # fp32 on the bf16 matrix cores (exact 3-way split, six products), weight planes packed once per step;
                 # the result is the gradient arriving at the previous block's last BatchNorm: reduced in the epilogue
                 link = ctx.link
+                pl, pkw = _pair_planes(ctx.conv, _absmax_of(gy), 1, ctx.planes)
                 if link is not None and link[0].shape == x.shape and cin % 32 == 0:
-                    out, partial, ns = _entry_gemm(a, ctx.planes[1], cin, d, bn_bwd=link[:5])
+                    out, partial, ns = _entry_gemm(a, pl, cin, d, bn_bwd=link[:5], **pkw)
                     _note_bn_bwd(out, link, partial, ns)
                 else:
-                    out = _entry_gemm(a, ctx.planes[1], cin, d)
+                    out = _entry_gemm(a, pl, cin, d, **pkw)
             elif ctx.use_bwd:
                 wt = weight.detach().reshape(cmid, cin).t().contiguous()
                 out = _capi.gemm_x6(a, wt, d, tag="conv1x1_dgrad_add_x6")
             else:
                 out = _capi.gemm_add(_capi.GEMM_NN, a, weight.reshape(cmid, cin), d, tag="conv1x1_dgrad_add")
             dx = out.view(n, h, w, cin).permute(0, 3, 1, 2)       # back to a channels_last NCHW tensor
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 class _ForkConvH(torch.autograd.Function):
@@ -1327,7 +1411,9 @@ def fork_conv1x1(conv: nn.Conv2d, x: Tensor, stats_for=None):
     if ok:
         stats = [stats_for] if stats_for is not None else None
         flags = []
-        out, identity = _ForkConv1x1.apply(x, conv.weight, conv, stats, _bn_link_of(x), flags)
+        out, identity = _ForkConv1x1.apply(x, conv.weight, conv, stats, _bn_link_of(x), flags, _absmax_of(x))
+        if _absmax_of(x) is not None:
+            identity._peclr_absmax = x._peclr_absmax        # (the same values: the downsample convolution reads them too)
         if flags and flags[0]:
             identity._peclr_compact_ok = True     # a 1x1 / stride-2 shortcut may hand its input gradient over compact
         return _attach_stats(out, stats), identity
@@ -1400,8 +1486,12 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
                 if (res_deferred[2] or not self._takes_deferred_residual(x) or res_deferred[0].shape != x.shape
                         or res_deferred[0].dtype != x.dtype):
                     residual, res_deferred = _materialized(residual, res_deferred), None
+            amax = [] if (ROUTING.x6_pair and x.dtype == torch.float32) else None
             if pool:
-                return _BN2dReluPool.apply(x, self.weight, self.bias, self, pre)
+                y = _BN2dReluPool.apply(x, self.weight, self.bias, self, pre, amax)
+                if amax:
+                    y._peclr_absmax = amax[0]
+                return y
             if self.tail_avgpool and relu and residual is not None and self.num_features % 32 == 0:
                 return _BN2dAddReluAvgPool.apply(x, self.weight, self.bias, residual, self, pre)
             link = [] if (ROUTING.bn_bwd_in_gemm and torch.is_grad_enabled() and x.requires_grad) else None
@@ -1411,7 +1501,9 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
             if consumer is not None and residual is None:
                 if not relu and isinstance(consumer, FusedBatchNormAct2d) and consumer._takes_deferred_residual(x):
                     defer = []
-            y = _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre, link, lazy_res, defer, res_deferred)
+            y = _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre, link, lazy_res, defer, res_deferred, amax)
+            if amax:
+                y._peclr_absmax = amax[0]       # max |y|, on the device: the "pair" GEMMs that read y derive its power of two from it
             if link:
                 y._peclr_bn_link = link
             if defer:

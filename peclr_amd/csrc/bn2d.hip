@@ -504,6 +504,16 @@ __device__ __forceinline__ unsigned mask_load(const unsigned* __restrict__ mask,
     return (mask[(size_t)row * (C / 32) + col / 32] >> ((threadIdx.x % LPW) * W)) & ((1u << W) - 1u);
 }
 
+// absmax (nullable): the pass also leaves max |output| over everything it wrote in *absmax (one atomic per wave onto a slot its
+// caller zeroed: non-negative floats order like their bit patterns, and a maximum does not depend on the order) -- what the "pair"
+// GEMMs that consume the tensor derive its power of two from (include/peclr_hip.h peclr_x6_pair); a NaN output is not seen here
+// (fmaxf drops it) and still poisons the products it enters, as it would in fp32
+__device__ __forceinline__ void absmax_commit(float* absmax, float m) {
+    if (!absmax) return;
+    m = wave_max(m);
+    if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(m));
+}
+
 // RES: 0 no residual; 1 a residual tensor; 2 `res` is the INPUT of the shortcut's BatchNorm2d (the downsample branch of a
 // layer's first block: conv1x1 -> bn, torchvision Bottleneck.downsample behind resnet_model.py:15) and res_ss its [2][C] scale /
 // shift: the residual is fmaf(res, scale, shift) rounded to the storage format -- the value peclr_bn2d_apply would have written
@@ -511,11 +521,13 @@ __device__ __forceinline__ unsigned mask_load(const unsigned* __restrict__ mask,
 template <typename IO, int RES, bool RELU>
 __global__ __launch_bounds__(T) void bn2d_apply_kernel(const IO* __restrict__ x, const IO* __restrict__ res, Geo g,
                                                        const float* __restrict__ scale_shift, IO* __restrict__ y,
-                                                       unsigned* __restrict__ relu_mask, const float* __restrict__ res_ss) {
+                                                       unsigned* __restrict__ relu_mask, const float* __restrict__ res_ss,
+                                                       float* __restrict__ absmax) {
     constexpr int W = Word<IO>::W, U = Word<IO>::U;
     int col, r0, r1, rl;
     thread_geo<W>(g, col, r0, r1, rl);
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
+    float amax = 0.f;
     Fv<W> rsc = sc, rsh = sh;
     if (RES == 2) { rsc = loadp<W>(res_ss + col); rsh = loadp<W>(res_ss + g.C + col); }
     auto emit = [&](int row, const Fv<W>& v, const Fv<W>& w) {
@@ -529,6 +541,7 @@ __global__ __launch_bounds__(T) void bn2d_apply_kernel(const IO* __restrict__ x,
             if (RES == 2) a += Word<IO>::round(fmaf(w.v[k], rsc.v[k], rsh.v[k]));
             if (RELU) bits |= (a > 0.f ? 1u : 0u) << k;
             t.v[k] = RELU ? fmaxf(a, 0.f) : a;
+            amax = fmaxf(amax, fabsf(t.v[k]));
         }
         Word<IO>::store(y + o, t);
         if (RELU && relu_mask) mask_store<W>(relu_mask, row, col, g.C, bits);  // the word's lanes share `row`
@@ -550,6 +563,7 @@ __global__ __launch_bounds__(T) void bn2d_apply_kernel(const IO* __restrict__ x,
         const Fv<W> v = Word<IO>::load(x + o);
         emit(r, v, RES ? Word<IO>::load(res + o) : v);
     }
+    absmax_commit(absmax, amax);
 }
 
 // Last block of layer4: BatchNorm2d + identity + ReLU + AdaptiveAvgPool2d((1, 1)) + flatten in one pass
@@ -710,10 +724,12 @@ __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict_
                                                            const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                            const float* __restrict__ scale_shift, const float* __restrict__ coef,
                                                            IO* __restrict__ dx, IO* __restrict__ dres,
-                                                           const float* __restrict__ d_pooled = nullptr, int hw = 1, float inv_hw = 1.f) {
+                                                           const float* __restrict__ d_pooled = nullptr, int hw = 1, float inv_hw = 1.f,
+                                                           float* __restrict__ absmax = nullptr) {
     constexpr int W = Word<IO>::W, U = Word<IO>::U;
     int col, r0, r1, rl;
     thread_geo<W>(g, col, r0, r1, rl);
+    float amax = 0.f;
     auto load_dy = [&](int row) -> Fv<W> {
         if constexpr (POOL) return pooled_dy<W>(d_pooled, row, hw, inv_hw, g.C, col);
         else return Word<IO>::load(dy + (size_t)row * g.C + col);
@@ -744,6 +760,7 @@ __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict_
                 const float xh = (xv.v[k] - mean.v[k]) * invstd.v[k];
                 t.v[k] = fmaf(d.v[k], sc.v[k], fmaf(xh, k3.v[k], k2.v[k]));
             }
+            amax = fmaxf(amax, fabsf(t.v[k]));
         }
         Word<IO>::store(dx + o, t);
     };
@@ -776,6 +793,7 @@ __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict_
         emit(o, load_dy(r), xv, MASK == 2 ? Word<IO>::load(y + o) : xv,
              MASK == 3 ? mask_load<W>(relu_mask, r, col, g.C) : 0u);
     }
+    absmax_commit(absmax, amax);
 }
 
 // ------------------------------------------------------------------ host
@@ -813,8 +831,10 @@ constexpr int kPoolIter = 4;  // pixels per thread in the two apply kernels (few
 template <typename IO>
 __global__ __launch_bounds__(T) void bn2d_pool_apply_kernel(const IO* __restrict__ x, PoolGeo g,
                                                             const float* __restrict__ scale_shift, IO* __restrict__ y,
-                                                            IO* __restrict__ x_at_max, uint8_t* __restrict__ code) {
+                                                            IO* __restrict__ x_at_max, uint8_t* __restrict__ code,
+                                                            float* __restrict__ absmax) {
     constexpr int W = Word<IO>::W;
+    float amax = 0.f;
     const int cg = threadIdx.x % g.CW, pl = threadIdx.x / g.CW, col = cg * W;
     const Fv<W> sc = loadp<W>(scale_shift + col), sh = loadp<W>(scale_shift + g.C + col);
     const int per_image = g.PH * g.PW, span = g.PPB * kPoolIter;
@@ -847,6 +867,8 @@ __global__ __launch_bounds__(T) void bn2d_pool_apply_kernel(const IO* __restrict
             }
         }
         Word<IO>::store(y + (size_t)p * g.C + col, best);
+#pragma unroll
+        for (int k = 0; k < W; ++k) amax = fmaxf(amax, best.v[k]);       // (rectified: non-negative)
         Word<IO>::store(x_at_max + (size_t)p * g.C + col, xb);   // exact: x is an IO value already
         unsigned packed[W / 4];
 #pragma unroll
@@ -854,6 +876,7 @@ __global__ __launch_bounds__(T) void bn2d_pool_apply_kernel(const IO* __restrict
 #pragma unroll
         for (int k = 0; k < W / 4; ++k) reinterpret_cast<unsigned*>(code + (size_t)p * g.C + col)[k] = packed[k];
     }
+    absmax_commit(absmax, amax);
 }
 
 // partial: [gridDim.x][2][C] = (sum of masked dy, sum of masked dy * xhat) over the block's pooled pixels
@@ -1098,16 +1121,16 @@ inline bool all_aligned(std::initializer_list<const void*> ps) {
 
 template <typename IO>
 void launch_apply(const Plan& p, hipStream_t s, const void* x, const void* res, const float* ss, int relu, void* y,
-                  unsigned* mask, const float* res_ss = nullptr) {
+                  unsigned* mask, const float* res_ss, float* absmax) {
     const IO* xp = static_cast<const IO*>(x);
     const IO* rp = static_cast<const IO*>(res);
     IO* yp = static_cast<IO*>(y);
-    if (res && res_ss && relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 2, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss);
-    else if (res && res_ss) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 2, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss);
-    else if (res && relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 1, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss);
-    else if (res) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 1, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss);
-    else if (relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 0, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss);
-    else hipLaunchKernelGGL((bn2d_apply_kernel<IO, 0, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss);
+    if (res && res_ss && relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 2, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss, absmax);
+    else if (res && res_ss) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 2, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss, absmax);
+    else if (res && relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 1, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss, absmax);
+    else if (res) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 1, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss, absmax);
+    else if (relu) hipLaunchKernelGGL((bn2d_apply_kernel<IO, 0, true>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss, absmax);
+    else hipLaunchKernelGGL((bn2d_apply_kernel<IO, 0, false>), p.grid, dim3(T), 0, s, xp, rp, p.g, ss, yp, mask, res_ss, absmax);
 }
 
 inline int mask_mode(int relu, const void* y, const void* mask) { return !relu ? 0 : (mask ? 3 : (y ? 2 : 1)); }
@@ -1123,10 +1146,11 @@ void launch_reduce(const Plan& p, hipStream_t s, int mm, const void* dy, const v
 
 template <typename IO>
 void launch_bwd_apply(const Plan& p, hipStream_t s, int mm, const void* dy, const void* x, const void* y, const unsigned* mask,
-                      const float* mean, const float* invstd, const float* ss, const float* coef, void* dx, void* dres) {
+                      const float* mean, const float* invstd, const float* ss, const float* coef, void* dx, void* dres, float* absmax) {
     const IO *d = static_cast<const IO*>(dy), *xp = static_cast<const IO*>(x), *yp = static_cast<const IO*>(y);
     IO *o = static_cast<IO*>(dx), *r = static_cast<IO*>(dres);
-#define PECLR_LAUNCH(M, D) hipLaunchKernelGGL((bn2d_bwd_apply_kernel<IO, M, D>), p.grid, dim3(T), 0, s, d, xp, yp, mask, p.g, mean, invstd, ss, coef, o, r)
+#define PECLR_LAUNCH(M, D) hipLaunchKernelGGL((bn2d_bwd_apply_kernel<IO, M, D>), p.grid, dim3(T), 0, s, d, xp, yp, mask, p.g, mean, invstd, ss, coef, o, r, \
+                                              (const float*)nullptr, 1, 1.f, absmax)
     if (dres) {
         if (mm == 0) PECLR_LAUNCH(0, true); else if (mm == 1) PECLR_LAUNCH(1, true); else if (mm == 2) PECLR_LAUNCH(2, true); else PECLR_LAUNCH(3, true);
     } else {
@@ -1214,7 +1238,7 @@ extern "C" int peclr_bn2d_finalize_f32(float* partial, int n_split, int R, int C
 }
 
 extern "C" int peclr_bn2d_apply(const void* x, const void* residual, int io_dtype, int R, int C,
-                                const float* scale_shift, int relu, void* y, uint32_t* relu_mask,
+                                const float* scale_shift, int relu, void* y, uint32_t* relu_mask, float* absmax_out,
                                 peclr_stream_t stream) {
     if (!x || !scale_shift || !y) return PECLR_ERR_NULL;
     Plan p;
@@ -1222,21 +1246,22 @@ extern "C" int peclr_bn2d_apply(const void* x, const void* residual, int io_dtyp
     if (relu_mask && (C % 32 || !relu)) return PECLR_ERR_SHAPE;
     if (!all_aligned({x, y, scale_shift, residual})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    PECLR_IO_SWITCH(io_dtype, launch_apply<IO>(p, s, x, residual, scale_shift, relu, y, relu_mask));
+    PECLR_IO_SWITCH(io_dtype, launch_apply<IO>(p, s, x, residual, scale_shift, relu, y, relu_mask, nullptr, absmax_out));
     return launch_status();
 }
 
 // y = (relu)(bn(x) + bn_s(res_x)): the last pass of a layer's FIRST block, whose shortcut is conv1x1 -> BatchNorm2d.  res_x is
 // that BatchNorm's input, res_scale_shift its [2][C] table; the shortcut's own apply pass and output tensor are not needed.
 extern "C" int peclr_bn2d_apply_res_bn(const void* x, const void* res_x, const float* res_scale_shift, int io_dtype, int R, int C,
-                                       const float* scale_shift, int relu, void* y, uint32_t* relu_mask, peclr_stream_t stream) {
+                                       const float* scale_shift, int relu, void* y, uint32_t* relu_mask, float* absmax_out,
+                                       peclr_stream_t stream) {
     if (!x || !res_x || !res_scale_shift || !scale_shift || !y) return PECLR_ERR_NULL;
     Plan p;
     if (!plan_for(io_dtype, R, C, 0, p)) return PECLR_ERR_SHAPE;
     if (relu_mask && (C % 32 || !relu)) return PECLR_ERR_SHAPE;
     if (!all_aligned({x, y, scale_shift, res_x, res_scale_shift})) return PECLR_ERR_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    PECLR_IO_SWITCH(io_dtype, launch_apply<IO>(p, s, x, res_x, scale_shift, relu, y, relu_mask, res_scale_shift));
+    PECLR_IO_SWITCH(io_dtype, launch_apply<IO>(p, s, x, res_x, scale_shift, relu, y, relu_mask, res_scale_shift, absmax_out));
     return launch_status();
 }
 
@@ -1274,7 +1299,7 @@ extern "C" int peclr_bn2d_bwd_finalize_f32(float* partial, int n_split, int R, i
 extern "C" int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y, const uint32_t* relu_mask, int io_dtype,
                                     int R, int C, int relu,
                                     const float* save_mean, const float* save_invstd, const float* scale_shift,
-                                    const float* coef, void* dx, void* d_residual, peclr_stream_t stream) {
+                                    const float* coef, void* dx, void* d_residual, float* absmax_out, peclr_stream_t stream) {
     if (!dy || !x || !save_mean || !save_invstd || !scale_shift || !coef || !dx) return PECLR_ERR_NULL;
     Plan p;
     if (!plan_for(io_dtype, R, C, 0, p)) return PECLR_ERR_SHAPE;
@@ -1282,7 +1307,7 @@ extern "C" int peclr_bn2d_bwd_apply(const void* dy, const void* x, const void* y
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (relu_mask && C % 32) return PECLR_ERR_SHAPE;
     const int mm = mask_mode(relu, y, relu_mask);
-    PECLR_IO_SWITCH(io_dtype, launch_bwd_apply<IO>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, coef, dx, d_residual));
+    PECLR_IO_SWITCH(io_dtype, launch_bwd_apply<IO>(p, s, mm, dy, x, y, relu_mask, save_mean, save_invstd, scale_shift, coef, dx, d_residual, absmax_out));
     return launch_status();
 }
 
@@ -1315,7 +1340,7 @@ extern "C" int peclr_bn2d_pool_n_split(int N, int H, int W, int C, int io_dtype)
 }
 
 extern "C" int peclr_bn2d_pool_apply(const void* x, int io_dtype, int N, int H, int W, int C, const float* scale_shift,
-                                     void* y, void* x_at_max, uint8_t* code, peclr_stream_t stream) {
+                                     void* y, void* x_at_max, uint8_t* code, float* absmax_out, peclr_stream_t stream) {
     if (!x || !scale_shift || !y || !x_at_max || !code) return PECLR_ERR_NULL;
     PoolGeo g;
     if (!pool_geo(io_dtype, N, H, W, C, g)) return PECLR_ERR_SHAPE;
@@ -1323,7 +1348,7 @@ extern "C" int peclr_bn2d_pool_apply(const void* x, int io_dtype, int N, int H, 
     const int blocks = pool_blocks(g, g.PH * g.PW, kPoolIter);
     hipStream_t s = static_cast<hipStream_t>(stream);
     PECLR_IO_SWITCH(io_dtype, hipLaunchKernelGGL((bn2d_pool_apply_kernel<IO>), dim3(blocks), dim3(T), 0, s, static_cast<const IO*>(x), g,
-                           scale_shift, static_cast<IO*>(y), static_cast<IO*>(x_at_max), code));
+                           scale_shift, static_cast<IO*>(y), static_cast<IO*>(x_at_max), code, absmax_out));
     return launch_status();
 }
 
@@ -1405,7 +1430,7 @@ extern "C" int peclr_bn2d_bwd_reduce_avgpool(const float* d_pooled, const void* 
 extern "C" int peclr_bn2d_bwd_apply_avgpool(const float* d_pooled, const void* x, const uint32_t* relu_mask, int io_dtype,
                                             int N, int HW, int C, const float* save_mean, const float* save_invstd,
                                             const float* scale_shift, const float* coef, void* dx, void* d_residual,
-                                            peclr_stream_t stream) {
+                                            float* absmax_out, peclr_stream_t stream) {
     if (!d_pooled || !x || !relu_mask || !save_mean || !save_invstd || !scale_shift || !coef || !dx || !d_residual)
         return PECLR_ERR_NULL;
     if (N <= 0 || HW <= 0 || C % 32 || (long long)N * HW > 0x7fffffffLL) return PECLR_ERR_SHAPE;
@@ -1416,6 +1441,6 @@ extern "C" int peclr_bn2d_bwd_apply_avgpool(const float* d_pooled, const void* x
     const float inv = 1.0f / (float)HW;
     PECLR_IO_SWITCH(io_dtype, hipLaunchKernelGGL((bn2d_bwd_apply_kernel<IO, 3, true, true>), p.grid, dim3(T), 0, s, (const IO*)nullptr,
                            static_cast<const IO*>(x), (const IO*)nullptr, relu_mask, p.g, save_mean, save_invstd, scale_shift,
-                           coef, static_cast<IO*>(dx), static_cast<IO*>(d_residual), d_pooled, HW, inv));
+                           coef, static_cast<IO*>(dx), static_cast<IO*>(d_residual), d_pooled, HW, inv, absmax_out));
     return launch_status();
 }

@@ -57,6 +57,39 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& h, unsig
     l = pk_bf16(sub_f32(r0, __uint_as_float(m << 16)), sub_f32(r1, __uint_as_float(m & 0xFFFF0000u)));
 }
 
+// ---- two-way fp16 split of SCALED fp32 numbers (the "pair" GEMMs, round 6): with s a power of two chosen per tensor so that
+// max |s x| lies in [2^14, 2^15) (pair_scale below; fp16 overflows at 65 504), s x == hi + lo + e with hi = fp16(s x), lo =
+// fp16(s x - hi) (the residual is exact in fp32), |e| <= 2^-23 |s x|: 11 + 1 (lo's sign) + 11 of fp32's 24 significand bits.
+// Three of the four partial products (hi.hi, hi.lo, lo.hi; lo.lo <= 2^-22 of the product is dropped) on v_mfma_f32_32x32x16_f16
+// with fp32 accumulation, the accumulators multiplied by 1 / (s_a s_b) -- exact, both are powers of two -- afterwards.  Elements
+// below 2^-18 of the tensor's maximum lose low bits of `lo` gradually (fp16 subnormals; absolute error <= 2^-40 max |x|).
+// Measured on real layer tensors (tools/exp/fp16_pair_probe.py, tools/exp/pair_probe.py): the error class of an fp32 BLAS GEMM,
+// 1.2 - 2.4 x the six-product scheme's, a fraction of a k-ordered fp32 chain's (what v_mfma_f32 computes).
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));      // round to nearest even
+}
+__device__ __forceinline__ float f16_lo(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)w); }
+__device__ __forceinline__ float f16_hi(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+__device__ __forceinline__ void split2_pk(float x0, float x1, float s, unsigned& h, unsigned& l) {
+    const float y0 = x0 * s, y1 = x1 * s;                    // exact: s is a power of two
+    h = pk_f16(y0, y1);
+    l = pk_f16(sub_f32(y0, f16_lo(h)), sub_f32(y1, f16_hi(h)));
+}
+// the power of two s with amax * s in [2^14, 2^15); exponent clamped to +-50 (amax = 0 / subnormal / inf / nan: any s will do --
+// zeros stay zeros, non-finite operands give non-finite results as they would in fp32)
+__host__ __device__ __forceinline__ float pair_scale(float amax) {
+    unsigned bits;
+    __builtin_memcpy(&bits, &amax, 4);
+    int k = 14 - ((int)((bits >> 23) & 0xFFu) - 127);
+    k = k < -50 ? -50 : (k > 50 ? 50 : k);
+    bits = (unsigned)(k + 127) << 23;
+    float s;
+    __builtin_memcpy(&s, &bits, 4);
+    return s;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Returns the hipError_t of the most recent launch as a positive int (0 = ok).

@@ -41,7 +41,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 constexpr int PN = 128;                  // output columns per workgroup (and per packed chunk)
 constexpr int PK = 16;                   // k per step = one MFMA k-extent
-constexpr int CHUNK = 12 * 1024;         // bytes of packed B per (128 columns, 16 k)
+constexpr int CHUNK3 = 12 * 1024;        // bytes of packed B per (128 columns, 16 k): three bf16 planes
 
 struct X6PArgs {
     const float* A;
@@ -78,6 +78,11 @@ struct X6PArgs {
     // stride-1 input gradient (K order (tap, Cout)).
     int s2d;
     const float* zeros;                  // >= 64 bytes of zeros (source of the padding pixels)
+    // NP = 2 instantiations ("pair" arithmetic, common.hpp split2_pk): Bp holds TWO fp16 planes per chunk (peclr_x6_pack_pair_f32),
+    // *w_scale the power of two they were multiplied by; *a_absmax = max |A| over the WHOLE activation tensor (written by the pass
+    // that produced it), from which every workgroup derives the same power of two for A
+    const float* a_absmax;
+    const float* w_scale;
     // optional: C is the gradient dY arriving at a BatchNorm2d(+ReLU) layer (this GEMM is the input gradient of the
     // convolution that consumed that layer's output).  The epilogue then performs the layer's backward REDUCTION on the tile
     // it holds: per row block and column, sum of dY' and of dY' * xhat with dY' = dY where the ReLU passed (recomputed from
@@ -94,6 +99,12 @@ struct X6PArgs {
 
 __device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, f32x16 acc) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int NP>
+__device__ __forceinline__ f32x16 mman(const uint4& a, const uint4& b, f32x16 acc) {
+    if constexpr (NP == 3) return mma(a, b, acc);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 // 16 bytes per lane, global -> LDS at (wave-uniform) dst + lane * 16.  Issued through inline assembly on purpose: for
 // the builtin, hipcc's wait-count pass makes EVERY later ds_read wait for the DMA (vmcnt(0) right behind the issue --
@@ -118,8 +129,12 @@ __device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_offset)
 // (Two more forms were built in round 5, measured slower and taken out of the library in round 6 -- persistent workgroups walking the
 // tile index space, and the BatchNorm + ReLU in front of A applied in the row split: tools/exp/x6p_persist_tra.patch, numbers in
 // docs/history.md E.)
-template <int WM, int ABL = 0, bool AREG = true, bool ILV = true, int TAPS = 1, int NTL = 4, bool HALO = false>
+// NP: planes per operand.  3 = the exact bf16 triple, six products (PECLR_X6).  2 = the fp16 pair of the scaled operands, three
+// products (PECLR_X2): two thirds of the plane traffic through the LDS, half the matrix-core work, a cheaper split.
+template <int WM, int ABL = 0, bool AREG = true, bool ILV = true, int TAPS = 1, int NTL = 4, bool HALO = false, int NP = 3>
 __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
+    static_assert(NP == 3 || (NP == 2 && AREG), "planes per operand: bf16 triple or fp16 pair");
+    constexpr int CHUNK = NP * 4 * 1024;                 // bytes of packed B per (128 columns, 16 k): [32-column block][plane] pieces of 1 KiB
     constexpr int RM = 32 * WM;                          // rows per wave
     constexpr int TM = 4 * RM;                           // rows per workgroup
     constexpr int NRAW = RM / 16;                        // 1 KiB pieces of fp32 rows per wave and k-step
@@ -128,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                                                          // land on different banks for the 8-byte plane stores)
     constexpr int PLANE = 2 * HALF;
     constexpr int XEPL = 36;                             // floats per row of the epilogue's 32 x 32 transpose buffer
-    constexpr int WAVE_PL = 3 * PLANE;
+    constexpr int WAVE_PL = NP * PLANE;
     // bytes of one filter buffer: a 64-column workgroup lands only its six 1 KiB pieces of a chunk (18 instead of 36 KiB of
     // buffers: with its 120 VGPRs a fourth workgroup per CU; the halo variant's 128-row tile: a third)
     constexpr int CHL = CHUNK * NTL / 4;
@@ -139,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     // lanes on 32 banks of 4 bytes, and a group of the patch store holds 4 pixels x both k-halves: with the bare pitch
     // (1528 dwords = 24 mod 32 at TM = 256) the second half's banks overlapped the first's, a 2-way conflict on every store
     // (0.187 of the kernel's LDS cycles, profiles/r04f_fp32_bench_mfma.txt; every other six-product kernel: <= 0.06)
-    constexpr int PHALF = (NPXM * 16 + 63) / 128 * 128 + 64, PPLANE = 2 * PHALF, PATCH = 3 * PPLANE;
+    constexpr int PHALF = (NPXM * 16 + 63) / 128 * 128 + 64, PPLANE = 2 * PHALF, PATCH = NP * PPLANE;
     constexpr int ZOFF = RAW0 + PATCH;                   // HALO: 16 bytes of zeros
     // + 2.5 KiB at the end: the epilogue's per-column constants ([shift | mean | invstd | scale | shift'][128] floats), fetched
     // BEFORE the main loop -- in the epilogue each of the four column tiles used to wait a full memory round trip for them
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     const int nk = s2d ? ntap * (g.lda / PK) : g.K / PK;
     const int nk_all = g.K / PK;                                      // k-steps of a column tile's packed chunks
     // packed chunk of this column tile (NTL = 2: the first or second half of a 128-column chunk's twelve pieces)
-    const int piece0 = NTL == 4 ? 0 : (ct & 1) * 6;
+    const int piece0 = NTL == 4 ? 0 : (ct & 1) * 2 * NP;
     const unsigned char* bsrc = static_cast<const unsigned char*>(g.Bp) + (size_t)(NTL == 4 ? ct : ct >> 1) * nk_all * CHUNK +
                                 piece0 * 1024 + lane * 16;
 
@@ -182,6 +197,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][y][r] = 0.f;
 
+    float pair_s = 1.f, pair_inv = 1.f;                   // NP = 2: the activation's power of two, and what undoes both operands' scaling
+    if constexpr (NP == 2) {
+        pair_s = pair_scale(*g.a_absmax);
+        pair_inv = 1.f / (pair_s * *g.w_scale);           // (exact: powers of two, exponents within +-50 each)
+    }
     float* const cst = reinterpret_cast<float*>(lds + CST0);
     {
         constexpr int PNL0 = 32 * NTL;
@@ -247,10 +267,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         const unsigned d = b_a + (t % NB) * CHL;
         if constexpr (NTL == 4) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) dma16(s + (3 * wave_s + q) * 1024, d + (3 * wave_s + q) * 1024);
-        } else {                                          // six pieces: waves 0, 1 two each, waves 2, 3 one
+            for (int q = 0; q < NP; ++q) dma16(s + (NP * wave_s + q) * 1024, d + (NP * wave_s + q) * 1024);
+        } else {                                          // 2 NP pieces: (six: waves 0, 1 two each, waves 2, 3 one; four: one each)
             dma16(s + wave_s * 1024, d + wave_s * 1024);
-            if (wave_s < 2) dma16(s + (4 + wave_s) * 1024, d + (4 + wave_s) * 1024);
+            if (NP == 3 && wave_s < 2) dma16(s + (4 + wave_s) * 1024, d + (4 + wave_s) * 1024);
         }
     };
     auto issue_a = [&](int t) {
@@ -292,13 +312,21 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
             f32x4 v;
             if constexpr (AREG) v = ar[c];
             else v = *reinterpret_cast<const f32x4*>(raw + c * 1024 + lane * 16);
-            unsigned h[2], m[2], l[2];
-            split3_pk(v[0], v[1], h[0], m[0], l[0]);
-            split3_pk(v[2], v[3], h[1], m[1], l[1]);
             unsigned char* d = planes + poff + c * 256;
-            *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
-            *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(m[0], m[1]);
-            *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(l[0], l[1]);
+            if constexpr (NP == 2) {
+                unsigned h[2], l[2];
+                split2_pk(v[0], v[1], pair_s, h[0], l[0]);
+                split2_pk(v[2], v[3], pair_s, h[1], l[1]);
+                *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
+                *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(l[0], l[1]);
+            } else {
+                unsigned h[2], m[2], l[2];
+                split3_pk(v[0], v[1], h[0], m[0], l[0]);
+                split3_pk(v[2], v[3], h[1], m[1], l[1]);
+                *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
+                *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(m[0], m[1]);
+                *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(l[0], l[1]);
+            }
         }
     };
 
@@ -320,36 +348,37 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         constexpr bool SPLIT = decltype(split_next)::value;
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        uint4 af[WM][3];
+        uint4 af[WM][NP];
 #pragma unroll
         for (int a = 0; a < WM; ++a)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const uint4*>(planes + p * PLANE + foff + a * 512);
+            for (int p = 0; p < NP; ++p) af[a][p] = *reinterpret_cast<const uint4*>(planes + p * PLANE + foff + a * 512);
         const unsigned char* bt = lds + ((ABL & 32) ? 0 : (t % NB)) * CHL + lane * 16;
 #pragma unroll
         for (int half = 0; half < NTL / 2; ++half) {
-            uint4 bf[2][3];
+            uint4 bf[2][NP];
 #pragma unroll
             for (int y = 0; y < 2; ++y)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bf[y][p] = *reinterpret_cast<const uint4*>(bt + ((2 * half + y) * 3 + p) * 1024);
+                for (int p = 0; p < NP; ++p) bf[y][p] = *reinterpret_cast<const uint4*>(bt + ((2 * half + y) * NP + p) * 1024);
 #define PECLR_X6(P, Q)                                                                        \
     _Pragma("unroll") for (int y = 0; y < 2; ++y) _Pragma("unroll") for (int a = 0; a < WM; ++a) \
         if constexpr (ABL & 8) { asm volatile("" :: "v"(af[a][P].x), "v"(af[a][P].w), "v"(bf[y][Q].x), "v"(bf[y][Q].w)); } \
-        else acc[a][2 * half + y] = mma(af[a][P], bf[y][Q], acc[a][2 * half + y]);
-            PECLR_X6(2, 0) PECLR_X6(0, 2) PECLR_X6(1, 1) PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)
+        else acc[a][2 * half + y] = mman<NP>(af[a][P], bf[y][Q], acc[a][2 * half + y]);
+            if constexpr (NP == 3 && !(ABL & 64)) { PECLR_X6(NP - 1, 0) PECLR_X6(0, NP - 1) PECLR_X6(1, 1) }       // (ABL 64: three products only -- timing probe)
+            PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)                  // (NP = 2: lo.hi, hi.lo, hi.hi -- smallest first)
 #undef PECLR_X6
             if (half == 0 && SPLIT) {
                 if constexpr (!AREG) PECLR_VMCNT(0);
                 if constexpr (!(ABL & 1)) split_store();       // after this step's fragment reads in program (= LDS) order
                 else if constexpr (AREG) { asm volatile("" :: "v"(ar[0]), "v"(ar[NRAW - 1])); }
-                if constexpr (AREG && !(ABL & 9) && ILV) {
+                if constexpr (AREG && !(ABL & 9) && ILV) {   // (ABL 64: the interleave pattern below still assumes 24 WM products: harmless)
                     // one MFMA, then four of the split's VALU instructions (the two pipes run side by side), a plane store now and then
 #pragma unroll
-                    for (int q = 0; q < 12 * WM; ++q) {
+                    for (int q = 0; q < (NP == 3 ? 12 : 6) * WM; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                        if (q % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 4 : 6, 0);
+                        if (q % 4 == 3 || NP == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                     }
                 }
                 if constexpr (!AREG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -364,9 +393,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     for (int t = 0; t + 1 < nk; ++t) kstep(t, std::true_type{});
     kstep(nk - 1, std::false_type{});
     } else {
-        static_assert(!HALO || (TAPS == 9 && AREG && ABL == 0), "HALO is the 3x3 / stride-1 path");
+        static_assert(!HALO || (TAPS == 9 && AREG && (ABL & ~67) == 0), "HALO is the 3x3 / stride-1 path (ABL: 1 no split / plane stores, 2 no patch loads, 64 three products)");
         constexpr int NLD = (NPXM * 4 + 255) / 256;      // 16-byte loads per thread and chunk
-        constexpr int NDMA = NTL == 4 ? 3 : 1;           // B DMA instructions per wave and k-step (at least)
+        constexpr int NDMA = NTL == 4 ? NP : 1;          // B DMA instructions per wave and k-step (at least)
         unsigned char* const patch = lds + RAW0;
         if (tid < 4) reinterpret_cast<unsigned*>(lds + ZOFF)[tid] = 0u;
         const int W = g.W, npx = TM + 2 * W + 2;
@@ -408,13 +437,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
 #pragma unroll
             for (int u = 0; u < NLD; ++u) {
                 unsigned h[2], m[2], l[2];
-                split3_pk(pr[u][0], pr[u][1], h[0], m[0], l[0]);
-                split3_pk(pr[u][2], pr[u][3], h[1], m[1], l[1]);
+                if constexpr (NP == 2) {
+                    split2_pk(pr[u][0], pr[u][1], pair_s, h[0], m[0]);
+                    split2_pk(pr[u][2], pr[u][3], pair_s, h[1], m[1]);
+                } else {
+                    split3_pk(pr[u][0], pr[u][1], h[0], m[0], l[0]);
+                    split3_pk(pr[u][2], pr[u][3], h[1], m[1], l[1]);
+                }
                 if (px0 + 64 * u < npx) {
                     unsigned char* d = patch + pd0 + u * 1024;
                     *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
                     *reinterpret_cast<uint2*>(d + PPLANE) = make_uint2(m[0], m[1]);
-                    *reinterpret_cast<uint2*>(d + 2 * PPLANE) = make_uint2(l[0], l[1]);
+                    if constexpr (NP == 3) *reinterpret_cast<uint2*>(d + 2 * PPLANE) = make_uint2(l[0], l[1]);
                 }
             }
         };
@@ -424,10 +458,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
             const unsigned d = b_a + (s % NB) * CHL;
             if constexpr (NTL == 4) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) dma16(src + (3 * wave_s + q) * 1024, d + (3 * wave_s + q) * 1024);
+                for (int q = 0; q < NP; ++q) dma16(src + (NP * wave_s + q) * 1024, d + (NP * wave_s + q) * 1024);
             } else {
                 dma16(src + wave_s * 1024, d + wave_s * 1024);
-                if (wave_s < 2) dma16(src + (4 + wave_s) * 1024, d + (4 + wave_s) * 1024);
+                if (NP == 3 && wave_s < 2) dma16(src + (4 + wave_s) * 1024, d + (4 + wave_s) * 1024);
             }
         };
         const int nsteps = 9 * nkc;
@@ -442,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
             for (int j = 0; j < 9; ++j) {
                 const int s = kc * 9 + j;
                 // B chunk s has landed: issued after it are chunk s + 1 (and, at j == 1, the next patch's rows)
-                if (j == 1 && kc + 1 < nkc) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA + NLD) : "memory");
+                if (j == 1 && kc + 1 < nkc) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((ABL & 2) ? NDMA : NDMA + NLD) : "memory");
                 else if (s + 1 == nsteps) PECLR_VMCNT(0);        // (nothing was issued after the last chunk)
                 else if (s > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
                 __builtin_amdgcn_s_barrier();
@@ -450,12 +484,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                 const int ja = j / 3, jb = j - 3 * ja;
                 const int dh = g.flip ? 1 - ja : ja - 1, dw = g.flip ? 1 - jb : jb - 1;
                 const int shift = (dh * W + dw) * 16;
-                uint4 af[WM][3];
+                uint4 af[WM][NP];
 #pragma unroll
                 for (int a = 0; a < WM; ++a) {
                     const bool in = (fmask[a] >> j) & 1u;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
+                    for (int p = 0; p < NP; ++p) {
                         const int off = in ? RAW0 + p * PPLANE + kh * PHALF + fpix[a] * 16 + shift : ZOFF;
                         af[a][p] = *reinterpret_cast<const uint4*>(lds + off);
                     }
@@ -463,18 +497,19 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                 const unsigned char* bt = lds + (s % NB) * CHL + lane * 16;
 #pragma unroll
                 for (int half = 0; half < NTL / 2; ++half) {
-                    uint4 bf[2][3];
+                    uint4 bf[2][NP];
 #pragma unroll
                     for (int y = 0; y < 2; ++y)
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) bf[y][p] = *reinterpret_cast<const uint4*>(bt + ((2 * half + y) * 3 + p) * 1024);
+                        for (int p = 0; p < NP; ++p) bf[y][p] = *reinterpret_cast<const uint4*>(bt + ((2 * half + y) * NP + p) * 1024);
 #define PECLR_X6(P, Q)                                                                        \
     _Pragma("unroll") for (int y = 0; y < 2; ++y) _Pragma("unroll") for (int a = 0; a < WM; ++a) \
-        acc[a][2 * half + y] = mma(af[a][P], bf[y][Q], acc[a][2 * half + y]);
-                    PECLR_X6(2, 0) PECLR_X6(0, 2) PECLR_X6(1, 1) PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)
+        acc[a][2 * half + y] = mman<NP>(af[a][P], bf[y][Q], acc[a][2 * half + y]);
+                    if constexpr (NP == 3 && !(ABL & 64)) { PECLR_X6(NP - 1, 0) PECLR_X6(0, NP - 1) PECLR_X6(1, 1) }
+                    PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)
 #undef PECLR_X6
                     if (half == 0) {
-                        if (j == 0 && kc + 1 < nkc) { load_patch(kc + 1); asm volatile("" ::: "memory"); }
+                        if (j == 0 && kc + 1 < nkc && !(ABL & 2)) { load_patch(kc + 1); asm volatile("" ::: "memory"); }
                         if (j == 3 && kc + 1 < nkc) {     // the next patch's rows are in (hipcc places its own wait here, long after the issue)
 #pragma unroll
                             for (int u = 0; u < NLD; ++u) asm volatile("" :: "v"(pr[u][0]), "v"(pr[u][3]));
@@ -483,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                     }
                 }
             }
-            if (kc + 1 < nkc) {
+            if (kc + 1 < nkc && !(ABL & 1)) {
                 __builtin_amdgcn_s_barrier();             // every wave has read this chunk's patch
                 asm volatile("" ::: "memory");
                 store_patch();
@@ -492,6 +527,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
         }
     }
 
+    if constexpr (NP == 2) {                              // undo the operands' powers of two (exact)
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+            for (int y = 0; y < NTL; ++y)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][y][r] *= pair_inv;
+    }
     // epilogue: wave-private 32 x 32 transposes through LDS (the B buffers, once every wave is done with them), 16 bytes per lane
     __syncthreads();
     float* wlds = reinterpret_cast<float*>(lds + wave * (32 * XEPL * 4));
@@ -679,17 +722,92 @@ __global__ __launch_bounds__(256) void x6_pack_kernel(const PackDesc* descs, int
     unsigned h[4], m[4], l[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) split3_pk(v[2 * q], v[2 * q + 1], h[q], m[q], l[q]);
-    unsigned char* dst = reinterpret_cast<unsigned char*>(e.dst) + (size_t)chunk * CHUNK + ((col >> 5) * 3) * 1024 +
+    unsigned char* dst = reinterpret_cast<unsigned char*>(e.dst) + (size_t)chunk * CHUNK3 + ((col >> 5) * 3) * 1024 +
                          ((col & 31) + 32 * kh) * 16;
     *reinterpret_cast<uint4*>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
     *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(m[0], m[1], m[2], m[3]);
     *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// ---- the same for the fp16 pair (NP = 2): per (128 columns, 16 k) an 8 KiB chunk of eight pieces [32-column block][hi | lo].
+// The matrix's power of two needs max |W| over the WHOLE matrix first: x6_absmax_kernel (same grid: one workgroup per chunk,
+// one atomic per wave on the matrix's slot -- a maximum does not depend on the order) fills absmax[d]; the pack kernel derives
+// the scale from it, applies it, and leaves it in scales[d] for the GEMMs.
+__device__ __forceinline__ void pack_load8(const PackDesc& e, int n, int k0, float (&v)[8]) {
+    const float* src = reinterpret_cast<const float*>(e.src);
+    if (n >= e.n) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.f;
+    } else if (e.transposed > 1) {
+        const int taps = (int)e.transposed, cout = (int)(e.k / taps);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q, tap = k / cout, co = k - tap * cout;
+            v[q] = src[((size_t)co * taps + tap) * e.ld + n];
+        }
+    } else if (e.transposed) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = src[(size_t)(k0 + q) * e.ld + n];
+    } else {
+        const float4 lo = *reinterpret_cast<const float4*>(src + (size_t)n * e.ld + k0);
+        const float4 hi = *reinterpret_cast<const float4*>(src + (size_t)n * e.ld + k0 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    }
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void x6_pair_kernel(const PackDesc* descs, int count, float* absmax, float* scales) {
+    int d = 0;
+    while (d + 1 < count && (int64_t)blockIdx.x >= descs[d + 1].chunk_begin) ++d;
+    const PackDesc e = descs[d];
+    const int chunk = (int)(blockIdx.x - e.chunk_begin);
+    const int nks = (int)(e.k / PK);
+    const int ct = chunk / nks, ks = chunk % nks;
+    const int col = threadIdx.x & 127, kh = threadIdx.x >> 7;
+    float v[8];
+    pack_load8(e, ct * PN + col, ks * PK + 8 * kh, v);
+    if constexpr (!PACK) {
+        float m = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m = fmaxf(m, fabsf(v[q]));       // (a NaN weight is not seen here: it still makes its products NaN)
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(absmax + d), __float_as_uint(m));    // (non-negative floats order like their bits)
+    } else {
+        const float sc = pair_scale(absmax[d]);
+        if (chunk == 0 && threadIdx.x == 0) scales[d] = sc;
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split2_pk(v[2 * q], v[2 * q + 1], sc, h[q], l[q]);
+        unsigned char* dst = reinterpret_cast<unsigned char*>(e.dst) + (size_t)chunk * (8 * 1024) + ((col >> 5) * 2) * 1024 +
+                             ((col & 31) + 32 * kh) * 16;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+
 }  // namespace
 }  // namespace peclr
 
 using namespace peclr;
+
+extern "C" int64_t peclr_x6_pack_pair_bytes(int N, int K) {
+    if (N <= 0 || K <= 0 || N % 64 || K % PK) return 0;
+    return (int64_t)((N + PN - 1) / PN * PN) * K * 4;
+}
+
+// Pack the matrices of a descriptor table (the table peclr_x6_pack_f32 takes, dst sized by peclr_x6_pack_pair_bytes) as fp16
+// pairs for the NP = 2 GEMMs.  absmax: float [count] scratch; scales: float [count], entry d = the power of two matrix d was
+// multiplied by -- what the GEMM entry points take as peclr_x6_pair.w_scale.
+extern "C" int peclr_x6_pack_pair_f32(const void* desc_table, int count, int total_chunks, float* absmax, float* scales,
+                                      peclr_stream_t stream) {
+    if (!desc_table || !absmax || !scales) return PECLR_ERR_NULL;
+    if (count <= 0 || total_chunks <= 0) return PECLR_ERR_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(absmax, 0, sizeof(float) * (size_t)count, s) != hipSuccess) return launch_status();
+    hipLaunchKernelGGL(x6_pair_kernel<false>, dim3(total_chunks), dim3(256), 0, s, static_cast<const PackDesc*>(desc_table), count, absmax, scales);
+    hipLaunchKernelGGL(x6_pair_kernel<true>, dim3(total_chunks), dim3(256), 0, s, static_cast<const PackDesc*>(desc_table), count, absmax, scales);
+    return launch_status();
+}
 
 extern "C" int64_t peclr_x6_pack_bytes(int N, int K) {
     if (N <= 0 || K <= 0 || N % 64 || K % PK) return 0;      // (N is padded to whole 128-column chunks with zero columns)
@@ -717,6 +835,12 @@ extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K) {
 
 extern "C" int peclr_gemm_x6p_tile_rows(int M, int N, int K);
 
+static int set_pair(X6PArgs& g, const peclr_x6_pair* pair) {
+    g.a_absmax = pair ? pair->a_absmax : nullptr;
+    g.w_scale = pair ? pair->w_scale : nullptr;
+    return pair && (!pair->a_absmax || !pair->w_scale) ? PECLR_ERR_NULL : PECLR_OK;
+}
+
 static void set_bb(X6PArgs& g, const peclr_bn_bwd_fuse* bb) {
     g.bb_x = bb ? bb->x : nullptr; g.bb_mean = bb ? bb->mean : nullptr; g.bb_invstd = bb ? bb->invstd : nullptr;
     g.bb_ss = bb ? bb->scale_shift : nullptr; g.bb_mask = bb ? bb->relu_mask : nullptr; g.bb_relu = bb ? bb->relu : 0;
@@ -742,30 +866,36 @@ static int launch_x6p(const X6PArgs& g, int tile_rows, int taps, hipStream_t str
 #ifndef PECLR_X6P_ILV
 #define PECLR_X6P_ILV true
 #endif
+    const bool pair = g.a_absmax != nullptr;              // fp16-pair arithmetic (NP = 2): Bp holds pair planes
 #define PECLR_LAUNCH(WM_, TAPS_)                                                                                      \
     do {                                                                                                              \
-        if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, PECLR_X6P_ILV, TAPS_, 2>), grid, dim3(256), 0, stream, g); \
+        if (pair) {                                                                                                   \
+            if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, PECLR_X6P_ILV, TAPS_, 2, false, 2>), grid, dim3(256), 0, stream, g); \
+            else hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, PECLR_X6P_ILV, TAPS_, 4, false, 2>), grid, dim3(256), 0, stream, g);       \
+        } else if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, PECLR_X6P_ILV, TAPS_, 2>), grid, dim3(256), 0, stream, g); \
         else hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, PECLR_X6P_ILV, TAPS_, 4>), grid, dim3(256), 0, stream, g);       \
     } while (0)
+#define PECLR_LAUNCH_HALO(WM_, NP_)                                                                                   \
+    do {                                                                                                              \
+        if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, true, 9, 2, true, NP_>), grid, dim3(256), 0, stream, g); \
+        else hipLaunchKernelGGL((gemm_x6p_kernel<WM_, 0, true, true, 9, 4, true, NP_>), grid, dim3(256), 0, stream, g);       \
+    } while (0)
     if (taps == 9 && halo) {
-        if (tile_rows == 256) {
-            if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<2, 0, true, true, 9, 2, true>), grid, dim3(256), 0, stream, g);
-            else hipLaunchKernelGGL((gemm_x6p_kernel<2, 0, true, true, 9, 4, true>), grid, dim3(256), 0, stream, g);
-        } else {
-            if (narrow) hipLaunchKernelGGL((gemm_x6p_kernel<1, 0, true, true, 9, 2, true>), grid, dim3(256), 0, stream, g);
-            else hipLaunchKernelGGL((gemm_x6p_kernel<1, 0, true, true, 9, 4, true>), grid, dim3(256), 0, stream, g);
-        }
+        if (tile_rows == 256) { if (pair) PECLR_LAUNCH_HALO(2, 2); else PECLR_LAUNCH_HALO(2, 3); }
+        else { if (pair) PECLR_LAUNCH_HALO(1, 2); else PECLR_LAUNCH_HALO(1, 3); }
     } else if (taps == 9) {
         if (tile_rows == 256) PECLR_LAUNCH(2, 9); else PECLR_LAUNCH(1, 9);
     } else {
         if (tile_rows == 256) PECLR_LAUNCH(2, 1); else PECLR_LAUNCH(1, 1);
     }
 #undef PECLR_LAUNCH
+#undef PECLR_LAUNCH_HALO
     return launch_status();
 }
 
 extern "C" int peclr_conv3x3_s2_dgrad_x6p_f32(int NB, int Ho, int Wo, int Cout, int Cin, const float* dY, const void* Bp, float* dX,
-                                              int tile_rows, const float* zeros, const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
+                                              int tile_rows, const float* zeros, const peclr_bn_bwd_fuse* bb, const peclr_x6_pair* pair,
+                                              peclr_stream_t stream) {
     if (!dY || !Bp || !dX || !zeros) return PECLR_ERR_NULL;
     if (bb && (!bb->x || !bb->mean || !bb->invstd || !bb->scale_shift || !bb->partial)) return PECLR_ERR_NULL;
     if (NB <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % PK) return PECLR_ERR_SHAPE;
@@ -781,12 +911,13 @@ extern "C" int peclr_conv3x3_s2_dgrad_x6p_f32(int NB, int Ho, int Wo, int Cout, 
     g.stat_shift = nullptr; g.stat_partial = nullptr;
     g.H = Ho; g.W = Wo; g.flip = 1; g.zeros = zeros; g.stride = 1; g.Hin = Ho; g.Win = Wo; g.s2d = 1;
     set_bb(g, bb);
+    if (set_pair(g, pair)) return PECLR_ERR_NULL;
     return launch_x6p(g, tile_rows, 9, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int peclr_conv_s2_x6p_f32(int NB, int H, int W, int Cin, int Cout, int taps, const float* X, const void* Bp, float* Y,
                                      int tile_rows, const float* zeros, const float* stat_shift, float* stat_partial,
-                                     peclr_stream_t stream) {
+                                     const peclr_x6_pair* pair, peclr_stream_t stream) {
     if (!X || !Bp || !Y || !zeros || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
     if (NB <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2 || Cin <= 0 || Cout <= 0 || Cout % 64 || Cin % PK || (taps != 1 && taps != 9))
         return PECLR_ERR_SHAPE;
@@ -801,13 +932,14 @@ extern "C" int peclr_conv_s2_x6p_f32(int NB, int H, int W, int Cin, int Cout, in
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = Ho; g.W = Wo; g.flip = 0; g.zeros = zeros; g.stride = 2; g.Hin = H; g.Win = W; g.s2d = 0;
     set_bb(g, nullptr);
+    if (set_pair(g, pair)) return PECLR_ERR_NULL;
     return launch_x6p(g, tile_rows, taps, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* X, const void* Bp, float* Y,
                                      const float* addend, int flip, int tile_rows, int variant, const float* zeros,
                                      const float* stat_shift, float* stat_partial, const peclr_bn_bwd_fuse* bb,
-                                     peclr_stream_t stream) {
+                                     const peclr_x6_pair* pair, peclr_stream_t stream) {
     if (!X || !Bp || !Y || !zeros || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
     if (variant != 0 && variant != 1) return PECLR_ERR_UNSUPPORTED;
     if (bb && (stat_partial || !bb->x || !bb->mean || !bb->invstd || !bb->scale_shift || !bb->partial || Cout % 32)) return PECLR_ERR_NULL;
@@ -824,13 +956,14 @@ extern "C" int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, co
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = H; g.W = W; g.flip = flip ? 1 : 0; g.zeros = zeros; g.stride = 1; g.Hin = H; g.Win = W; g.s2d = 0;
     set_bb(g, bb);
+    if (set_pair(g, pair)) return PECLR_ERR_NULL;
     return launch_x6p(g, tile_rows, 9, static_cast<hipStream_t>(stream), variant == 1 && W <= 62 && Cin >= 2 * PK);
 }
 
 static int gemm_x6p_host(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc, int add_h, int add_w,
                          const unsigned* add_mask,
                                   const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
-                                  const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
+                                  const peclr_bn_bwd_fuse* bb, const peclr_x6_pair* pair, peclr_stream_t stream) {
     if (!A || !Bp || !C || (stat_partial && !stat_shift)) return PECLR_ERR_NULL;
     if (bb && (stat_partial || !bb->x || !bb->mean || !bb->invstd || !bb->scale_shift || !bb->partial || ldc != N)) return PECLR_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % PK) return PECLR_ERR_SHAPE;
@@ -847,26 +980,27 @@ static int gemm_x6p_host(int M, int N, int K, const float* A, int lda, const voi
     g.stat_shift = stat_shift; g.stat_partial = stat_partial;
     g.H = g.W = 1; g.flip = 0; g.zeros = nullptr; g.stride = 1; g.Hin = g.Win = 1; g.s2d = 0;
     set_bb(g, bb);
+    if (set_pair(g, pair)) return PECLR_ERR_NULL;
     return launch_x6p(g, tile_rows, 1, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int peclr_gemm_x6p_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                                   const float* addend, int ldd, int tile_rows, const float* stat_shift, float* stat_partial,
-                                  const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
-    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, 0, 0, nullptr, addend, ldd, tile_rows, stat_shift, stat_partial, bb, stream);
+                                  const peclr_bn_bwd_fuse* bb, const peclr_x6_pair* pair, peclr_stream_t stream) {
+    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, 0, 0, nullptr, addend, ldd, tile_rows, stat_shift, stat_partial, bb, pair, stream);
 }
 
 extern "C" int peclr_gemm_x6p_s2add_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                                         const float* addend_half, int ldd, int H, int W, int tile_rows,
-                                        const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
+                                        const peclr_bn_bwd_fuse* bb, const peclr_x6_pair* pair, peclr_stream_t stream) {
     if (!addend_half || H <= 0 || W <= 0) return PECLR_ERR_NULL;
-    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, H, W, nullptr, addend_half, ldd, tile_rows, nullptr, nullptr, bb, stream);
+    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, H, W, nullptr, addend_half, ldd, tile_rows, nullptr, nullptr, bb, pair, stream);
 }
 
 extern "C" int peclr_gemm_x6p_maskadd_f32(int M, int N, int K, const float* A, int lda, const void* Bp, float* C, int ldc,
                                           const float* addend, int ldd, const unsigned* addend_mask, int tile_rows,
-                                          const peclr_bn_bwd_fuse* bb, peclr_stream_t stream) {
+                                          const peclr_bn_bwd_fuse* bb, const peclr_x6_pair* pair, peclr_stream_t stream) {
     if (!addend || !addend_mask) return PECLR_ERR_NULL;
     if (N % 32 || ((size_t)addend_mask & 3)) return PECLR_ERR_SHAPE;
-    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, 0, 0, addend_mask, addend, ldd, tile_rows, nullptr, nullptr, bb, stream);
+    return gemm_x6p_host(M, N, K, A, lda, Bp, C, ldc, 0, 0, addend_mask, addend, ldd, tile_rows, nullptr, nullptr, bb, pair, stream);
 }

@@ -85,21 +85,30 @@ def test_a_capture_survives_dead_graphs_in_garbage_cycles_and_garbage_made_insid
     assert t2._graphs_alive == [] and t2._graph is None
 
 
-def test_recapturing_keeps_the_earlier_graphs_until_close():
+def test_recapturing_releases_the_superseded_graphs_at_a_safe_point():
+    """A second capture on the same trainer (another batch shape, a repeated fit) supersedes the first: its graphs -- and the pool
+    memory they pin -- are released BEFORE the new capture starts (outside any capture, device idle), not kept until close();
+    what is referenced at any time is the latest generation only (round 5 kept every generation: unbounded for a caller that
+    re-captures)."""
+    import weakref
+
     from peclr_amd import Trainer
 
     m, b = _model_and_batch(7)
     t = Trainer(max_epochs=10, accumulate_grad_batches=2).attach(m)
     t.zero_grad()
     t.capture_micro_graph(b, warmup_windows=1)
-    first = t._graph
+    first = weakref.ref(t._graph)
     t.replay_micro()
     t.replay_micro()
     t.optimizer.zero_grad(set_to_none=True)
-    t.capture_micro_graph(b, warmup_windows=1)          # a second capture on the same trainer
-    assert t._graph is not first and first in t._graphs_alive and len(t._graphs_alive) == 2
-    t.replay_micro()
-    t.replay_micro()
+    for _ in range(3):
+        t.capture_micro_graph(b, warmup_windows=1)      # further captures on the same trainer
+        assert len(t._graphs_alive) == 1 and t._graphs_alive[0] is t._graph
+        t.replay_micro()
+        t.replay_micro()
+        t.optimizer.zero_grad(set_to_none=True)
+    assert first() is None, "the superseded graph is still referenced"
     torch.cuda.synchronize()
     t.close()
     assert t._graphs_alive == []

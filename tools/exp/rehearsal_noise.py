@@ -1,6 +1,6 @@
 """Calibration of tests/test_dist_gpu_rehearsal.py::test_two_ranks_on_one_gpu_equal_one_rank: runs its measurement N times
 per arm and prints the largest deviations seen (two ranks vs one rank, both arms deterministic), next to the test's bars.
-usage: python tools/exp/rehearsal_noise.py [N=20]"""
+usage: python tools/exp/rehearsal_noise.py [N=20] [frozen|sync|both]"""
 import pathlib
 import sys
 import tempfile
@@ -9,7 +9,8 @@ sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 from tests import test_dist_gpu_rehearsal as T  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-for sync_bn in (False, True):
+arms = {"frozen": (False,), "sync": (True,), "both": (False, True)}[sys.argv[2] if len(sys.argv) > 2 else "both"]
+for sync_bn in arms:
     top, fails = {}, 0
     for i in range(n):
         with tempfile.TemporaryDirectory() as d:

@@ -1,4 +1,7 @@
-// Ablation harness for gemm_x6p_kernel (not part of the library): times the kernel with parts of its loop switched off.
+// Ablation harness for gemm_x6p_kernel (not part of the library): times the kernel with parts of its loop switched off, at the
+// shapes of the C2 step (ResNet-50, 2 x 128 views @224).  Round 6 question: what would activations that arrive ALREADY split
+// (three bf16 planes written by their producer) buy?  Upper bound = the variant without split and plane stores (the planes would
+// still have to be fetched: 6 instead of 4 bytes per element).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm -I peclr_amd/csrc tools/exp/x6p_ablate.hip -o tools/exp/x6p_ablate
 #include "gemm_x6p.hip"
 
@@ -16,43 +19,85 @@ __global__ void fill(float* p, size_t n, unsigned seed, float scale) {
     }
 }
 
-template <int WM, int ABL, bool AREG = true, bool ILV = true>
+template <int WM, int ABL, int NTL = 4>
 static void launch(const X6PArgs& g, hipStream_t st) {
     const int tm = 128 * WM, nrb = (g.M + tm - 1) / tm;
-    hipLaunchKernelGGL((gemm_x6p_kernel<WM, ABL, AREG, ILV>), dim3(8 * ((nrb + 7) / 8) * (g.N / PN)), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_x6p_kernel<WM, ABL, true, true, 1, NTL>), dim3(8 * ((nrb + 7) / 8) * (g.N / (32 * NTL))), dim3(256), 0, st, g);
+}
+template <int WM, int ABL, int NTL = 4>
+static void launch3(const X6PArgs& g, hipStream_t st) {
+    const int tm = 128 * WM, nrb = (g.M + tm - 1) / tm;
+    hipLaunchKernelGGL((gemm_x6p_kernel<WM, ABL, true, true, 9, NTL, true>), dim3(8 * ((nrb + 7) / 8) * (g.N / (32 * NTL))), dim3(256), 0, st, g);
+}
+
+struct V { const char* name; void (*fn)(const X6PArgs&, hipStream_t); };
+
+static int run(const char* what, const X6PArgs& g, const V* vs, int nv, double flops, unsigned char* junk) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    printf("%s  (six products at 2.5 PFLOP/s: %.1f us)\n", what, flops * 6 / 2.5e15 * 1e6);
+    float base = 0.f;
+    for (int i = 0; i < nv; ++i) {
+        std::vector<float> ts;
+        for (int r = 0; r < 9; ++r) {
+            CK(hipMemsetAsync(junk, r, 512u << 20, 0));
+            CK(hipEventRecord(e0, 0)); vs[i].fn(g, 0); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms * 1e3f);
+        }
+        CK(hipGetLastError());
+        std::sort(ts.begin() + 1, ts.end());
+        if (i == 0 || !base) base = ts[5];
+        if (vs[i].name[0] == 'f') base = ts[5];              // "full ..." rows are the reference of the rows below them
+        printf("   %-44s %8.1f us (min %8.1f)  %6.1f TF  %+5.1f %%\n", vs[i].name, ts[5], ts[1], flops / ts[5] / 1e6, 100.0 * (ts[5] - base) / base);
+    }
+    return 0;
 }
 
 int main() {
-    const int shapes[][3] = {{16384, 2048, 512}, {16384, 2048, 4096}};
-    float *A, *C, *W; unsigned char *Bp, *junk;
-    CK(hipMalloc(&A, (size_t)200704 * 2048 * 4)); CK(hipMalloc(&C, (size_t)200704 * 2048 * 4));
-    CK(hipMalloc(&W, (size_t)2048 * 4096 * 4)); CK(hipMalloc(&Bp, (size_t)2048 * 4096 * 6)); CK(hipMalloc(&junk, 512u << 20));
-    fill<<<4096, 256>>>(A, (size_t)200704 * 2048, 1, 1.f);
-    fill<<<4096, 256>>>(W, (size_t)2048 * 4096, 2, 0.05f);
-    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    // 1x1 forward shapes of ResNet-50 at 2 x 128 views @224: (rows, Cout, Cin)
+    const int shapes[][3] = {{802816, 256, 64}, {200704, 512, 128}, {200704, 128, 512}, {50176, 1024, 256}, {50176, 256, 1024},
+                             {12544, 2048, 512}, {12544, 512, 2048}, {16384, 2048, 512}};
+    // 3x3 / stride-1 shapes: (images, H = W, C)
+    const int shapes3[][3] = {{256, 56, 64}, {256, 28, 128}, {256, 14, 256}, {256, 7, 512}};
+    float *A, *C, *W, *zeros; unsigned char *Bp, *junk;
+    CK(hipMalloc(&A, (size_t)802816 * 512 * 4)); CK(hipMalloc(&C, (size_t)802816 * 512 * 4));
+    CK(hipMalloc(&W, (size_t)2048 * 4608 * 4)); CK(hipMalloc(&Bp, (size_t)2048 * 4608 * 6)); CK(hipMalloc(&junk, 512u << 20));
+    CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256));
+    fill<<<4096, 256>>>(A, (size_t)802816 * 512, 1, 1.f);
+    fill<<<4096, 256>>>(W, (size_t)2048 * 4608, 2, 0.05f);
     for (auto& sh : shapes) {
         const int M = sh[0], N = sh[1], K = sh[2];
         PackDesc d{(int64_t)W, (int64_t)Bp, N, K, K, 0, 0, 0}, *dd;
         CK(hipMalloc(&dd, sizeof(d))); CK(hipMemcpy(dd, &d, sizeof(d), hipMemcpyHostToDevice));
         x6_pack_kernel<<<(N / 128) * (K / 16), 256>>>(dd, 1);
         X6PArgs g{};
-        g.A = A; g.Bp = Bp; g.out = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldo = N; g.stride = 1;
+        g.A = A; g.Bp = Bp; g.out = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldo = N; g.stride = 1; g.H = g.W = g.Hin = g.Win = 1;
         g.stream_out = (size_t)M * N * 4 > ((size_t)64 << 20);
-        struct V { const char* name; void (*fn)(const X6PArgs&, hipStream_t); };
-        const V vs[] = {{"full/256", launch<2, 0>}, {"full/128", launch<1, 0>},
-                        {"mfma only/256", launch<2, 7>}, {"mfma only/128", launch<1, 7>},
-                        {"mfma only, no barrier/256", launch<2, 23>}, {"mfma only, no barrier/128", launch<1, 23>},
-                        {"mfma only, no barrier, one B buffer/256", launch<2, 55>}, {"mfma only, no barrier, one B buffer/128", launch<1, 55>}};
-        printf("M=%d N=%d K=%d  (ideal MFMA time %.1f us)\n", M, N, K, 2.0 * M * N * K * 6 / 2.5e15 * 1e6);
-        for (auto& v : vs) {
-            std::vector<float> ts;
-            for (int r = 0; r < 9; ++r) {
-                CK(hipMemsetAsync(junk, r, 512u << 20, 0));
-                CK(hipEventRecord(e0, 0)); v.fn(g, 0); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
-                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms * 1e3f);
-            }
-            std::sort(ts.begin() + 1, ts.end());
-            printf("   %-20s %7.1f us (min %7.1f)  %6.1f TF\n", v.name, ts[5], ts[1], 2.0 * M * N * K / ts[5] / 1e6);
+        const V vs[] = {{"full / 256-row tiles", launch<2, 0>}, {"  no split, no plane stores", launch<2, 1>}, {"  ... and no activation loads", launch<2, 3>},
+                        {"  MFMAs + fragment reads + barrier", launch<2, 7>}, {"  THREE products of the six (rest as full)", launch<2, 64>},
+                        {"full / 128-row tiles", launch<1, 0>}, {"  no split, no plane stores", launch<1, 1>}, {"  ... and no activation loads", launch<1, 3>},
+                        {"  MFMAs + fragment reads + barrier", launch<1, 7>}, {"  THREE products of the six (rest as full)", launch<1, 64>}};
+        char what[128];
+        snprintf(what, sizeof what, "1x1: rows %d, Cin %d -> Cout %d", M, K, N);
+        if (run(what, g, vs, 10, 2.0 * M * N * K, junk)) return 1;
+        CK(hipFree(dd));
+    }
+    for (auto& sh : shapes3) {
+        const int NB = sh[0], H = sh[1], Cc = sh[2], M = NB * H * H, N = Cc, K = 9 * Cc;
+        PackDesc d{(int64_t)W, (int64_t)Bp, N, K, K, 0, 0, 0}, *dd;       // (any filter: timing only)
+        CK(hipMalloc(&dd, sizeof(d))); CK(hipMemcpy(dd, &d, sizeof(d), hipMemcpyHostToDevice));
+        x6_pack_kernel<<<((N + 127) / 128) * (K / 16), 256>>>(dd, 1);
+        X6PArgs g{};
+        g.A = A; g.Bp = Bp; g.out = C; g.M = M; g.N = N; g.K = K; g.lda = Cc; g.ldo = N; g.stride = 1; g.H = g.Hin = H; g.W = g.Win = H;
+        g.zeros = zeros;
+        g.stream_out = (size_t)M * N * 4 > ((size_t)64 << 20);
+        char what[128];
+        snprintf(what, sizeof what, "3x3 halo: %d images %d x %d, %d channels", NB, H, H, Cc);
+        if (Cc == 64) {
+            const V vs[] = {{"full / 256-row tiles", launch3<2, 0, 2>}, {"  no split, no plane stores", launch3<2, 1, 2>}, {"  ... and no patch loads", launch3<2, 3, 2>}, {"  THREE products of the six (rest as full)", launch3<2, 64, 2>}};
+            if (run(what, g, vs, 4, 2.0 * M * N * K, junk)) return 1;
+        } else {
+            const V vs[] = {{"full / 256-row tiles", launch3<2, 0>}, {"  no split, no plane stores", launch3<2, 1>}, {"  ... and no patch loads", launch3<2, 3>}, {"  THREE products of the six (rest as full)", launch3<2, 64>}};
+            if (run(what, g, vs, 4, 2.0 * M * N * K, junk)) return 1;
         }
         CK(hipFree(dd));
     }
