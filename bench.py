@@ -194,8 +194,9 @@ def kernel_table(event_log, m_rows, m_global, din, hid, n_params):
         if ran:
             entry["kernel"] = ran[0] if len(ran) == 1 else ran
         x6 = any(k.startswith("gemm_x6") for k in ran) if ran else name in X6_TAGS
+        pair = bool(ran) and all("<pair>" in k for k in ran)       # fp32 operands as two fp16 numbers, three products
         h16 = bool(ran) and all(k.startswith(("conv_h", "wgrad_h", "wgrad3_h")) for k in ran)     # 16-bit operands: the dense bf16 / fp16 MFMA peak
-        peak_tf = MFMA_BF16_PEAK_TF if h16 else MFMA_BF16_PEAK_TF / 6.0 if x6 else MFMA_F32_PEAK_TF
+        peak_tf = MFMA_BF16_PEAK_TF if h16 else MFMA_BF16_PEAK_TF / 3.0 if pair else MFMA_BF16_PEAK_TF / 6.0 if x6 else MFMA_F32_PEAK_TF
         if bound is None:
             bound = entry["bound"] = "mfma" if flops / (peak_tf * 1e12) > nbytes / (HBM_PEAK_GBS * 1e9) else "hbm"
         if bound == "hbm":
@@ -204,7 +205,9 @@ def kernel_table(event_log, m_rows, m_global, din, hid, n_params):
         else:
             ach = flops / (avg_us * 1e-6) / 1e12
             entry.update(achieved=round(ach, 3), peak=round(peak_tf, 1), unit="TFLOP/s", frac=round(ach / peak_tf, 5))
-            if x6:
+            if pair:
+                entry["peak_note"] = "fp32 GEMM as three fp16 MFMA products of the scaled, two-way split operands: dense fp16 peak / 3"
+            elif x6:
                 entry["peak_note"] = "fp32 GEMM as six bf16 MFMA products: dense bf16 peak / 6"
 
         out[name] = entry
@@ -214,6 +217,9 @@ def kernel_table(event_log, m_rows, m_global, din, hid, n_params):
 # launches of peclr_gemm_x6_f32 / _tn_f32 (fp32 operands split into three bf16 numbers, six products on the bf16 MFMA):
 # their MFMA roof is the dense bf16 peak / 6 fp32-equivalent flop/s, not the v_mfma_f32 peak
 X6_TAGS = {"conv1x1_fwd", "conv1x1_dgrad", "conv1x1_dgrad_add_x6", "conv1x1_wgrad", "gemm_x6", "gemm_x6p", "gemm_x6_tn", "conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "gemm_x6t"}
+
+
+X6_PRODUCTS = 3.0 if os.environ.get("PECLR_X6_PAIR", "1") != "0" else 6.0      # MFMA products per fp32 multiply-add of the step's GEMMs
 
 
 def mfma_peak(name):
@@ -653,7 +659,15 @@ def fp32_gemm_check(device):
     w = (torch.randn(256, 256, 3, 3, device=device, generator=g) * 0.03).contiguous(memory_format=torch.channels_last)
     p3 = _capi.X6Planes([(w.permute(0, 2, 3, 1).reshape(256, 9 * 256), False)]).pack().planes[0]
     y3 = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
-    return {"shape": [m, n, k], "x6p_max_err_over_scale": err(_capi.gemm_x6p(a, planes, n)),
+    # the "pair" arithmetic the step runs by default (PECLR_X6_PAIR=1): per-tensor power of two, two fp16 planes, three products
+    am = lambda t: t.abs().max().reshape(1).float()             # noqa: E731
+    pp = _capi.X6Planes([(bt, False)], pair=True).pack()
+    pp3 = _capi.X6Planes([(w.permute(0, 2, 3, 1).reshape(256, 9 * 256), False)], pair=True).pack()
+    btc = bt.t().contiguous()
+    pair = {"pair_x6p_max_err_over_scale": err(_capi.gemm_x6p(a, pp.planes[0], n, pair=(am(a), pp.scale(0)))),
+            "pair_x6t_max_err_over_scale": err(_capi.gemm_x6t(at, btc, absmax=(am(at), am(btc)))),
+            "pair_conv3x3_max_err_over_scale": float((_capi.conv3x3_x6p(x, pp3.planes[0], 256, pair=(am(x), pp3.scale(0))).double() - y3).abs().max()) / float(y3.abs().max())}
+    return {"shape": [m, n, k], **pair, "x6p_max_err_over_scale": err(_capi.gemm_x6p(a, planes, n)),
             "x6t_max_err_over_scale": err(_capi.gemm_x6t(at, bt.t().contiguous())),
             "conv3x3_x6p_max_err_over_scale": float((_capi.conv3x3_x6p(x, p3, 256).double() - y3).abs().max()) / float(y3.abs().max()),
             "conv3x3_miopen_max_err_over_scale": float((torch.nn.functional.conv2d(x, w, padding=1).double() - y3).abs().max()) / float(y3.abs().max()),
@@ -936,7 +950,11 @@ def main():
                                   "in-tree (conv_h / wgrad_h: LDS-DMA operands, fp32 accumulate, fused BatchNorm epilogues, weights packed "
                                   "from the fp32 masters); MIOpen: 7x7 stem, 3x3 / stride-2 weight gradients"
                                   if (fused_bn and os.environ.get("PECLR_CONV16", "1") != "0") else "MIOpen"),
-                       "fp32_gemm": (("exact 3-way bf16 split, 6 MFMA products, fp32 accumulate (fp32 accuracy)"
+                       "fp32_gemm": ((("pair arithmetic: both operands x a per-tensor power of two, split into 2 fp16 numbers, 3 MFMA products, "
+                                       "fp32 accumulate (error vs float64 <= the six-product kernels': fp32_gemm_check); six bf16 products "
+                                       "where an operand carries no maximum (stem)"
+                                       if os.environ.get("PECLR_X6_PAIR", "1") != "0" else
+                                       "exact 3-way bf16 split, 6 MFMA products, fp32 accumulate (fp32 accuracy)")
                                       if os.environ.get("PECLR_GEMM_X6", "1") != "0" else "v_mfma_f32 / MIOpen fp32")
                                      if args.dtype == "fp32" else None),
                        # fp16: dynamic loss scaling skips a step whose scaled gradients overflow (the launches still
@@ -950,14 +968,15 @@ def main():
             "fp32_gemm_check": x6_check,
             "roofline": roof,
             "kernels": kernels,
-            # fp32: the step's GEMM work runs on the six-product kernels, whose own roof is the dense bf16 peak / 6 = 417
-            # TFLOP/s fp32-equivalent; `frac` is priced against THAT roof (the kernels that run), frac_vs_v_mfma_f32
-            # against the 157.3 TFLOP/s of the v_mfma_f32 instructions they no longer use
+            # fp32: the step's GEMM work runs in pair arithmetic (three fp16 products: own roof = the dense fp16 peak / 3 = 833
+            # TFLOP/s fp32-equivalent) or, with PECLR_X6_PAIR=0, on the six-product kernels (dense bf16 peak / 6 = 417); `frac` is
+            # priced against the roof of the kernels that run, frac_vs_v_mfma_f32 against the 157.3 TFLOP/s of the v_mfma_f32
+            # instructions they no longer use
             "backbone": {"note": "whole encoder, 3x forward conv FLOPs over the step time; fp32: every 1x1 and 3x3 convolution of the "
-                                 "residual blocks (stride 1 and 2; forward, input gradient, weight gradient) runs on the in-tree "
-                                 "six-product kernels (config.fp32_gemm), only the 7x7 stem on PyTorch-ROCm/MIOpen; 16-bit: see config.conv16",
+                                 "residual blocks (stride 1 and 2; forward, input gradient, weight gradient) and the 7x7 stem run on the "
+                                 "in-tree split-operand kernels (config.fp32_gemm); 16-bit: see config.conv16",
                          "flops_per_step_per_gpu": step_flops, "achieved": round(ach_tf, 2), "unit": "TFLOP/s",
-                         **({"peak": round(MFMA_BF16_PEAK_TF / 6.0, 1), "frac": round(ach_tf / (MFMA_BF16_PEAK_TF / 6.0), 4),
+                         **({"peak": round(MFMA_BF16_PEAK_TF / X6_PRODUCTS, 1), "frac": round(ach_tf / (MFMA_BF16_PEAK_TF / X6_PRODUCTS), 4),
                              "frac_vs_x6_roof": round(ach_tf / (MFMA_BF16_PEAK_TF / 6.0), 4),
                              "frac_vs_v_mfma_f32": round(ach_tf / MFMA_F32_PEAK_TF, 4)}
                             if (args.dtype == "fp32" and os.environ.get("PECLR_GEMM_X6", "1") != "0") else

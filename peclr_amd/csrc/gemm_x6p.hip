@@ -795,17 +795,27 @@ extern "C" int64_t peclr_x6_pack_pair_bytes(int N, int K) {
     return (int64_t)((N + PN - 1) / PN * PN) * K * 4;
 }
 
-// Pack the matrices of a descriptor table (the table peclr_x6_pack_f32 takes, dst sized by peclr_x6_pack_pair_bytes) as fp16
-// pairs for the NP = 2 GEMMs.  absmax: float [count] scratch; scales: float [count], entry d = the power of two matrix d was
-// multiplied by -- what the GEMM entry points take as peclr_x6_pair.w_scale.
-extern "C" int peclr_x6_pack_pair_f32(const void* desc_table, int count, int total_chunks, float* absmax, float* scales,
-                                      peclr_stream_t stream) {
-    if (!desc_table || !absmax || !scales) return PECLR_ERR_NULL;
+// max |W| of every matrix of a descriptor table (the table peclr_x6_pack_f32 takes) -> absmax[count] (zeroed here, then one
+// launch over the pack's grid).  First half of the pair-format pack.
+extern "C" int peclr_x6_absmax_f32(const void* desc_table, int count, int total_chunks, float* absmax, peclr_stream_t stream) {
+    if (!desc_table || !absmax) return PECLR_ERR_NULL;
     if (count <= 0 || total_chunks <= 0) return PECLR_ERR_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(absmax, 0, sizeof(float) * (size_t)count, s) != hipSuccess) return launch_status();
-    hipLaunchKernelGGL(x6_pair_kernel<false>, dim3(total_chunks), dim3(256), 0, s, static_cast<const PackDesc*>(desc_table), count, absmax, scales);
-    hipLaunchKernelGGL(x6_pair_kernel<true>, dim3(total_chunks), dim3(256), 0, s, static_cast<const PackDesc*>(desc_table), count, absmax, scales);
+    hipLaunchKernelGGL(x6_pair_kernel<false>, dim3(total_chunks), dim3(256), 0, s, static_cast<const PackDesc*>(desc_table), count, absmax,
+                       static_cast<float*>(nullptr));
+    return launch_status();
+}
+
+// Pack the matrices of the table (dst sized by peclr_x6_pack_pair_bytes) as fp16 pairs for the NP = 2 GEMMs, each multiplied by the
+// power of two its maximum (absmax[d], from peclr_x6_absmax_f32) gives; scales: float [count], entry d = that power of two -- what
+// the GEMM entry points take as peclr_x6_pair.w_scale.
+extern "C" int peclr_x6_pack_pair_f32(const void* desc_table, int count, int total_chunks, const float* absmax, float* scales,
+                                      peclr_stream_t stream) {
+    if (!desc_table || !absmax || !scales) return PECLR_ERR_NULL;
+    if (count <= 0 || total_chunks <= 0) return PECLR_ERR_SHAPE;
+    hipLaunchKernelGGL(x6_pair_kernel<true>, dim3(total_chunks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const PackDesc*>(desc_table), count, const_cast<float*>(absmax), scales);
     return launch_status();
 }
 

@@ -4,6 +4,7 @@ Every test needs a real MI355X (`-m gpu`).  Tolerance: BASELINE.json:north_star 
 on the loss and the per-pair similarities; the kernels are held to tighter bounds where fp32
 round-off allows (stated per assertion).
 """
+import contextlib
 import os
 
 import numpy as np
@@ -1584,12 +1585,18 @@ def test_precision_16_trains_on_the_fused_glue_with_a_grad_scaler():
     batch = {k: v.to(DEV) for k, v in batch.items()}
     for k in ("transformed_image1", "transformed_image2"):
         batch[k] = batch[k].contiguous(memory_format=torch.channels_last)
+    from peclr_amd import bn2d as B
+
     curves = {}
     for precision in ("fp32", 16):
         model = copy.deepcopy(base)
         tr = Trainer(max_epochs=10, precision=precision).attach(model)
         tr.zero_grad()
-        curves[precision] = [float(tr.training_micro_step(batch, i)["loss"]) for i in range(12)]
+        # (the fp32 reference curve is taken on the six-product kernels, the arithmetic the bars below were calibrated on: twelve
+        # LARS steps at this learning rate are a chaotic trajectory -- the pair kernels' different last bits move its minimum by 0.2
+        # from step 4 on; tests/test_pair_gpu.py holds the two fp32 arithmetics against each other over the steps before that)
+        with B.routing(x6_pair=False) if precision == "fp32" else contextlib.nullcontext():
+            curves[precision] = [float(tr.training_micro_step(batch, i)["loss"]) for i in range(12)]
         if precision == 16:
             assert tr.precision == "fp16" and tr._scaler is not None and 0 < tr._scaler.get_scale() <= 65536.0
             assert tr.global_step == 12

@@ -110,7 +110,7 @@ def _in_tree_activations(net, x):
     for m in net.modules():
         if isinstance(m, B.FusedBatchNormAct2d):
             hooks.append(m.register_forward_hook(lambda mod, args, out: outs.__setitem__(names[mod], out.detach())))
-    with torch.no_grad(), B.routing(force=True, bn_apply_in_gemm=False):     # (every layer's output has to exist to be looked at)
+    with torch.no_grad(), B.routing(force=True):
         net(x)
     for h in hooks:
         h.remove()

@@ -69,6 +69,35 @@ if "--real-only" not in sys.argv:
         print(f"  {nb} x {hw:2d} x {hw:2d} x {c:3d}: {t6:7.1f} / {t2:7.1f} ({t2 / t6 - 1:+.0%}; 128-row tiles {t2b:7.1f})   err {e6:.2e} / {e2:.2e} / {em:.2e}", flush=True)
         del x, w
 
+if "--real-only" not in sys.argv:
+    print("== weight gradients (rows, Cout, Cin): us six-product / pair, component-wise err (six / pair)")
+    for k, m, n in ((802816, 64, 256), (802816, 256, 64), (200704, 512, 128), (200704, 128, 512), (50176, 1024, 256), (50176, 256, 1024),
+                    (12544, 2048, 512), (12544, 512, 2048)):
+        a = torch.randn(k, m, device=DEV) * 1e-4
+        b = torch.randn(k, n, device=DEV).clamp_min(0)
+        ab = (am(a), am(b))
+        t6, t2 = timed(lambda: capi.gemm_x6t(a, b)), timed(lambda: capi.gemm_x6t(a, b, absmax=ab))
+        sl = slice(0, min(k, 32768))
+        a_, b_ = a[sl].contiguous(), b[sl].contiguous()
+        ref = a_.double().t() @ b_.double()
+        bound = a_.double().abs().t() @ b_.double().abs()
+        e6 = float(((capi.gemm_x6t(a_, b_).double() - ref).abs() / bound).max())
+        e2 = float(((capi.gemm_x6t(a_, b_, absmax=(am(a_), am(b_))).double() - ref).abs() / bound).max())
+        print(f"  1x1 {k:7d} {m:5d} x {n:5d}: {t6:7.1f} / {t2:7.1f} ({t2 / t6 - 1:+.0%})   err {e6:.2e} / {e2:.2e}", flush=True)
+        del a, b
+    for nb, hw, c in ((256, 56, 64), (256, 28, 128), (256, 14, 256), (256, 7, 512)):
+        x = torch.randn(nb, c, hw, hw, device=DEV).clamp_min(0).contiguous(memory_format=torch.channels_last)
+        gy = (torch.randn(nb, c, hw, hw, device=DEV) * 1e-4).contiguous(memory_format=torch.channels_last)
+        ab = (am(gy), am(x))
+        if capi.wgrad3_x6r_ok(gy, x):
+            t6, t2 = timed(lambda: capi.wgrad3_x6r(gy, x)), timed(lambda: capi.wgrad3_x6r(gy, x, absmax=ab))
+            print(f"  3x3 ring {nb} x {hw} x {hw} x {c}: {t6:7.1f} / {t2:7.1f} ({t2 / t6 - 1:+.0%})", flush=True)
+        r = nb * hw * hw
+        gy2, x2 = gy.permute(0, 2, 3, 1).reshape(r, c), x.permute(0, 2, 3, 1).reshape(r, c)
+        t6, t2 = timed(lambda: capi.gemm_x6t(gy2, x2, taps=9, hw=(hw, hw))), timed(lambda: capi.gemm_x6t(gy2, x2, taps=9, hw=(hw, hw), absmax=ab))
+        print(f"  3x3 nine-tap {nb} x {hw} x {hw} x {c}: {t6:7.1f} / {t2:7.1f} ({t2 / t6 - 1:+.0%})", flush=True)
+        del x, gy
+
 # ---- real layer tensors
 print("== real layer tensors (ResNet-50 training step, 2 x 16 views @224): err/scale vs float64, six-product / pair / v_mfma_f32 (1x1) or MIOpen (3x3)")
 from peclr_amd.resnet import resnet50  # noqa: E402
@@ -107,6 +136,15 @@ for name, (X, W, dY) in taps.items():
             print(f"  {name:22s} {what:6s} [{a.shape[0]} x {a.shape[1]}] . [{n}]: {e6:.2e} / {e2:.2e} / {ef:.2e}   {rng}", flush=True)
             w_ = worst.setdefault(what, [0.0, 0.0, 0.0])
             worst[what] = [max(w_[0], e6), max(w_[1], e2), max(w_[2], ef)]
+        if cout % 4 == 0 and cin % 4 == 0 and cout >= 64 and cin >= 64:
+            ref = dY2.double().t() @ X2.double()
+            e6 = err(capi.gemm_x6t(dY2, X2), ref)
+            e2 = err(capi.gemm_x6t(dY2, X2, absmax=(am(dY2), am(X2))), ref)
+            ef = err(torch.ops.aten.convolution_backward(dY.contiguous(memory_format=torch.channels_last), X.contiguous(memory_format=torch.channels_last),
+                                                        W, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1].reshape(cout, cin), ref)
+            print(f"  {name:22s} wgrad  [{dY2.shape[0]} x {cout}]^T . [{cin}]: {e6:.2e} / {e2:.2e} / {ef:.2e} (MIOpen)", flush=True)
+            w_ = worst.setdefault("wgrad", [0.0, 0.0, 0.0])
+            worst["wgrad"] = [max(w_[0], e6), max(w_[1], e2), max(w_[2], ef)]
     else:
         Xc, dYc = X.contiguous(memory_format=torch.channels_last), dY.contiguous(memory_format=torch.channels_last)
         Wc = W.contiguous(memory_format=torch.channels_last)
