@@ -133,7 +133,8 @@ class Routing:
     conv3x3_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV3X3_X6"))        # 3x3 stride-1 convolutions as implicit GEMMs
     conv3x3_wgrad_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV3X3_WGRAD_X6"))   # their weight gradients (nine taps, one launch)
     conv3x3_tile_rows: int = dataclasses.field(default_factory=lambda: int(os.environ.get("PECLR_CONV3X3_TILE_ROWS", "256")))
-    conv3x3_pair_tile_rows: int = dataclasses.field(default_factory=lambda: int(os.environ.get("PECLR_CONV3X3_PAIR_TILE_ROWS", "256")))
+    # (pair arithmetic: the rounds-of-slots policy, 0 -- same-box A/B at C2: 47.53 ms per step against 47.73 / 47.94 with 128 / 256 rows)
+    conv3x3_pair_tile_rows: int = dataclasses.field(default_factory=lambda: int(os.environ.get("PECLR_CONV3X3_PAIR_TILE_ROWS", "0")))
     conv_s2_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV_S2_X6"))        # forward of the stride-2 convolutions
     conv_s2_wgrad_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV_S2_WGRAD_X6"))
     conv_s2_dgrad_x6: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_CONV_S2_DGRAD_X6"))   # 3x3 / stride-2 input gradient by parity classes
@@ -618,10 +619,19 @@ def _x6_wgrad_pays(rows: int, cout: int, cin: int) -> bool:
     return ROUTING.gemm_x6 and cout >= wide and cin >= wide and cout % 4 == 0 and cin % 4 == 0 and (rows >= 8192 or ROUTING.force)
 
 
-def _absmax_both(gy: Tensor, x_amax):
-    """(max |gy|, max |x|) when both operands of a weight gradient carry their maxima (pair arithmetic), else None."""
+def _absmax_both(gy: Tensor, x_amax, cout: int = 0, cin: int = 0):
+    """(max |gy|, max |x|) when both operands of a weight gradient carry their maxima (pair arithmetic), else None.
+    cout, cin > 0 (1x1 weight gradients): only where the product is bound by the matrix cores -- cout cin / (cout + cin) > 104, the
+    crossover of 8 bytes per row and channel at 8 TB/s against 2 flops per row and channel pair at the six-product roof.  The
+    HBM-bound shapes (layer1 / layer2: 64 x 256 ... 128 x 512, 8e5 / 2e5 rows) run 15 - 31 % SLOWER in pair arithmetic
+    (tools/exp/pair_probe.py: 259 -> 298, 191 -> 251 us; the k-steps of those launches are one memory round trip each, and the
+    shorter product phase overlaps less of it), the MFMA-bound ones 21 - 28 % faster."""
     ga = _absmax_of(gy)
-    return (ga, x_amax) if (ga is not None and x_amax is not None and ROUTING.x6_pair) else None
+    if ga is None or x_amax is None or not ROUTING.x6_pair:
+        return None
+    if cout and cin and not ROUTING.force and cout * cin <= 104 * (cout + cin):
+        return None
+    return (ga, x_amax)
 
 
 def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, x_amax=None):
@@ -632,7 +642,7 @@ def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, x_amax=None
 
     def run():
         gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
-        dw = (_capi.gemm_x6t(gy2, x2, tag="conv1x1_wgrad", absmax=_absmax_both(gy, x_amax)) if ROUTING.gemm_x6t
+        dw = (_capi.gemm_x6t(gy2, x2, tag="conv1x1_wgrad", absmax=_absmax_both(gy, x_amax, cout, cin)) if ROUTING.gemm_x6t
               else _capi.gemm_x6_tn(gy2, x2, tag="conv1x1_wgrad"))
         ref = param if param is not None else weight
         return dw.as_strided(ref.shape, ref.stride())       # same memory, the parameter's (channels_last) strides
@@ -677,7 +687,7 @@ def _wgrad_3x3_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, stride: int
             return _capi.wgrad3_x6r(gy, x, absmax=_absmax_both(gy, x_amax)).view(cout, 3, 3, cin).permute(0, 3, 1, 2)
         gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
         dw = _capi.gemm_x6t(gy2, x2, taps=taps, hw=(ho, wo), stride=stride, tag="conv3x3_wgrad" if taps == 9 else "conv1x1_wgrad",
-                            absmax=_absmax_both(gy, x_amax))
+                            absmax=_absmax_both(gy, x_amax, *((cout, cin) if taps == 1 else (0, 0))))
         if taps == 9:
             return dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2)      # = a channels_last [Cout, Cin, 3, 3] tensor
         ref = param if param is not None else weight

@@ -760,6 +760,10 @@ __global__ __launch_bounds__(256) void x6_pair_kernel(const PackDesc* descs, int
     int d = 0;
     while (d + 1 < count && (int64_t)blockIdx.x >= descs[d + 1].chunk_begin) ++d;
     const PackDesc e = descs[d];
+    // a matrix and its transpose (forward and input-gradient planes of one weight: neighbours in the table, same source) share
+    // their maximum: found once, through the first of the two entries
+    const int dm = (d > 0 && e.transposed && descs[d - 1].src == e.src && !descs[d - 1].transposed) ? d - 1 : d;
+    if (!PACK && dm != d) return;
     const int chunk = (int)(blockIdx.x - e.chunk_begin);
     const int nks = (int)(e.k / PK);
     const int ct = chunk / nks, ks = chunk % nks;
@@ -771,9 +775,13 @@ __global__ __launch_bounds__(256) void x6_pair_kernel(const PackDesc* descs, int
 #pragma unroll
         for (int q = 0; q < 8; ++q) m = fmaxf(m, fabsf(v[q]));       // (a NaN weight is not seen here: it still makes its products NaN)
         m = wave_max(m);
-        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(absmax + d), __float_as_uint(m));    // (non-negative floats order like their bits)
+        if ((threadIdx.x & 63) == 0) {                        // (non-negative floats order like their bits; look before the atomic:
+            unsigned* p = reinterpret_cast<unsigned*>(absmax + d);   //  ~1e5 waves share a few dozen addresses)
+            const unsigned mine = __float_as_uint(m);
+            if (mine > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, mine);
+        }
     } else {
-        const float sc = pair_scale(absmax[d]);
+        const float sc = pair_scale(absmax[dm]);
         if (chunk == 0 && threadIdx.x == 0) scales[d] = sc;
         unsigned h[4], l[4];
 #pragma unroll
