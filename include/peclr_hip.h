@@ -206,12 +206,8 @@ int peclr_conv3x3_x6p_f32(int NB, int H, int W, int Cin, int Cout, const float* 
  * W >= 6 when taps = 9 or stride = 2.  Replaces MIOpen's fp32 weight gradients of the Bottleneck's convolutions
  * (resnet_model.py:15).                                                                                                  */
 int peclr_gemm_x6t_slabs(int M, int N, int K, int taps);
-/* a_absmax, b_absmax (both NULL, or both set): "pair" arithmetic as in peclr_x6_pair -- here BOTH operands are activations, each
- * scaled by the power of two its own maximum gives (device floats: max |A|, max |B| over the whole tensors) and split into two
- * fp16 numbers in the kernel; three products instead of six.                                                                */
 int peclr_gemm_x6t_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs, int n_slabs,
-                       int taps, int H, int W, int stride, const float* zeros, const float* a_absmax, const float* b_absmax,
-                       peclr_stream_t stream);
+                       int taps, int H, int W, int stride, const float* zeros, peclr_stream_t stream);
 /* Input gradient of the 3x3 / padding-1 / STRIDE-2 convolution of a layer's first block (resnet_model.py:15), on the same
  * kernel: dY [NB, Ho, Wo, Cout] NHWC -> dX [NB, 2 Ho, 2 Wo, Cin].  Input pixel (2 i + ph, 2 j + pw) receives filter row a only
  * where ph + 1 - a is even, so the transposed convolution splits into four dense ones, one per parity class (ph, pw), with
@@ -579,7 +575,7 @@ int peclr_conv3x3_s2_dgrad_h(int dtype, int NB, int Ho, int Wo, int Cout, int Ci
  * [peclr_wgrad3_x6r_slabs(...)][M][9 N].  Replaces MIOpen's fp32 3x3 weight gradient behind resnet_model.py:15. */
 int peclr_wgrad3_x6r_slabs(int M, int N, int images, int H, int W);
 int peclr_wgrad3_x6r_f32(int M, int N, int images, int H, int W, const float* dY, const float* X, float* slabs, int n_slabs,
-                         const float* a_absmax, const float* b_absmax, peclr_stream_t stream);
+                         peclr_stream_t stream);
 /* Weight gradient of a 16-bit 1x1 convolution (csrc/wgrad_h.hip): dW[Cout][Cin] (fp32) = dY^T X over the rows of two NHWC
  * activations -- A = dY [K][lda] (M = Cout), B = X [K][ldb] (N = Cin); stride = 2 (the 1x1 / stride-2 shortcut): A's K rows are
  * the Ho x Wo output pixels, B holds the 2 Ho x 2 Wo input pixels.  Both operands go global -> LDS by LDS-DMA as they lie in

@@ -88,7 +88,7 @@ SIGNATURES = {
     "peclr_gemm_x6p_s2add_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "peclr_gemm_x6p_maskadd_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
     "peclr_gemm_x6t_slabs": (c_int, [c_int, c_int, c_int, c_int]),
-    "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "peclr_gemm_x6t_f32": (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "peclr_conv_s2_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "peclr_conv3x3_x6p_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "peclr_h_pack_bytes": (c_int64, [c_int, c_int]),
@@ -99,7 +99,7 @@ SIGNATURES = {
     "peclr_conv_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_conv3x3_s2_dgrad_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
     "peclr_wgrad3_x6r_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "peclr_wgrad3_x6r_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
+    "peclr_wgrad3_x6r_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P]),
     "peclr_wgrad3_h_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "peclr_wgrad3_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "peclr_wgrad_h_slabs": (c_int, [c_int, c_int, c_int]),
@@ -707,12 +707,13 @@ def gemm_x6_tn(a: torch.Tensor, b: torch.Tensor, tag: str = "gemm_x6_tn") -> tor
     return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
 
 
-def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, stride: int = 1, tag: str = "gemm_x6t", absmax=None) -> torch.Tensor:
+def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, stride: int = 1, tag: str = "gemm_x6t") -> torch.Tensor:
     """C[M, taps * N] (fp32) = sum over rows of A[K, M]^T . B[K (shifted by the tap), N] -- the weight gradient of a 1x1
     (taps = 1) or 3x3 / padding-1 (taps = 9, hw = (H, W) of the images A's rows are the pixels of) convolution on NHWC
     storage, on the bf16 matrix cores at fp32 accuracy (peclr_gemm_x6t_f32 + peclr_slab_reduce_f32: fixed-order split-K,
     deterministic).  stride = 2: A = dY over the H x W output pixels, B = X over the 2H x 2W input pixels (4 K rows).
-    absmax = (max |A|, max |B|) device floats: pair arithmetic (two fp16 numbers per scaled operand, three products)."""
+    (Weight gradients stay on six products: in pair arithmetic they were 21 - 29 % faster and, on real layer tensors, 3 - 46 % less
+    accurate than this kernel -- tools/exp/pair_wgrad.patch)"""
     (k, m), (k2, n) = a.shape, b.shape
     if k * stride * stride != k2 or taps not in (1, 9) or stride not in (1, 2) or ((taps == 9 or stride == 2) and hw is None):
         raise PeclrHipError(f"gemm_x6t: shapes {tuple(a.shape)}^T x {tuple(b.shape)}, taps {taps}, stride {stride}")
@@ -721,11 +722,10 @@ def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, stride: i
     if ns < 1:
         raise PeclrHipError(f"gemm_x6t: unsupported shape M={m} N={n} K={k}")
     slabs = torch.empty((ns, m, taps * n), device=a.device, dtype=torch.float32)
-    pa, pb = _absmax_pair(absmax, "gemm_x6t")
     with _timed(tag, 4 * (k * m + k2 * n // (stride * stride) * (1 if taps == 1 else stride * stride) + ns * m * n * taps),
-                2 * m * n * k * taps, kernel="gemm_x6t_kernel" if pa is None else "gemm_x6t_kernel<pair>"):
+                2 * m * n * k * taps, kernel="gemm_x6t_kernel"):
         rc = lib().peclr_gemm_x6t_f32(m, n, k, _ptr(a), a.stride(0), _ptr(b), b.stride(0), slabs.data_ptr(), ns, taps, h, w, stride,
-                                      _zeros(a.device).data_ptr(), pa, pb, _stream())
+                                      _zeros(a.device).data_ptr(), _stream())
     _check(rc, "peclr_gemm_x6t_f32")
     return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
 
@@ -744,17 +744,7 @@ def wgrad3_x6r_ok(gy: torch.Tensor, x: torch.Tensor) -> bool:
             and gy.shape[1] % 64 == 0 and x.shape[1] % 64 == 0 and gy.shape[0] * gy.shape[2] * gy.shape[3] >= 1024)
 
 
-def _absmax_pair(absmax, who: str):
-    """absmax = None or (max |A|, max |B|): one-element fp32 HIP tensors -> the two pointers a weight-gradient entry point takes."""
-    if absmax is None:
-        return None, None
-    for t in absmax:
-        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.numel() == 1):
-            raise PeclrHipError(f"{who}: absmax = (max |A|, max |B|), one-element fp32 HIP tensors")
-    return absmax[0].data_ptr(), absmax[1].data_ptr()
-
-
-def wgrad3_x6r(gy: torch.Tensor, x: torch.Tensor, tag: str = "conv3x3_wgrad", absmax=None) -> torch.Tensor:
+def wgrad3_x6r(gy: torch.Tensor, x: torch.Tensor, tag: str = "conv3x3_wgrad") -> torch.Tensor:
     """dW [Cout, 9 * Cin] (fp32; = the [Cout][3][3][Cin] storage of a channels_last weight) of a 3x3 / padding-1 / stride-1
     convolution from fp32 NHWC gy [N, Cout, H, W], x [N, Cin, H, W]: every element split once, nine taps by transposing LDS
     reads of a ring (peclr_wgrad3_x6r_f32 + peclr_slab_reduce_f32: deterministic)."""
@@ -768,10 +758,8 @@ def wgrad3_x6r(gy: torch.Tensor, x: torch.Tensor, tag: str = "conv3x3_wgrad", ab
         raise PeclrHipError(f"wgrad3_x6r: unsupported shape M={cout} N={cin} {nb} x {h} x {w}")
     slabs = torch.empty((ns, cout, 9 * cin), device=gy.device, dtype=torch.float32)
     k = nb * h * w
-    pa, pb = _absmax_pair(absmax, "wgrad3_x6r")
-    with _timed(tag, 4 * (k * cout + k * cin + ns * cout * 9 * cin), 18 * cout * cin * k,
-                kernel="gemm_x6t_kernel" if pa is None else "gemm_x6t_kernel<pair>"):
-        rc = lib().peclr_wgrad3_x6r_f32(cout, cin, nb, h, w, gp, xp, slabs.data_ptr(), ns, pa, pb, _stream())
+    with _timed(tag, 4 * (k * cout + k * cin + ns * cout * 9 * cin), 18 * cout * cin * k, kernel="gemm_x6t_kernel"):
+        rc = lib().peclr_wgrad3_x6r_f32(cout, cin, nb, h, w, gp, xp, slabs.data_ptr(), ns, _stream())
     _check(rc, "peclr_wgrad3_x6r_f32")
     return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
 

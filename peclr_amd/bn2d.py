@@ -619,22 +619,7 @@ def _x6_wgrad_pays(rows: int, cout: int, cin: int) -> bool:
     return ROUTING.gemm_x6 and cout >= wide and cin >= wide and cout % 4 == 0 and cin % 4 == 0 and (rows >= 8192 or ROUTING.force)
 
 
-def _absmax_both(gy: Tensor, x_amax, cout: int = 0, cin: int = 0):
-    """(max |gy|, max |x|) when both operands of a weight gradient carry their maxima (pair arithmetic), else None.
-    cout, cin > 0 (1x1 weight gradients): only where the product is bound by the matrix cores -- cout cin / (cout + cin) > 104, the
-    crossover of 8 bytes per row and channel at 8 TB/s against 2 flops per row and channel pair at the six-product roof.  The
-    HBM-bound shapes (layer1 / layer2: 64 x 256 ... 128 x 512, 8e5 / 2e5 rows) run 15 - 31 % SLOWER in pair arithmetic
-    (tools/exp/pair_probe.py: 259 -> 298, 191 -> 251 us; the k-steps of those launches are one memory round trip each, and the
-    shorter product phase overlaps less of it), the MFMA-bound ones 21 - 28 % faster."""
-    ga = _absmax_of(gy)
-    if ga is None or x_amax is None or not ROUTING.x6_pair:
-        return None
-    if cout and cin and not ROUTING.force and cout * cin <= 104 * (cout + cin):
-        return None
-    return (ga, x_amax)
-
-
-def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, x_amax=None):
+def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None):
     """d(weight) of a 1x1 / stride-1 convolution as dY^T X on the bf16 matrix cores (fp32 accuracy, deterministic
     split-K), shaped and strided like the weight; parked for `param` on the side stream when that mode is on."""
     n, cin, h, w = x.shape
@@ -642,7 +627,7 @@ def _wgrad_1x1_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, x_amax=None
 
     def run():
         gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * h * w, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
-        dw = (_capi.gemm_x6t(gy2, x2, tag="conv1x1_wgrad", absmax=_absmax_both(gy, x_amax, cout, cin)) if ROUTING.gemm_x6t
+        dw = (_capi.gemm_x6t(gy2, x2, tag="conv1x1_wgrad") if ROUTING.gemm_x6t
               else _capi.gemm_x6_tn(gy2, x2, tag="conv1x1_wgrad"))
         ref = param if param is not None else weight
         return dw.as_strided(ref.shape, ref.stride())       # same memory, the parameter's (channels_last) strides
@@ -673,7 +658,7 @@ def _stat_shift_for(bn, cout: int):
     return kept if kept is not None else bn.running_mean
 
 
-def _wgrad_3x3_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, stride: int = 1, taps: int = 9, x_amax=None):
+def _wgrad_3x3_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, stride: int = 1, taps: int = 9):
     """d(weight) of a 3x3 / padding-1 convolution (stride 1 or 2): nine dY^T X products with X read at the pixel each tap
     points at, all in one launch that splits dY once for the nine taps (peclr_gemm_x6t_f32, taps = 9; fp32 accuracy,
     fixed-order split-K: deterministic), written in the weight's own channels_last storage order [Cout][3][3][Cin].
@@ -684,10 +669,9 @@ def _wgrad_3x3_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, stride: int
     def run():
         if taps == 9 and stride == 1 and ROUTING.wgrad3_ring and (_capi.wgrad3_x6r_pays(gy, x) or (ROUTING.force and _capi.wgrad3_x6r_ok(gy, x))):
             # every element split once, the nine taps by transposing reads of an LDS ring (peclr_wgrad3_x6r_f32)
-            return _capi.wgrad3_x6r(gy, x, absmax=_absmax_both(gy, x_amax)).view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+            return _capi.wgrad3_x6r(gy, x).view(cout, 3, 3, cin).permute(0, 3, 1, 2)
         gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
-        dw = _capi.gemm_x6t(gy2, x2, taps=taps, hw=(ho, wo), stride=stride, tag="conv3x3_wgrad" if taps == 9 else "conv1x1_wgrad",
-                            absmax=_absmax_both(gy, x_amax, *((cout, cin) if taps == 1 else (0, 0))))
+        dw = _capi.gemm_x6t(gy2, x2, taps=taps, hw=(ho, wo), stride=stride, tag="conv3x3_wgrad" if taps == 9 else "conv1x1_wgrad")
         if taps == 9:
             return dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2)      # = a channels_last [Cout, Cin, 3, 3] tensor
         ref = param if param is not None else weight
@@ -715,7 +699,6 @@ class _Conv1x1Gemm(torch.autograd.Function):
         and the list comes back as [partial, n_split, shift, bn] (left untouched when that is not possible).
         amax: the device float holding max |x| (`_absmax_of`) -> the forward runs in pair arithmetic."""
         ctx.save_for_backward(x, weight)
-        ctx.amax_x = amax
         planes = _x6_planes(conv) if (use_fwd or use_bwd) else None
         ctx.cfg = (conv, use_bwd, planes)
         ctx.link = link
@@ -746,7 +729,7 @@ class _Conv1x1Gemm(torch.autograd.Function):
         gy = gy.contiguous(memory_format=torch.channels_last)
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = (_wgrad_1x1_x6(gy, x, weight, param, x_amax=ctx.amax_x) if _x6_wgrad_pays(n * h * w, cout, cin)
+            dw = (_wgrad_1x1_x6(gy, x, weight, param) if _x6_wgrad_pays(n * h * w, cout, cin)
                   else _conv_wgrad(gy, x, weight, (1, 1), (0, 0), param))
         dx = None
         if ctx.needs_input_grad[0]:
@@ -782,7 +765,6 @@ class _Conv3x3Gemm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, conv, stats=None, link=None, amax=None):
         ctx.save_for_backward(x, weight)
-        ctx.amax_x = amax
         planes = _x6_planes(conv)
         ctx.cfg = (conv, planes)
         ctx.link = link
@@ -806,8 +788,7 @@ class _Conv3x3Gemm(torch.autograd.Function):
             in_tree = (ROUTING.gemm_x6t and ROUTING.conv3x3_wgrad_x6 and weight.is_contiguous(memory_format=torch.channels_last)
                        and x.shape[3] >= 6 and x.shape[1] % 4 == 0 and gy.shape[1] % 4 == 0
                        and gy.shape[1] >= (64 if ROUTING.x6_layer1_wgrad else 128))   # (64 output channels: the 64 x 64 block with two tap halves)
-            dw = (_wgrad_3x3_x6(gy, x, weight, conv.weight, x_amax=ctx.amax_x) if in_tree
-                  else _conv_wgrad(gy, x, weight, (1, 1), (1, 1), conv.weight))
+            dw = _wgrad_3x3_x6(gy, x, weight, conv.weight) if in_tree else _conv_wgrad(gy, x, weight, (1, 1), (1, 1), conv.weight)
         dx = None
         if ctx.needs_input_grad[0]:
             link = ctx.link
@@ -835,7 +816,6 @@ class _ConvS2Gemm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, conv, stats=None, compact=False, link=None, amax=None):
         ctx.save_for_backward(x, weight)
-        ctx.amax_x = amax
         ctx.conv = conv
         ctx.compact = compact
         ctx.link = link
@@ -861,7 +841,7 @@ class _ConvS2Gemm(torch.autograd.Function):
             in_tree = (ROUTING.gemm_x6t and ROUTING.conv_s2_wgrad_x6 and weight.is_contiguous(memory_format=torch.channels_last)
                        and x.shape[2] == 2 * gy.shape[2] and x.shape[3] == 2 * gy.shape[3] and gy.shape[3] >= 6
                        and x.shape[1] % 4 == 0 and gy.shape[1] % 4 == 0 and gy.shape[1] >= 64 and x.shape[1] >= 64)
-            dw = (_wgrad_3x3_x6(gy, x, weight, conv.weight, stride=2, taps=taps, x_amax=ctx.amax_x) if in_tree
+            dw = (_wgrad_3x3_x6(gy, x, weight, conv.weight, stride=2, taps=taps) if in_tree
                   else _conv_wgrad(gy, x, weight, (2, 2), pad, conv.weight))
         dx = None
         if ctx.needs_input_grad[0]:
@@ -1278,7 +1258,6 @@ class _ForkConv1x1(torch.autograd.Function):
         ctx.param = weight if isinstance(weight, nn.Parameter) else None
         ctx.link = link
         ctx.conv = conv
-        ctx.amax_x = amax
         n, cin, h, w = x.shape
         cmid = weight.shape[0]
         r = n * h * w
@@ -1315,7 +1294,7 @@ class _ForkConv1x1(torch.autograd.Function):
         gy = gy.to(x.dtype)
         if ctx.needs_input_grad[1]:
             gyc = gy.contiguous(memory_format=torch.channels_last)
-            dw = (_wgrad_1x1_x6(gyc, x, weight, ctx.param, x_amax=ctx.amax_x) if (x.dtype == torch.float32 and _x6_wgrad_pays(n * h * w, cmid, cin))
+            dw = (_wgrad_1x1_x6(gyc, x, weight, ctx.param) if (x.dtype == torch.float32 and _x6_wgrad_pays(n * h * w, cmid, cin))
                   else _conv_wgrad(gyc, x, weight, (1, 1), (0, 0), ctx.param))
         dx = None
         if ctx.needs_input_grad[0]:

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(T) void bn2d_apply_kernel(const IO* __restrict__ x,
             if (RES == 2) a += Word<IO>::round(fmaf(w.v[k], rsc.v[k], rsh.v[k]));
             if (RELU) bits |= (a > 0.f ? 1u : 0u) << k;
             t.v[k] = RELU ? fmaxf(a, 0.f) : a;
-            amax = fmaxf(amax, fabsf(t.v[k]));
+            if constexpr (sizeof(IO) == 4) amax = fmaxf(amax, fabsf(t.v[k]));      // (fp32 tensors only: the pair GEMMs' operands)
         }
         Word<IO>::store(y + o, t);
         if (RELU && relu_mask) mask_store<W>(relu_mask, row, col, g.C, bits);  // the word's lanes share `row`
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(T) void bn2d_apply_kernel(const IO* __restrict__ x,
         const Fv<W> v = Word<IO>::load(x + o);
         emit(r, v, RES ? Word<IO>::load(res + o) : v);
     }
-    absmax_commit(absmax, amax);
+    if constexpr (sizeof(IO) == 4) absmax_commit(absmax, amax);
 }
 
 // Last block of layer4: BatchNorm2d + identity + ReLU + AdaptiveAvgPool2d((1, 1)) + flatten in one pass
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict_
                 const float xh = (xv.v[k] - mean.v[k]) * invstd.v[k];
                 t.v[k] = fmaf(d.v[k], sc.v[k], fmaf(xh, k3.v[k], k2.v[k]));
             }
-            amax = fmaxf(amax, fabsf(t.v[k]));
+            if constexpr (sizeof(IO) == 4) amax = fmaxf(amax, fabsf(t.v[k]));
         }
         Word<IO>::store(dx + o, t);
     };
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(T) void bn2d_bwd_apply_kernel(const IO* __restrict_
         emit(o, load_dy(r), xv, MASK == 2 ? Word<IO>::load(y + o) : xv,
              MASK == 3 ? mask_load<W>(relu_mask, r, col, g.C) : 0u);
     }
-    absmax_commit(absmax, amax);
+    if constexpr (sizeof(IO) == 4) absmax_commit(absmax, amax);
 }
 
 // ------------------------------------------------------------------ host
@@ -875,7 +875,8 @@ __global__ __launch_bounds__(T) void bn2d_pool_apply_kernel(const IO* __restrict
         }
         Word<IO>::store(y + (size_t)p * g.C + col, best);
 #pragma unroll
-        for (int k = 0; k < W; ++k) amax = fmaxf(amax, best.v[k]);       // (rectified: non-negative)
+        for (int k = 0; k < W; ++k)
+            if constexpr (sizeof(IO) == 4) amax = fmaxf(amax, best.v[k]);    // (rectified: non-negative)
         Word<IO>::store(x_at_max + (size_t)p * g.C + col, xb);   // exact: x is an IO value already
         unsigned packed[W / 4];
 #pragma unroll
@@ -883,7 +884,7 @@ __global__ __launch_bounds__(T) void bn2d_pool_apply_kernel(const IO* __restrict
 #pragma unroll
         for (int k = 0; k < W / 4; ++k) reinterpret_cast<unsigned*>(code + (size_t)p * g.C + col)[k] = packed[k];
     }
-    absmax_commit(absmax, amax);
+    if constexpr (sizeof(IO) == 4) absmax_commit(absmax, amax);
 }
 
 // partial: [gridDim.x][2][C] = (sum of masked dy, sum of masked dy * xhat) over the block's pooled pixels

@@ -774,10 +774,13 @@ __global__ __launch_bounds__(256) void x6_pair_kernel(const PackDesc* descs, int
         float m = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) m = fmaxf(m, fabsf(v[q]));       // (a NaN weight is not seen here: it still makes its products NaN)
+        __shared__ float wmax[4];
         m = wave_max(m);
-        if ((threadIdx.x & 63) == 0) {                        // (non-negative floats order like their bits; look before the atomic:
-            unsigned* p = reinterpret_cast<unsigned*>(absmax + d);   //  ~1e5 waves share a few dozen addresses)
-            const unsigned mine = __float_as_uint(m);
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {                               // (non-negative floats order like their bits; look before the atomic:
+            unsigned* p = reinterpret_cast<unsigned*>(absmax + d);   //  ~2e4 workgroups share a few dozen addresses)
+            const unsigned mine = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
             if (mine > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, mine);
         }
     } else {

@@ -36,20 +36,10 @@ struct X6TArgs {
     int taps, H, W;                  // taps = 9: the nine 3x3 filter taps; H x W: image extents of A's rows (output pixels)
     int stride;                      // 2: B's rows are the pixels of 2H x 2W images, read at (2 oh + dh, 2 ow + dw)
     const float* zeros;
-    // NP = 2 instantiations ("pair" arithmetic, common.hpp split2_pk): max |A| and max |B| over the WHOLE tensors (device floats
-    // written by the BatchNorm passes that produced them): every workgroup derives the same two powers of two from them
-    const float* a_absmax;
-    const float* b_absmax;
 };
 
 __device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, f32x16 acc) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-}
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <int NP>
-__device__ __forceinline__ f32x16 mman(const uint4& a, const uint4& b, f32x16 acc) {
-    if constexpr (NP == 3) return mma(a, b, acc);
-    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 __device__ __forceinline__ int slot_of(int i) { return (i & 3) * 8 + ((i >> 2) ^ (((i >> 1) & 1) << 2)); }
 
@@ -59,19 +49,17 @@ __device__ __forceinline__ int slot_of(int i) { return (i & 3) * 8 + ((i >> 2) ^
 // PF: k-steps of global loads in flight per thread (register stages).  (Measured on the 64-wide gradients, whose k-steps
 // are short: PF = 2 changes nothing -- hipcc's wait-count pass still drains every load before the split -- and PF = 4
 // costs the second workgroup per CU its registers, 262 -> 298 us.  PF = 1 everywhere.)
-// NP: planes per operand -- 3: exact bf16 triple, six products; 2: fp16 pair of the scaled operands, three products.
-template <int MT, int NT, int WGM, bool GEO, int PF, int NP = 3>
+template <int MT, int NT, int WGM, bool GEO, int PF>
 __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
     constexpr int WGN = 8 / WGM;
     constexpr int TM = 32 * WGM * MT, TN = 32 * WGN * NT;
     static_assert((TM + TN) / 64 <= 8 && TM % 64 == 0 && TN % 64 == 0, "one 64-column group of the split per wave");
     constexpr int HALF_A = TM * 16, HALF_B = TN * 16;         // bytes of one k-half of a plane
     constexpr int PL_A = 2 * HALF_A, PL_B = 2 * HALF_B;
-    constexpr int BUF = NP * (PL_A + PL_B);                   // one k-step of both operands
+    constexpr int BUF = 3 * (PL_A + PL_B);                    // one k-step of both operands
     constexpr int XEPL = 36;
-    constexpr int EPIL = 8 * 32 * XEPL * 4;                   // the epilogue's transposes live in the plane buffers
-    static_assert(NP == 2 || 2 * BUF >= EPIL, "epilogue transposes live in the plane buffers");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF > EPIL ? 2 * BUF : EPIL];
+    static_assert(2 * BUF >= 8 * 32 * XEPL * 4, "epilogue transposes live in the plane buffers");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int i = lane & 31, kh = lane >> 5;
@@ -95,14 +83,8 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
     const bool col_ok = active && (is_a ? m0 + col < g.M : n0 + col < g.N);
     // plane store address of column col + j: tile (col >> 5), slot of ((col & 31) + j), k-quad half
     const int tile = col >> 5, cin = col & 31;
-    const int st_base = (kq >> 1) * (is_a ? HALF_A : HALF_B) + tile * 512 + (kq & 1) * 8 + (is_a ? 0 : NP * PL_A);
+    const int st_base = (kq >> 1) * (is_a ? HALF_A : HALF_B) + tile * 512 + (kq & 1) * 8 + (is_a ? 0 : 3 * PL_A);
     const int st_plane = is_a ? PL_A : PL_B;
-    float pair_me = 1.f, pair_inv = 1.f;                      // NP = 2: this thread's operand's power of two; what undoes both
-    if constexpr (NP == 2) {
-        const float sa = pair_scale(*g.a_absmax), sb = pair_scale(*g.b_absmax);
-        pair_me = is_a ? sa : sb;
-        pair_inv = 1.f / (sa * sb);
-    }
 
     // rows that exactly ONE workgroup of a split reads (the operand whose other side fits one tile: both operands of layer1's
     // 256 x 64 / 64 x 256 gradients) are loaded with the non-temporal hint: a linear read runs at 6.8 TB/s with it, 4.3 without
@@ -147,17 +129,12 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
         for (int j = 0; j < 4; ++j) {
             unsigned h[2], m[2], l[2];
             float v[4] = {ld4[0][j], ld4[1][j], ld4[2][j], ld4[3][j]};
+            split3_pk(v[0], v[1], h[0], m[0], l[0]);
+            split3_pk(v[2], v[3], h[1], m[1], l[1]);
             unsigned char* d = base + slot_of(cin + j) * 16;
-            if constexpr (NP == 2) {
-                split2_pk(v[0], v[1], pair_me, h[0], m[0]);
-                split2_pk(v[2], v[3], pair_me, h[1], m[1]);
-            } else {
-                split3_pk(v[0], v[1], h[0], m[0], l[0]);
-                split3_pk(v[2], v[3], h[1], m[1], l[1]);
-                *reinterpret_cast<uint2*>(d + 2 * st_plane) = make_uint2(l[0], l[1]);
-            }
             *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
             *reinterpret_cast<uint2*>(d + st_plane) = make_uint2(m[0], m[1]);
+            *reinterpret_cast<uint2*>(d + 2 * st_plane) = make_uint2(l[0], l[1]);
         }
     };
 
@@ -170,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
             for (int r = 0; r < 16; ++r) acc[a][y][r] = 0.f;
 
     const int fa = kh * HALF_A + (wm * MT) * 512 + slot_of(i) * 16;                  // + a * 512 + plane * PL_A
-    const int fb = NP * PL_A + kh * HALF_B + (wn * NT) * 512 + slot_of(i) * 16;      // + y * 512 + plane * PL_B
+    const int fb = 3 * PL_A + kh * HALF_B + (wn * NT) * 512 + slot_of(i) * 16;       // + y * 512 + plane * PL_B
 
     // step u lives in register stage u % PF: loaded PF steps ahead, split into the planes one step ahead
     if (nk > 0) {
@@ -187,24 +164,23 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
         const int t = t0 + st;
         if (t >= nk) break;                                   // (uniform)
         const unsigned char* bufp = lds + (t & 1) * BUF;
-        uint4 af[MT][NP];
+        uint4 af[MT][3];
 #pragma unroll
         for (int a = 0; a < MT; ++a)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) af[a][p] = *reinterpret_cast<const uint4*>(bufp + fa + a * 512 + p * PL_A);
+            for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const uint4*>(bufp + fa + a * 512 + p * PL_A);
         constexpr int NH = NT > 2 ? 2 : 1, YH = NT / NH;          // B fragments in two halves (registers)
 #pragma unroll
         for (int half = 0; half < NH; ++half) {
-            uint4 bf[YH][NP];
+            uint4 bf[YH][3];
 #pragma unroll
             for (int y = 0; y < YH; ++y)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) bf[y][p] = *reinterpret_cast<const uint4*>(bufp + fb + (half * YH + y) * 512 + p * PL_B);
+                for (int p = 0; p < 3; ++p) bf[y][p] = *reinterpret_cast<const uint4*>(bufp + fb + (half * YH + y) * 512 + p * PL_B);
 #define PECLR_X6(P, Q)                                                                        \
     _Pragma("unroll") for (int y = 0; y < YH; ++y) _Pragma("unroll") for (int a = 0; a < MT; ++a) \
-        acc[a][half * YH + y] = mman<NP>(af[a][P], bf[y][Q], acc[a][half * YH + y]);
-            if constexpr (NP == 3) { PECLR_X6(NP - 1, 0) PECLR_X6(0, NP - 1) PECLR_X6(1, 1) }
-            PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)
+        acc[a][half * YH + y] = mma(af[a][P], bf[y][Q], acc[a][half * YH + y]);
+            PECLR_X6(2, 0) PECLR_X6(0, 2) PECLR_X6(1, 1) PECLR_X6(1, 0) PECLR_X6(0, 1) PECLR_X6(0, 0)
 #undef PECLR_X6
             if (half == 0 && t + 1 < nk) {
                 split_store((t + 1) & 1, ld4[(st + 1) % PF]);       // rows of step t + 1 -> the other buffer
@@ -224,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
         for (int y = 0; y < NT; ++y) {
             const int mt = m0 + (wm * MT + a) * 32, nt = n0 + (wn * NT + y) * 32;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = NP == 2 ? acc[a][y][r] * pair_inv : acc[a][y][r];
+            for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = acc[a][y][r];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int m = mt + er + 8 * jj, n = nt + ec;
@@ -243,9 +219,9 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
 // WGM = 2 (the 64-channel convolutions of layer1): a 64 (Cout) x 64 (Cin) block, one group of dY, waves 2 x 2 x two tap
 // halves (taps 0-4 and 5-8: five and four accumulators).
 // stride 2 (the first block of layers 2-4): X's rows are the pixels of the 2H x 2W input, read at (2 oh + dh, 2 ow + dw).
-template <int WGM, int NP = 3>
+template <int WGM>
 __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
-    constexpr int GRP = NP * 2 * 64 * 16;                     // bytes of one 64-column group: [plane][k-half][tile][slot][16]
+    constexpr int GRP = 3 * 2 * 64 * 16;                      // bytes of one 64-column group: [plane][k-half][tile][slot][16]
     constexpr int NGA = WGM / 2, NG = NGA + 9, BUF = NG * GRP;
     constexpr int NACC = WGM == 4 ? 9 : 5;
     constexpr int XEPL = 36;
@@ -311,26 +287,17 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
         for (int it = 0; it < 3; ++it)
             if (ow_t >= g.W) { ow_t -= g.W; oh_t = oh_t + 1 == g.H ? 0 : oh_t + 1; }
     };
-    float pair_a = 1.f, pair_b = 1.f;                         // NP = 2: the operands' powers of two
-    if constexpr (NP == 2) { pair_a = pair_scale(*g.a_absmax); pair_b = pair_scale(*g.b_absmax); }
-    const float pair_inv = 1.f / (pair_a * pair_b);
     auto store1 = [&](int buf, int gi, const f32x4 (&r)[4]) {
         unsigned char* base = lds + buf * BUF + gi * GRP + st_off;
-        const float sc = gi < NGA ? pair_a : pair_b;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             unsigned h[2], m[2], l[2];
+            split3_pk(r[0][j], r[1][j], h[0], m[0], l[0]);
+            split3_pk(r[2][j], r[3][j], h[1], m[1], l[1]);
             unsigned char* d = base + slot_of(cin + j) * 16;
-            if constexpr (NP == 2) {
-                split2_pk(r[0][j], r[1][j], sc, h[0], m[0]);
-                split2_pk(r[2][j], r[3][j], sc, h[1], m[1]);
-            } else {
-                split3_pk(r[0][j], r[1][j], h[0], m[0], l[0]);
-                split3_pk(r[2][j], r[3][j], h[1], m[1], l[1]);
-                *reinterpret_cast<uint2*>(d + 4096) = make_uint2(l[0], l[1]);
-            }
             *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
             *reinterpret_cast<uint2*>(d + 2048) = make_uint2(m[0], m[1]);
+            *reinterpret_cast<uint2*>(d + 4096) = make_uint2(l[0], l[1]);
         }
     };
     auto split_store = [&](int buf) {
@@ -354,23 +321,21 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const unsigned char* bufp = lds + (t & 1) * BUF;
-        uint4 af[NP];
+        uint4 af[3];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) af[p] = *reinterpret_cast<const uint4*>(bufp + fa + p * 2048);
+        for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const uint4*>(bufp + fa + p * 2048);
 #pragma unroll
         for (int tp = 0; tp < NACC; ++tp) {
             if (WGM == 4 || tp < ntap) {                      // (wave-uniform: the second tap half has four taps)
-                uint4 bf[NP];
+                uint4 bf[3];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) bf[p] = *reinterpret_cast<const uint4*>(bufp + fb + tp * GRP + p * 2048);
-                if constexpr (NP == 3) {
-                    acc[tp] = mma(af[NP - 1], bf[0], acc[tp]);
-                    acc[tp] = mma(af[0], bf[NP - 1], acc[tp]);
-                    acc[tp] = mma(af[1], bf[1], acc[tp]);
-                }
-                acc[tp] = mman<NP>(af[1], bf[0], acc[tp]);
-                acc[tp] = mman<NP>(af[0], bf[1], acc[tp]);
-                acc[tp] = mman<NP>(af[0], bf[0], acc[tp]);
+                for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const uint4*>(bufp + fb + tp * GRP + p * 2048);
+                acc[tp] = mma(af[2], bf[0], acc[tp]);
+                acc[tp] = mma(af[0], bf[2], acc[tp]);
+                acc[tp] = mma(af[1], bf[1], acc[tp]);
+                acc[tp] = mma(af[1], bf[0], acc[tp]);
+                acc[tp] = mma(af[0], bf[1], acc[tp]);
+                acc[tp] = mma(af[0], bf[0], acc[tp]);
             }
             if (tp == (WGM == 4 ? 2 : 1) && t + 1 < nk) {
                 split_store((t + 1) & 1);
@@ -388,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
     for (int tp = 0; tp < NACC; ++tp) {
         if (WGM != 4 && tp >= ntap) break;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = NP == 2 ? acc[tp][r] * pair_inv : acc[tp][r];
+        for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = acc[tp][r];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int m = mt + er + 8 * jj, n = nt + ec;
@@ -433,9 +398,8 @@ extern "C" int peclr_gemm_x6t_slabs(int M, int N, int K, int taps) {
 // stride 2: A's K rows are the H x W output pixels of a stride-2 convolution (1x1 without padding, or 3x3 with padding 1),
 // B's 4 K rows the 2H x 2W input pixels.
 static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs,
-                         int n_slabs, int taps, int H, int W, int stride, const float* zeros, const float* a_absmax,
-                         const float* b_absmax, peclr_stream_t stream) {
-    if (!A || !B || !slabs || !zeros || (a_absmax != nullptr) != (b_absmax != nullptr)) return PECLR_ERR_NULL;
+                         int n_slabs, int taps, int H, int W, int stride, const float* zeros, peclr_stream_t stream) {
+    if (!A || !B || !slabs || !zeros) return PECLR_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || n_slabs < 1 || (taps != 1 && taps != 9) || (stride != 1 && stride != 2)) return PECLR_ERR_SHAPE;
     if (M % 4 || N % 4 || lda % 4 || ldb % 4 || lda < M || ldb < N) return PECLR_ERR_SHAPE;
     if ((taps == 9 || stride == 2) && (H <= 0 || W < 6 || K % (H * W))) return PECLR_ERR_SHAPE;
@@ -446,23 +410,18 @@ static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const flo
     g.A = A; g.B = B; g.slabs = slabs;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = taps * N;
     g.kchunk = ((K + n_slabs - 1) / n_slabs + TK - 1) / TK * TK;
-    g.taps = taps; g.H = H; g.W = W; g.stride = stride; g.zeros = zeros; g.a_absmax = a_absmax; g.b_absmax = b_absmax;
+    g.taps = taps; g.H = H; g.W = W; g.stride = stride; g.zeros = zeros;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool pair = a_absmax != nullptr;
     if (taps == 9) {
-        const dim3 g2(((M + 63) / 64) * ((N + 63) / 64), n_slabs), g4(((M + 127) / 128) * ((N + 63) / 64), n_slabs);
-        if (M <= 64) { if (pair) hipLaunchKernelGGL((gemm_x6w_kernel<2, 2>), g2, dim3(512), 0, s, g); else hipLaunchKernelGGL((gemm_x6w_kernel<2, 3>), g2, dim3(512), 0, s, g); }
-        else { if (pair) hipLaunchKernelGGL((gemm_x6w_kernel<4, 2>), g4, dim3(512), 0, s, g); else hipLaunchKernelGGL((gemm_x6w_kernel<4, 3>), g4, dim3(512), 0, s, g); }
+        if (M <= 64) hipLaunchKernelGGL(gemm_x6w_kernel<2>, dim3(((M + 63) / 64) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
+        else hipLaunchKernelGGL(gemm_x6w_kernel<4>, dim3(((M + 127) / 128) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
         return launch_status();
     }
     const TilePick t = pick_tile(M, N);
     const dim3 grid(((M + tile_m(t) - 1) / tile_m(t)) * ((N + tile_n(t) - 1) / tile_n(t)), n_slabs);
 #define PECLR_LAUNCH(MT_, NT_, WGM_, PF_)                                                                            \
     do {                                                                                                             \
-        if (pair) {                                                                                                  \
-            if (stride == 2) hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, true, PF_, 2>), grid, dim3(512), 0, s, g); \
-            else hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, false, PF_, 2>), grid, dim3(512), 0, s, g);     \
-        } else if (stride == 2) hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, true, PF_>), grid, dim3(512), 0, s, g); \
+        if (stride == 2) hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, true, PF_>), grid, dim3(512), 0, s, g); \
         else hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, false, PF_>), grid, dim3(512), 0, s, g);            \
     } while (0)
     if (t.wgm == 2) {
@@ -480,7 +439,6 @@ static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const flo
 }
 
 extern "C" int peclr_gemm_x6t_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* slabs,
-                                  int n_slabs, int taps, int H, int W, int stride, const float* zeros, const float* a_absmax,
-                                  const float* b_absmax, peclr_stream_t stream) {
-    return gemm_x6t_host(M, N, K, A, lda, B, ldb, slabs, n_slabs, taps, H, W, stride, zeros, a_absmax, b_absmax, stream);
+                                  int n_slabs, int taps, int H, int W, int stride, const float* zeros, peclr_stream_t stream) {
+    return gemm_x6t_host(M, N, K, A, lda, B, ldb, slabs, n_slabs, taps, H, W, stride, zeros, stream);
 }

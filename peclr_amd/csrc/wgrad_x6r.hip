@@ -30,8 +30,6 @@ struct X6RArgs {
     int H, W, images;
     int P;                               // padded slots: images * (H + 1) * (W + 1)
     int pchunk;                          // padded slots per slab (multiple of 32)
-    const float* a_absmax;               // NP = 2 ("pair" arithmetic): max |dY|, max |X| over the whole tensors (device floats)
-    const float* b_absmax;
 };
 
 __device__ __forceinline__ f32x16 rmma(const uint4& a, const uint4& b, f32x16 acc) {
@@ -49,26 +47,14 @@ constexpr int RING = 256;                // slots of the X ring (W <= 62: lead +
 // Eight waves: wave = (32 x 32 block, tap group): taps 0 - 4 or 5 - 8 -- two waves per SIMD, so that one wave's transposing reads
 // and their latency run under the other's MFMAs (four waves of nine taps: 150 TFLOP/s; a wave alone on its SIMD exposes
 // every LDS round trip)
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <int NP>
-__device__ __forceinline__ f32x16 rmman(const uint4& a, const uint4& b, f32x16 acc) {
-    if constexpr (NP == 3) return rmma(a, b, acc);
-    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
-}
-
-// NP: planes per operand -- 3: exact bf16 triple, six products; 2: fp16 pair of the scaled operands, three products (two thirds of
-// the transposing reads per k-step, half the products).
-template <int MBLK, int NBLK, int NP = 3>
+template <int MBLK, int NBLK>
 __global__ __launch_bounds__(512, 1) void wgrad_x6r_kernel(X6RArgs g) {
     static_assert(MBLK * NBLK == 4, "four 32 x 32 blocks, two tap groups each");
     constexpr int APL = MBLK * 2048;                     // bytes of one dY plane of a stage: [block][32 slots][64 B]
-    constexpr int ASTG = NP * APL;
+    constexpr int ASTG = 3 * APL;
     constexpr int XPL = NBLK * RING * 64;                // bytes of one X ring plane: [block][RING slots][64 B]
     constexpr int X0 = 2 * ASTG;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[X0 + NP * XPL];
-    float pair_a = 1.f, pair_b = 1.f;
-    if constexpr (NP == 2) { pair_a = pair_scale(*g.a_absmax); pair_b = pair_scale(*g.b_absmax); }
-    const float pair_inv = 1.f / (pair_a * pair_b);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X0 + 3 * XPL];
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, tapg = tid >> 8;
     const int tap0 = tapg * 5, ntaps = tapg ? 4 : 5;      // this wave's taps: [tap0, tap0 + ntaps)
     const int W1 = g.W + 1, HW1 = (g.H + 1) * W1;
@@ -119,25 +105,20 @@ __global__ __launch_bounds__(512, 1) void wgrad_x6r_kernel(X6RArgs g) {
     };
     // four channels of one slot -> 8 bytes in each of the three planes: float4 column q = c4 + 16 j lies in channel block q >> 3,
     // at byte (q & 7) * 8 of the slot's 64
-    auto split_to = [&](const f32x4& v, unsigned char* d, int plane_stride, float sc) {
+    auto split_to = [&](const f32x4& v, unsigned char* d, int plane_stride) {
         unsigned h[2], m[2], l[2];
-        if constexpr (NP == 2) {
-            split2_pk(v[0], v[1], sc, h[0], m[0]);
-            split2_pk(v[2], v[3], sc, h[1], m[1]);
-        } else {
-            split3_pk(v[0], v[1], h[0], m[0], l[0]);
-            split3_pk(v[2], v[3], h[1], m[1], l[1]);
-            *reinterpret_cast<uint2*>(d + 2 * plane_stride) = make_uint2(l[0], l[1]);
-        }
+        split3_pk(v[0], v[1], h[0], m[0], l[0]);
+        split3_pk(v[2], v[3], h[1], m[1], l[1]);
         *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
         *reinterpret_cast<uint2*>(d + plane_stride) = make_uint2(m[0], m[1]);
+        *reinterpret_cast<uint2*>(d + 2 * plane_stride) = make_uint2(l[0], l[1]);
     };
     auto store_a = [&](int t) {
         unsigned char* d = lds + (t & 1) * ASTG + lslot * 64;
 #pragma unroll
         for (int j = 0; j < NFA; ++j) {
             const int q = c4 + 16 * j;
-            if (q < 8 * MBLK) split_to(ra[j], d + (q >> 3) * 2048 + (q & 7) * 8, APL, pair_a);
+            if (q < 8 * MBLK) split_to(ra[j], d + (q >> 3) * 2048 + (q & 7) * 8, APL);
         }
     };
     auto store_x = [&](int u) {
@@ -145,7 +126,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x6r_kernel(X6RArgs g) {
 #pragma unroll
         for (int j = 0; j < NFX; ++j) {
             const int q = c4 + 16 * j;
-            if (q < 8 * NBLK) split_to(rx[j], d + (q >> 3) * RING * 64 + (q & 7) * 8, XPL, pair_b);
+            if (q < 8 * NBLK) split_to(rx[j], d + (q >> 3) * RING * 64 + (q & 7) * 8, XPL);
         }
     };
 
@@ -166,13 +147,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_x6r_kernel(X6RArgs g) {
         const int xbase = 32 * t + L + fpix;              // ring slot (before the wrap) of this lane's first pixel at shift 0
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            uint4 af[NP];
+            uint4 af[3];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
+            for (int p = 0; p < 3; ++p) {
                 const unsigned char* b = sa + p * APL + (kk * 16 + fpix) * 64;
                 af[p] = rtr(b, b + 4 * 64);
             }
-            uint4 bf[5][NP];
+            uint4 bf[5][3];
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
                 const int tap = tap0 + (u < ntaps ? u : 0);           // (the four-tap group reads its first tap twice; that product is dropped)
@@ -180,13 +161,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_x6r_kernel(X6RArgs g) {
                 const int shift = (ta - 1) * W1 + (tb - 1);
                 const unsigned s0 = (unsigned)(xbase + kk * 16 + shift) & (RING - 1), s1 = (unsigned)(xbase + kk * 16 + shift + 4) & (RING - 1);
 #pragma unroll
-                for (int p = 0; p < NP; ++p) bf[u][p] = rtr(sx + p * XPL + s0 * 64, sx + p * XPL + s1 * 64);
+                for (int p = 0; p < 3; ++p) bf[u][p] = rtr(sx + p * XPL + s0 * 64, sx + p * XPL + s1 * 64);
             }
             // six of the nine partial products, smallest first (planes: 0 = h, 1 = m, 2 = l); consecutive MFMAs write different accumulators
-            // (NP = 2: lo.hi, hi.lo, hi.hi)
-#define PECLR_X6R(P, Q) _Pragma("unroll") for (int u = 0; u < 5; ++u) if (u < 4 || ntaps == 5) acc[u] = rmman<NP>(af[P], bf[u][Q], acc[u]);
-            if constexpr (NP == 3) { PECLR_X6R(NP - 1, 0) PECLR_X6R(0, NP - 1) PECLR_X6R(1, 1) }
-            PECLR_X6R(1, 0) PECLR_X6R(0, 1) PECLR_X6R(0, 0)
+#define PECLR_X6R(P, Q) _Pragma("unroll") for (int u = 0; u < 5; ++u) if (u < 4 || ntaps == 5) acc[u] = rmma(af[P], bf[u][Q], acc[u]);
+            PECLR_X6R(2, 0) PECLR_X6R(0, 2) PECLR_X6R(1, 1) PECLR_X6R(1, 0) PECLR_X6R(0, 1) PECLR_X6R(0, 0)
 #undef PECLR_X6R
         }
         if (more) { store_a(t + 1); store_x(t + G0); }    // other stage / the ring group no step <= t reads
@@ -198,8 +177,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x6r_kernel(X6RArgs g) {
     for (int u = 0; u < 5; ++u)
         if (u < ntaps) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                slab[(size_t)(mb + mfma32_row(r, kh)) * (9 * g.N) + (tap0 + u) * g.N + nb + i] = NP == 2 ? acc[u][r] * pair_inv : acc[u][r];
+            for (int r = 0; r < 16; ++r) slab[(size_t)(mb + mfma32_row(r, kh)) * (9 * g.N) + (tap0 + u) * g.N + nb + i] = acc[u][r];
         }
 }
 
@@ -223,8 +201,8 @@ extern "C" int peclr_wgrad3_x6r_slabs(int M, int N, int images, int H, int W) {
 // dW slabs [n_slabs][Cout][9 * Cin] (fp32) of a 3x3 / padding-1 / stride-1 convolution from fp32 NHWC activations dY [images, H,
 // W, M = Cout], X [images, H, W, N = Cin]; M, N multiples of 64, W <= 62.  Sum the slabs with peclr_slab_reduce_f32.
 extern "C" int peclr_wgrad3_x6r_f32(int M, int N, int images, int H, int W, const float* A, const float* B, float* slabs, int n_slabs,
-                                    const float* a_absmax, const float* b_absmax, peclr_stream_t stream) {
-    if (!A || !B || !slabs || (a_absmax != nullptr) != (b_absmax != nullptr)) return PECLR_ERR_NULL;
+                                    peclr_stream_t stream) {
+    if (!A || !B || !slabs) return PECLR_ERR_NULL;
     if (M <= 0 || N <= 0 || images <= 0 || H <= 0 || W <= 0 || M % 64 || N % 64 || W > 62) return PECLR_ERR_SHAPE;
     if ((long)images * (H + 1) * (W + 1) > 0x7fffffffL / 2) return PECLR_ERR_SHAPE;
     if (!aligned16(A) || !aligned16(B) || !aligned16(slabs)) return PECLR_ERR_ALIGN;
@@ -233,13 +211,8 @@ extern "C" int peclr_wgrad3_x6r_f32(int M, int N, int images, int H, int W, cons
     g.A = A; g.B = B; g.slabs = slabs; g.M = M; g.N = N; g.lda = M; g.ldb = N; g.H = H; g.W = W; g.images = images;
     g.P = images * (H + 1) * (W + 1);
     g.pchunk = ((g.P + n_slabs - 1) / n_slabs + 31) / 32 * 32;
-    g.a_absmax = a_absmax; g.b_absmax = b_absmax;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 g22((M / 64) * (N / 64), n_slabs), g41((M / 128) * (N / 32), n_slabs);
-    if (a_absmax) {
-        if (M % 128) hipLaunchKernelGGL((wgrad_x6r_kernel<2, 2, 2>), g22, dim3(512), 0, s, g);
-        else hipLaunchKernelGGL((wgrad_x6r_kernel<4, 1, 2>), g41, dim3(512), 0, s, g);
-    } else if (M % 128) hipLaunchKernelGGL((wgrad_x6r_kernel<2, 2>), g22, dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((wgrad_x6r_kernel<4, 1>), g41, dim3(512), 0, s, g);
+    if (M % 128) hipLaunchKernelGGL((wgrad_x6r_kernel<2, 2>), dim3((M / 64) * (N / 64), n_slabs), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((wgrad_x6r_kernel<4, 1>), dim3((M / 128) * (N / 32), n_slabs), dim3(512), 0, s, g);
     return launch_status();
 }

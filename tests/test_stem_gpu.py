@@ -109,7 +109,7 @@ def test_stem_statistics_from_the_epilogue_equal_a_pass_over_the_output(dtype, n
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_encoder_routes_the_stem_in_tree_with_its_statistics_and_trains(precision):
+def test_encoder_routes_the_stem_in_tree_with_its_statistics_and_trains(precision, request):
     """Through the module surface: `ResNetModel.features` hands the stem its BatchNorm, the stem runs in-tree (event log) with
     the statistics fused (no bn2d_stats launch at all in the forward), forward and gradients equal the MIOpen-stem arm's."""
     import copy
@@ -119,6 +119,14 @@ def test_encoder_routes_the_stem_in_tree_with_its_statistics_and_trains(precisio
     from peclr_amd.config import Config
     from peclr_amd.encoder import get_wrapper_model
 
+    # Both arms repeat themselves bit for bit: every convolution the in-tree kernels accept runs on them (`force`: fixed-order weight
+    # gradients) and what stays on MIOpen must pick a deterministic algorithm -- left alone, MIOpen's atomically accumulated weight
+    # gradients at these small shapes made this comparison a TWO-OUTCOME test (round 6: 1 run in 6 -- and 2 in 3 of the round-5
+    # arithmetic -- landed on the same second outcome, median 8.19e-3: one early rectifier decision falling the other way).
+    det = torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled(), torch.backends.cudnn.deterministic
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.backends.cudnn.deterministic = True
+    request.addfinalizer(lambda: (torch.use_deterministic_algorithms(det[0], warn_only=det[1]), setattr(torch.backends.cudnn, "deterministic", det[2])))
     torch.manual_seed(3)
     net = get_wrapper_model(Config({"resnet_size": "18"}), False).to(DEV).to(memory_format=torch.channels_last).train()
     for p in net.final_layer.parameters():
@@ -134,9 +142,10 @@ def test_encoder_routes_the_stem_in_tree_with_its_statistics_and_trains(precisio
     def run(model, stem):
         capi.EVENT_LOG = {}
         try:
-            with B.routing(stem=stem), cast:
-                y = model(x)
-            y.float().backward(gy)
+            with B.routing(stem=stem, force=True):
+                with cast:
+                    y = model(x)
+                y.float().backward(gy)
             torch.cuda.synchronize()
             tags = {k: len(v) for k, v in capi.EVENT_LOG.items()}
         finally:
@@ -152,14 +161,14 @@ def test_encoder_routes_the_stem_in_tree_with_its_statistics_and_trains(precisio
     assert torch.allclose(net.features[1].running_mean, other.features[1].running_mean, rtol=1e-3, atol=2e-4 if precision == "fp32" else 2e-3)
     assert int(net.features[1].num_batches_tracked) == 1
     if precision == "fp32":
-        assert rel(y1, y0) <= 2e-4, rel(y1, y0)
-        # (two fp32 evaluations of the stem that round differently: a ReLU decision within round-off of zero that falls the
-        # other way moves one gradient element -- 3e-3 ... 9e-3 norm-wise in a network this small, tests/test_round4_gpu.py;
-        # a wrong stem output or a missing statistics hand-over is O(0.1 - 1))
-        # ... so the bar on single gradients is loose and the bar on their MEDIAN tight: a flipped decision touches a few
-        # parameters, a defect of the stem every one behind it)
+        assert rel(y1, y0) <= 2e-5, rel(y1, y0)
+        # With both arms deterministic the comparison is a CONSTANT of the build: output 1.7e-6, gradients 2.4e-6 (median) / 5.1e-6
+        # (worst) norm-wise at this seed (no rectifier decision falls differently in the two arms; seed 4 has one early in the
+        # network: 7.8e-3 on most parameters -- what round 5's bars, 2e-4 / 2e-3 / 1e-1, had been widened for).  A wrong stem output
+        # or a missing statistics hand-over is O(0.1 - 1).
         rels = sorted(rel(g1[n], g0[n]) for n in g0)
-        assert rels[len(rels) // 2] <= 2e-3 and rels[-1] <= 1e-1, (rels[len(rels) // 2], rels[-1])
+        print(f"stem arms, fp32: output {rel(y1, y0):.2e}, gradients median {rels[len(rels) // 2]:.2e} worst {rels[-1]:.2e}")
+        assert rels[len(rels) // 2] <= 3e-5 and rels[-1] <= 1e-4, (rels[len(rels) // 2], rels[-1])
         return
     # bf16: eight images through twenty train-mode BatchNorm layers amplify one-ulp differences of the stem's output (the two
     # arms round differently: one rounding of the exact product here, MIOpen's kernel there) into O(1) differences of single

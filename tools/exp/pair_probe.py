@@ -1,7 +1,10 @@
 """Round 6: the fp16-pair kernels (three products) against the six-product kernels at the shapes of the C2 step -- time per
 launch (cold caches) and error against float64 -- first on synthetic operands, then on REAL layer tensors: the inputs X, weights W
 and output gradients dY of ResNet-50's 1x1 and 3x3 convolutions captured from one training step (2 x 16 views @224, random
-initialisation, batch statistics), including dY of layers 1 - 4.   python tools/exp/pair_probe.py [--real-only]"""
+initialisation, batch statistics), including dY of layers 1 - 4.   python tools/exp/pair_probe.py [--real-only]
+(The weight-gradient sections need the pair arms of the weight-gradient kernels: tools/exp/pair_wgrad.patch -- not adopted, see
+DESIGN.md section 0; without them those sections are skipped.)"""
+import inspect
 import sys
 
 import torch
@@ -30,6 +33,9 @@ def err(c, ref):
 
 def am(t):
     return t.abs().max().reshape(1).float()
+
+
+WGRAD_PAIR = "absmax" in inspect.signature(capi.gemm_x6t).parameters
 
 
 if "--real-only" not in sys.argv:
@@ -69,7 +75,7 @@ if "--real-only" not in sys.argv:
         print(f"  {nb} x {hw:2d} x {hw:2d} x {c:3d}: {t6:7.1f} / {t2:7.1f} ({t2 / t6 - 1:+.0%}; 128-row tiles {t2b:7.1f})   err {e6:.2e} / {e2:.2e} / {em:.2e}", flush=True)
         del x, w
 
-if "--real-only" not in sys.argv:
+if "--real-only" not in sys.argv and WGRAD_PAIR:
     print("== weight gradients (rows, Cout, Cin): us six-product / pair, component-wise err (six / pair)")
     for k, m, n in ((802816, 64, 256), (802816, 256, 64), (200704, 512, 128), (200704, 128, 512), (50176, 1024, 256), (50176, 256, 1024),
                     (12544, 2048, 512), (12544, 512, 2048)):
@@ -136,7 +142,7 @@ for name, (X, W, dY) in taps.items():
             print(f"  {name:22s} {what:6s} [{a.shape[0]} x {a.shape[1]}] . [{n}]: {e6:.2e} / {e2:.2e} / {ef:.2e}   {rng}", flush=True)
             w_ = worst.setdefault(what, [0.0, 0.0, 0.0])
             worst[what] = [max(w_[0], e6), max(w_[1], e2), max(w_[2], ef)]
-        if cout % 4 == 0 and cin % 4 == 0 and cout >= 64 and cin >= 64:
+        if WGRAD_PAIR and cout % 4 == 0 and cin % 4 == 0 and cout >= 64 and cin >= 64:
             ref = dY2.double().t() @ X2.double()
             e6 = err(capi.gemm_x6t(dY2, X2), ref)
             e2 = err(capi.gemm_x6t(dY2, X2, absmax=(am(dY2), am(X2))), ref)
@@ -161,6 +167,29 @@ for name, (X, W, dY) in taps.items():
             print(f"  {name:22s} {what:6s} {tuple(a.shape)}: {e6:.2e} / {e2:.2e} / {em:.2e}   {rng}", flush=True)
             w_ = worst.setdefault(what, [0.0, 0.0, 0.0])
             worst[what] = [max(w_[0], e6), max(w_[1], e2), max(w_[2], em)]
+        if not WGRAD_PAIR:
+            continue
+        # the 3x3 weight gradient: nine-tap kernel and (where it takes the shape) the ring kernel
+        wz = torch.zeros_like(Wc)
+        args = (None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])
+        ref = torch.ops.aten.convolution_backward(dYc.double(), Xc.double(), wz.double(), *args)[1]
+        em = err(torch.ops.aten.convolution_backward(dYc, Xc, wz, *args)[1], ref)
+        r_ = Xc.shape[0] * Xc.shape[2] * Xc.shape[3]
+        gy2, x2 = dYc.permute(0, 2, 3, 1).reshape(r_, cout), Xc.permute(0, 2, 3, 1).reshape(r_, cin)
+        as_w = lambda t: t.view(cout, 3, 3, cin).permute(0, 3, 1, 2)          # noqa: E731
+        hw_ = (Xc.shape[2], Xc.shape[3])
+        e6 = err(as_w(capi.gemm_x6t(gy2, x2, taps=9, hw=hw_)), ref)
+        e2 = err(as_w(capi.gemm_x6t(gy2, x2, taps=9, hw=hw_, absmax=(am(gy2), am(x2)))), ref)
+        line = f"  {name:22s} wgrad3 nine-tap: {e6:.2e} / {e2:.2e} / {em:.2e}"
+        w_ = worst.setdefault("wgrad3", [0.0, 0.0, 0.0])
+        worst["wgrad3"] = [max(w_[0], e6), max(w_[1], e2), max(w_[2], em)]
+        if capi.wgrad3_x6r_ok(dYc, Xc):
+            e6r = err(as_w(capi.wgrad3_x6r(dYc, Xc)), ref)
+            e2r = err(as_w(capi.wgrad3_x6r(dYc, Xc, absmax=(am(dYc), am(Xc)))), ref)
+            line += f"   ring: {e6r:.2e} / {e2r:.2e}"
+            w_ = worst.setdefault("wgrad3r", [0.0, 0.0, 0.0])
+            worst["wgrad3r"] = [max(w_[0], e6r), max(w_[1], e2r), max(w_[2], em)]
+        print(line, flush=True)
 print("worst over the layers (six-product / pair / fp32 reference kernel):")
 for k_, v in worst.items():
     print(f"  {k_:7s} {v[0]:.2e} / {v[1]:.2e} / {v[2]:.2e}")
