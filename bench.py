@@ -602,7 +602,7 @@ def companion_from_line(line_obj):
             "loss_delta_vs_oracle": line_obj.get("loss_delta_vs_oracle"),
             "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_us", "launches_per_step",
                                                   "algorithmic_bytes", "traffic") if k in roof},
-            "how": "same command with --dtype bf16 in a child process, after the fp32 timed region and outside it"}
+            "how": "same command, --dtype bf16, in a child process after the fp32 run"}
 
 
 def bf16_companion():
