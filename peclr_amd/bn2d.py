@@ -298,8 +298,18 @@ class _LazyPlanes:
 
 
 def _absmax_of(t):
-    """The device float holding max |t| if the pass that wrote `t` left one (fp32 tensors, `ROUTING.x6_pair`), else None."""
-    return getattr(t, "_peclr_absmax", None) if (ROUTING.x6_pair and t is not None) else None
+    """The device float holding max |t| if the pass that wrote `t` left one (fp32 tensors, `ROUTING.x6_pair`) AND nothing has
+    written to `t` since (its version counter stands where the pass left it: an in-place update would make the maximum -- and with
+    it the fp16 range the pair kernels scale into -- stale), else None."""
+    if not ROUTING.x6_pair or t is None:
+        return None
+    tag = getattr(t, "_peclr_absmax", None)
+    return tag[0] if (tag is not None and tag[1] == t._version) else None
+
+
+def _tag_absmax(t: Tensor, slot):
+    """Attach the maximum `slot` (a one-element device tensor) to the tensor it describes."""
+    t._peclr_absmax = (slot, t._version)
 
 
 def _new_absmax(x: Tensor):
@@ -390,7 +400,7 @@ class _BN2dAct(torch.autograd.Function):
                                                  has_res and ctx.needs_input_grad[3] and not lazy, sync_group=ctx.sync_group, pre=pre,
                                                  absmax=slot)
         if slot is not None:
-            dx._peclr_absmax = slot             # (the convolution whose output x is reads it off its `gy`: same tensor object)
+            _tag_absmax(dx, slot)               # (the convolution whose output x is reads it off its `gy`: same tensor object)
         if lazy:
             dres = _lazy_grad(("mask", dy, mask), x.shape, x.device, x.dtype)
         elif has_res and dres is None and ctx.needs_input_grad[3]:
@@ -431,7 +441,7 @@ def _materialized(x: Tensor, deferred) -> Tensor:
     amax = []
     y = _Materialize.apply(x, deferred, amax)
     if amax:
-        y._peclr_absmax = amax[0]
+        _tag_absmax(y, amax[0])
     link = getattr(x, "_peclr_bn_link", None)
     if link:
         y._peclr_bn_link = link
@@ -490,7 +500,7 @@ class _BN2dAddReluAvgPool(torch.autograd.Function):
         dx, dgamma, dbeta, dres = _capi.bn2d_avgpool_bwd(d_pooled.float().contiguous(), x, mask, save, ss, training,
                                                          sync_group=sync, absmax=slot)
         if slot is not None:
-            dx._peclr_absmax = slot
+            _tag_absmax(dx, slot)
         return dx, dgamma, dbeta, dres, None, None
 
 
@@ -1414,7 +1424,7 @@ def fork_conv1x1(conv: nn.Conv2d, x: Tensor, stats_for=None):
         flags = []
         out, identity = _ForkConv1x1.apply(x, conv.weight, conv, stats, _bn_link_of(x), flags, _absmax_of(x))
         if _absmax_of(x) is not None:
-            identity._peclr_absmax = x._peclr_absmax        # (the same values: the downsample convolution reads them too)
+            _tag_absmax(identity, _absmax_of(x))            # (the same values: the downsample convolution reads them too)
         if flags and flags[0]:
             identity._peclr_compact_ok = True     # a 1x1 / stride-2 shortcut may hand its input gradient over compact
         return _attach_stats(out, stats), identity
@@ -1491,7 +1501,7 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
             if pool:
                 y = _BN2dReluPool.apply(x, self.weight, self.bias, self, pre, amax)
                 if amax:
-                    y._peclr_absmax = amax[0]
+                    _tag_absmax(y, amax[0])
                 return y
             if self.tail_avgpool and relu and residual is not None and self.num_features % 32 == 0:
                 return _BN2dAddReluAvgPool.apply(x, self.weight, self.bias, residual, self, pre)
@@ -1504,7 +1514,7 @@ class FusedBatchNormAct2d(nn.BatchNorm2d):
                     defer = []
             y = _BN2dAct.apply(x, self.weight, self.bias, residual, self, relu, pre, link, lazy_res, defer, res_deferred, amax)
             if amax:
-                y._peclr_absmax = amax[0]       # max |y|, on the device: the "pair" GEMMs that read y derive its power of two from it
+                _tag_absmax(y, amax[0])         # max |y|, on the device: the "pair" GEMMs that read y derive its power of two from it
             if link:
                 y._peclr_bn_link = link
             if defer:

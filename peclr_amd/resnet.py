@@ -152,9 +152,10 @@ class ResNet(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         t = _bn(self.bn1, _conv(self.conv1, x, self.bn1), relu=True)
         x = self.maxpool(t)
-        if getattr(t, "_peclr_absmax", None) is not None and isinstance(self.maxpool, nn.MaxPool2d):
+        tag = getattr(t, "_peclr_absmax", None)
+        if tag is not None and tag[1] == t._version and isinstance(self.maxpool, nn.MaxPool2d):
             # (the rectified tensor is non-negative and every element lies in some pooling window: the maximum carries over exactly)
-            x._peclr_absmax = t._peclr_absmax
+            x._peclr_absmax = (tag[0], x._version)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 

@@ -843,3 +843,24 @@ def test_deferred_batchnorm_placeholder_and_who_may_take_it():
         assert not bn._takes_deferred_residual(x)      # (no HIP tensors, layers not switched to the HIP kernels)
     y = bn(x, None, True, consumer=conv)                       # stock path: a real tensor, no placeholder
     assert not hasattr(y, "_peclr_deferred") and not torch.isnan(y).any()
+
+
+def test_absmax_tag_is_dropped_when_the_tensor_is_written_after_the_pass_that_measured_it():
+    """The "pair" GEMMs scale an operand into fp16 range by the maximum its producing pass left beside it; a later in-place write
+    would make that maximum stale (overflow to inf in the worst case), so the tag carries the tensor's version counter and an
+    out-of-date tag reads as "no maximum known" -- the launch then takes the six-product kernel, which needs none."""
+    from peclr_amd import bn2d
+
+    with bn2d.routing(x6_pair=True):
+        t = torch.ones(4, 4)
+        slot = torch.ones(1)
+        assert bn2d._absmax_of(t) is None
+        bn2d._tag_absmax(t, slot)
+        assert bn2d._absmax_of(t) is slot
+        assert bn2d._absmax_of(t.view(16)) is None          # the tag belongs to the tensor object, not to its storage
+        t.mul_(3.0)
+        assert bn2d._absmax_of(t) is None
+        bn2d._tag_absmax(t, slot)
+        assert bn2d._absmax_of(t) is slot
+    with bn2d.routing(x6_pair=False):
+        assert bn2d._absmax_of(t) is None
