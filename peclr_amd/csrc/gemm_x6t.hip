@@ -219,7 +219,9 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t_kernel(X6TArgs g) {
 // WGM = 2 (the 64-channel convolutions of layer1): a 64 (Cout) x 64 (Cin) block, one group of dY, waves 2 x 2 x two tap
 // halves (taps 0-4 and 5-8: five and four accumulators).
 // stride 2 (the first block of layers 2-4): X's rows are the pixels of the 2H x 2W input, read at (2 oh + dh, 2 ow + dw).
-template <int WGM>
+// ABL: ablation switches for tools/exp/x6w_ablate.hip (0 in the library): 1 = X groups stored without the split (raw halves as
+// "planes"), 2 = dY groups likewise, 4 = no plane stores after the first k-step, 8 = no global loads after the prologue
+template <int WGM, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
     constexpr int GRP = 3 * 2 * 64 * 16;                      // bytes of one 64-column group: [plane][k-half][tile][slot][16]
     constexpr int NGA = WGM / 2, NG = NGA + 9, BUF = NG * GRP;
@@ -292,8 +294,13 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             unsigned h[2], m[2], l[2];
-            split3_pk(r[0][j], r[1][j], h[0], m[0], l[0]);
-            split3_pk(r[2][j], r[3][j], h[1], m[1], l[1]);
+            if ((ABL & 1) && gi >= NGA || (ABL & 2) && gi < NGA) {
+                h[0] = __float_as_uint(r[0][j]); m[0] = __float_as_uint(r[1][j]); l[0] = h[0] ^ m[0];
+                h[1] = __float_as_uint(r[2][j]); m[1] = __float_as_uint(r[3][j]); l[1] = h[1] ^ m[1];
+            } else {
+                split3_pk(r[0][j], r[1][j], h[0], m[0], l[0]);
+                split3_pk(r[2][j], r[3][j], h[1], m[1], l[1]);
+            }
             unsigned char* d = base + slot_of(cin + j) * 16;
             *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
             *reinterpret_cast<uint2*>(d + 2048) = make_uint2(m[0], m[1]);
@@ -338,8 +345,8 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
                 acc[tp] = mma(af[0], bf[0], acc[tp]);
             }
             if (tp == (WGM == 4 ? 2 : 1) && t + 1 < nk) {
-                split_store((t + 1) & 1);
-                if (t + 2 < nk) gload(t + 2);
+                if constexpr (!(ABL & 4)) split_store((t + 1) & 1);
+                if constexpr (!(ABL & 8)) if (t + 2 < nk) gload(t + 2);
             }
         }
         __syncthreads();

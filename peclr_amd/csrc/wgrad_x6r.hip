@@ -47,7 +47,9 @@ constexpr int RING = 256;                // slots of the X ring (W <= 62: lead +
 // Eight waves: wave = (32 x 32 block, tap group): taps 0 - 4 or 5 - 8 -- two waves per SIMD, so that one wave's transposing reads
 // and their latency run under the other's MFMAs (four waves of nine taps: 150 TFLOP/s; a wave alone on its SIMD exposes
 // every LDS round trip)
-template <int MBLK, int NBLK>
+// ABL: ablation switches for tools/exp/x6w_ablate.hip (0 in the library): 1 = planes stored without the split (raw halves),
+// 2 = no plane stores inside the loop, 4 = no global loads inside the loop
+template <int MBLK, int NBLK, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void wgrad_x6r_kernel(X6RArgs g) {
     static_assert(MBLK * NBLK == 4, "four 32 x 32 blocks, two tap groups each");
     constexpr int APL = MBLK * 2048;                     // bytes of one dY plane of a stage: [block][32 slots][64 B]
@@ -107,8 +109,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_x6r_kernel(X6RArgs g) {
     // at byte (q & 7) * 8 of the slot's 64
     auto split_to = [&](const f32x4& v, unsigned char* d, int plane_stride) {
         unsigned h[2], m[2], l[2];
-        split3_pk(v[0], v[1], h[0], m[0], l[0]);
-        split3_pk(v[2], v[3], h[1], m[1], l[1]);
+        if constexpr (ABL & 1) {
+            h[0] = __float_as_uint(v[0]); m[0] = __float_as_uint(v[1]); l[0] = h[0] ^ m[0];
+            h[1] = __float_as_uint(v[2]); m[1] = __float_as_uint(v[3]); l[1] = h[1] ^ m[1];
+        } else {
+            split3_pk(v[0], v[1], h[0], m[0], l[0]);
+            split3_pk(v[2], v[3], h[1], m[1], l[1]);
+        }
         *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
         *reinterpret_cast<uint2*>(d + plane_stride) = make_uint2(m[0], m[1]);
         *reinterpret_cast<uint2*>(d + 2 * plane_stride) = make_uint2(l[0], l[1]);
@@ -141,7 +148,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_x6r_kernel(X6RArgs g) {
     for (int t = 0; t < nk; ++t) {
         __syncthreads();                                  // planes of step t are in the LDS; every wave is done with step t - 1
         const bool more = t + 1 < nk;
-        if (more) { load_a(t + 1); load_x(t + G0); }      // in flight under this step's MFMAs
+        if constexpr (!(ABL & 4))
+            if (more) { load_a(t + 1); load_x(t + G0); }  // in flight under this step's MFMAs
         const unsigned char* sa = lds + (t & 1) * ASTG + mblk * 2048 + fch;
         const unsigned char* sx = lds + X0 + nblk * RING * 64 + fch;
         const int xbase = 32 * t + L + fpix;              // ring slot (before the wrap) of this lane's first pixel at shift 0
@@ -168,7 +176,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_x6r_kernel(X6RArgs g) {
             PECLR_X6R(2, 0) PECLR_X6R(0, 2) PECLR_X6R(1, 1) PECLR_X6R(1, 0) PECLR_X6R(0, 1) PECLR_X6R(0, 0)
 #undef PECLR_X6R
         }
-        if (more) { store_a(t + 1); store_x(t + G0); }    // other stage / the ring group no step <= t reads
+        if constexpr (!(ABL & 2))
+            if (more) { store_a(t + 1); store_x(t + G0); }    // other stage / the ring group no step <= t reads
     }
     float* slab = g.slabs + (size_t)blockIdx.y * g.M * 9 * g.N;
     const int i = lane & 31, kh = lane >> 5;
