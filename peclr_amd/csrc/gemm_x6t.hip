@@ -20,6 +20,8 @@
 // output columns tap * N + n (the [Cout][3][3][Cin] layout of a channels_last weight).
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace peclr {
 namespace {
 
@@ -370,6 +372,236 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
     }
 }
 
+// ---- the same product (3x3 / stride 1, all nine taps in one workgroup, same LDS layout, same order of MFMAs per accumulator:
+// bit-identical slabs) with the loop re-scheduled (round 6).  In gemm_x6w_kernel hipcc leaves a k-step as "54 MFMAs, then ~550
+// vector instructions" -- address arithmetic (64-bit row pointers, per-row bounds tests through exec-mask branches), splits,
+// plane stores -- in blocks that hold no MFMA, and the workgroup's barrier keeps the two waves of a SIMD in phase, so the matrix
+// cores idle through them (tools/exp/x6w_ablate.hip: the loop without that work runs at 0.70 of the six-product peak, with it
+// at 0.45).  Here
+//   * rows are fetched by BUFFER loads: 32-bit offsets (one add per row), a row that does not exist -- before the tensor, past
+//     its end, or masked -- is an out-of-range offset and reads as zeros: no pointer selects, no branches;
+//   * whether the tap's neighbour of an output pixel lies inside the image comes from a table in LDS (per tap and pixel of an
+//     image: 4 bits for the pixel and its three successors), built once per workgroup, instead of (oh, ow) arithmetic per row;
+//   * the step is ONE basic block in which the split / store / load-issue work of the NEXT steps is cut into half-units (two
+//     rows of one 64-column group: 4 splits, 12 4-byte plane stores, 2 loads) placed between the MFMAs of taps 0 - 7
+//     (sched_barrier fences keep hipcc from clustering them again); fragments of tap t + 1 are read under the MFMAs of tap t.
+// Waves 0 .. NG - 9 own two column groups, the others one: the loop is instantiated for both (TWO) and chosen per wave.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int X6W2_MAX_HW = 3136;                             // table bytes per tap (an image of up to 56 x 56 output pixels)
+
+template <int WGM>
+__global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
+    constexpr int GRP = 3 * 2 * 64 * 16;                      // bytes of one 64-column group: [plane][k-half][tile][slot][16]
+    constexpr int NGA = WGM / 2, NG = NGA + 9, BUF = NG * GRP;
+    constexpr int NACC = WGM == 4 ? 9 : 5;
+    constexpr int XEPL = 36;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF + 9 * X6W2_MAX_HW];
+    unsigned char* const tab = lds + 2 * BUF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = WGM == 4 ? wave >> 1 : (wave >> 1) & 1, wn = wave & 1;
+    const int tap0 = WGM == 4 ? 0 : (wave >> 2) * 5;          // first tap of this wave
+    const int ntap = WGM == 4 ? 9 : (wave >> 2 ? 4 : 5);
+    const int i = lane & 31, kh = lane >> 5;
+    const int nct = (g.N + 63) / 64;
+    const int m0 = (int)(blockIdx.x / nct) * (32 * WGM), n0 = (int)(blockIdx.x % nct) * 64;
+    const int kbeg = blockIdx.y * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (kend - kbeg + TK - 1) / TK;
+    const int HW = g.H * g.W;
+
+    // the table: tab[tap][p] bit q = the tap's neighbour of pixel (p + q) mod HW of an image lies inside it.  First the nine
+    // taps of every pixel (one division per pixel; 16 bits each, in the plane buffers, which nothing uses yet), then the quads
+    {
+        unsigned short* pm = reinterpret_cast<unsigned short*>(lds);
+        for (int p = tid; p < HW; p += 512) {
+            const int oh = p / g.W, ow = p - oh * g.W;
+            const unsigned rv = (oh > 0 ? 1u : 0u) | 2u | (oh + 1 < g.H ? 4u : 0u), cv = (ow > 0 ? 1u : 0u) | 2u | (ow + 1 < g.W ? 4u : 0u);
+            unsigned bits = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) bits |= ((rv >> (tap / 3)) & (cv >> (tap % 3)) & 1u) << tap;
+            pm[p] = (unsigned short)bits;
+        }
+        __syncthreads();
+        for (int p = tid; p < HW; p += 512) {
+            unsigned v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = pm[p + q < HW ? p + q : p + q - HW];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                tab[tap * X6W2_MAX_HW + p] = (unsigned char)(((v[0] >> tap) & 1u) | ((v[1] >> tap) & 1u) << 1 | ((v[2] >> tap) & 1u) << 2 | ((v[3] >> tap) & 1u) << 3);
+        }
+        __syncthreads();
+    }
+
+    const int chunk = (lane & 7) + 8 * (lane >> 5), kq = (lane >> 3) & 3;
+    const int cin = 4 * (chunk & 7), tile = chunk >> 3;
+    const int st_off = (kq >> 1) * 1024 + tile * 512 + (kq & 1) * 8;     // inside a group's plane
+    // group gi: 0 .. NGA - 1 = dY columns m0 + 64 gi ...; NGA + tap = X columns n0 ..., rows shifted by the tap
+    struct Grp {
+        __amdgpu_buffer_rsrc_t rs;       // (wave-uniform) the operand, cut off after the last row this group may read
+        unsigned off;                    // byte offset of row k0 + shift, this lane's four columns (columns that do not exist: 2^31 + ...,
+                                         // out of range whatever is added)
+        unsigned step, ld4;              // (wave-uniform) bytes per k-step / per row
+        int tb;                          // (wave-uniform) LDS offset of this group's table row (dY: the centre tap's, all ones)
+        int st;                          // LDS offset of this lane's stores inside buffer 0
+    };
+    auto grp_of = [&](int gi) {
+        Grp s;
+        const bool is_a = gi < NGA;
+        const int tap = is_a ? 4 : gi - NGA;
+        const int shift = (tap / 3 - 1) * g.W + (tap % 3 - 1);
+        const int ld = is_a ? g.lda : g.ldb;
+        const int c = 4 * chunk + (is_a ? 64 * gi : 0);
+        const bool ok = is_a ? m0 + c < g.M : n0 + c < g.N;
+        const long rows = (long)g.K + (shift < 0 ? shift : 0);
+        // (every word through readfirstlane: the descriptor must sit in scalar registers, or each load becomes a waterfall loop)
+        const unsigned long long bp = reinterpret_cast<unsigned long long>(is_a ? g.A : g.B);
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bp), bhi = __builtin_amdgcn_readfirstlane((unsigned)(bp >> 32));
+        s.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((unsigned long long)bhi << 32 | blo), (short)0,
+                                                 __builtin_amdgcn_readfirstlane((int)(rows * ld * 4)), 0x00020000);
+        s.ld4 = __builtin_amdgcn_readfirstlane((unsigned)ld * 4u);
+        s.step = TK * s.ld4;
+        s.off = ok ? (unsigned)(((kbeg + 4 * kq + shift) * ld + (is_a ? m0 : n0) + c) * 4) : 0x80000000u;
+        s.tb = __builtin_amdgcn_readfirstlane(2 * BUF + tap * X6W2_MAX_HW);
+        s.st = gi * GRP + st_off;
+        return s;
+    };
+    Grp G1 = grp_of(wave), G2 = grp_of(wave + 8 < NG ? wave + 8 : wave);
+    const bool two = wave + 8 < NG;
+    int pk = (kbeg + 4 * kq) % HW;                            // pixel (inside its image) of this lane's first row of the step being loaded
+
+    f32x4 la[4], lb[4];
+    unsigned m1 = 0, m2 = 0;                                  // table bytes of the step being loaded
+    // rows 2 qp, 2 qp + 1 of the lane's quad for the step whose offsets G holds
+    auto issue = [&](const Grp& G, unsigned msk, int qp, f32x4 (&r)[4]) {
+#pragma unroll
+        for (int q = 2 * qp; q < 2 * qp + 2; ++q) {
+            const unsigned o = (msk >> q) & 1u ? G.off + q * G.ld4 : 0x80000000u;
+            r[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(G.rs, (int)o, 0, 0));
+        }
+    };
+    auto advance = [&](Grp& G) { G.off += G.step; };
+    auto next_pixel = [&]() { pk += TK; pk = pk >= HW ? pk - HW : pk; };
+    // two of the lane's four rows (2 qp, 2 qp + 1), one of its four channels -> 4 bytes in each plane (a quarter-unit: the loop places
+    // them between MFMAs one at a time)
+    auto quarter = [&](const Grp& G, int buf, int qp, int j, const f32x4 (&r)[4]) {
+        unsigned h, m, l;
+        split3_pk(r[2 * qp][j], r[2 * qp + 1][j], h, m, l);
+        unsigned char* d = lds + G.st + buf * BUF + 4 * qp + slot_of(cin + j) * 16;
+        *reinterpret_cast<unsigned*>(d) = h;
+        *reinterpret_cast<unsigned*>(d + 2048) = m;
+        *reinterpret_cast<unsigned*>(d + 4096) = l;
+    };
+
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int tp = 0; tp < NACC; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+    const int fa = (wm >> 1) * GRP + kh * 1024 + (wm & 1) * 512 + slot_of(i) * 16;       // + plane * 2048
+    const int fb = (NGA + tap0) * GRP + kh * 1024 + wn * 512 + slot_of(i) * 16;           // + tap * GRP + plane * 2048
+
+    __syncthreads();                                          // the table
+    // prologue: step 0 -> buffer 0; step 1 in flight
+    m1 = lds[G1.tb + pk]; m2 = lds[G2.tb + pk];
+    issue(G1, m1, 0, la); issue(G1, m1, 1, la);
+    if (two) { issue(G2, m2, 0, lb); issue(G2, m2, 1, lb); }
+    advance(G1); advance(G2); next_pixel();
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            quarter(G1, 0, qp, j, la);
+            if (two) quarter(G2, 0, qp, j, lb);
+        }
+    m1 = lds[G1.tb + pk]; m2 = lds[G2.tb + pk];
+    issue(G1, m1, 0, la); issue(G1, m1, 1, la);
+    if (two) { issue(G2, m2, 0, lb); issue(G2, m2, 1, lb); }
+    advance(G1); advance(G2); next_pixel();
+    __syncthreads();
+
+    // step t: MFMAs on buffer t & 1; the registers hold step t + 1 (-> buffer (t + 1) & 1), loads for step t + 2 follow each half
+    // of a group as soon as its registers are free.  Past the slab's end this splits and stores rows that nobody reads and loads
+    // rows of the next slab (or zeros past the tensor): harmless, and it keeps the step free of branches.
+    auto run = [&](auto two_c) {
+        constexpr bool TWO = decltype(two_c)::value;
+        for (int t = 0; t < nk; ++t) {
+            const unsigned char* bufp = lds + (t & 1) * BUF;
+            const int nb = (t + 1) & 1;
+            // fragments: dY's three planes once per step; X's per tap -- plane 0 (first and last product of a tap) double-buffered,
+            // planes 2 and 1 re-read into the same registers as soon as their last product of the tap has issued
+            uint4 af[3], b0[2], b1, b2;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const uint4*>(bufp + fa + p * 2048);
+            b0[0] = *reinterpret_cast<const uint4*>(bufp + fb);
+            b1 = *reinterpret_cast<const uint4*>(bufp + fb + 2048);
+            b2 = *reinterpret_cast<const uint4*>(bufp + fb + 4096);
+            const unsigned n1 = lds[G1.tb + pk], n2 = TWO ? lds[G2.tb + pk] : 0u;          // masks of step t + 2
+#pragma unroll
+            for (int tp = 0; tp < NACC; ++tp) {
+                if (WGM != 4 && tp >= ntap) break;            // (wave-uniform; WGM = 4: never)
+                const int cb = tp & 1;
+                const bool more = tp + 1 < NACC;
+                const unsigned char* nx = bufp + fb + (tp + 1) * GRP;
+                // Work between this tap's MFMAs.  Quarter-unit u = 0 .. 15: group u >> 3, rows qp = (u >> 2) & 1, channel j = u & 3; after
+                // the fourth quarter of a row pair, that pair's loads for step t + 2.  WGM = 4 (nine taps): two quarters per tap;
+                // WGM = 2 (five or four taps): four
+                auto work = [&](int u) {
+                    if (u >= (TWO ? 16 : 8)) return;
+                    const int qp = (u >> 2) & 1, j = u & 3;
+                    if (u < 8) {
+                        quarter(G1, nb, qp, j, la);
+                        if (j == 3) issue(G1, n1, qp, la);
+                    } else {
+                        quarter(G2, nb, qp, j, lb);
+                        if (j == 3) issue(G2, n2, qp, lb);
+                    }
+                };
+                constexpr int PER = WGM == 4 ? 2 : 4;
+#define PECLR_FENCE __builtin_amdgcn_sched_barrier(0)
+                acc[tp] = mma(af[2], b0[cb], acc[tp]);       PECLR_FENCE;
+                if (more) b0[cb ^ 1] = *reinterpret_cast<const uint4*>(nx);
+                work(PER * tp);                               PECLR_FENCE;
+                acc[tp] = mma(af[0], b2, acc[tp]);           PECLR_FENCE;
+                if (more) b2 = *reinterpret_cast<const uint4*>(nx + 4096);
+                work(PER * tp + 1);                           PECLR_FENCE;
+                acc[tp] = mma(af[1], b1, acc[tp]);           PECLR_FENCE;
+                if (PER == 4) work(PER * tp + 2);             PECLR_FENCE;
+                acc[tp] = mma(af[1], b0[cb], acc[tp]);       PECLR_FENCE;
+                if (PER == 4) work(PER * tp + 3);             PECLR_FENCE;
+                acc[tp] = mma(af[0], b1, acc[tp]);           PECLR_FENCE;
+                if (more) b1 = *reinterpret_cast<const uint4*>(nx + 2048);
+                PECLR_FENCE;
+                acc[tp] = mma(af[0], b0[cb], acc[tp]);       PECLR_FENCE;
+#undef PECLR_FENCE
+            }
+            advance(G1);
+            if (TWO) advance(G2);
+            next_pixel();
+            __syncthreads();
+        }
+    };
+    if (two) run(std::true_type{});
+    else run(std::false_type{});
+
+    float* out = g.slabs + (size_t)blockIdx.y * g.M * g.ldc;
+    float* wlds = reinterpret_cast<float*>(lds) + wave * (32 * XEPL);
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+    const int mt = m0 + wm * 32, nt = n0 + wn * 32;
+#pragma unroll
+    for (int tp = 0; tp < NACC; ++tp) {
+        if (WGM != 4 && tp >= ntap) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = acc[tp][r];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int m = mt + er + 8 * jj, n = nt + ec;
+            const float4 c = *reinterpret_cast<const float4*>(wlds + (er + 8 * jj) * XEPL + ec);
+            if (m < g.M && n < g.N) *reinterpret_cast<float4*>(out + (size_t)m * g.ldc + (tap0 + tp) * g.N + n) = c;
+        }
+    }
+}
+
 constexpr int PF_SKINNY = 1;
 struct TilePick { int mt, nt, wgm; };
 // 1x1: workgroup tile 32 wgm mt x 256 / wgm nt.  64-wide sides (layer1) get tiles that are 64 wide on that side.
@@ -420,6 +652,14 @@ static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const flo
     g.taps = taps; g.H = H; g.W = W; g.stride = stride; g.zeros = zeros;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (taps == 9) {
+        // the re-scheduled loop (gemm_x6w2_kernel): stride 1, images of at most 56 x 56 output pixels (its table), operands below 2 GiB
+        // (32-bit buffer offsets); PECLR_X6W2=0 keeps the first form for A/B runs
+        static const bool x6w2 = getenv("PECLR_X6W2") ? atoi(getenv("PECLR_X6W2")) != 0 : true;
+        if (x6w2 && stride == 1 && H * W <= X6W2_MAX_HW && H * W >= TK && (long)(K + W + 2) * (lda > ldb ? lda : ldb) * 4 < 0x7fffffffL) {
+            if (M <= 64) hipLaunchKernelGGL(gemm_x6w2_kernel<2>, dim3(((M + 63) / 64) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
+            else hipLaunchKernelGGL(gemm_x6w2_kernel<4>, dim3(((M + 127) / 128) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
+            return launch_status();
+        }
         if (M <= 64) hipLaunchKernelGGL(gemm_x6w_kernel<2>, dim3(((M + 63) / 64) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
         else hipLaunchKernelGGL(gemm_x6w_kernel<4>, dim3(((M + 127) / 128) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
         return launch_status();

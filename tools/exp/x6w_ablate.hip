@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -31,6 +32,12 @@ template <int ABL> static void lw(hipStream_t st) {
 }
 template <int ABL> static void lr(hipStream_t st) {
     hipLaunchKernelGGL((wgrad_x6r_kernel<4, 1, ABL>), dim3((GR.M / 128) * (GR.N / 32), SR), dim3(512), 0, st, GR);
+}
+static void lv4(hipStream_t st) {
+    hipLaunchKernelGGL((gemm_x6w2_kernel<4>), dim3(((GW.M + 127) / 128) * ((GW.N + 63) / 64), SW), dim3(512), 0, st, GW);
+}
+static void lv2(hipStream_t st) {
+    hipLaunchKernelGGL((gemm_x6w2_kernel<2>), dim3(((GW.M + 63) / 64) * ((GW.N + 63) / 64), SW), dim3(512), 0, st, GW);
 }
 template <int ABL> static void lw2(hipStream_t st) {
     hipLaunchKernelGGL((gemm_x6w_kernel<2, ABL>), dim3(((GW.M + 63) / 64) * ((GW.N + 63) / 64), SW), dim3(512), 0, st, GW);
@@ -81,18 +88,31 @@ int main() {
         GR.pchunk = ((GR.P + SR - 1) / SR + 31) / 32 * 32;
         char what[160];
         snprintf(what, sizeof what, "3x3 weight gradient: %d images %d x %d, %d channels (slabs: nine-tap %d, ring %d)", NB, H, H, C, SW, SR);
+        {   // the re-scheduled kernel must reproduce the first form bit for bit (same products, same order per accumulator)
+            const size_t nb = (size_t)SW * C * 9 * C * 4;
+            std::vector<unsigned char> h0(nb), h1(nb);
+            CK(hipMemset(slabs, 0xFF, nb));
+            if (C == 64) lw2<0>(0); else lw<0>(0);
+            CK(hipMemcpy(h0.data(), slabs, nb, hipMemcpyDeviceToHost));
+            CK(hipMemset(slabs, 0xFF, nb));
+            if (C == 64) lv2(0); else lv4(0);
+            CK(hipMemcpy(h1.data(), slabs, nb, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t i = 0; i < nb; ++i) bad += h0[i] != h1[i];
+            printf("   gemm_x6w2 vs gemm_x6w: %zu of %zu bytes differ%s\n", bad, nb, bad ? "  <-- MISMATCH" : " (bit-identical)");
+        }
         if (C == 64) {
             const V vs[] = {{"nine-tap kernel (gemm_x6w), full", lw2<0>}, {"  X stored without the split", lw2<1>}, {"  X and dY stored without the split", lw2<3>},
-                            {"  no plane stores in the loop", lw2<7>}, {"  ... and no global loads: MFMAs + fragment reads", lw2<15>},
+                            {"  no plane stores in the loop", lw2<7>}, {"  ... and no global loads: MFMAs + fragment reads", lw2<15>}, {"  re-scheduled loop (gemm_x6w2)", lv2},
                             {"ring kernel (wgrad_x6r), full", lr2<0>}, {"  planes stored without the split", lr2<1>}, {"  no plane stores in the loop", lr2<3>},
                             {"  ... and no global loads: MFMAs + transposing reads", lr2<7>}};
-            if (run(what, vs, 9, 2.0 * K * C * 9 * C, junk)) return 1;
+            if (run(what, vs, 10, 2.0 * K * C * 9 * C, junk)) return 1;
         } else {
             const V vs[] = {{"nine-tap kernel (gemm_x6w), full", lw<0>}, {"  X stored without the split", lw<1>}, {"  X and dY stored without the split", lw<3>},
-                            {"  no plane stores in the loop", lw<7>}, {"  ... and no global loads: MFMAs + fragment reads", lw<15>},
+                            {"  no plane stores in the loop", lw<7>}, {"  ... and no global loads: MFMAs + fragment reads", lw<15>}, {"  re-scheduled loop (gemm_x6w2)", lv4},
                             {"ring kernel (wgrad_x6r), full", lr<0>}, {"  planes stored without the split", lr<1>}, {"  no plane stores in the loop", lr<3>},
                             {"  ... and no global loads: MFMAs + transposing reads", lr<7>}};
-            if (run(what, vs, 9, 2.0 * K * C * 9 * C, junk)) return 1;
+            if (run(what, vs, 10, 2.0 * K * C * 9 * C, junk)) return 1;
         }
     }
     return 0;
