@@ -472,25 +472,42 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
 
     f32x4 la[4], lb[4];
     unsigned m1 = 0, m2 = 0;                                  // table bytes of the step being loaded
-    // rows 2 qp, 2 qp + 1 of the lane's quad for the step whose offsets G holds
+    // row q of the lane's quad for the step whose offsets G holds
+    auto issue_row = [&](const Grp& G, unsigned msk, int q, f32x4 (&r)[4]) {
+        const unsigned o = (msk >> q) & 1u ? G.off + q * G.ld4 : 0x80000000u;
+        r[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(G.rs, (int)o, 0, 0));
+    };
     auto issue = [&](const Grp& G, unsigned msk, int qp, f32x4 (&r)[4]) {
-#pragma unroll
-        for (int q = 2 * qp; q < 2 * qp + 2; ++q) {
-            const unsigned o = (msk >> q) & 1u ? G.off + q * G.ld4 : 0x80000000u;
-            r[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(G.rs, (int)o, 0, 0));
-        }
+        issue_row(G, msk, 2 * qp, r);
+        issue_row(G, msk, 2 * qp + 1, r);
     };
     auto advance = [&](Grp& G) { G.off += G.step; };
     auto next_pixel = [&]() { pk += TK; pk = pk >= HW ? pk - HW : pk; };
-    // two of the lane's four rows (2 qp, 2 qp + 1), one of its four channels -> 4 bytes in each plane (a quarter-unit: the loop places
-    // them between MFMAs one at a time)
-    auto quarter = [&](const Grp& G, int buf, int qp, int j, const f32x4 (&r)[4]) {
-        unsigned h, m, l;
-        split3_pk(r[2 * qp][j], r[2 * qp + 1][j], h, m, l);
+    // two of the lane's four rows (2 qp, 2 qp + 1), one of its four channels -> 4 bytes in each plane: a quarter-unit, cut into three
+    // pieces of ~5 vector instructions (split3_pk of common.hpp, step by step) so that each fits under ONE MFMA of the loop
+    struct Quarter { unsigned h, m; float r0, r1; };
+    auto q_first = [&](Quarter& s, int qp, int j, const f32x4 (&r)[4]) {
+        const float x0 = r[2 * qp][j], x1 = r[2 * qp + 1][j];
+        s.h = pk_bf16(x0, x1);
+        s.r0 = sub_f32(x0, __uint_as_float(s.h << 16));
+        s.r1 = sub_f32(x1, __uint_as_float(s.h & 0xFFFF0000u));
+    };
+    auto q_second = [&](Quarter& s) {
+        s.m = pk_bf16(s.r0, s.r1);
+        s.r0 = sub_f32(s.r0, __uint_as_float(s.m << 16));
+        s.r1 = sub_f32(s.r1, __uint_as_float(s.m & 0xFFFF0000u));
+    };
+    auto q_third = [&](const Quarter& s, const Grp& G, int buf, int qp, int j) {
         unsigned char* d = lds + G.st + buf * BUF + 4 * qp + slot_of(cin + j) * 16;
-        *reinterpret_cast<unsigned*>(d) = h;
-        *reinterpret_cast<unsigned*>(d + 2048) = m;
-        *reinterpret_cast<unsigned*>(d + 4096) = l;
+        *reinterpret_cast<unsigned*>(d) = s.h;
+        *reinterpret_cast<unsigned*>(d + 2048) = s.m;
+        *reinterpret_cast<unsigned*>(d + 4096) = pk_bf16(s.r0, s.r1);
+    };
+    auto quarter = [&](const Grp& G, int buf, int qp, int j, const f32x4 (&r)[4]) {
+        Quarter s;
+        q_first(s, qp, j, r);
+        q_second(s);
+        q_third(s, G, buf, qp, j);
     };
 
     f32x16 acc[NACC];
@@ -543,36 +560,47 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
                 const int cb = tp & 1;
                 const bool more = tp + 1 < NACC;
                 const unsigned char* nx = bufp + fb + (tp + 1) * GRP;
-                // Work between this tap's MFMAs.  Quarter-unit u = 0 .. 15: group u >> 3, rows qp = (u >> 2) & 1, channel j = u & 3; after
-                // the fourth quarter of a row pair, that pair's loads for step t + 2.  WGM = 4 (nine taps): two quarters per tap;
-                // WGM = 2 (five or four taps): four
-                auto work = [&](int u) {
+                // Work between this tap's MFMAs.  Quarter-unit u = 0 .. 15: group u >> 3, rows qp = (u >> 2) & 1, channel j = u & 3, in three
+                // pieces; the fourth quarter of a row pair re-issues that pair's loads (for step t + 2) with its second and third piece,
+                // when the rows' registers are free.  WGM = 4 (nine taps): two quarters per tap, one piece per MFMA; WGM = 2 (five or
+                // four taps): four quarters per tap, two pieces per MFMA
+                constexpr int PER = WGM == 4 ? 2 : 4;
+                Quarter qs[PER];
+                auto piece = [&](int e) {                     // e = 0 .. 3 PER - 1: piece e % 3 of the tap's quarter e / 3
+                    const int u = PER * tp + e / 3, k = e % 3;
                     if (u >= (TWO ? 16 : 8)) return;
                     const int qp = (u >> 2) & 1, j = u & 3;
+                    Quarter& s = qs[e / 3];
                     if (u < 8) {
-                        quarter(G1, nb, qp, j, la);
-                        if (j == 3) issue(G1, n1, qp, la);
+                        if (k == 0) q_first(s, qp, j, la);
+                        else if (k == 1) { q_second(s); if (j == 3) issue_row(G1, n1, 2 * qp, la); }
+                        else { q_third(s, G1, nb, qp, j); if (j == 3) issue_row(G1, n1, 2 * qp + 1, la); }
                     } else {
-                        quarter(G2, nb, qp, j, lb);
-                        if (j == 3) issue(G2, n2, qp, lb);
+                        if (k == 0) q_first(s, qp, j, lb);
+                        else if (k == 1) { q_second(s); if (j == 3) issue_row(G2, n2, 2 * qp, lb); }
+                        else { q_third(s, G2, nb, qp, j); if (j == 3) issue_row(G2, n2, 2 * qp + 1, lb); }
                     }
                 };
-                constexpr int PER = WGM == 4 ? 2 : 4;
+                auto slot = [&](int si) {                     // the work after the tap's MFMA si
+                    if (WGM == 4) piece(si);
+                    else { piece(2 * si); piece(2 * si + 1); }
+                };
 #define PECLR_FENCE __builtin_amdgcn_sched_barrier(0)
                 acc[tp] = mma(af[2], b0[cb], acc[tp]);       PECLR_FENCE;
                 if (more) b0[cb ^ 1] = *reinterpret_cast<const uint4*>(nx);
-                work(PER * tp);                               PECLR_FENCE;
+                slot(0);                                      PECLR_FENCE;
                 acc[tp] = mma(af[0], b2, acc[tp]);           PECLR_FENCE;
                 if (more) b2 = *reinterpret_cast<const uint4*>(nx + 4096);
-                work(PER * tp + 1);                           PECLR_FENCE;
+                slot(1);                                      PECLR_FENCE;
                 acc[tp] = mma(af[1], b1, acc[tp]);           PECLR_FENCE;
-                if (PER == 4) work(PER * tp + 2);             PECLR_FENCE;
+                slot(2);                                      PECLR_FENCE;
                 acc[tp] = mma(af[1], b0[cb], acc[tp]);       PECLR_FENCE;
-                if (PER == 4) work(PER * tp + 3);             PECLR_FENCE;
+                slot(3);                                      PECLR_FENCE;
                 acc[tp] = mma(af[0], b1, acc[tp]);           PECLR_FENCE;
                 if (more) b1 = *reinterpret_cast<const uint4*>(nx + 2048);
-                PECLR_FENCE;
+                slot(4);                                      PECLR_FENCE;
                 acc[tp] = mma(af[0], b0[cb], acc[tp]);       PECLR_FENCE;
+                slot(5);                                      PECLR_FENCE;
 #undef PECLR_FENCE
             }
             advance(G1);
@@ -600,6 +628,199 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
             if (m < g.M && n < g.N) *reinterpret_cast<float4*>(out + (size_t)m * g.ldc + (tap0 + tp) * g.N + n) = c;
         }
     }
+}
+
+// ---- gemm_x6t_kernel (1x1 weight gradients, GEO = false) with its loop re-scheduled the same way (round 6): same tiles, same LDS
+// layout, same order of MFMAs per accumulator (bit-identical slabs).  Every wave owns one 64-column group of the split (or none);
+// its eight quarter-units, three pieces each, follow the step's 6 MT NT MFMAs at even distances; rows arrive by buffer loads
+// (out of range = zeros; the non-temporal hint of rows only one workgroup reads is kept -- a wave-uniform choice between two
+// load instructions); the B fragments of the second half of the output columns are fetched under the MFMAs of the first.
+// Measured at ResNet-50's shapes (tools/exp/x6w_ablate.hip 1, profiles/r06_x6t_ablate.txt): 5 - 28 % faster on every tile EXCEPT
+// 256 x 256 (12 - 26 % slower in every variant tried: fenced / unfenced, 24 pieces / four lumps) -- there the 48 MFMAs of a step
+// write eight independent accumulators, hipcc's "all MFMAs, then all vector work" already keeps the matrix cores fed from the
+// SIMD's other wave, and pieces between them only add issue stalls.  So the library keeps the first form for that tile.
+template <int MT, int NT, int WGM>
+__global__ __launch_bounds__(512, 2) void gemm_x6t2_kernel(X6TArgs g) {
+    constexpr int WGN = 8 / WGM;
+    constexpr int TM = 32 * WGM * MT, TN = 32 * WGN * NT;
+    static_assert((TM + TN) / 64 <= 8 && TM % 64 == 0 && TN % 64 == 0, "one 64-column group of the split per wave");
+    constexpr int HALF_A = TM * 16, HALF_B = TN * 16;         // bytes of one k-half of a plane
+    constexpr int PL_A = 2 * HALF_A, PL_B = 2 * HALF_B;
+    constexpr int BUF = 3 * (PL_A + PL_B);                    // one k-step of both operands
+    constexpr int XEPL = 36;
+    static_assert(2 * BUF >= 8 * 32 * XEPL * 4, "epilogue transposes live in the plane buffers");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int i = lane & 31, kh = lane >> 5;
+    const int nct = (g.N + TN - 1) / TN;
+    const int m0 = (int)(blockIdx.x / nct) * TM, n0 = (int)(blockIdx.x % nct) * TN;
+    const int kbeg = blockIdx.y * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (kend - kbeg + TK - 1) / TK;
+
+    // this wave's group of the split (gemm_x6t_kernel's roles)
+    const bool is_a = wave < TM / 64;
+    const bool active = wave < (TM + TN) / 64;
+    const int cgrp = is_a ? wave : wave - TM / 64;
+    const int chunk = (lane & 7) + 8 * (lane >> 5);           // 0..15 within the 64-column group
+    const int kq = (lane >> 3) & 3;
+    const int col = cgrp * 64 + 4 * chunk;                    // first of this thread's 4 columns inside the tile
+    const int ld = is_a ? g.lda : g.ldb;
+    const bool col_ok = active && (is_a ? m0 + col < g.M : n0 + col < g.N);
+    const int tile = col >> 5, cin = col & 31;
+    const int st_base = (kq >> 1) * (is_a ? HALF_A : HALF_B) + tile * 512 + (kq & 1) * 8 + (is_a ? 0 : 3 * PL_A);
+    const int st_plane = is_a ? PL_A : PL_B;
+    const bool once = is_a ? nct == 1 : (int)gridDim.x == nct;     // rows exactly one workgroup of a split reads: non-temporal
+
+    const unsigned long long bp = reinterpret_cast<unsigned long long>(is_a ? g.A : g.B);
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bp), bhi = __builtin_amdgcn_readfirstlane((unsigned)(bp >> 32));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((unsigned long long)bhi << 32 | blo), (short)0,
+                                                                        __builtin_amdgcn_readfirstlane(g.K * ld * 4), 0x00020000);
+    const unsigned ld4b = __builtin_amdgcn_readfirstlane((unsigned)ld * 4u), stepb = TK * ld4b;
+    unsigned off = col_ok ? (unsigned)(((kbeg + 4 * kq) * ld + (is_a ? m0 : n0) + col) * 4) : 0x80000000u;
+
+    f32x4 r4[4];
+    auto issue_row = [&](int q) {                             // row q of the lane's quad, step = where `off` stands
+        if (once) r4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + q * ld4b), 0, 2));
+        else r4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + q * ld4b), 0, 0));
+    };
+    struct Quarter { unsigned h, m; float r0, r1; };
+    auto q_first = [&](Quarter& s, int qp, int j) {
+        const float x0 = r4[2 * qp][j], x1 = r4[2 * qp + 1][j];
+        s.h = pk_bf16(x0, x1);
+        s.r0 = sub_f32(x0, __uint_as_float(s.h << 16));
+        s.r1 = sub_f32(x1, __uint_as_float(s.h & 0xFFFF0000u));
+    };
+    auto q_second = [&](Quarter& s) {
+        s.m = pk_bf16(s.r0, s.r1);
+        s.r0 = sub_f32(s.r0, __uint_as_float(s.m << 16));
+        s.r1 = sub_f32(s.r1, __uint_as_float(s.m & 0xFFFF0000u));
+    };
+    auto q_third = [&](const Quarter& s, int buf, int qp, int j) {
+        unsigned char* d = lds + buf * BUF + st_base + 4 * qp + slot_of(cin + j) * 16;
+        *reinterpret_cast<unsigned*>(d) = s.h;
+        *reinterpret_cast<unsigned*>(d + st_plane) = s.m;
+        *reinterpret_cast<unsigned*>(d + 2 * st_plane) = pk_bf16(s.r0, s.r1);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int y = 0; y < NT; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][y][r] = 0.f;
+
+    const int fa = kh * HALF_A + (wm * MT) * 512 + slot_of(i) * 16;                  // + a * 512 + plane * PL_A
+    const int fb = 3 * PL_A + kh * HALF_B + (wn * NT) * 512 + slot_of(i) * 16;       // + y * 512 + plane * PL_B
+
+    // prologue: step 0 -> buffer 0; step 1 in flight.  (Rows past the tensor read as zeros, rows past this slab are never multiplied.)
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_row(q);
+        off += stepb;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            Quarter s;
+            q_first(s, u >> 2, u & 3);
+            q_second(s);
+            q_third(s, 0, u >> 2, u & 3);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_row(q);
+        off += stepb;
+    }
+    __syncthreads();
+
+    constexpr int NH = NT > 2 ? 2 : 1, YH = NT / NH;          // B fragments in two halves (registers)
+    constexpr int NM = 6 * MT * NT;                           // MFMAs per step; piece e of 24 follows MFMA e NM / 24
+    auto run = [&](auto active_c) {
+        constexpr bool ACT = decltype(active_c)::value;
+        for (int t = 0; t < nk; ++t) {
+            const unsigned char* bufp = lds + (t & 1) * BUF;
+            const int nb = (t + 1) & 1;
+            uint4 af[MT][3], b0[2][YH], b1[YH], b2[YH];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const uint4*>(bufp + fa + a * 512 + p * PL_A);
+#pragma unroll
+            for (int y = 0; y < YH; ++y) {
+                b0[0][y] = *reinterpret_cast<const uint4*>(bufp + fb + y * 512);
+                b1[y] = *reinterpret_cast<const uint4*>(bufp + fb + y * 512 + PL_B);
+                b2[y] = *reinterpret_cast<const uint4*>(bufp + fb + y * 512 + 2 * PL_B);
+            }
+            Quarter qs;
+            auto work_after = [&](int n) {                    // the pieces that follow MFMA n of the step
+                if (!ACT) return;
+#pragma unroll
+                for (int e = 0; e < 24; ++e) {
+                    if (e * NM / 24 != n) continue;
+                    const int u = e / 3, k = e % 3, qp = u >> 2, j = u & 3;
+                    if (k == 0) q_first(qs, qp, j);
+                    else if (k == 1) { q_second(qs); if (j == 3) issue_row(2 * qp); }
+                    else { q_third(qs, nb, qp, j); if (j == 3) issue_row(2 * qp + 1); }
+                }
+            };
+#define PECLR_FENCE __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+            for (int half = 0; half < NH; ++half) {
+                const bool more = half + 1 < NH;
+                const unsigned char* nx = bufp + fb + (half + 1) * YH * 512;
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) {
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int y = 0; y < YH; ++y)
+#pragma unroll
+                        for (int a = 0; a < MT; ++a) {
+                            const uint4& bb = QB[pr] == 0 ? b0[half & 1][y] : (QB[pr] == 1 ? b1[y] : b2[y]);
+                            acc[a][half * YH + y] = mma(af[a][PA[pr]], bb, acc[a][half * YH + y]);
+                            PECLR_FENCE;
+                            const int n = (half * 6 + pr) * YH * MT + y * MT + a;
+                            // fragments of the second half: plane 0 into its second register set at once, planes 2 / 1 into the
+                            // registers their last product of this half has just left
+                            if (more && pr == 0 && a == MT - 1) b0[(half + 1) & 1][y] = *reinterpret_cast<const uint4*>(nx + y * 512);
+                            if (more && pr == 1 && a == MT - 1 && y == YH - 1) {
+#pragma unroll
+                                for (int yy = 0; yy < YH; ++yy) b2[yy] = *reinterpret_cast<const uint4*>(nx + yy * 512 + 2 * PL_B);
+                            }
+                            if (more && pr == 4 && a == MT - 1 && y == YH - 1) {
+#pragma unroll
+                                for (int yy = 0; yy < YH; ++yy) b1[yy] = *reinterpret_cast<const uint4*>(nx + yy * 512 + PL_B);
+                            }
+                            work_after(n);
+                            PECLR_FENCE;
+                        }
+                }
+            }
+#undef PECLR_FENCE
+            if (ACT) off += stepb;
+            __syncthreads();
+        }
+    };
+    if (active) run(std::true_type{});
+    else run(std::false_type{});
+
+    // epilogue: wave-private 32 x 32 transposes through LDS, 16-byte stores into this split's slab
+    float* out = g.slabs + (size_t)blockIdx.y * g.M * g.ldc;
+    float* wlds = reinterpret_cast<float*>(lds) + wave * (32 * XEPL);
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int y = 0; y < NT; ++y) {
+            const int mt = m0 + (wm * MT + a) * 32, nt = n0 + (wn * NT + y) * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wlds[mfma32_row(r, kh) * XEPL + i] = acc[a][y][r];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = mt + er + 8 * jj, n = nt + ec;
+                const float4 c = *reinterpret_cast<const float4*>(wlds + (er + 8 * jj) * XEPL + ec);
+                if (m < g.M && n < g.N) *reinterpret_cast<float4*>(out + (size_t)m * g.ldc + n) = c;
+            }
+        }
 }
 
 constexpr int PF_SKINNY = 1;
@@ -666,9 +887,13 @@ static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const flo
     }
     const TilePick t = pick_tile(M, N);
     const dim3 grid(((M + tile_m(t) - 1) / tile_m(t)) * ((N + tile_n(t) - 1) / tile_n(t)), n_slabs);
+    // the re-scheduled loop (gemm_x6t2_kernel): stride 1, operands below 2 GiB (32-bit buffer offsets); PECLR_X6T2=0 keeps the first form
+    static const bool x6t2_on = getenv("PECLR_X6T2") ? atoi(getenv("PECLR_X6T2")) != 0 : true;
+    const bool x6t2 = x6t2_on && stride == 1 && (long)(K + 2 * TK) * (lda > ldb ? lda : ldb) * 4 < 0x7fffffffL;
 #define PECLR_LAUNCH(MT_, NT_, WGM_, PF_)                                                                            \
     do {                                                                                                             \
         if (stride == 2) hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, true, PF_>), grid, dim3(512), 0, s, g); \
+        else if (x6t2) hipLaunchKernelGGL((gemm_x6t2_kernel<MT_, NT_, WGM_>), grid, dim3(512), 0, s, g);             \
         else hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, false, PF_>), grid, dim3(512), 0, s, g);            \
     } while (0)
     if (t.wgm == 2) {
@@ -677,7 +902,10 @@ static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const flo
     } else if (t.nt == 1) {
         if (t.mt == 2) PECLR_LAUNCH(2, 1, 4, PF_SKINNY);
         else PECLR_LAUNCH(1, 1, 4, PF_SKINNY);
-    } else if (t.mt == 2 && t.nt == 4) PECLR_LAUNCH(2, 4, 4, 1);
+    } else if (t.mt == 2 && t.nt == 4) {                       // 256 x 256: the first form is the faster one (see gemm_x6t2_kernel)
+        if (stride == 2) hipLaunchKernelGGL((gemm_x6t_kernel<2, 4, 4, true, 1>), grid, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((gemm_x6t_kernel<2, 4, 4, false, 1>), grid, dim3(512), 0, s, g);
+    }
     else if (t.mt == 2) PECLR_LAUNCH(2, 2, 4, 1);
     else if (t.nt == 4) PECLR_LAUNCH(1, 4, 4, 1);
     else PECLR_LAUNCH(1, 2, 4, 1);

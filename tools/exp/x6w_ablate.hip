@@ -65,14 +65,61 @@ static int run(const char* what, const V* vs, int nv, double flops, unsigned cha
     return 0;
 }
 
-int main() {
+// 1x1 weight gradients: the first form (gemm_x6t_kernel) against the re-scheduled one (gemm_x6t2_kernel), tile choice as the library's
+template <int MT, int NT, int WGM> static void l1(bool two, dim3 grid, hipStream_t st) {
+    if (two) hipLaunchKernelGGL((gemm_x6t2_kernel<MT, NT, WGM>), grid, dim3(512), 0, st, GW);
+    else hipLaunchKernelGGL((gemm_x6t_kernel<MT, NT, WGM, false, 1>), grid, dim3(512), 0, st, GW);
+}
+static bool L1_TWO;
+static void launch1(hipStream_t st) {
+    const TilePick t = pick_tile(GW.M, GW.N);
+    const dim3 grid(((GW.M + tile_m(t) - 1) / tile_m(t)) * ((GW.N + tile_n(t) - 1) / tile_n(t)), SW);
+    if (t.wgm == 2) { if (t.nt == 2) l1<1, 2, 2>(L1_TWO, grid, st); else l1<1, 1, 2>(L1_TWO, grid, st); }
+    else if (t.nt == 1) { if (t.mt == 2) l1<2, 1, 4>(L1_TWO, grid, st); else l1<1, 1, 4>(L1_TWO, grid, st); }
+    else if (t.mt == 2 && t.nt == 4) l1<2, 4, 4>(L1_TWO, grid, st);
+    else if (t.mt == 2) l1<2, 2, 4>(L1_TWO, grid, st);
+    else if (t.nt == 4) l1<1, 4, 4>(L1_TWO, grid, st);
+    else l1<1, 2, 4>(L1_TWO, grid, st);
+}
+static void l1_old(hipStream_t st) { L1_TWO = false; launch1(st); }
+static void l1_new(hipStream_t st) { L1_TWO = true; launch1(st); }
+
+static int one_by_one(float* A, float* B, float* slabs, float* zeros, unsigned char* junk) {
+    // (rows, Cout = M, Cin = N) of ResNet-50's 1x1 convolutions at 2 x 128 views @224
+    const int shapes[][3] = {{802816, 64, 64}, {802816, 256, 64}, {802816, 64, 256}, {200704, 128, 512}, {200704, 512, 128}, {200704, 128, 256},
+                             {50176, 256, 1024}, {50176, 1024, 256}, {50176, 256, 512}, {12544, 512, 2048}, {12544, 2048, 512}, {12544, 512, 1024}};
+    for (auto& sh : shapes) {
+        const int K = sh[0], M = sh[1], N = sh[2];
+        SW = peclr_gemm_x6t_slabs(M, N, K, 1);
+        GW = X6TArgs{};
+        GW.A = A; GW.B = B; GW.slabs = slabs; GW.M = M; GW.N = N; GW.K = K; GW.lda = M; GW.ldb = N; GW.ldc = N;
+        GW.kchunk = ((K + SW - 1) / SW + TK - 1) / TK * TK;
+        GW.taps = 1; GW.H = 1; GW.W = 1; GW.stride = 1; GW.zeros = zeros;
+        const size_t nb = (size_t)SW * M * N * 4;
+        if (nb > ((size_t)512 << 20)) { printf("slabs too large\n"); return 1; }
+        std::vector<unsigned char> h0(nb), h1(nb);
+        CK(hipMemset(slabs, 0xFF, nb)); l1_old(0); CK(hipMemcpy(h0.data(), slabs, nb, hipMemcpyDeviceToHost));
+        CK(hipMemset(slabs, 0xFF, nb)); l1_new(0); CK(hipMemcpy(h1.data(), slabs, nb, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (size_t i = 0; i < nb; ++i) bad += h0[i] != h1[i];
+        printf("   gemm_x6t2 vs gemm_x6t: %zu of %zu bytes differ%s\n", bad, nb, bad ? "  <-- MISMATCH" : " (bit-identical)");
+        char what[160];
+        snprintf(what, sizeof what, "1x1 weight gradient: %d rows, Cout %d x Cin %d (slabs %d)", K, M, N, SW);
+        const V vs[] = {{"first form (gemm_x6t)", l1_old}, {"  re-scheduled loop (gemm_x6t2)", l1_new}};
+        if (run(what, vs, 2, 2.0 * K * M * N, junk)) return 1;
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
     const int shapes3[][3] = {{256, 56, 64}, {256, 28, 128}, {256, 14, 256}, {256, 7, 512}};       // (images, H = W, C)
     float *A, *B, *slabs, *zeros; unsigned char* junk;
-    const size_t nel = (size_t)256 * 56 * 56 * 64;
+    const size_t nel = (size_t)802816 * 256;                  // (the widest 1x1 operand)
     CK(hipMalloc(&A, nel * 4)); CK(hipMalloc(&B, nel * 4)); CK(hipMalloc(&slabs, (size_t)512 << 20)); CK(hipMalloc(&junk, 512u << 20));
     CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256));
     fill<<<4096, 256>>>(A, nel, 1, 1.f);
     fill<<<4096, 256>>>(B, nel, 2, 1.f);
+    if (argc > 1 && argv[1][0] == '1') return one_by_one(A, B, slabs, zeros, junk);
     for (auto& sh : shapes3) {
         const int NB = sh[0], H = sh[1], C = sh[2], K = NB * H * H;
         SW = peclr_gemm_x6t_slabs(C, C, K, 9);
