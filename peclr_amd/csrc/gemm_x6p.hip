@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
     for (int t = 0; t + 1 < nk; ++t) kstep(t, std::true_type{});
     kstep(nk - 1, std::false_type{});
     } else {
-        static_assert(!HALO || (TAPS == 9 && AREG && (ABL & ~67) == 0), "HALO is the 3x3 / stride-1 path (ABL: 1 no split / plane stores, 2 no patch loads, 64 three products)");
+        static_assert(!HALO || (TAPS == 9 && AREG && (ABL & ~127) == 0 && !(ABL & 8)), "HALO is the 3x3 / stride-1 path (ABL: 1 no split / plane stores, 2 no patch loads, 4 no B DMA in the loop, 16 no barriers, 32 B fragments from buffer 0, 64 three products)");
         constexpr int NLD = (NPXM * 4 + 255) / 256;      // 16-byte loads per thread and chunk
         constexpr int NDMA = NTL == 4 ? NP : 1;          // B DMA instructions per wave and k-step (at least)
         unsigned char* const patch = lds + RAW0;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                 if (j == 1 && kc + 1 < nkc) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((ABL & 2) ? NDMA : NDMA + NLD) : "memory");
                 else if (s + 1 == nsteps) PECLR_VMCNT(0);        // (nothing was issued after the last chunk)
                 else if (s > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
-                __builtin_amdgcn_s_barrier();
+                if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 const int ja = j / 3, jb = j - 3 * ja;
                 const int dh = g.flip ? 1 - ja : ja - 1, dw = g.flip ? 1 - jb : jb - 1;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
                         af[a][p] = *reinterpret_cast<const uint4*>(lds + off);
                     }
                 }
-                const unsigned char* bt = lds + (s % NB) * CHL + lane * 16;
+                const unsigned char* bt = lds + ((ABL & 32) ? 0 : (s % NB)) * CHL + lane * 16;
 #pragma unroll
                 for (int half = 0; half < NTL / 2; ++half) {
                     uint4 bf[2][NP];
@@ -514,12 +514,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x6p_kernel(X6PArgs g) {
 #pragma unroll
                             for (int u = 0; u < NLD; ++u) asm volatile("" :: "v"(pr[u][0]), "v"(pr[u][3]));
                         }
-                        if (s + 2 < nsteps) issue_bh(s + 2);
+                        if (s + 2 < nsteps && !(ABL & 4)) issue_bh(s + 2);
                     }
                 }
             }
             if (kc + 1 < nkc && !(ABL & 1)) {
-                __builtin_amdgcn_s_barrier();             // every wave has read this chunk's patch
+                if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();             // every wave has read this chunk's patch
                 asm volatile("" ::: "memory");
                 store_patch();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (published by the barrier at the top of the next step)

@@ -30,6 +30,12 @@ static void launch3(const X6PArgs& g, hipStream_t st) {
     hipLaunchKernelGGL((gemm_x6p_kernel<WM, ABL, true, true, 9, NTL, true>), dim3(8 * ((nrb + 7) / 8) * (g.N / (32 * NTL))), dim3(256), 0, st, g);
 }
 
+template <int WM, int ABL, int NTL = 4>
+static void launch3p(const X6PArgs& g, hipStream_t st) {      // the fp16-pair arm (NP = 2) of the halo kernel
+    const int tm = 128 * WM, nrb = (g.M + tm - 1) / tm;
+    hipLaunchKernelGGL((gemm_x6p_kernel<WM, ABL, true, true, 9, NTL, true, 2>), dim3(8 * ((nrb + 7) / 8) * (g.N / (32 * NTL))), dim3(256), 0, st, g);
+}
+
 struct V { const char* name; void (*fn)(const X6PArgs&, hipStream_t); };
 
 static int run(const char* what, const X6PArgs& g, const V* vs, int nv, double flops, unsigned char* junk) {
@@ -52,7 +58,8 @@ static int run(const char* what, const X6PArgs& g, const V* vs, int nv, double f
     return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {          // no argument: everything; "3": the 3x3 shapes only; "3p": their fp16-pair arm
+    const bool only3 = argc > 1 && argv[1][0] == '3';
     // 1x1 forward shapes of ResNet-50 at 2 x 128 views @224: (rows, Cout, Cin)
     const int shapes[][3] = {{802816, 256, 64}, {200704, 512, 128}, {200704, 128, 512}, {50176, 1024, 256}, {50176, 256, 1024},
                              {12544, 2048, 512}, {12544, 512, 2048}, {16384, 2048, 512}};
@@ -65,6 +72,7 @@ int main() {
     fill<<<4096, 256>>>(A, (size_t)802816 * 512, 1, 1.f);
     fill<<<4096, 256>>>(W, (size_t)2048 * 4608, 2, 0.05f);
     for (auto& sh : shapes) {
+        if (only3) break;
         const int M = sh[0], N = sh[1], K = sh[2];
         PackDesc d{(int64_t)W, (int64_t)Bp, N, K, K, 0, 0, 0}, *dd;
         CK(hipMalloc(&dd, sizeof(d))); CK(hipMemcpy(dd, &d, sizeof(d), hipMemcpyHostToDevice));
@@ -92,12 +100,35 @@ int main() {
         g.stream_out = (size_t)M * N * 4 > ((size_t)64 << 20);
         char what[128];
         snprintf(what, sizeof what, "3x3 halo: %d images %d x %d, %d channels", NB, H, H, Cc);
+        {
+            static float* sc = nullptr;
+            if (!sc) { const float one[2] = {1.f, 1.f}; CK(hipMalloc(&sc, 8)); CK(hipMemcpy(sc, one, 8, hipMemcpyHostToDevice)); }
+            g.a_absmax = sc; g.w_scale = sc + 1;
+        }
+        if (only3 && argv[1][1] == 'p') {                 // "3p": the pair arm only (any bytes as planes: timing)
+            if (Cc == 64) {
+                const V vs[] = {{"fpair / 256-row tiles", launch3p<2, 0, 2>}, {"  no B DMA in the loop", launch3p<2, 36, 2>}, {"  ... and no barriers", launch3p<2, 52, 2>},
+                                {"  ... and no patch work", launch3p<2, 55, 2>}, {"fpair / 128-row tiles", launch3p<1, 0, 2>}};
+                if (run(what, g, vs, 5, 2.0 * M * N * K, junk)) return 1;
+            } else {
+                const V vs[] = {{"fpair / 256-row tiles", launch3p<2, 0>}, {"  no B DMA in the loop", launch3p<2, 36>}, {"  ... and no barriers", launch3p<2, 52>},
+                                {"  ... and no patch work", launch3p<2, 55>}, {"fpair / 128-row tiles", launch3p<1, 0>}};
+                if (run(what, g, vs, 5, 2.0 * M * N * K, junk)) return 1;
+            }
+            CK(hipFree(dd));
+            continue;
+        }
         if (Cc == 64) {
             const V vs[] = {{"full / 256-row tiles", launch3<2, 0, 2>}, {"  no split, no plane stores", launch3<2, 1, 2>}, {"  ... and no patch loads", launch3<2, 3, 2>}, {"  THREE products of the six (rest as full)", launch3<2, 64, 2>}};
             if (run(what, g, vs, 4, 2.0 * M * N * K, junk)) return 1;
         } else {
-            const V vs[] = {{"full / 256-row tiles", launch3<2, 0>}, {"  no split, no plane stores", launch3<2, 1>}, {"  ... and no patch loads", launch3<2, 3>}, {"  THREE products of the six (rest as full)", launch3<2, 64>}};
-            if (run(what, g, vs, 4, 2.0 * M * N * K, junk)) return 1;
+            const V vs[] = {{"full / 256-row tiles", launch3<2, 0>}, {"  no split, no plane stores", launch3<2, 1>}, {"  ... and no patch loads", launch3<2, 3>}, {"  THREE products of the six (rest as full)", launch3<2, 64>},
+                            {"fTHREE products / 256-row tiles", launch3<2, 64>}, {"  no B DMA in the loop (fragments from buffer 0)", launch3<2, 64 + 4 + 32>},
+                            {"  ... and no barriers", launch3<2, 64 + 4 + 32 + 16>}, {"  ... and no patch loads / split / stores", launch3<2, 64 + 4 + 32 + 16 + 3>},
+                            {"  barriers and DMA, but no patch work", launch3<2, 64 + 3>},
+                            {"fTHREE products / 128-row tiles", launch3<1, 64>}, {"  no B DMA in the loop (fragments from buffer 0)", launch3<1, 64 + 4 + 32>},
+                            {"  ... and no barriers", launch3<1, 64 + 4 + 32 + 16>}, {"  ... and no patch loads / split / stores", launch3<1, 64 + 4 + 32 + 16 + 3>}};
+            if (run(what, g, vs, 13, 2.0 * M * N * K, junk)) return 1;
         }
         CK(hipFree(dd));
     }
