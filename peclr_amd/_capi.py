@@ -723,7 +723,7 @@ def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, stride: i
         raise PeclrHipError(f"gemm_x6t: unsupported shape M={m} N={n} K={k}")
     slabs = torch.empty((ns, m, taps * n), device=a.device, dtype=torch.float32)
     with _timed(tag, 4 * (k * m + k2 * n // (stride * stride) * (1 if taps == 1 else stride * stride) + ns * m * n * taps),
-                2 * m * n * k * taps, kernel="gemm_x6t_kernel"):
+                2 * m * n * k * taps, kernel="gemm_x6w2_kernel | gemm_x6w_kernel" if taps == 9 else "gemm_x6t2_kernel | gemm_x6t_kernel"):
         rc = lib().peclr_gemm_x6t_f32(m, n, k, _ptr(a), a.stride(0), _ptr(b), b.stride(0), slabs.data_ptr(), ns, taps, h, w, stride,
                                       _zeros(a.device).data_ptr(), _stream())
     _check(rc, "peclr_gemm_x6t_f32")
@@ -758,7 +758,7 @@ def wgrad3_x6r(gy: torch.Tensor, x: torch.Tensor, tag: str = "conv3x3_wgrad") ->
         raise PeclrHipError(f"wgrad3_x6r: unsupported shape M={cout} N={cin} {nb} x {h} x {w}")
     slabs = torch.empty((ns, cout, 9 * cin), device=gy.device, dtype=torch.float32)
     k = nb * h * w
-    with _timed(tag, 4 * (k * cout + k * cin + ns * cout * 9 * cin), 18 * cout * cin * k, kernel="gemm_x6t_kernel"):
+    with _timed(tag, 4 * (k * cout + k * cin + ns * cout * 9 * cin), 18 * cout * cin * k, kernel="wgrad_x6r_kernel"):
         rc = lib().peclr_wgrad3_x6r_f32(cout, cin, nb, h, w, gp, xp, slabs.data_ptr(), ns, _stream())
     _check(rc, "peclr_wgrad3_x6r_f32")
     return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
