@@ -388,14 +388,21 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w_kernel(X6TArgs g) {
 // Waves 0 .. NG - 9 own two column groups, the others one: the loop is instantiated for both (TWO) and chosen per wave.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int X6W2_MAX_HW = 3136;                             // table bytes per tap (an image of up to 56 x 56 output pixels)
+constexpr int X6W2_TAB = 9 * X6W2_MAX_HW + 192;               // bytes of the table area
+constexpr int X6W2_S2_MAX_HW = X6W2_TAB / 36 - 3;             // stride 2: four bytes per tap and pixel (+ 3 wrap entries per tap): 28 x 28
 
-template <int WGM>
+// S2: the 3x3 / STRIDE-2 weight gradient (dY over the H x W output pixels, X over the 2H x 2W input pixels, read at (2 oh + dh,
+// 2 ow + dw)).  The row of X a (tap, output pixel) reads is not linear in the output pixel, so the table holds, per tap and pixel
+// of an image, the BYTE OFFSET of that row inside the image (or 2^30: no such row) -- with three more entries per tap for the quads
+// that run into the next image -- and a lane's offset is (its image's base + its columns) + the entry.
+
+template <int WGM, bool S2 = false>
 __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
     constexpr int GRP = 3 * 2 * 64 * 16;                      // bytes of one 64-column group: [plane][k-half][tile][slot][16]
     constexpr int NGA = WGM / 2, NG = NGA + 9, BUF = NG * GRP;
     constexpr int NACC = WGM == 4 ? 9 : 5;
     constexpr int XEPL = 36;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF + 9 * X6W2_MAX_HW];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF + X6W2_TAB];
     unsigned char* const tab = lds + 2 * BUF;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -409,9 +416,26 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
     const int nk = (kend - kbeg + TK - 1) / TK;
     const int HW = g.H * g.W;
 
+    const unsigned s2_ld4 = (unsigned)g.ldb * 4u, s2_img = 4u * HW * s2_ld4;      // S2: bytes per row / per image of X
+    const int s2_row = (HW + 3) * 4;                                               // S2: bytes of a tap's table row
+    if constexpr (S2) {
+        unsigned* t32 = reinterpret_cast<unsigned*>(tab);
+        for (int p = tid; p < HW; p += 512) {
+            const int oh = p / g.W, ow = p - oh * g.W;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ih = 2 * oh + tap / 3 - 1, iw = 2 * ow + tap % 3 - 1;          // (never past the bottom / right edge)
+                const bool in = ih >= 0 && iw >= 0;
+                const unsigned e = in ? (unsigned)(ih * 2 * g.W + iw) * s2_ld4 : 0x40000000u;
+                t32[tap * (HW + 3) + p] = e;
+                if (p < 3) t32[tap * (HW + 3) + HW + p] = in ? e + s2_img : 0x40000000u;
+            }
+        }
+        __syncthreads();
+    } else {
     // the table: tab[tap][p] bit q = the tap's neighbour of pixel (p + q) mod HW of an image lies inside it.  First the nine
     // taps of every pixel (one division per pixel; 16 bits each, in the plane buffers, which nothing uses yet), then the quads
-    {
+
         unsigned short* pm = reinterpret_cast<unsigned short*>(lds);
         for (int p = tid; p < HW; p += 512) {
             const int oh = p / g.W, ow = p - oh * g.W;
@@ -444,6 +468,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
         unsigned step, ld4;              // (wave-uniform) bytes per k-step / per row
         int tb;                          // (wave-uniform) LDS offset of this group's table row (dY: the centre tap's, all ones)
         int st;                          // LDS offset of this lane's stores inside buffer 0
+        bool isx;                        // (wave-uniform) S2: a group of X (offsets through the table)
     };
     auto grp_of = [&](int gi) {
         Grp s;
@@ -453,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
         const int ld = is_a ? g.lda : g.ldb;
         const int c = 4 * chunk + (is_a ? 64 * gi : 0);
         const bool ok = is_a ? m0 + c < g.M : n0 + c < g.N;
-        const long rows = (long)g.K + (shift < 0 ? shift : 0);
+        const long rows = S2 ? (is_a ? (long)g.K : 4L * g.K) : (long)g.K + (shift < 0 ? shift : 0);
         // (every word through readfirstlane: the descriptor must sit in scalar registers, or each load becomes a waterfall loop)
         const unsigned long long bp = reinterpret_cast<unsigned long long>(is_a ? g.A : g.B);
         const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bp), bhi = __builtin_amdgcn_readfirstlane((unsigned)(bp >> 32));
@@ -463,6 +488,11 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
         s.step = TK * s.ld4;
         s.off = ok ? (unsigned)(((kbeg + 4 * kq + shift) * ld + (is_a ? m0 : n0) + c) * 4) : 0x80000000u;
         s.tb = __builtin_amdgcn_readfirstlane(2 * BUF + tap * X6W2_MAX_HW);
+        s.isx = !is_a;
+        if constexpr (S2) {
+            if (!is_a) s.off = ok ? (unsigned)((kbeg + 4 * kq) / HW) * s2_img + (unsigned)(n0 + c) * 4u : 0x80000000u;
+            s.tb = __builtin_amdgcn_readfirstlane(2 * BUF + tap * s2_row);
+        }
         s.st = gi * GRP + st_off;
         return s;
     };
@@ -473,16 +503,33 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
     f32x4 la[4], lb[4];
     unsigned m1 = 0, m2 = 0;                                  // table bytes of the step being loaded
     // row q of the lane's quad for the step whose offsets G holds
+    // (S2: `msk` is the table entry of the row -- read some MFMAs earlier -- for a group of X, unused for dY)
     auto issue_row = [&](const Grp& G, unsigned msk, int q, f32x4 (&r)[4]) {
-        const unsigned o = (msk >> q) & 1u ? G.off + q * G.ld4 : 0x80000000u;
+        unsigned o;
+        if constexpr (S2) o = G.off + (G.isx ? msk : q * G.ld4);
+        else o = (msk >> q) & 1u ? G.off + q * G.ld4 : 0x80000000u;
         r[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(G.rs, (int)o, 0, 0));
     };
+    auto entry = [&](const Grp& G, int q) { return *reinterpret_cast<const unsigned*>(lds + G.tb + 4 * (pk + q)); };   // S2
     auto issue = [&](const Grp& G, unsigned msk, int qp, f32x4 (&r)[4]) {
-        issue_row(G, msk, 2 * qp, r);
-        issue_row(G, msk, 2 * qp + 1, r);
+        if constexpr (S2) {
+            issue_row(G, entry(G, 2 * qp), 2 * qp, r);
+            issue_row(G, entry(G, 2 * qp + 1), 2 * qp + 1, r);
+        } else {
+            issue_row(G, msk, 2 * qp, r);
+            issue_row(G, msk, 2 * qp + 1, r);
+        }
     };
-    auto advance = [&](Grp& G) { G.off += G.step; };
-    auto next_pixel = [&]() { pk += TK; pk = pk >= HW ? pk - HW : pk; };
+    unsigned winc = 0;                                        // S2: what the step just passed added to the image base
+    auto next_pixel = [&]() {
+        pk += TK;
+        if constexpr (S2) winc = pk >= HW ? s2_img : 0u;
+        pk = pk >= HW ? pk - HW : pk;
+    };
+    auto advance = [&](Grp& G) {                              // (after next_pixel)
+        if constexpr (S2) G.off += G.isx ? winc : G.step;
+        else G.off += G.step;
+    };
     // two of the lane's four rows (2 qp, 2 qp + 1), one of its four channels -> 4 bytes in each plane: a quarter-unit, cut into three
     // pieces of ~5 vector instructions (split3_pk of common.hpp, step by step) so that each fits under ONE MFMA of the loop
     struct Quarter { unsigned h, m; float r0, r1; };
@@ -520,10 +567,10 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
 
     __syncthreads();                                          // the table
     // prologue: step 0 -> buffer 0; step 1 in flight
-    m1 = lds[G1.tb + pk]; m2 = lds[G2.tb + pk];
+    if constexpr (!S2) { m1 = lds[G1.tb + pk]; m2 = lds[G2.tb + pk]; }
     issue(G1, m1, 0, la); issue(G1, m1, 1, la);
     if (two) { issue(G2, m2, 0, lb); issue(G2, m2, 1, lb); }
-    advance(G1); advance(G2); next_pixel();
+    next_pixel(); advance(G1); advance(G2);
 #pragma unroll
     for (int qp = 0; qp < 2; ++qp)
 #pragma unroll
@@ -531,10 +578,10 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
             quarter(G1, 0, qp, j, la);
             if (two) quarter(G2, 0, qp, j, lb);
         }
-    m1 = lds[G1.tb + pk]; m2 = lds[G2.tb + pk];
+    if constexpr (!S2) { m1 = lds[G1.tb + pk]; m2 = lds[G2.tb + pk]; }
     issue(G1, m1, 0, la); issue(G1, m1, 1, la);
     if (two) { issue(G2, m2, 0, lb); issue(G2, m2, 1, lb); }
-    advance(G1); advance(G2); next_pixel();
+    next_pixel(); advance(G1); advance(G2);
     __syncthreads();
 
     // step t: MFMAs on buffer t & 1; the registers hold step t + 1 (-> buffer (t + 1) & 1), loads for step t + 2 follow each half
@@ -553,7 +600,8 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
             b0[0] = *reinterpret_cast<const uint4*>(bufp + fb);
             b1 = *reinterpret_cast<const uint4*>(bufp + fb + 2048);
             b2 = *reinterpret_cast<const uint4*>(bufp + fb + 4096);
-            const unsigned n1 = lds[G1.tb + pk], n2 = TWO ? lds[G2.tb + pk] : 0u;          // masks of step t + 2
+            const unsigned n1 = S2 ? 0u : lds[G1.tb + pk], n2 = (!S2 && TWO) ? lds[G2.tb + pk] : 0u;          // masks of step t + 2
+            unsigned tq[2] = {0u, 0u};                        // S2: the table entries of the row pair about to be re-loaded
 #pragma unroll
             for (int tp = 0; tp < NACC; ++tp) {
                 if (WGM != 4 && tp >= ntap) break;            // (wave-uniform; WGM = 4: never)
@@ -572,13 +620,13 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
                     const int qp = (u >> 2) & 1, j = u & 3;
                     Quarter& s = qs[e / 3];
                     if (u < 8) {
-                        if (k == 0) q_first(s, qp, j, la);
-                        else if (k == 1) { q_second(s); if (j == 3) issue_row(G1, n1, 2 * qp, la); }
-                        else { q_third(s, G1, nb, qp, j); if (j == 3) issue_row(G1, n1, 2 * qp + 1, la); }
+                        if (k == 0) { q_first(s, qp, j, la); if (S2 && j == 2) { tq[0] = entry(G1, 2 * qp); tq[1] = entry(G1, 2 * qp + 1); } }
+                        else if (k == 1) { q_second(s); if (j == 3) issue_row(G1, S2 ? tq[0] : n1, 2 * qp, la); }
+                        else { q_third(s, G1, nb, qp, j); if (j == 3) issue_row(G1, S2 ? tq[1] : n1, 2 * qp + 1, la); }
                     } else {
-                        if (k == 0) q_first(s, qp, j, lb);
-                        else if (k == 1) { q_second(s); if (j == 3) issue_row(G2, n2, 2 * qp, lb); }
-                        else { q_third(s, G2, nb, qp, j); if (j == 3) issue_row(G2, n2, 2 * qp + 1, lb); }
+                        if (k == 0) { q_first(s, qp, j, lb); if (S2 && j == 2) { tq[0] = entry(G2, 2 * qp); tq[1] = entry(G2, 2 * qp + 1); } }
+                        else if (k == 1) { q_second(s); if (j == 3) issue_row(G2, S2 ? tq[0] : n2, 2 * qp, lb); }
+                        else { q_third(s, G2, nb, qp, j); if (j == 3) issue_row(G2, S2 ? tq[1] : n2, 2 * qp + 1, lb); }
                     }
                 };
                 auto slot = [&](int si) {                     // the work after the tap's MFMA si
@@ -603,9 +651,9 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
                 slot(5);                                      PECLR_FENCE;
 #undef PECLR_FENCE
             }
+            next_pixel();
             advance(G1);
             if (TWO) advance(G2);
-            next_pixel();
             __syncthreads();
         }
     };
@@ -879,6 +927,13 @@ static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const flo
         if (x6w2 && stride == 1 && H * W <= X6W2_MAX_HW && H * W >= TK && (long)(K + W + 2) * (lda > ldb ? lda : ldb) * 4 < 0x7fffffffL) {
             if (M <= 64) hipLaunchKernelGGL(gemm_x6w2_kernel<2>, dim3(((M + 63) / 64) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
             else hipLaunchKernelGGL(gemm_x6w2_kernel<4>, dim3(((M + 127) / 128) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
+            return launch_status();
+        }
+        // ... its stride-2 arm: output images of at most 28 x 28 pixels (four table bytes per tap and pixel), X below 1 GiB (2^30 marks "no row")
+        if (x6w2 && stride == 2 && H * W <= X6W2_S2_MAX_HW && H * W >= TK && (long)(K + 2 * TK) * lda * 4 < 0x7fffffffL &&
+            4L * (K + 2 * H * W) * ldb * 4 < 0x3fffffffL) {
+            if (M <= 64) hipLaunchKernelGGL((gemm_x6w2_kernel<2, true>), dim3(((M + 63) / 64) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
+            else hipLaunchKernelGGL((gemm_x6w2_kernel<4, true>), dim3(((M + 127) / 128) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
             return launch_status();
         }
         if (M <= 64) hipLaunchKernelGGL(gemm_x6w_kernel<2>, dim3(((M + 63) / 64) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);

@@ -22,6 +22,8 @@ ONE = [(50176, 128, 512), (40000 + 36, 256, 64), (8192 + 4, 132, 260), (3000, 51
 # (images, channels out, channels in, H, W) of 3x3 / stride-1 weight gradients: both workgroup shapes, H W % 4 != 0, W != H
 NINE = [(6, 128, 128, 9, 9), (4, 256, 256, 7, 7), (16, 256, 256, 14, 14), (5, 64, 64, 10, 10), (3, 36, 36, 11, 11), (2, 64, 64, 56, 56),
         (3, 132, 68, 7, 9), (7, 64, 128, 6, 13), (2, 192, 64, 28, 28)]
+# (images, channels out, channels in, H out, W out) of 3x3 / stride-2 weight gradients (X has 2H x 2W pixels)
+NINE_S2 = [(6, 128, 128, 9, 9), (3, 64, 64, 14, 14), (4, 256, 256, 7, 7), (3, 132, 68, 7, 6), (9, 64, 36, 10, 10), (2, 128, 128, 28, 28), (5, 512, 512, 7, 7)]
 
 
 def _inputs(seed, k, m, n):
@@ -39,6 +41,10 @@ def _all_results():
     for i, (nb, co, ci, h, w) in enumerate(NINE):
         a, b = _inputs(200 + i, nb * h * w, co, ci)
         out[f"nine{i}"] = _capi.gemm_x6t(a, b, taps=9, hw=(h, w)).cpu().numpy()
+    for i, (nb, co, ci, h, w) in enumerate(NINE_S2):
+        g = torch.Generator().manual_seed(300 + i)
+        a, b = torch.randn(nb * h * w, co, generator=g).to(DEV), torch.randn(4 * nb * h * w, ci, generator=g).to(DEV)
+        out[f"nine_s2_{i}"] = _capi.gemm_x6t(a, b, taps=9, hw=(h, w), stride=2).cpu().numpy()
     return out
 
 
@@ -71,13 +77,14 @@ def test_rescheduled_loops_leave_no_trace_of_rows_they_must_not_read():
     k = nb * h * w
     g = torch.Generator().manual_seed(7)
     pad = 4096
-    for taps, hw in ((9, (h, w)), (1, None)):
+    for taps, hw, stride in ((9, (h, w), 1), (1, None, 1), (9, (h, w), 2)):
+        kb = k * stride * stride
         big_a = torch.full((k + 2 * pad, c), float("nan"), device=DEV)
-        big_b = torch.full((k + 2 * pad, c), float("nan"), device=DEV)
-        a, b = torch.randn(k, c, generator=g).to(DEV), torch.randn(k, c, generator=g).to(DEV)
+        big_b = torch.full((kb + 2 * pad, c), float("nan"), device=DEV)
+        a, b = torch.randn(k, c, generator=g).to(DEV), torch.randn(kb, c, generator=g).to(DEV)
         big_a[pad:pad + k] = a
-        big_b[pad:pad + k] = b
-        inside = _capi.gemm_x6t(big_a[pad:pad + k], big_b[pad:pad + k], taps=taps, hw=hw)
-        alone = _capi.gemm_x6t(a, b, taps=taps, hw=hw)
+        big_b[pad:pad + kb] = b
+        inside = _capi.gemm_x6t(big_a[pad:pad + k], big_b[pad:pad + kb], taps=taps, hw=hw, stride=stride)
+        alone = _capi.gemm_x6t(a, b, taps=taps, hw=hw, stride=stride)
         assert torch.isfinite(inside).all()
         assert torch.equal(inside, alone)
