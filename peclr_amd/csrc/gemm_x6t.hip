@@ -924,7 +924,7 @@ static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const flo
         // the re-scheduled loop (gemm_x6w2_kernel): stride 1, images of at most 56 x 56 output pixels (its table), operands below 2 GiB
         // (32-bit buffer offsets); PECLR_X6W2=0 keeps the first form for A/B runs
         static const bool x6w2 = getenv("PECLR_X6W2") ? atoi(getenv("PECLR_X6W2")) != 0 : true;
-        if (x6w2 && stride == 1 && H * W <= X6W2_MAX_HW && H * W >= TK && (long)(K + W + 2) * (lda > ldb ? lda : ldb) * 4 < 0x7fffffffL) {
+        if (x6w2 && stride == 1 && H * W <= X6W2_MAX_HW && H * W >= TK && K > 2 * (W + 2) && (long)(K + W + 2) * (lda > ldb ? lda : ldb) * 4 < 0x7fffffffL) {
             if (M <= 64) hipLaunchKernelGGL(gemm_x6w2_kernel<2>, dim3(((M + 63) / 64) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
             else hipLaunchKernelGGL(gemm_x6w2_kernel<4>, dim3(((M + 127) / 128) * ((N + 63) / 64), n_slabs), dim3(512), 0, s, g);
             return launch_status();
