@@ -687,7 +687,11 @@ __global__ __launch_bounds__(512, 2) void gemm_x6w2_kernel(X6TArgs g) {
 // 256 x 256 (12 - 26 % slower in every variant tried: fenced / unfenced, 24 pieces / four lumps) -- there the 48 MFMAs of a step
 // write eight independent accumulators, hipcc's "all MFMAs, then all vector work" already keeps the matrix cores fed from the
 // SIMD's other wave, and pieces between them only add issue stalls.  So the library keeps the first form for that tile.
-template <int MT, int NT, int WGM>
+// PF2: two register sets for the rows -- loads run TWO k-steps ahead of the split (the loop unrolled by two: a set holds the steps
+// of one parity).  For the 64-wide tiles (layer1's gradients: HBM-bound, four to eight MFMAs per wave and step, so that one step
+// does not cover a round trip to HBM): 122 / 217 / 220 us against 135 / 237 / 242 with one set, 137 / 238 / 246 in the first form
+// (profiles/r06_x6t_ablate_pf2.txt); no gain, or a loss, on the wider tiles, which keep one set.
+template <int MT, int NT, int WGM, bool PF2 = false>
 __global__ __launch_bounds__(512, 2) void gemm_x6t2_kernel(X6TArgs g) {
     constexpr int WGN = 8 / WGM;
     constexpr int TM = 32 * WGM * MT, TN = 32 * WGN * NT;
@@ -728,14 +732,14 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t2_kernel(X6TArgs g) {
     const unsigned ld4b = __builtin_amdgcn_readfirstlane((unsigned)ld * 4u), stepb = TK * ld4b;
     unsigned off = col_ok ? (unsigned)(((kbeg + 4 * kq) * ld + (is_a ? m0 : n0) + col) * 4) : 0x80000000u;
 
-    f32x4 r4[4];
-    auto issue_row = [&](int q) {                             // row q of the lane's quad, step = where `off` stands
-        if (once) r4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + q * ld4b), 0, 2));
-        else r4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + q * ld4b), 0, 0));
+    f32x4 r4s[PF2 ? 2 : 1][4];
+    auto issue_row = [&](int q, int set = 0) {                // row q of the lane's quad, step = where `off` stands
+        if (once) r4s[set][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + q * ld4b), 0, 2));
+        else r4s[set][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + q * ld4b), 0, 0));
     };
     struct Quarter { unsigned h, m; float r0, r1; };
-    auto q_first = [&](Quarter& s, int qp, int j) {
-        const float x0 = r4[2 * qp][j], x1 = r4[2 * qp + 1][j];
+    auto q_first = [&](Quarter& s, int qp, int j, int set = 0) {
+        const float x0 = r4s[set][2 * qp][j], x1 = r4s[set][2 * qp + 1][j];
         s.h = pk_bf16(x0, x1);
         s.r0 = sub_f32(x0, __uint_as_float(s.h << 16));
         s.r1 = sub_f32(x1, __uint_as_float(s.h & 0xFFFF0000u));
@@ -776,8 +780,13 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t2_kernel(X6TArgs g) {
             q_third(s, 0, u >> 2, u & 3);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) issue_row(q);
+        for (int q = 0; q < 4; ++q) issue_row(q, PF2 ? 1 : 0);
         off += stepb;
+        if constexpr (PF2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) issue_row(q, 0);                              // step 2
+            off += stepb;
+        }
     }
     __syncthreads();
 
@@ -785,7 +794,12 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t2_kernel(X6TArgs g) {
     constexpr int NM = 6 * MT * NT;                           // MFMAs per step; piece e of 24 follows MFMA e NM / 24
     auto run = [&](auto active_c) {
         constexpr bool ACT = decltype(active_c)::value;
-        for (int t = 0; t < nk; ++t) {
+        for (int t0 = 0; t0 < nk; t0 += (PF2 ? 2 : 1))
+#pragma unroll
+        for (int par = 0; par < (PF2 ? 2 : 1); ++par) {
+            const int t = t0 + par;
+            if (PF2 && t >= nk) break;                        // (uniform)
+            const int set = PF2 ? (par ^ 1) : 0;              // the set that holds step t + 1
             const unsigned char* bufp = lds + (t & 1) * BUF;
             const int nb = (t + 1) & 1;
             uint4 af[MT][3], b0[2][YH], b1[YH], b2[YH];
@@ -806,9 +820,9 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t2_kernel(X6TArgs g) {
                 for (int e = 0; e < 24; ++e) {
                     if (e * NM / 24 != n) continue;
                     const int u = e / 3, k = e % 3, qp = u >> 2, j = u & 3;
-                    if (k == 0) q_first(qs, qp, j);
-                    else if (k == 1) { q_second(qs); if (j == 3) issue_row(2 * qp); }
-                    else { q_third(qs, nb, qp, j); if (j == 3) issue_row(2 * qp + 1); }
+                    if (k == 0) q_first(qs, qp, j, set);
+                    else if (k == 1) { q_second(qs); if (j == 3) issue_row(2 * qp, set); }
+                    else { q_third(qs, nb, qp, j); if (j == 3) issue_row(2 * qp + 1, set); }
                 }
             };
 #define PECLR_FENCE __builtin_amdgcn_sched_barrier(0)
@@ -871,7 +885,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x6t2_kernel(X6TArgs g) {
         }
 }
 
-constexpr int PF_SKINNY = 1;
+constexpr int PF_SKINNY = 0;                                 // (tag of the 64-wide tiles in the launch table below; the first form's PF is 1 for every tile)
 struct TilePick { int mt, nt, wgm; };
 // 1x1: workgroup tile 32 wgm mt x 256 / wgm nt.  64-wide sides (layer1) get tiles that are 64 wide on that side.
 inline TilePick pick_tile(int M, int N) {
@@ -947,9 +961,9 @@ static int gemm_x6t_host(int M, int N, int K, const float* A, int lda, const flo
     const bool x6t2 = x6t2_on && stride == 1 && (long)(K + 2 * TK) * (lda > ldb ? lda : ldb) * 4 < 0x7fffffffL;
 #define PECLR_LAUNCH(MT_, NT_, WGM_, PF_)                                                                            \
     do {                                                                                                             \
-        if (stride == 2) hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, true, PF_>), grid, dim3(512), 0, s, g); \
-        else if (x6t2) hipLaunchKernelGGL((gemm_x6t2_kernel<MT_, NT_, WGM_>), grid, dim3(512), 0, s, g);             \
-        else hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, false, PF_>), grid, dim3(512), 0, s, g);            \
+        if (stride == 2) hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, true, 1>), grid, dim3(512), 0, s, g);   \
+        else if (x6t2) hipLaunchKernelGGL((gemm_x6t2_kernel<MT_, NT_, WGM_, (PF_) == PF_SKINNY>), grid, dim3(512), 0, s, g); \
+        else hipLaunchKernelGGL((gemm_x6t_kernel<MT_, NT_, WGM_, false, 1>), grid, dim3(512), 0, s, g);              \
     } while (0)
     if (t.wgm == 2) {
         if (t.nt == 2) PECLR_LAUNCH(1, 2, 2, PF_SKINNY);

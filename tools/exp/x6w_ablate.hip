@@ -66,8 +66,10 @@ static int run(const char* what, const V* vs, int nv, double flops, unsigned cha
 }
 
 // 1x1 weight gradients: the first form (gemm_x6t_kernel) against the re-scheduled one (gemm_x6t2_kernel), tile choice as the library's
+static bool L1_PF2;
 template <int MT, int NT, int WGM> static void l1(bool two, dim3 grid, hipStream_t st) {
-    if (two) hipLaunchKernelGGL((gemm_x6t2_kernel<MT, NT, WGM>), grid, dim3(512), 0, st, GW);
+    if (two && L1_PF2) hipLaunchKernelGGL((gemm_x6t2_kernel<MT, NT, WGM, true>), grid, dim3(512), 0, st, GW);
+    else if (two) hipLaunchKernelGGL((gemm_x6t2_kernel<MT, NT, WGM>), grid, dim3(512), 0, st, GW);
     else hipLaunchKernelGGL((gemm_x6t_kernel<MT, NT, WGM, false, 1>), grid, dim3(512), 0, st, GW);
 }
 static bool L1_TWO;
@@ -81,8 +83,9 @@ static void launch1(hipStream_t st) {
     else if (t.nt == 4) l1<1, 4, 4>(L1_TWO, grid, st);
     else l1<1, 2, 4>(L1_TWO, grid, st);
 }
-static void l1_old(hipStream_t st) { L1_TWO = false; launch1(st); }
-static void l1_new(hipStream_t st) { L1_TWO = true; launch1(st); }
+static void l1_old(hipStream_t st) { L1_TWO = false; L1_PF2 = false; launch1(st); }
+static void l1_new(hipStream_t st) { L1_TWO = true; L1_PF2 = false; launch1(st); }
+static void l1_pf2(hipStream_t st) { L1_TWO = true; L1_PF2 = true; launch1(st); }
 
 static int one_by_one(float* A, float* B, float* slabs, float* zeros, unsigned char* junk) {
     // (rows, Cout = M, Cin = N) of ResNet-50's 1x1 convolutions at 2 x 128 views @224
@@ -105,8 +108,12 @@ static int one_by_one(float* A, float* B, float* slabs, float* zeros, unsigned c
         printf("   gemm_x6t2 vs gemm_x6t: %zu of %zu bytes differ%s\n", bad, nb, bad ? "  <-- MISMATCH" : " (bit-identical)");
         char what[160];
         snprintf(what, sizeof what, "1x1 weight gradient: %d rows, Cout %d x Cin %d (slabs %d)", K, M, N, SW);
-        const V vs[] = {{"first form (gemm_x6t)", l1_old}, {"  re-scheduled loop (gemm_x6t2)", l1_new}};
-        if (run(what, vs, 2, 2.0 * K * M * N, junk)) return 1;
+        CK(hipMemset(slabs, 0xFF, nb)); l1_pf2(0); CK(hipMemcpy(h1.data(), slabs, nb, hipMemcpyDeviceToHost));
+        bad = 0;
+        for (size_t i = 0; i < nb; ++i) bad += h0[i] != h1[i];
+        printf("   gemm_x6t2 (loads two steps ahead) vs gemm_x6t: %zu of %zu bytes differ%s\n", bad, nb, bad ? "  <-- MISMATCH" : " (bit-identical)");
+        const V vs[] = {{"first form (gemm_x6t)", l1_old}, {"  re-scheduled loop (gemm_x6t2)", l1_new}, {"  ... loads two k-steps ahead", l1_pf2}};
+        if (run(what, vs, 3, 2.0 * K * M * N, junk)) return 1;
     }
     return 0;
 }
