@@ -567,15 +567,6 @@ int peclr_conv_h(int dtype, int NB, int H, int W, int Cin, int Cout, int taps, i
                  const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
 int peclr_conv3x3_s2_dgrad_h(int dtype, int NB, int Ho, int Wo, int Cout, int Cin, const void* dY, const void* Bp, void* dX,
                              int tile_rows, const void* zeros, const peclr_bn_bwd_fuse* bn_bwd, peclr_stream_t stream);
-/* fp32 weight gradient of the 3x3 / padding-1 / stride-1 convolutions, third generation (csrc/wgrad_x6r.hip): the same six-product
- * arithmetic as peclr_gemm_x6t_f32 with taps = 9 (fp32 accuracy on the bf16 matrix cores, fixed-order slabs), but every element
- * of dY and X is split ONCE per workgroup: the bf16 planes lie pixel-major in LDS, X in a ring that each k-step advances, and
- * ds_read_b64_tr_b16 builds the nine taps' fragments at their slot offsets over a padded linear pixel space (see
- * peclr_wgrad3_h).  dY [images, H, W, M = Cout], X [images, H, W, N = Cin] fp32 NHWC; M, N multiples of 64, W <= 62; slabs
- * [peclr_wgrad3_x6r_slabs(...)][M][9 N].  Replaces MIOpen's fp32 3x3 weight gradient behind resnet_model.py:15. */
-int peclr_wgrad3_x6r_slabs(int M, int N, int images, int H, int W);
-int peclr_wgrad3_x6r_f32(int M, int N, int images, int H, int W, const float* dY, const float* X, float* slabs, int n_slabs,
-                         peclr_stream_t stream);
 /* Weight gradient of a 16-bit 1x1 convolution (csrc/wgrad_h.hip): dW[Cout][Cin] (fp32) = dY^T X over the rows of two NHWC
  * activations -- A = dY [K][lda] (M = Cout), B = X [K][ldb] (N = Cin); stride = 2 (the 1x1 / stride-2 shortcut): A's K rows are
  * the Ho x Wo output pixels, B holds the 2 Ho x 2 Wo input pixels.  Both operands go global -> LDS by LDS-DMA as they lie in

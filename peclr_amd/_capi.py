@@ -98,8 +98,6 @@ SIGNATURES = {
     "peclr_gemm_h": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
     "peclr_conv_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "peclr_conv3x3_s2_dgrad_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
-    "peclr_wgrad3_x6r_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "peclr_wgrad3_x6r_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P]),
     "peclr_wgrad3_h_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "peclr_wgrad3_h": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "peclr_wgrad_h_slabs": (c_int, [c_int, c_int, c_int]),
@@ -727,40 +725,6 @@ def gemm_x6t(a: torch.Tensor, b: torch.Tensor, taps: int = 1, hw=None, stride: i
         rc = lib().peclr_gemm_x6t_f32(m, n, k, _ptr(a), a.stride(0), _ptr(b), b.stride(0), slabs.data_ptr(), ns, taps, h, w, stride,
                                       _zeros(a.device).data_ptr(), _stream())
     _check(rc, "peclr_gemm_x6t_f32")
-    return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
-
-
-def wgrad3_x6r_pays(gy: torch.Tensor, x: torch.Tensor) -> bool:
-    """Is the ring kernel the faster one?  Measured at ResNet-50's shapes (tools/exp/wgrad3_probe.py, 2 x 128 views @224): 64
-    channels at 56 x 56: 425 us against the nine-splits kernel's 527; 128 / 256 / 512 channels: 384 / 405 / 461 against 360 / 360 /
-    344 -- there the padded pixel space (+ 7 ... 31 % MFMA work) and the exposed LDS round trips of its one workgroup per CU
-    cost more than the eight saved splits bring."""
-    return wgrad3_x6r_ok(gy, x) and gy.shape[1] <= 64
-
-
-def wgrad3_x6r_ok(gy: torch.Tensor, x: torch.Tensor) -> bool:
-    """Does peclr_wgrad3_x6r_f32 take this 3x3 / stride-1 weight gradient?"""
-    return (gy.dtype == torch.float32 and x.dtype == torch.float32 and x.shape[2:] == gy.shape[2:] and x.shape[3] <= 62
-            and gy.shape[1] % 64 == 0 and x.shape[1] % 64 == 0 and gy.shape[0] * gy.shape[2] * gy.shape[3] >= 1024)
-
-
-def wgrad3_x6r(gy: torch.Tensor, x: torch.Tensor, tag: str = "conv3x3_wgrad") -> torch.Tensor:
-    """dW [Cout, 9 * Cin] (fp32; = the [Cout][3][3][Cin] storage of a channels_last weight) of a 3x3 / padding-1 / stride-1
-    convolution from fp32 NHWC gy [N, Cout, H, W], x [N, Cin, H, W]: every element split once, nine taps by transposing LDS
-    reads of a ring (peclr_wgrad3_x6r_f32 + peclr_slab_reduce_f32: deterministic)."""
-    if not wgrad3_x6r_ok(gy, x):
-        raise PeclrHipError(f"wgrad3_x6r: unsupported problem gy {tuple(gy.shape)} x {tuple(x.shape)}")
-    nb, cout, h, w = gy.shape
-    cin = x.shape[1]
-    gp, xp = _nhwc_ptr(gy, "wgrad3_x6r gy", torch.float32), _nhwc_ptr(x, "wgrad3_x6r x", torch.float32)
-    ns = lib().peclr_wgrad3_x6r_slabs(cout, cin, nb, h, w)
-    if ns < 1:
-        raise PeclrHipError(f"wgrad3_x6r: unsupported shape M={cout} N={cin} {nb} x {h} x {w}")
-    slabs = torch.empty((ns, cout, 9 * cin), device=gy.device, dtype=torch.float32)
-    k = nb * h * w
-    with _timed(tag, 4 * (k * cout + k * cin + ns * cout * 9 * cin), 18 * cout * cin * k, kernel="wgrad_x6r_kernel"):
-        rc = lib().peclr_wgrad3_x6r_f32(cout, cin, nb, h, w, gp, xp, slabs.data_ptr(), ns, _stream())
-    _check(rc, "peclr_wgrad3_x6r_f32")
     return slabs[0] if ns == 1 else slab_reduce(slabs, tag="wgrad_slab_reduce")
 
 

@@ -146,7 +146,6 @@ class Routing:
     # two fp16 numbers, three MFMA products instead of six -- where the operand tensor carries its maximum (`_peclr_absmax`, written
     # by the BatchNorm pass that produced it); anything else runs the six-product kernels as before
     x6_pair: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_X6_PAIR"))
-    wgrad3_ring: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD3_RING"))      # fp32 3x3 weight gradient: one split per element (LDS ring + transposing reads)
     wgrad16: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_WGRAD16"))              # ... and their weight gradients
     stem_wgrad: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_STEM_WGRAD"))        # ... and its weight gradient
     stem: bool = dataclasses.field(default_factory=lambda: _env_flag("PECLR_STEM"))                    # the 7x7 / stride-2 stem forward in-tree (csrc/stem.hip)
@@ -677,9 +676,6 @@ def _wgrad_3x3_x6(gy: Tensor, x: Tensor, weight: Tensor, param=None, stride: int
     cout, ho, wo = gy.shape[1:]
 
     def run():
-        if taps == 9 and stride == 1 and ROUTING.wgrad3_ring and (_capi.wgrad3_x6r_pays(gy, x) or (ROUTING.force and _capi.wgrad3_x6r_ok(gy, x))):
-            # every element split once, the nine taps by transposing reads of an LDS ring (peclr_wgrad3_x6r_f32)
-            return _capi.wgrad3_x6r(gy, x).view(cout, 3, 3, cin).permute(0, 3, 1, 2)
         gy2, x2 = gy.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
         dw = _capi.gemm_x6t(gy2, x2, taps=taps, hw=(ho, wo), stride=stride, tag="conv3x3_wgrad" if taps == 9 else "conv1x1_wgrad")
         if taps == 9:

@@ -448,30 +448,3 @@ def test_3x3_weight_gradient_and_stride_2_kernels_repeat_themselves_bit_for_bit(
         d0 = capi.gemm_x6t(ys2, x2, taps=taps, hw=(hw // 2, hw // 2), stride=2)
         for _ in range(6):
             assert torch.equal(capi.gemm_x6t(ys2, x2, taps=taps, hw=(hw // 2, hw // 2), stride=2), d0), taps
-
-
-@pytest.mark.parametrize("nb,cout,cin,h,w", [(16, 128, 128, 28, 28), (8, 64, 64, 56, 56), (7, 256, 256, 14, 14), (32, 512, 512, 7, 7), (9, 128, 64, 9, 13),
-                                             (2, 64, 192, 30, 62)])
-def test_wgrad3_x6r_is_an_fp32_weight_gradient(nb, cout, cin, h, w):
-    """peclr_wgrad3_x6r_f32 (every element split once, the nine taps by transposing reads of an LDS ring over the padded pixel
-    space): error against float64 no worse than the nine-splits kernel's (peclr_gemm_x6t_f32, taps = 9) on the same data -- the
-    same six products per term --, every tap at the image borders included, bit-identical when repeated."""
-    from peclr_amd import _capi as capi
-
-    g = torch.Generator(device=DEV).manual_seed(nb + cout + cin + h)
-    x = torch.randn(nb, cin, h, w, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
-    gy = torch.randn(nb, cout, h, w, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
-    assert capi.wgrad3_x6r_ok(gy, x)
-    dw = capi.wgrad3_x6r(gy, x)
-    wz = torch.zeros(cout, cin, 3, 3, device=DEV, dtype=torch.float64)
-    ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), wz, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                              [False, True, False])[1]
-    got = dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2).double()
-    scale = float(ref.abs().max())
-    err = float((got - ref).abs().max()) / scale
-    gy2, x2 = gy.permute(0, 2, 3, 1).reshape(-1, cout), x.permute(0, 2, 3, 1).reshape(-1, cin)
-    old = capi.gemm_x6t(gy2, x2, taps=9, hw=(h, w)).view(cout, 3, 3, cin).permute(0, 3, 1, 2).double() if w >= 6 else None
-    err_old = float((old - ref).abs().max()) / scale if old is not None else 0.0
-    assert err <= max(2 * err_old, 3e-6), (err, err_old)
-    for _ in range(6):
-        assert torch.equal(capi.wgrad3_x6r(gy, x), dw)

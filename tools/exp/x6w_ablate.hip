@@ -3,9 +3,10 @@
 // C2 step (ResNet-50, 2 x 128 views @224).  Round 6 question: what would X / dY that arrive ALREADY split (bf16 planes written by
 // the BatchNorm pass that produces them) buy the weight gradients?  Upper bounds: "no split" = the planes still travel through
 // registers and ds_write; "no plane stores" = they arrive by LDS-DMA (no VALU, no ds_write).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm -I peclr_amd/csrc tools/exp/x6w_ablate.hip -o tools/exp/x6w_ablate
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm -I peclr_amd/csrc -I tools/exp tools/exp/x6w_ablate.hip -o tools/exp/x6w_ablate
+// (wgrad_x6r.hip, the ring kernel, left the library at the end of round 6 and lives next to this file)
 #include "gemm_x6t.hip"
-#include "wgrad_x6r.hip"
+#include "wgrad_x6r.hip"                                  // (tools/exp: -I tools/exp)
 
 #include <algorithm>
 #include <cstdio>
