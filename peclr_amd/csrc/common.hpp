@@ -90,6 +90,22 @@ __host__ __device__ __forceinline__ float pair_scale(float amax) {
     return s;
 }
 
+// The entry of a pack table (8 x int64 per entry, field 6 = the entry's first chunk) that chunk `blockIdx.x` of a launch belongs to:
+// the LAST entry whose first chunk is <= blockIdx.x.  Every thread tests a few entries and the one that holds the chunk says so
+// through LDS -- a workgroup-uniform linear walk over the table was ~100 dependent loads per workgroup (tables of 106 ... 310
+// matrices): 88 us for a pass that moves 94 MB.
+__device__ __forceinline__ int pack_entry_of_chunk(const int64_t* table, int count) {
+    __shared__ int sel;
+    const int64_t c = (int64_t)blockIdx.x;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        const int64_t b = table[8 * i + 6];
+        const bool last = i + 1 == count || c < table[8 * (i + 1) + 6];
+        if (c >= b && last) sel = i;                          // (entries that own no chunk share their successor's first chunk: never chosen)
+    }
+    __syncthreads();
+    return sel;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Returns the hipError_t of the most recent launch as a positive int (0 = ok).

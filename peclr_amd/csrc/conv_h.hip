@@ -24,6 +24,8 @@
 
 #include "common.hpp"
 
+#include <cstddef>
+
 namespace peclr {
 namespace {
 
@@ -653,8 +655,8 @@ struct HPackDesc {          // device table entry (8 x int64): as PackDesc of ge
 };
 
 __global__ __launch_bounds__(256) void h_pack_kernel(const HPackDesc* descs, int count) {
-    int d = 0;
-    while (d + 1 < count && (int64_t)blockIdx.x >= descs[d + 1].chunk_begin) ++d;
+    static_assert(sizeof(HPackDesc) == 64 && offsetof(HPackDesc, chunk_begin) == 48, "pack_entry_of_chunk reads field 6 of 8 x int64 entries");
+    const int d = pack_entry_of_chunk(reinterpret_cast<const int64_t*>(descs), count);
     const HPackDesc e = descs[d];
     const int chunk = (int)(blockIdx.x - e.chunk_begin);
     const int nks = (int)(e.k / HK);

@@ -27,6 +27,8 @@
 
 #include "common.hpp"
 
+#include <cstddef>
+
 namespace peclr {
 namespace {
 
@@ -691,8 +693,8 @@ struct PackDesc {           // device table entry (8 x int64)
 };
 
 __global__ __launch_bounds__(256) void x6_pack_kernel(const PackDesc* descs, int count) {
-    int d = 0;
-    while (d + 1 < count && (int64_t)blockIdx.x >= descs[d + 1].chunk_begin) ++d;
+    static_assert(sizeof(PackDesc) == 64 && offsetof(PackDesc, chunk_begin) == 48, "pack_entry_of_chunk reads field 6 of 8 x int64 entries");
+    const int d = pack_entry_of_chunk(reinterpret_cast<const int64_t*>(descs), count);
     const PackDesc e = descs[d];
     const int chunk = (int)(blockIdx.x - e.chunk_begin);
     const int nks = (int)(e.k / PK);
@@ -757,8 +759,8 @@ __device__ __forceinline__ void pack_load8(const PackDesc& e, int n, int k0, flo
 
 template <bool PACK>
 __global__ __launch_bounds__(256) void x6_pair_kernel(const PackDesc* descs, int count, float* absmax, float* scales) {
-    int d = 0;
-    while (d + 1 < count && (int64_t)blockIdx.x >= descs[d + 1].chunk_begin) ++d;
+    static_assert(sizeof(PackDesc) == 64 && offsetof(PackDesc, chunk_begin) == 48, "pack_entry_of_chunk reads field 6 of 8 x int64 entries");
+    const int d = pack_entry_of_chunk(reinterpret_cast<const int64_t*>(descs), count);
     const PackDesc e = descs[d];
     // a matrix and its transpose (forward and input-gradient planes of one weight: neighbours in the table, same source) share
     // their maximum: found once, through the first of the two entries
