@@ -757,45 +757,68 @@ __device__ __forceinline__ void pack_load8(const PackDesc& e, int n, int k0, flo
     }
 }
 
-template <bool PACK>
-__global__ __launch_bounds__(256) void x6_pair_kernel(const PackDesc* descs, int count, float* absmax, float* scales) {
+// max |W| per matrix of a pack table: workgroup (x, d) walks chunks x, x + gridDim.x, ... of matrix d (a matrix and its transpose --
+// neighbours in the table, same source -- share the maximum: only the first of the two is read) and ends with ONE conditional atomic.
+// (Through round 6 this was the pack kernel's grid, one 8 KiB chunk per workgroup: 127 us for 94 MB.)
+__global__ __launch_bounds__(256) void x6_absmax_kernel(const PackDesc* descs, int count, float* absmax) {
+    const int d = blockIdx.y;
+    const PackDesc e = descs[d];
+    if (d > 0 && e.transposed && descs[d - 1].src == e.src && !descs[d - 1].transposed) return;
+    const int nks = (int)(e.k / PK), nchunks = (int)((e.n + PN - 1) / PN) * nks;
+    const int col = threadIdx.x & 127, kh = threadIdx.x >> 7;
+    float m = 0.f;
+    if (!e.transposed) {                                      // B_t[n][k] = src[n * ld + k]: rows of k contiguous floats, 16 bytes per lane
+        const float* src = reinterpret_cast<const float*>(e.src);
+        const int k4 = (int)(e.k / 4);
+        const long total = (long)e.n * k4;
+        for (long f = (long)blockIdx.x * 256 + threadIdx.x; f < total; f += (long)gridDim.x * 256) {
+            const long row = f / k4;
+            const float4 v = *reinterpret_cast<const float4*>(src + row * e.ld + 4 * (f - row * k4));
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    } else
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int ct = chunk / nks, ks = chunk % nks;
+        float v[8];
+        pack_load8(e, ct * PN + col, ks * PK + 8 * kh, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m = fmaxf(m, fabsf(v[q]));       // (a NaN weight is not seen here: it still makes its products NaN)
+    }
+    __shared__ float wmax[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {                                   // (non-negative floats order like their bits; look before the atomic)
+        unsigned* p = reinterpret_cast<unsigned*>(absmax + d);
+        const unsigned mine = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+        if (mine > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, mine);
+    }
+}
+
+// the fp16-pair planes of the matrices of a pack table, each multiplied by the power of two its maximum gives (one workgroup per
+// 8 KiB chunk)
+__global__ __launch_bounds__(256) void x6_pair_kernel(const PackDesc* descs, int count, const float* absmax, float* scales) {
     static_assert(sizeof(PackDesc) == 64 && offsetof(PackDesc, chunk_begin) == 48, "pack_entry_of_chunk reads field 6 of 8 x int64 entries");
     const int d = pack_entry_of_chunk(reinterpret_cast<const int64_t*>(descs), count);
     const PackDesc e = descs[d];
     // a matrix and its transpose (forward and input-gradient planes of one weight: neighbours in the table, same source) share
     // their maximum: found once, through the first of the two entries
     const int dm = (d > 0 && e.transposed && descs[d - 1].src == e.src && !descs[d - 1].transposed) ? d - 1 : d;
-    if (!PACK && dm != d) return;
     const int chunk = (int)(blockIdx.x - e.chunk_begin);
     const int nks = (int)(e.k / PK);
     const int ct = chunk / nks, ks = chunk % nks;
     const int col = threadIdx.x & 127, kh = threadIdx.x >> 7;
     float v[8];
     pack_load8(e, ct * PN + col, ks * PK + 8 * kh, v);
-    if constexpr (!PACK) {
-        float m = 0.f;
+    const float sc = pair_scale(absmax[dm]);
+    if (chunk == 0 && threadIdx.x == 0) scales[d] = sc;
+    unsigned h[4], l[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) m = fmaxf(m, fabsf(v[q]));       // (a NaN weight is not seen here: it still makes its products NaN)
-        __shared__ float wmax[4];
-        m = wave_max(m);
-        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) {                               // (non-negative floats order like their bits; look before the atomic:
-            unsigned* p = reinterpret_cast<unsigned*>(absmax + d);   //  ~2e4 workgroups share a few dozen addresses)
-            const unsigned mine = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
-            if (mine > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, mine);
-        }
-    } else {
-        const float sc = pair_scale(absmax[dm]);
-        if (chunk == 0 && threadIdx.x == 0) scales[d] = sc;
-        unsigned h[4], l[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) split2_pk(v[2 * q], v[2 * q + 1], sc, h[q], l[q]);
-        unsigned char* dst = reinterpret_cast<unsigned char*>(e.dst) + (size_t)chunk * (8 * 1024) + ((col >> 5) * 2) * 1024 +
-                             ((col & 31) + 32 * kh) * 16;
-        *reinterpret_cast<uint4*>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
-        *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(l[0], l[1], l[2], l[3]);
-    }
+    for (int q = 0; q < 4; ++q) split2_pk(v[2 * q], v[2 * q + 1], sc, h[q], l[q]);
+    unsigned char* dst = reinterpret_cast<unsigned char*>(e.dst) + (size_t)chunk * (8 * 1024) + ((col >> 5) * 2) * 1024 +
+                         ((col & 31) + 32 * kh) * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
 }  // namespace
@@ -815,8 +838,7 @@ extern "C" int peclr_x6_absmax_f32(const void* desc_table, int count, int total_
     if (count <= 0 || total_chunks <= 0) return PECLR_ERR_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(absmax, 0, sizeof(float) * (size_t)count, s) != hipSuccess) return launch_status();
-    hipLaunchKernelGGL(x6_pair_kernel<false>, dim3(total_chunks), dim3(256), 0, s, static_cast<const PackDesc*>(desc_table), count, absmax,
-                       static_cast<float*>(nullptr));
+    hipLaunchKernelGGL(x6_absmax_kernel, dim3(32, count), dim3(256), 0, s, static_cast<const PackDesc*>(desc_table), count, absmax);
     return launch_status();
 }
 
@@ -827,8 +849,8 @@ extern "C" int peclr_x6_pack_pair_f32(const void* desc_table, int count, int tot
                                       peclr_stream_t stream) {
     if (!desc_table || !absmax || !scales) return PECLR_ERR_NULL;
     if (count <= 0 || total_chunks <= 0) return PECLR_ERR_SHAPE;
-    hipLaunchKernelGGL(x6_pair_kernel<true>, dim3(total_chunks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const PackDesc*>(desc_table), count, const_cast<float*>(absmax), scales);
+    hipLaunchKernelGGL(x6_pair_kernel, dim3(total_chunks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const PackDesc*>(desc_table), count, absmax, scales);
     return launch_status();
 }
 

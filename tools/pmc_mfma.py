@@ -37,8 +37,8 @@ EXPECT = {
     "conv1x1_dgrad": ("gemm_x6", "conv_h_kernel"), "conv1x1_wgrad": ("gemm_x6", "wgrad_h_kernel"), "conv3x3_fwd": ("gemm_x6p", "conv_h_kernel"),
     "conv3x3_dgrad": ("gemm_x6p", "conv_h_kernel"), "conv3x3_wgrad": ("gemm_x6w", "wgrad3_h_kernel", "wgrad_x6r_kernel"), "gemm_x6p": "gemm_x6p",
     "gemm_x6t": "gemm_x6t", "conv3x3_x6p": "gemm_x6p", "conv_s2_fwd": ("gemm_x6p", "conv_h_kernel"), "conv_s2_dgrad": ("gemm_x6p", "conv_h_kernel"),
-    "conv3x3_s2_dgrad": ("gemm_x6p", "conv_h_kernel"), "conv_s2_x6p": "gemm_x6p", "wgrad_slab_reduce": "slab_reduce", "x6_pack": ("x6_pack_kernel", "x6_pair_kernel<true>"),
-    "x6_absmax": "x6_pair_kernel<false>",
+    "conv3x3_s2_dgrad": ("gemm_x6p", "conv_h_kernel"), "conv_s2_x6p": "gemm_x6p", "wgrad_slab_reduce": "slab_reduce", "x6_pack": ("x6_pack_kernel", "x6_pair_kernel"),
+    "x6_absmax": ("x6_absmax_kernel", "x6_pair_kernel<false>"),
     "h_pack": "h_pack_kernel", "bn_relu_fwd": "bn_relu_fwd_kernel", "bn_relu_bwd": "bn_relu_bwd_kernel",
     "align_fwd": "align_fwd_kernel", "align_bwd": "align_bwd_kernel", "ntxent_fwd": "ntxent_kernel<false>",
     "ntxent_bwd": "ntxent_kernel<true>", "ntxent_finalize": "ntxent_finalize_kernel", "slab_reduce": "slab_reduce",
